@@ -1,0 +1,211 @@
+"""Pin the CPU oracle (oracle/poccala_oracle.py) to the reference's own outputs.
+
+The golden vectors were produced by tests/golden/make_golden.py, which runs the
+reference (util.py, Clustering.GMM, LHMM, AcousticModel helpers) in the build
+container.  Every oracle function on the hot path is compared here; tolerance
+1e-10 relative (both sides are float64, only the summation order differs).
+"""
+import numpy as np
+import pytest
+
+from oracle import poccala_oracle as po
+
+RTOL = 1e-10
+S = 5
+
+
+def close(a, b, rtol=RTOL, atol=0.0):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------- G1
+def test_g1_gaussian_q1_constant(golden):
+    g = golden('G1_util')
+    for d in (13, 39):
+        y, mean, var = g['gauss_y_%d' % d], g['gauss_mean_%d' % d], g['gauss_var_%d' % d]
+        out = np.array([po.gaussian_logpdf(y[i], mean[i], var[i]) for i in range(len(y))])
+        close(out, g['gauss_out_%d' % d])
+        # quirk Q1: NOT the textbook log-determinant
+        textbook = -d / 2 * po.LOG_2PI - 0.5 * np.log(var).sum(1) - 0.5 * ((y - mean) ** 2 / var).sum(1)
+        assert np.abs(textbook - g['gauss_out_%d' % d]).max() > 1e-3
+
+
+def test_g1_log_sum_exp(golden):
+    g = golden('G1_util')
+    for i in range(5):
+        ref = g['lse_out_%d' % i]
+        got = po.lse(g['lse_in_%d' % i])
+        if np.isinf(ref):
+            assert got == ref            # quirk Q4: returns the max itself
+        else:
+            close(got, ref)
+    close(po.lse_rows(g['lse_vec_in']), g['lse_vec_out'])
+    close(po.matrix_lse(list(g['mlse_in']), 4), g['mlse_out_full'])
+    close(po.matrix_lse(list(g['mlse_in']), 3), g['mlse_out_3'])
+
+
+# ---------------------------------------------------------------- G2
+@pytest.mark.parametrize('key', ['4_13', '8_39', '256_39'])
+def test_g2_gmm_point_and_record(golden, key):
+    g = golden('G2_gmm_point')
+    out, rec = po.gmm_point(g['x_' + key], g['mean_' + key], g['var_' + key], g['w_' + key], record=True)
+    close(out, g['out_' + key])
+    close(rec, g['record_' + key])
+    one = po.faithful_gmm_point(g['x_' + key][3], g['mean_' + key], g['var_' + key], g['w_' + key])
+    close(one, g['out_' + key][3])
+
+
+def test_g2_dimension_error(golden):
+    g = golden('G2_gmm_point')
+    with pytest.raises(ValueError):
+        po.gmm_point(g['x_4_13'][:, :12], g['mean_4_13'], g['var_4_13'], g['w_4_13'])
+
+
+# ---------------------------------------------------------------- G3
+def test_g3_unit_observation(golden):
+    g = golden('G3_unit_B')
+    gmms = [(g['mean_%d' % k], g['var_%d' % k], g['w_%d' % k]) for k in range(3)]
+    b = po.unit_observation(g['x'], gmms)
+    assert b.shape == (5, 300)
+    assert np.all(b[0] == 0.0) and np.all(np.isneginf(b[4]))
+    close(b[1:4], g['B'][1:4])
+    assert np.array_equal(np.isneginf(b), np.isneginf(g['B']))
+
+
+# ---------------------------------------------------------------- G4..G8
+CASES = ['G6_small_fix0', 'G6_small_fix1', 'G6_small_fix2', 'G6_small_fix3', 'G6_small_fix4',
+         'G6_small_fix6', 'G8_floor', 'G6_n62_fix0', 'G6_n62_fix3']
+
+
+def load_case(g):
+    names = [str(u) for u in g['unit_names']]
+    label = [str(u) for u in g['label']]
+    model = {}
+    for ui, u in enumerate(names):
+        model[u] = dict(trans=g['trans_%d' % ui],
+                        gmms=[(g['mean_%d_%d' % (ui, k)], g['var_%d_%d' % (ui, k)], g['w_%d_%d' % (ui, k)])
+                              for k in range(S - 2)])
+    return label, model
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_g4_embedded(golden, case):
+    g = golden(case)
+    label, model = load_case(g)
+    states, a, b, pi = po.score_label(g['x'], label, model)
+    assert [states[i] for i in range(len(states))] == [str(s) for s in g['emb_states']]
+    close(a, g['emb_A'])
+    close(pi, g['emb_pi'])
+    assert np.array_equal(np.isneginf(b), np.isneginf(g['emb_B']))
+    fin = np.isfinite(b)
+    close(b[fin], g['emb_B'][fin])
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_g5_viterbi_on_sentence_hmm(golden, case):
+    g = golden(case)
+    label, model = load_case(g)
+    point, path = po.viterbi(g['emb_A'], g['emb_pi'], g['emb_B'])
+    assert np.array_equal(path, g['vit_path'])               # bit-exact given identical prob
+    assert point == float(g['vit_point'])
+    names = np.array([str(g['emb_states'][int(k)]) for k in path])
+    assert np.array_equal(names, g['vit_path_conv'].astype(str))
+    for u in set(label):
+        runs = po.discriminate(u, names)
+        assert len(runs) == int(g['disc_%s_n' % u])
+        for ri, r in enumerate(runs):
+            assert np.array_equal(r, g['disc_%s_%d' % (u, ri)])
+
+
+def test_g5_viterbi_cases(golden):
+    g = golden('G5_viterbi')
+    for tag in ('dense', 'tie', 'lr'):
+        point, path = po.viterbi(g[tag + '_A'], g[tag + '_pi'], g[tag + '_prob'])
+        assert np.array_equal(path, g[tag + '_path']), tag
+        assert point == float(g[tag + '_point']), tag
+    point, path = po.viterbi(g['tie_A'], g['tie_pi'], g['t1_prob'])
+    assert np.array_equal(path, g['t1_path']) and point == float(g['t1_point'])
+    point, path = po.viterbi(g['lr_A'], g['lr_pi'], g['lr_prob'], end_state_back=True)   # quirk Q9
+    assert np.array_equal(path, g['lr_esb_path']) and point == float(g['lr_esb_point'])
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_g6_baum_welch(golden, case):
+    g = golden(case)
+    fix = int(g['fix_code'])
+    bw = po.baum_welch(g['emb_A'], g['emb_pi'], [g['emb_B']], fix_code=fix)
+    assert bw['n_pass'] == int(g['bw_n_pass'])
+    assert bw['n_pass'] == (2 if fix & 1 else 3)             # quirk Q6
+    np.testing.assert_allclose(bw['q_trace'][1:], g['bw_q_trace'][1:], atol=2e-6)   # logged with %f
+    assert np.isneginf(bw['q_trace'][0])
+    close(bw['logp'][0], g['bw_logp'])
+    close(bw['pi'], g['bw_pi'], atol=1e-300)
+    for name, got in (('bw_ksai', bw['ksai']), ('bw_gamma', bw['gamma'])):
+        ref = g[name]
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+        fin = np.isfinite(ref)
+        close(got[fin], ref[fin])
+    if 'bw_alpha' in g.files:
+        for name, got in (('bw_alpha', bw['alpha'][0]), ('bw_beta', bw['beta'][0])):
+            ref = g[name]
+            assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+            fin = np.isfinite(ref)
+            close(got[fin], ref[fin])
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_g7_g8_accumulators_and_mstep(golden, case):
+    g = golden(case)
+    fix = int(g['fix_code'])
+    label, model = load_case(g)
+    bw, accs, _ = po.estep_utterance(g['x'], label, model, fix_code=fix)
+    for pos in range(len(label)):
+        ua = accs[pos]
+        for name, got in (('ksai_acc_%d' % pos, ua.ksai_acc), ('gamma_acc_%d' % pos, ua.gamma_acc)):
+            ref = g[name]
+            assert np.array_equal(np.isneginf(got), np.isneginf(ref)), name
+            fin = np.isfinite(ref)
+            close(got[fin], ref[fin])
+        for k in range(S - 2):
+            acc = ua.gmm[k]
+            for nm, key in (('acc', 'acc_%d_%d'), ('alpha_acc', 'alpha_acc_%d_%d'),
+                            ('mean_acc', 'mean_acc_%d_%d'), ('cov_acc', 'cov_acc_%d_%d')):
+                ref = g[key % (pos, k)]
+                got = np.asarray(acc[nm])
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)), key % (pos, k)
+                fin = np.isfinite(ref)
+                close(got[fin], ref[fin], rtol=1e-9)
+        # M-step (A15)
+        if not fix & 4:
+            close(po.hmm_update_param(model[label[pos]]['trans'], ua.ksai_acc, ua.gamma_acc),
+                  g['new_trans_%d' % pos], atol=1e-300)
+        if not fix & 2:
+            for k in range(S - 2):
+                w, mean, var = po.gmm_update_param(ua.gmm[k], c_covariance=float(g['c_covariance']))
+                close(w, g['new_w_%d_%d' % (pos, k)], rtol=1e-9)
+                # mean = exp(.) - 100: absolute error of the exp() is amplified by the bias
+                close(mean, g['new_mean_%d_%d' % (pos, k)], rtol=1e-7, atol=1e-9)
+                close(var, g['new_var_%d_%d' % (pos, k)], rtol=1e-8)
+
+
+def test_g8_floor_was_hit(golden):
+    g = golden('G8_floor')
+    assert (g['new_var_0_0'] == 0.9).any()
+
+
+def test_faithful_forward_backward_matches_vectorised(golden):
+    g = golden('G6_small_fix3')
+    al, be = po.faithful_forward_backward(g['emb_A'], g['emb_pi'], g['emb_B'])
+    fin = np.isfinite(g['bw_alpha'])
+    close(al[fin], g['bw_alpha'][fin])
+    fin = np.isfinite(g['bw_beta'])
+    close(be[fin], g['bw_beta'][fin])
+
+
+def test_g9_layout(golden):
+    listing = [str(s) for s in golden('G9_layout')['listing']]
+    assert 'HMM/transmat.npy|float64|5x5' in listing
+    assert 'HMM/pi.npy|float64|5' in listing
+    assert 'GMM_0/GMM_covariance.npy|float64|4x13x13' in listing     # full matrices, quirk Q2
+    assert 'GMM_2/covariance-acc/GMM_covariance_acc_<ts>.npy|float64|4x13' in listing
+    assert 'HMM/ksai-acc/ksai_acc_<ts>.npy|float64|3x5' in listing
