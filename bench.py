@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of GMM-score + forward-backward (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic utterances: state-major GMM scoring
+of every (frame, label state) pair of the batch followed by the Baum-Welch forward/backward pass loop
+(LHMM.baulm_welch: alpha, beta, xi, gamma, pi, per-frame posteriors).  The default workload is the
+per-GPU shard of BASELINE config 4 (the configuration the metric is quoted on: 39-dim MFCC, 2048-mix,
+3000 tied states; 8 GPUs x 1024 utterances = the full 8192-utterance E-step), so scaling is weak:
+every rank owns its own 1024 utterances and the path needs no collective (the statistics all-reduce
+belongs to the accumulate stage, measured separately under "extra").
+
+Inputs (frames, model, batch descriptors) are resident in HBM before the timed region.  Timing:
+barrier + device sync on both sides of exactly K steps, MAX over ranks; rank 0 prints ONE JSON line.
+Multi-GPU: one process per GPU (torch.distributed.run), torch.distributed (gloo) is used only for the
+barrier / max / unique-id broadcast; the GPU work goes through libpoccala_hip.so and RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--workload', default='C4shard', help='poccala_amd.synth.CONFIGS key')
+    p.add_argument('--utts', type=int, default=0, help='override utterances per GPU')
+    p.add_argument('--precision', default='f32', choices=['f32', 'f64'])
+    p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
+    p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
+    p.add_argument('--traffic-bytes', type=float, default=None,
+                   help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass (profiles/)')
+    return p.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline leg: the oracle (a port of the reference's arithmetic) timed on the host cores.
+# ------------------------------------------------------------------------------------------------
+def _cpu_vectorised_utt(args):
+    """One utterance of score + forward-backward with the vectorised float64 oracle."""
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import poccala_oracle as po
+    x, gmms_per_row, a, pi = args
+    t0 = time.perf_counter()
+    rows = [np.zeros(x.shape[0])]
+    for (mean, var, w) in gmms_per_row:
+        out = np.empty(x.shape[0])
+        for s in range(0, x.shape[0], 25):                      # chunked: bounds the (T,M,D) temporary
+            out[s:s + 25] = po.gmm_point(x[s:s + 25], mean, var, w)
+        rows.append(out)
+    rows.append(np.full(x.shape[0], -np.inf))
+    b = np.array(rows)
+    po.baum_welch(a, pi, [b])
+    return time.perf_counter() - t0
+
+
+def _cpu_faithful_sample(args):
+    """The reference's own loop nest (per frame x per mixture NumPy calls; per-(t,j) LSE) on a tiny
+    sample: `nf` frames of scoring for every row + one full forward/backward lattice."""
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import poccala_oracle as po
+    x, gmms_per_row, a, pi, nf = args
+    t0 = time.perf_counter()
+    for (mean, var, w) in gmms_per_row:
+        for t in range(nf):
+            po.faithful_gmm_point(x[t], mean, var, w)
+    t_score = (time.perf_counter() - t0) / nf                   # seconds per frame (all rows)
+    n, T = a.shape[0], x.shape[0]
+    b = np.random.default_rng(0).standard_normal((n, T)) - 60.0
+    b[0] = 0.0
+    b[-1] = -np.inf
+    t0 = time.perf_counter()
+    po.faithful_forward_backward(a, pi, b)
+    t_fb = 3 * (time.perf_counter() - t0) / T                    # 3 passes (quirk Q6), seconds per frame
+    return t_score + t_fb
+
+
+def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
+    import multiprocessing as mp
+    from poccala_amd.engine import embedded_structure
+    cores = os.cpu_count() or 1
+    e = 3
+    jobs_v, jobs_f = [], []
+    n_utt = min(cores, len(labels))
+    for u in range(n_utt):
+        lab = labels[u]
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        gm = [(mean[i * e + k], var[i * e + k], w[i * e + k]) for i in lab for k in range(e)]
+        a, pi = embedded_structure(len(lab), [trans[i] for i in lab])
+        jobs_v.append((x, gm, a, pi))
+        jobs_f.append((x, gm, a, pi, 1))
+    with mp.get_context('fork').Pool(min(cores, n_utt)) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_vectorised_utt, jobs_v, chunksize=1)
+        wall = time.perf_counter() - t0
+        per_frame = pool.map(_cpu_faithful_sample, jobs_f, chunksize=1)
+    frames_done = int(sum(len(j[0]) for j in jobs_v))
+    vec = frames_done / wall
+    faithful = len(per_frame) / float(np.mean(per_frame)) if n_utt == cores else cores / float(np.mean(per_frame))
+    return dict(value=vec, unit='frames/s', cores=min(cores, n_utt), kind='port',
+                sample='%d utterances x %d frames (one per core, multiprocessing), vectorised float64 NumPy oracle: '
+                       'score %d label states x %d mixtures + 3-pass forward-backward' % (n_utt, int(lens[0]), len(jobs_v[0][1]), cfg['M']),
+                faithful_value=faithful,
+                faithful_sample='reference loop nest (per frame x per mixture NumPy calls, per-(t,j) LSE): 1 frame x %d states '
+                                'of scoring + one faithful forward/backward lattice per core, scaled to frames/s over %d cores' % (len(jobs_v[0][1]), cores))
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+
+    # The HIP library first (so /opt/rocm's runtime is the one in the process), torch (gloo) second.
+    from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+    from poccala_amd.engine import make_sentence_batch
+    eng = Engine(local)
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    P = PCL_F32 if args.precision == 'f32' else PCL_F64
+    cfg = dict(synth.CONFIGS[args.workload])
+    if args.utts:
+        cfg['U'] = args.utts
+    t_setup = time.perf_counter()
+    mean, var, w, trans = synth.make_model(cfg['units'], cfg['M'], cfg['D'], seed=1)
+    frames, lens, begin = synth.make_frames(cfg['U'], cfg['T'], cfg['D'], seed=1000 * rank)      # each rank its own shard
+    labels = synth.make_labels(cfg['U'], cfg['L'], cfg['units'], seed=2 + 7919 * rank)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    batch, n_states = make_sentence_batch(eng, labels, lens, begin, trans)
+    if world > 1:
+        import torch
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(rank, world, uid[0])
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        batch.score(P)
+        batch.forward_backward(fix_pi=False)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.kernel_time('score')
+    eng.kernel_time('fb')
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    score_ms, score_n = eng.kernel_time('score')
+    fb_ms, fb_n = eng.kernel_time('fb')
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    frames_per_rank = int(lens.sum())
+    total_frames = frames_per_rank * world
+    value = total_frames * args.steps / elapsed
+
+    # dominant kernel: gmm_score.  Algorithmic FLOP per launch = scored (frame, state) pairs x M x (3D+4)
+    # (SURVEY.md section 8d); the emitting rows of an utterance are N-2.
+    pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
+    flop_per_launch = pairs * cfg['M'] * (3 * cfg['D'] + 4)
+    score_avg_ms = score_ms / max(score_n, 1)
+    achieved = flop_per_launch / (score_avg_ms * 1e-3) / 1e12 if score_n else None
+    # algorithmic HBM bytes per scoring launch: frames read once per scored state row (4D) is an upper
+    # bound served from L2; the honest algorithmic figure is frames once + parameters once + B written once
+    alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + pairs * 8
+    roofline = dict(bound='mfma', achieved=achieved, peak=FP32_VECTOR_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
+                    traffic=args.traffic_bytes,
+                    kernel='gmm_score_kernel<39,4,64,float>' if P == PCL_F32 else 'gmm_score_kernel<39,2,32,double>',
+                    kernel_avg_ms=score_avg_ms, launches=score_n,
+                    flop_per_launch=flop_per_launch,
+                    note='FP32 VALU kernel, no MFMA by design (diagonal Gaussians are not a dense contraction at f32 '
+                         'accuracy); peak = 157.3 TFLOP/s which is both the FP32 vector and the FP32-input MFMA peak',
+                    hbm_algorithmic_bytes_per_launch=alg_bytes,
+                    hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_n else None,
+                    fb_kernel_avg_ms=fb_ms / max(fb_n, 1))
+
+    extra = None
+    if args.extra:
+        # untimed-region extras: Viterbi forced alignment and the full E-step (accumulate + RCCL all-reduce)
+        eng.sync()
+        barrier()
+        t1 = time.perf_counter()
+        batch.viterbi()
+        eng.sync()
+        t_vit = time.perf_counter() - t1
+        eng.stats_zero()
+        eng.sync()
+        barrier()
+        t1 = time.perf_counter()
+        batch.score(P)
+        batch.forward_backward(fix_pi=False)
+        batch.accumulate(P)
+        eng.stats_allreduce()
+        eng.sync()
+        barrier()
+        t_estep = time.perf_counter() - t1
+        acc_ms, acc_n = eng.kernel_time('accumulate')
+        ar_ms, ar_n = eng.kernel_time('allreduce')
+        vit_ms, _ = eng.kernel_time('viterbi')
+        extra = dict(viterbi_frames_per_s_per_gpu=frames_per_rank / t_vit, viterbi_kernel_ms=vit_ms,
+                     estep_frames_per_s=total_frames / t_estep, accumulate_ms=acc_ms, allreduce_ms=ar_ms,
+                     setup_s=t_setup)
+
+    cpu = None
+    if args.cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels)
+
+    if rank == 0:
+        info = eng.device_info()
+        out = {
+            'metric': 'frames/sec GMM-score+fwd-bwd, 39-d MFCC, 2048-mix',
+            'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': '%s: %d utterances/GPU x %d frames, D=%d MFCC, M=%d mixtures, %d units (J=%d tied GMM states), '
+                                   'L=%d units/utterance (N=%d-state sentence HMMs); GMM scoring of the %d label states of every frame '
+                                   '+ Baum-Welch forward-backward pass loop (3 passes, xi/gamma/pi/posteriors)'
+                                   % (args.workload, cfg['U'], cfg['T'], cfg['D'], cfg['M'], cfg['units'], cfg['units'] * 3, cfg['L'],
+                                      3 * cfg['L'] + 2, 3 * cfg['L']),
+                       'utterances_total': cfg['U'] * world, 'frames_per_step_total': total_frames,
+                       'arithmetic': 'f32 Gaussian scoring, f64 dynamic programming' if P == PCL_F32 else 'f64',
+                       'device': info['name'], 'cus': info['cus']},
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        if extra:
+            out['extra'] = extra
+        if cpu:
+            out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value']}
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        eng._lib.pcl_comm_destroy(eng._ctx)
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

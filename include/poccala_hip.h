@@ -1,0 +1,162 @@
+/*
+ * poccala_hip.h  --  C-ABI of libpoccala_hip.so, the MI355X (gfx950) engine for the
+ * GMM-HMM hot path of Byshx/Poccala.
+ *
+ * The reference has no FFI layer: its boundary is the Python class surface
+ * (StatisticalModel/LHMM.py, StatisticalModel/Clustering.py, AcousticModel/AcousticModel.py).
+ * Every entry point below names the reference function(s) it replaces.  The Python
+ * drop-in classes in poccala_amd/ call these through ctypes and nothing else.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Return 0 on success, a negative
+ *     pcl_status on failure; pcl_last_error() gives the message.  Nothing throws
+ *     across the ABI.
+ *   - The caller owns every host buffer (C-contiguous NumPy arrays).  The library
+ *     owns all device memory (inside pcl_ctx / pcl_batch).
+ *   - One pcl_ctx = one GPU = one HIP stream.  Calls on a ctx are serialised by the
+ *     caller (one process or thread per GPU).  Every function is synchronous at
+ *     return unless it says "asynchronous" (then pcl_sync() completes it).
+ *   - Host-side matrices use the REFERENCE layout: (N,T) row-major emission /
+ *     alpha / beta matrices, float64, log domain, -inf for impossible.
+ *   - log A and log pi are passed ALREADY LOGGED by the caller (np.log), because
+ *     bit-exact Viterbi is defined on those values (LHMM.py:571,577).
+ */
+#ifndef POCCALA_HIP_H
+#define POCCALA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcl_ctx pcl_ctx;
+typedef struct pcl_batch pcl_batch;
+
+typedef enum {
+    PCL_OK = 0,
+    PCL_ERR_INVALID = -1,  /* bad argument / shape (reference: DataDimensionError, AssertionError) */
+    PCL_ERR_HIP = -2,      /* HIP runtime error */
+    PCL_ERR_STATE = -3,    /* call order (e.g. score before model upload) */
+    PCL_ERR_NOMEM = -4,
+    PCL_ERR_COMM = -5      /* RCCL error */
+} pcl_status;
+
+/* arithmetic of the scoring / accumulate kernels */
+#define PCL_F32 0 /* f32 Gaussian arithmetic, f64 dynamic programming (headline mode) */
+#define PCL_F64 1 /* everything float64 (alignment-parity mode)            */
+
+/* pcl_model_upload flags */
+#define PCL_MODEL_Q1_SUMVAR 0 /* reference constant: -D/2 ln2pi - 1/2 sum(var)   (util.py:29, quirk Q1) */
+#define PCL_MODEL_LOGDET 1    /* textbook constant:  -D/2 ln2pi - 1/2 sum(ln var) (opt-in, not parity)  */
+
+/* row kinds in pcl_batch_set_states: >=0 is a GMM state id */
+#define PCL_ROW_ENTRY (-1) /* VirtualState(1.): ln 1 = 0   (AcousticModel.py:218,1039-1043) */
+#define PCL_ROW_EXIT (-2)  /* VirtualState(0.): ln 0 = -inf (AcousticModel.py:219)          */
+
+/* pcl_batch_get selectors */
+typedef enum {
+    PCL_GET_B = 0,       /* emission matrices, ragged, (N_u,T_u) row-major f64  == LHMM.B_p / embedded() B   */
+    PCL_GET_ALPHA = 1,   /* forward  matrices of the final pass, same layout    == LHMM.__result_f           */
+    PCL_GET_BETA = 2,    /* backward matrices of the final pass                 == LHMM.__result_b           */
+    PCL_GET_LGAMMA = 3,  /* ln gamma_t(i) = alpha+beta - LSE_i(alpha+beta), (N_u,T_u)  (LHMM.py:486-500)      */
+    PCL_GET_KSAI = 4,    /* un-normalised ln xi, ragged dense (N_u,N_u) f64     == LHMM.__ksai (quirk Q5)    */
+    PCL_GET_GAMMA = 5,   /* un-normalised ln gamma, ragged (N_u,) f64           == LHMM.__gamma              */
+    PCL_GET_PI = 6,      /* pi after the final pass, ragged (N_u,) f64, LINEAR  == LHMM.pi                   */
+    PCL_GET_LOGP = 7,    /* LSE_i alpha_{T-1}(i) of the final pass, (U,) f64    == __expectation, LHMM.py:412 */
+    PCL_GET_NPASS = 8,   /* Baum-Welch passes run, (U,) int32 (quirk Q6)                                     */
+    PCL_GET_QTRACE = 9,  /* Q after each pass, (U, PCL_MAX_PASS) f64, unused = NaN                            */
+    PCL_GET_PATH = 10,   /* Viterbi state indices, ragged (T_u,) int32          == LHMM.viterbi mark_state   */
+    PCL_GET_POINT = 11   /* Viterbi score, (U,) f64                             == LHMM.viterbi point        */
+} pcl_get_what;
+#define PCL_MAX_PASS 16
+
+/* ---------------------------------------------------------------- context */
+int pcl_init(int device, pcl_ctx **out);
+int pcl_destroy(pcl_ctx *ctx);
+const char *pcl_last_error(pcl_ctx *ctx); /* ctx may be NULL: error of a failed pcl_init */
+int pcl_sync(pcl_ctx *ctx);
+/* name (cap bytes), compute units, HBM bytes */
+int pcl_device_info(pcl_ctx *ctx, char *name, int cap, int *cus, size_t *hbm_bytes);
+/* GPU time of a kernel group since the last query, measured with HIP events recorded on the ctx
+ * stream around every launch: which = "score" | "fb" | "viterbi" | "accumulate" | "allreduce".
+ * Returns the summed milliseconds and the number of launches, then resets the group. */
+int pcl_kernel_time(pcl_ctx *ctx, const char *which, float *total_ms, int *launches);
+
+/* ------------------------------------------------------------------ model
+ * Replaces Clustering.GMM parameter state (T2: mean (M,D), covariance (M,D,D) of which only the
+ * diagonal is used -- util.py:23 --, alpha (M,)) for J GMM states at once.  `var` is the DIAGONAL.
+ * Derived device layouts (f32 and f64) are built here, in float64, once. */
+int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean /* J*M*D */,
+                     const double *var /* J*M*D */, const double *weight /* J*M */, int flags);
+
+/* ----------------------------------------------------------------- frames
+ * The (F,D) MFCC matrix of the whole batch/corpus shard, rows = frames (LHMM.add_data, the `data`
+ * argument of cal_observation_pro).  dtype: PCL_F32 or PCL_F64 host element type. */
+int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dtype);
+
+/* ------------------------------------------------------------------ batch
+ * A batch = U sentence-level HMMs (AcousticModel.embedded, AcousticModel.py:957-1014), utterance u
+ * having N[u] states and T[u] frames starting at row frame_begin[u] of the uploaded frame matrix
+ * (frame_begin may be NULL when emissions are supplied with pcl_batch_set_emissions). */
+int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, const int64_t *frame_begin,
+                     pcl_batch **out);
+int pcl_batch_destroy(pcl_batch *b);
+
+/* ln A (ragged dense (N_u,N_u) row-major, -inf where A == 0) and ln pi (ragged (N_u,)).
+ * == the transmat / pi arguments of LHMM.__init__ (LHMM.py:19) and LHMM.viterbi (LHMM.py:547). */
+int pcl_batch_set_transitions(pcl_batch *b, const double *logA, const double *logpi);
+
+/* Row -> GMM state map, ragged (N_u,): state id in [0,J), or PCL_ROW_ENTRY / PCL_ROW_EXIT.
+ * == the profunction list of each unit HMM laid out by embedded() (AcousticModel.py:990-1001). */
+int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state);
+
+/* Emissions given by the caller (ragged (N_u,T_u) row-major f64) instead of scored here
+ * == LHMM(probmat=[B]) (LHMM.py:75) and the `prob` argument of LHMM.viterbi (LHMM.py:547). */
+int pcl_batch_set_emissions(pcl_batch *b, const double *B);
+
+/* A1+A4+A5+A6: fill every row of every emission matrix:  ln b_j(o_t) = LSE_m[ln w_m + N(o_t; mu_m, var_m)]
+ * == LHMM.cal_observation_pro (LHMM.py:163-187) -> Clustering.GMM.point (Clustering.py:740-767)
+ *    -> util.gaussian_function (util.py:20-31), batched state-major over the whole batch. */
+int pcl_batch_score(pcl_batch *b, int precision);
+
+/* A8..A11 (+ the per-frame posteriors of A12): the Baum-Welch pass loop of LHMM.baulm_welch
+ * (LHMM.py:526-544) for an LHMM built with probmat: forward (:335-351), backward (:353-366),
+ * xi/gamma/pi (:394-471), Q (:412-422); passes repeat while Q - Q_prev > threshold (0.64, :539).
+ * fix_pi = bit0 of the reference's fix_code (LHMM.py:140-145).  Results stay on the device;
+ * read them with pcl_batch_get. */
+int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold);
+
+/* A14: LHMM.viterbi (LHMM.py:546-609), end_state_back = 0|1 (quirk Q9). Bit-exact in f64. */
+int pcl_batch_viterbi(pcl_batch *b, int end_state_back);
+
+/* Copy a result to a caller buffer (layouts in pcl_get_what). */
+int pcl_batch_get(pcl_batch *b, int what, void *host);
+
+/* ----------------------------------------------------------------- E-step statistics
+ * A13: Clustering.GMM.update_acc (Clustering.py:653-680) for every (utterance, emitting row) of the
+ * batch, summed into ctx-resident per-state statistics.  The reference keeps them in the log domain
+ * per label position and merges files later (Clustering.py:314-367); here they are LINEAR sums
+ *   acc[j,m]      = sum_t gamma_t(j,m)                      (exp of GMM.acc)
+ *   alpha_acc[j]  = sum_t gamma_t(j)                        (exp of GMM.alpha_acc)
+ *   mean_acc[j,m,d] = sum_t gamma_t(j,m) (o_td + bias)      (exp of GMM.mean_acc, bias = 100)
+ *   cov_acc[j,m,d]  = sum_t gamma_t(j,m) (o_td - mu_jmd)^2  (exp of GMM.__covariance_acc)
+ * which is what RCCL can sum.  Needs pcl_batch_forward_backward first. */
+int pcl_stats_zero(pcl_ctx *ctx);
+int pcl_batch_accumulate(pcl_batch *b, int precision);
+/* J*M, J, J*M*D, J*M*D doubles */
+int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc);
+
+/* ----------------------------------------------------------------- multi-GPU (RCCL over xGMI)
+ * Replaces the reference's file-based accumulator merge (LHMM.py:256-290, Clustering.py:314-367).
+ * id_bytes is a 128-byte ncclUniqueId made by rank 0 and distributed by the caller. */
+int pcl_comm_unique_id(void *id_bytes128);
+int pcl_comm_init(pcl_ctx *ctx, int rank, int nranks, const void *id_bytes128);
+int pcl_stats_allreduce(pcl_ctx *ctx);
+int pcl_comm_destroy(pcl_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POCCALA_HIP_H */

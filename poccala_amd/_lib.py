@@ -1,0 +1,87 @@
+"""ctypes binding of libpoccala_hip.so (C-ABI: include/poccala_hip.h).
+
+The HIP library is the product; there is NO CPU fallback.  Importing this module
+without the built library, or calling into it without a GPU, raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpoccala_hip.so')
+
+PCL_F32, PCL_F64 = 0, 1
+PCL_MODEL_Q1_SUMVAR, PCL_MODEL_LOGDET = 0, 1
+PCL_ROW_ENTRY, PCL_ROW_EXIT = -1, -2
+PCL_MAX_PASS = 16
+GET = dict(B=0, alpha=1, beta=2, lgamma=3, ksai=4, gamma=5, pi=6, logp=7, npass=8, qtrace=9, path=10, point=11)
+
+# every symbol include/poccala_hip.h declares: (restype, argtypes)
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+PROTOTYPES = {
+    'pcl_init': (_i, [_i, C.POINTER(_vp)]),
+    'pcl_destroy': (_i, [_vp]),
+    'pcl_last_error': (C.c_char_p, [_vp]),
+    'pcl_sync': (_i, [_vp]),
+    'pcl_device_info': (_i, [_vp, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_size_t)]),
+    'pcl_kernel_time': (_i, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(_i)]),
+    'pcl_model_upload': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i]),
+    'pcl_frames_upload': (_i, [_vp, C.c_int64, _i, _vp, _i]),
+    'pcl_batch_create': (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_vp)]),
+    'pcl_batch_destroy': (_i, [_vp]),
+    'pcl_batch_set_transitions': (_i, [_vp, _vp, _vp]),
+    'pcl_batch_set_states': (_i, [_vp, _vp]),
+    'pcl_batch_set_emissions': (_i, [_vp, _vp]),
+    'pcl_batch_score': (_i, [_vp, _i]),
+    'pcl_batch_forward_backward': (_i, [_vp, _i, _d]),
+    'pcl_batch_viterbi': (_i, [_vp, _i]),
+    'pcl_batch_get': (_i, [_vp, _i, _vp]),
+    'pcl_stats_zero': (_i, [_vp]),
+    'pcl_batch_accumulate': (_i, [_vp, _i]),
+    'pcl_stats_download': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'pcl_comm_unique_id': (_i, [_vp]),
+    'pcl_comm_init': (_i, [_vp, _i, _i, _vp]),
+    'pcl_stats_allreduce': (_i, [_vp]),
+    'pcl_comm_destroy': (_i, [_vp]),
+}
+
+
+class PoccalaHipError(RuntimeError):
+    """A C-ABI call returned a negative pcl_status."""
+
+    def __init__(self, code, msg):
+        super().__init__('libpoccala_hip: %s (status %d)' % (msg, code))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(or make -C poccala_amd/csrc).  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """Pointer to a C-contiguous NumPy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)

@@ -1,0 +1,321 @@
+// gmm_accumulate.hip -- E-step sufficient statistics of the GMM states for gfx950 (MI355X).
+//
+// Replaces the reference's HOT LOOP 5:
+//   Clustering.GMM.update_acc   StatisticalModel/Clustering.py:653-680
+// called from LHMM.update_acc   StatisticalModel/LHMM.py:497-505 with
+//   l_value = ln gamma_t(j) = (alpha+beta)[j,t] - LSE_i (alpha+beta)[i,t],  b_value = ln b_j(o_t).
+// The reference materialises record (M,T) = ln w_m N_m(o_t) per state and adds (l - b) to get
+// ln gamma_t(j,m), then log-sum-exps over t.  Here the component values are RECOMPUTED (the record
+// would be 491 KB per frame at M = 2048) and the sums are kept in the linear domain:
+//   acc[j,m]        = sum_t g            g = gamma_t(j,m) = exp(ln w_m N_m(o_t) + l_t - b_t)
+//   mean_acc[j,m,d] = sum_t g (o_td + bias)
+//   cov_acc[j,m,d]  = sum_t g (o_td - mu_jmd)^2
+//   alpha_acc[j]    = sum_t gamma_t(j)
+//
+// Mapping (MI355X-first):
+//   1. compaction.  In a left-right sentence HMM almost every (frame, state) pair has a posterior
+//      that underflows: gamma_t(j,m) <= gamma_t(j), so when ln gamma_t(j) < UNDERFLOW every g is
+//      exactly 0 in the kernel's arithmetic and the frame can be dropped without changing a bit.
+//      Three small kernels (count per segment -> exclusive scan -> ordered fill) build, per state,
+//      the list of surviving frames in a fixed order, so sums are reproducible run to run.
+//   2. accumulate.  lanes = mixtures: a lane owns one mixture of one state and keeps its 2D+1
+//      running sums and its 2D+1 scoring parameters in VGPRs for the whole pass over the state's
+//      frame list -- there is no cross-lane reduction and no atomic.  Frames are staged through LDS
+//      in chunks and read back as broadcasts.  Per (frame, mixture, dim): y = x s + c; q += y^2
+//      (2 FMA), then z = g y; S1 += z; S2 += z y (3 ops).  Centred, scaled moments avoid the
+//      cancellation of raw moments: (o - mu) = y / s, (o - mu)^2 = y^2 / s^2.
+#include "pcl_internal.h"
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int FC = 32;  // frames per LDS chunk
+
+struct ActiveFrame {
+    long long frame;  // row of the frame matrix
+    double coef;      // ln gamma_t(j) - ln b_j(o_t)
+    double lg;        // ln gamma_t(j)
+};
+
+// one wave per segment: number of frames whose posterior survives
+__global__ void acc_count_kernel(const ScoreSeg *__restrict__ segs, int n_segs, const double *__restrict__ lgam,
+                                 double thr, int *__restrict__ cnt) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n_segs) return;
+    const int lane = threadIdx.x & 63;
+    const ScoreSeg sg = segs[k];
+    int c = 0;
+    for (int t = lane; t < sg.len; t += 64) c += lgam[sg.out0 + (long long)t * sg.out_stride] >= thr;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) cnt[k] = c;
+}
+
+// single-workgroup exclusive scan over the (state-sorted) segments; off[n] = total
+__global__ void acc_scan_kernel(const int *__restrict__ cnt, int n, long long *__restrict__ off) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int per = (n + nt - 1) / nt;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    long long s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < nt; ++i) {
+            const long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        off[n] = run;
+    }
+    __syncthreads();
+    long long run = part[tid];
+    for (int i = lo; i < hi; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+}
+
+// one wave per segment: ordered compaction of the surviving frames
+__global__ void acc_fill_kernel(const ScoreSeg *__restrict__ segs, int n_segs, const double *__restrict__ lgam,
+                                const double *__restrict__ Bt, double thr, const long long *__restrict__ off,
+                                ActiveFrame *__restrict__ list) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n_segs) return;
+    const int lane = threadIdx.x & 63;
+    const ScoreSeg sg = segs[k];
+    long long pos = off[k];
+    for (int t0 = 0; t0 < sg.len; t0 += 64) {
+        const int t = t0 + lane;
+        double lg = -INFINITY, lb = 0.0;
+        if (t < sg.len) {
+            lg = lgam[sg.out0 + (long long)t * sg.out_stride];
+            lb = Bt[sg.out0 + (long long)t * sg.out_stride];
+        }
+        const bool keep = (t < sg.len) && (lg >= thr);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            ActiveFrame a;
+            a.frame = sg.frame0 + t;
+            a.coef = lg - lb;
+            a.lg = lg;
+            list[pos + rank] = a;
+        }
+        pos += __popcll(mask);
+    }
+}
+
+template <typename real>
+struct Fast;
+template <>
+struct Fast<float> {
+    static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+};
+template <>
+struct Fast<double> {
+    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+};
+
+// grid = (mixture slices, states with work).  A lane owns mixture `m` of state `j`.
+template <int D, typename real, int MINW>
+__global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
+    const real *__restrict__ frames, const real *__restrict__ params, const real *__restrict__ means, int Mpad,
+    const int *__restrict__ work_states, const int *__restrict__ seg_lo, const int *__restrict__ seg_hi,
+    const long long *__restrict__ off, const ActiveFrame *__restrict__ list, double bias, double *__restrict__ st_acc,
+    double *__restrict__ st_alpha, double *__restrict__ st_mean, double *__restrict__ st_cov) {
+    constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
+    constexpr int XS = (D + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) real xs[FC * XS];
+    __shared__ real cf[FC];
+    __shared__ double red[WG / 64];
+
+    const int w = blockIdx.y;
+    const int j = work_states[w];
+    const long long beg = off[seg_lo[w]], end = off[seg_hi[w]];
+    if (beg == end) return;
+    const int m = blockIdx.x * WG + threadIdx.x;
+    const bool live = m < Mpad;
+    const real *p = params + ((size_t)j * Mpad + (live ? m : 0)) * ROW;
+
+    real s[D], c[D], S1[D], S2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        s[d] = p[2 * d];
+        c[d] = p[2 * d + 1];
+        S1[d] = 0;
+        S2[d] = 0;
+    }
+    const real k2 = p[2 * D];
+    real S0 = 0;
+    double galpha = 0.0;  // slice 0 only: sum_t gamma_t(j)
+    constexpr double LOG2E = 1.4426950408889634074;
+
+    for (long long f0 = beg; f0 < end; f0 += FC) {
+        const int nf = (int)min((long long)FC, end - f0);
+        __syncthreads();
+        // stage the chunk: FC x D features (rows gathered by index) and the per-frame coefficient
+        for (int e = threadIdx.x; e < nf * D; e += WG) {
+            const int f = e / D, d = e - f * D;
+            xs[f * XS + d] = frames[list[f0 + f].frame * D + d];
+        }
+        if (threadIdx.x < nf) {
+            const ActiveFrame a = list[f0 + threadIdx.x];
+            cf[threadIdx.x] = (real)(a.coef * LOG2E);
+            if (blockIdx.x == 0) galpha += exp(a.lg);
+        }
+        __syncthreads();
+        for (int f = 0; f < nf; ++f) {
+            const real *x = &xs[f * XS];
+            real y[D];
+            real q = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                y[d] = Fast<real>::fma(x[d], s[d], c[d]);
+                q = Fast<real>::fma(y[d], y[d], q);
+            }
+            const real g = Fast<real>::exp2((k2 - q) + cf[f]);   // gamma_t(j,m)  (Clustering.py:660-661)
+            S0 += g;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const real z = g * y[d];
+                S1[d] += z;
+                S2[d] = Fast<real>::fma(z, y[d], S2[d]);
+            }
+        }
+    }
+    if (live) {
+        const size_t jm = (size_t)j * Mpad + m;
+        const double a0 = (double)S0;
+        st_acc[jm] += a0;                                                   // Clustering.py:665
+        const real *mu = means + jm * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double sd = (double)s[d];
+            if (sd > 0.0) {
+                // sum g (o + bias) = sum g (o - mu) + (mu + bias) sum g    (Clustering.py:669-672)
+                st_mean[jm * D + d] += (double)S1[d] / sd + ((double)mu[d] + bias) * a0;
+                st_cov[jm * D + d] += (double)S2[d] / (sd * sd);            // Clustering.py:674-678
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        // deterministic block sum of the per-thread partial posteriors
+        double v = galpha;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int k = 0; k < WG / 64; ++k) t += red[k];
+            st_alpha[j] += t;                                               // Clustering.py:667
+        }
+    }
+}
+
+struct AccWork {
+    int *cnt = nullptr;
+    long long *off = nullptr;
+    ActiveFrame *list = nullptr;
+    int *work_states = nullptr, *seg_lo = nullptr, *seg_hi = nullptr;
+    size_t cap_list = 0, cap_segs = 0, cap_states = 0;
+};
+std::map<pcl_batch *, AccWork> g_work;   // freed with the batch (pcl_accumulate_release)
+
+template <int D, typename real, int MINW>
+void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const AccWork &w, const real *frames, const real *params,
+                  const real *means) {
+    dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)b->work_states.size());
+    hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
+                       ctx->Mpad, w.work_states, w.seg_lo, w.seg_hi, w.off, w.list, 100.0, ctx->st_acc, ctx->st_alpha,
+                       ctx->st_mean, ctx->st_cov);
+}
+
+}  // namespace
+
+void pcl_accumulate_release(pcl_batch *b) {
+    auto it = g_work.find(b);
+    if (it == g_work.end()) return;
+    AccWork &w = it->second;
+    if (w.cnt) (void)hipFree(w.cnt);
+    if (w.off) (void)hipFree(w.off);
+    if (w.list) (void)hipFree(w.list);
+    if (w.work_states) (void)hipFree(w.work_states);
+    if (w.seg_lo) (void)hipFree(w.seg_lo);
+    if (w.seg_hi) (void)hipFree(w.seg_hi);
+    g_work.erase(it);
+}
+
+int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
+    if (b->n_segs == 0) return PCL_OK;
+    AccWork &w = g_work[b];
+    size_t cap = 0;
+    for (size_t k = 0; k < b->work_states.size(); ++k) {
+        const ScoreSeg &last = b->segs[b->state_seg_hi[k] - 1];
+        cap += (size_t)last.vstart + last.len;
+    }
+    if (w.cap_segs < (size_t)b->n_segs + 1) {
+        if (w.cnt) (void)hipFree(w.cnt);
+        if (w.off) (void)hipFree(w.off);
+        HIPCHK(ctx, hipMalloc((void **)&w.cnt, ((size_t)b->n_segs + 1) * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void **)&w.off, ((size_t)b->n_segs + 1) * sizeof(long long)));
+        w.cap_segs = (size_t)b->n_segs + 1;
+    }
+    if (w.cap_list < cap) {
+        if (w.list) (void)hipFree(w.list);
+        HIPCHK(ctx, hipMalloc((void **)&w.list, cap * sizeof(ActiveFrame)));
+        w.cap_list = cap;
+    }
+    const size_t ns = b->work_states.size();
+    if (w.cap_states < ns) {
+        if (w.work_states) (void)hipFree(w.work_states);
+        if (w.seg_lo) (void)hipFree(w.seg_lo);
+        if (w.seg_hi) (void)hipFree(w.seg_hi);
+        HIPCHK(ctx, hipMalloc((void **)&w.work_states, ns * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void **)&w.seg_lo, ns * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void **)&w.seg_hi, ns * sizeof(int)));
+        w.cap_states = ns;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(w.work_states, b->work_states.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(w.seg_lo, b->state_seg_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(w.seg_hi, b->state_seg_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+
+    // a frame survives unless every gamma_t(j,m) <= gamma_t(j) underflows to exactly 0 in the
+    // kernel's arithmetic (f32: 2^-149, f64: 2^-1074)
+    const double LN2 = 0.693147180559945309417232121458;
+    const double thr = (precision == PCL_F64 ? -1076.0 : -150.0) * LN2;
+    pcl_timer_begin(ctx, "accumulate");
+    const int wpb = 4;
+    dim3 gseg((b->n_segs + wpb - 1) / wpb);
+    hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, w.cnt);
+    hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.cnt, b->n_segs, w.off);
+    hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
+                       w.off, w.list);
+    const int D = ctx->D;
+    if (precision == PCL_F32) {
+        switch (D) {
+#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, w, ctx->frames32, ctx->params32, ctx->mean32); break;
+            CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)
+#undef CASE32
+#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, w, ctx->frames32, ctx->params32, ctx->mean32); break;
+            CASE32W(48) CASE32W(64)
+#undef CASE32W
+            default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 accumulate kernel for padded D=%d", D);
+        }
+    } else {
+        switch (D) {
+#define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, w, ctx->frames64, ctx->params64, ctx->mean64); break;
+            CASE64(13) CASE64(26) CASE64(39) CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
+#undef CASE64
+            default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 accumulate kernel for padded D=%d", D);
+        }
+    }
+    pcl_timer_end(ctx, "accumulate");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}

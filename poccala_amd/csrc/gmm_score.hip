@@ -1,0 +1,241 @@
+// gmm_score.hip -- batched diagonal-GMM log-likelihood  ln b_j(o_t)  for gfx950 (MI355X).
+//
+// Replaces the reference's HOT LOOP 1:
+//   LHMM.cal_observation_pro          StatisticalModel/LHMM.py:163-187
+//   -> Clustering.GMM.point(log=True)  StatisticalModel/Clustering.py:740-767
+//   -> util.gaussian_function(log=True) StatisticalModel/util.py:20-31   (quirk Q1 constant)
+//
+// Mapping (MI355X-first, VALU bound, no MFMA -- see DESIGN.md):
+//   * state-major batching: a workgroup scores TILE frames of ONE GMM state, gathered from all
+//     utterances of the batch that contain the state, so the state's M x (2D+1) parameter block is
+//     streamed through LDS once per TILE frames.
+//   * lanes = frames.  Each lane keeps R frames x D features in VGPRs; the per-mixture parameters
+//     are wave-uniform and read from LDS as broadcast ds_read_b128 (no bank conflicts).
+//   * per (frame, mixture, dim) exactly two FMAs:  y = x*s + c ;  q += y*y   with
+//        s = sqrt(log2e / (2 var)),  c = -mu*s   =>  q = log2e * (x-mu)^2 / (2 var)
+//     and the mixture value (log2 domain)  v = const2 - q,
+//        const2 = log2e * (ln w - D/2 ln 2pi - 1/2 sum(var))          [util.py:29, quirk Q1]
+//   * log-sum-exp over mixtures is an online (running max, running sum) per lane in the log2 domain,
+//     rescaled once per group of G mixtures: (1 + 1/G) v_exp_f32 per Gaussian, no cross-lane traffic.
+//   * result  ln b = ln2 * (max + log2(sum))  is finished in float64 and written to the time-major
+//     emission matrix consumed by the DP kernels.
+#include "pcl_internal.h"
+
+namespace {
+
+constexpr int WG = 256;  // 4 waves
+#ifndef PCL_GROUP
+#define PCL_GROUP 4
+#endif
+#ifndef PCL_R32
+#define PCL_R32 4
+#endif
+constexpr int GROUP = PCL_GROUP;  // mixtures per LSE rescale (Mpad is a multiple of 4 >= this)
+
+template <typename real>
+struct Fast;
+template <>
+struct Fast<float> {
+    static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ float neg_big() { return -1.0e30f; }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
+};
+template <>
+struct Fast<double> {
+    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+    static __device__ __forceinline__ double neg_big() { return -1.0e300; }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+};
+
+template <int D, int R, int CH, typename real>
+__global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict__ frames,
+                                                          const real *__restrict__ params, int Mpad,
+                                                          const ScoreTile *__restrict__ tiles,
+                                                          const ScoreSeg *__restrict__ segs,
+                                                          double *__restrict__ out) {
+    constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) real lds[CH * ROW];
+
+    const ScoreTile tile = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
+
+    real x[R][D];
+    long long oidx[R];
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int v = tile.vstart + (wave * R + r) * 64 + lane;
+        valid[r] = v < vend;
+        if (!valid[r]) v = tile.vstart;  // any in-range frame: keeps loads safe, result discarded
+        int lo = tile.seg_lo, hi = tile.seg_hi - 1;  // last segment with vstart <= v
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        }
+        const ScoreSeg sg = segs[lo];
+        const long long t = v - sg.vstart;
+        const real *fp = frames + (sg.frame0 + t) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[r][d] = fp[d];
+        oidx[r] = sg.out0 + t * (long long)sg.out_stride;
+    }
+
+    real mx[R], sm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mx[r] = Fast<real>::neg_big();
+        sm[r] = 0;
+    }
+
+    const real *pbase = params + (size_t)tile.state * Mpad * ROW;
+    for (int c0 = 0; c0 < Mpad; c0 += CH) {
+        const int n = min(CH, Mpad - c0);
+        __syncthreads();
+        {
+            constexpr int VEC = 16 / sizeof(real);
+            const real *src = pbase + (size_t)c0 * ROW;
+            for (int i = threadIdx.x * VEC; i < n * ROW; i += WG * VEC) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) lds[i + k] = src[i + k];
+            }
+        }
+        __syncthreads();
+        for (int m = 0; m < n; m += GROUP) {
+            real v[GROUP][R];
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g) {
+                const real *p = &lds[(m + g) * ROW];
+                real q[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) q[r] = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const real s = p[2 * d], c = p[2 * d + 1];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const real y = Fast<real>::fma(x[r][d], s, c);
+                        q[r] = Fast<real>::fma(y, y, q[r]);
+                    }
+                }
+                const real k2 = p[2 * D];
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[g][r] = k2 - q[r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                real gm = v[0][r];
+#pragma unroll
+                for (int g = 1; g < GROUP; ++g) gm = Fast<real>::max(gm, v[g][r]);
+                const real nm = Fast<real>::max(mx[r], gm);
+                real acc = sm[r] * Fast<real>::exp2(mx[r] - nm);
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) acc += Fast<real>::exp2(v[g][r] - nm);
+                sm[r] = acc;
+                mx[r] = nm;
+            }
+        }
+    }
+    constexpr double LN2 = 0.693147180559945309417232121458;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (valid[r]) {
+            // all-(-inf) components (every weight zero): sum stays 0 -> log2(0) = -inf, as util.py:63-65
+            const double res = (sm[r] > 0) ? LN2 * ((double)mx[r] + ::log2((double)sm[r])) : -INFINITY;
+            out[oidx[r]] = res;
+        }
+    }
+}
+
+// rows of the sentence HMMs that are not GMM states: entry -> 0, exit -> -inf
+__global__ void fill_virtual_rows_kernel(const UttDesc *__restrict__ utt, const int32_t *__restrict__ row_state,
+                                         double *__restrict__ Bt, int U) {
+    const int u = blockIdx.y;
+    const UttDesc d = utt[u];
+    const long long total = (long long)d.T * d.N;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(e % d.N);
+        const int st = row_state[d.vec_off + n];
+        if (st == PCL_ROW_ENTRY) Bt[d.b_off + e] = 0.0;
+        else if (st == PCL_ROW_EXIT) Bt[d.b_off + e] = -INFINITY;
+    }
+}
+
+// (N,T) row-major host layout <-> (T,N) time-major device layout, per utterance
+__global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *__restrict__ src,
+                                 double *__restrict__ dst, int to_time_major) {
+    const UttDesc d = utt[blockIdx.y];
+    const long long total = (long long)d.T * d.N;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        // e indexes the destination
+        if (to_time_major) {
+            const int t = (int)(e / d.N), n = (int)(e % d.N);
+            dst[d.b_off + e] = src[d.b_off + (long long)n * d.T + t];
+        } else {
+            const int n = (int)(e / d.T), t = (int)(e % d.T);
+            dst[d.b_off + e] = src[d.b_off + (long long)t * d.N + n];
+        }
+    }
+}
+
+template <int D, int R, int CH, typename real>
+void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params) {
+    hipLaunchKernelGGL((gmm_score_kernel<D, R, CH, real>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, frames, params,
+                       ctx->Mpad, b->d_tiles, b->d_segs, b->Bt);
+}
+
+// frames per lane for each (D, precision); the tile is WG * R frames.  x[R][D] must stay in VGPRs
+// (2 waves per SIMD => 256 VGPRs per lane).
+constexpr int r32(int D) { return D <= 40 ? PCL_R32 : 2; }
+constexpr int r64(int D) { return D <= 40 ? 2 : 1; }
+
+}  // namespace
+
+int pcl_score_tile_frames(int D, int precision) {
+    return WG * (precision == PCL_F64 ? r64(D) : r32(D));
+}
+
+int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b) {
+    dim3 grid(8, b->U);
+    hipLaunchKernelGGL(fill_virtual_rows_kernel, grid, dim3(256), 0, ctx->stream, b->d_utt, b->d_row_state, b->Bt, b->U);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major) {
+    dim3 grid(8, b->U);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, b->d_utt, src, dst, to_time_major);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision) {
+    if (b->n_tiles == 0) return PCL_OK;
+    const int D = ctx->D;
+    pcl_timer_begin(ctx, "score");
+    if (precision == PCL_F32) {
+        switch (D) {
+#define CASE32(DD) case DD: launch_score_t<DD, r32(DD), 64, float>(ctx, b, ctx->frames32, ctx->params32); break;
+            CASE32(13) CASE32(26) CASE32(39)
+            CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40) CASE32(48) CASE32(64)
+#undef CASE32
+            default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 scoring kernel for padded D=%d", D);
+        }
+    } else {
+        switch (D) {
+#define CASE64(DD) case DD: launch_score_t<DD, r64(DD), 32, double>(ctx, b, ctx->frames64, ctx->params64); break;
+            CASE64(13) CASE64(26) CASE64(39)
+            CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
+#undef CASE64
+            default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 scoring kernel for padded D=%d", D);
+        }
+    }
+    pcl_timer_end(ctx, "score");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}

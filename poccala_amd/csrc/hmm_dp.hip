@@ -1,0 +1,374 @@
+// hmm_dp.hip -- log-domain HMM dynamic programming for gfx950 (MI355X): Baum-Welch forward/backward
+// with xi/gamma/pi statistics, and Viterbi, batched one workgroup per sentence HMM.
+//
+// Replaces:
+//   LHMM.__forward_algorithm   StatisticalModel/LHMM.py:335-351   HOT LOOP 2
+//   LHMM.__backward_algorithm  StatisticalModel/LHMM.py:353-366   HOT LOOP 3
+//   LHMM.__maximization        StatisticalModel/LHMM.py:426-471   HOT LOOP 4 (cal_ksai / cal_gamma / cal_pi)
+//   LHMM.__expectation         StatisticalModel/LHMM.py:412-422
+//   LHMM.baulm_welch           StatisticalModel/LHMM.py:526-544   (pass loop, quirk Q6)
+//   LHMM.update_acc            StatisticalModel/LHMM.py:486-500   (per-frame posteriors l - sum_value)
+//   LHMM.viterbi               StatisticalModel/LHMM.py:546-609   HOT LOOP 6
+//
+// Mapping: the T-long recursion is strictly sequential, so parallelism is utterances x states.
+// One workgroup per utterance, lane i <-> state i (one 64-lane wavefront when N <= 64, which is
+// the canonical N = 62 sentence HMM).  All state is float64 (alpha/beta reach -2e4,
+// f32 would lose the posteriors).  Transitions are held sparse (CSR successors / CSC predecessors
+// built on the host from ln A): entries with ln A = -inf contribute exp(-inf) = 0 to every
+// log-sum-exp and can never win a max unless everything is -inf, so skipping them is exact;
+// a sentence HMM built by AcousticModel.embedded has <= 2 non-zeros per row.  The running
+// alpha/beta vectors are exchanged through LDS; emission rows are read time-major (one
+// coalesced N-vector per step).
+#include "pcl_internal.h"
+
+namespace {
+
+constexpr int MAXW = 16;  // waves per workgroup (N <= 1024)
+
+struct Red {
+    double buf[2][MAXW];
+    int ibuf[2][MAXW];
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide reductions.  `slot` alternates so that consecutive calls need one barrier each.
+__device__ __forceinline__ double block_max(double v, Red &red, int &slot) {
+    v = wave_max(v);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return v;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red.buf[slot][w] = v;
+    __syncthreads();
+    double r = red.buf[slot][0];
+    for (int k = 1; k < nw; ++k) r = fmax(r, red.buf[slot][k]);
+    slot ^= 1;
+    return r;
+}
+__device__ __forceinline__ double block_sum(double v, Red &red, int &slot) {
+    v = wave_sum(v);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return v;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red.buf[slot][w] = v;
+    __syncthreads();
+    double r = red.buf[slot][0];
+    for (int k = 1; k < nw; ++k) r += red.buf[slot][k];
+    slot ^= 1;
+    return r;
+}
+// util.log_sum_exp over the block (quirk Q4: returns the max itself when it is +-inf, util.py:62-65)
+__device__ __forceinline__ double block_lse(double v, Red &red, int &slot) {
+    const double m = block_max(v, red, slot);
+    if (isinf(m)) return m;
+    const double s = block_sum(exp(v - m), red, slot);
+    return m + log(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Baum-Welch pass loop for one utterance per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                              const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                              const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
+                              const int *__restrict__ row_idx, const double *__restrict__ csc_val,
+                              const double *__restrict__ logpi_in, double *__restrict__ alpha,
+                              double *__restrict__ beta, double *__restrict__ lgam, double *__restrict__ xi_m,
+                              double *__restrict__ xi_s, double *__restrict__ ksai, double *__restrict__ gamma_out,
+                              double *__restrict__ pi_out, double *__restrict__ logp, double *__restrict__ qtrace,
+                              int32_t *__restrict__ npass_out, int fix_pi, double threshold) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ Red red;
+    const UttDesc d = utts[blockIdx.x];
+    const int N = d.N, T = d.T;
+    const int NP = blockDim.x;
+    double *vec0 = smem;            // ping
+    double *vec1 = smem + NP;       // pong
+    double *lpi = smem + 2 * NP;    // current ln pi
+    const int i = threadIdx.x;
+    const bool act = i < N;
+    int slot = 0;
+
+    const double *B = Bt + d.b_off;
+    double *A_ = alpha + d.b_off;
+    double *Bv = beta + d.b_off;
+    double *G = lgam + d.b_off;
+
+    // this lane's predecessor (CSC) and successor (CSR) ranges
+    int pc0 = 0, pc1 = 0, sr0 = 0, sr1 = 0;
+    if (act) {
+        pc0 = col_ptr[d.ptr_off + i] + d.nnz_off;
+        pc1 = col_ptr[d.ptr_off + i + 1] + d.nnz_off;
+        sr0 = row_ptr[d.ptr_off + i] + d.nnz_off;
+        sr1 = row_ptr[d.ptr_off + i + 1] + d.nnz_off;
+    }
+    lpi[i] = act ? logpi_in[d.vec_off + i] : -INFINITY;
+    // dense xi output starts at -inf (LHMM.py:404: ln 0 entries stay -inf)
+    for (long long e = i; e < (long long)N * N; e += NP) ksai[d.mat_off + e] = -INFINITY;
+    __syncthreads();
+
+    double q = -INFINITY;
+    int npass = 0;
+    for (;;) {
+        // ---------------------------------------------------------------- forward (LHMM.py:335-351)
+        double a = -INFINITY;
+        if (act) {
+            a = lpi[i] + B[i];
+            A_[i] = a;
+        }
+        vec0[i] = a;
+        __syncthreads();
+        for (int t = 1; t < T; ++t) {
+            const double *prev = (t & 1) ? vec0 : vec1;
+            double *cur = (t & 1) ? vec1 : vec0;
+            if (act) {
+                double m = -INFINITY;
+                for (int k = pc0; k < pc1; ++k) m = fmax(m, prev[row_idx[k]] + csc_val[k]);
+                double r = m;
+                if (!isinf(m)) {
+                    double s = 0.0;
+                    for (int k = pc0; k < pc1; ++k) s += exp(prev[row_idx[k]] + csc_val[k] - m);
+                    r = m + log(s);
+                }
+                a = r + B[(long long)t * N + i];
+                A_[(long long)t * N + i] = a;
+            }
+            cur[i] = a;
+            __syncthreads();
+        }
+        // Q = LSE_i alpha_{T-1}(i)   (LHMM.py:412-422, datasize == 1 on this path)
+        const double qnew = block_lse(act ? a : -INFINITY, red, slot);
+        bool final_pass = !(qnew - q > threshold) || (npass + 1 >= PCL_MAX_PASS);   // LHMM.py:539
+        if (i == 0) qtrace[(long long)blockIdx.x * PCL_MAX_PASS + npass] = qnew;
+        ++npass;
+        if (fix_pi && !final_pass && threshold >= 0.0 && npass < PCL_MAX_PASS) {
+            // quirk Q6: with pi locked nothing changes between passes, so the next pass would
+            // reproduce this one bit for bit and then stop (Q - Q = 0 <= threshold).  Take its
+            // statistics now and report the pass the reference would have run.
+            if (i == 0) qtrace[(long long)blockIdx.x * PCL_MAX_PASS + npass] = qnew;
+            ++npass;
+            final_pass = true;
+        }
+
+        // ---------------------------------------------------------------- backward (LHMM.py:353-366)
+        // beta_{T-1} = 0 for every state (quirk Q8)
+        double bcur = 0.0;
+        double gm = -INFINITY, gs = 0.0;   // online LSE for gamma_i over t < T-1 (LHMM.py:442-445)
+        if (final_pass && act) {
+            for (int k = sr0; k < sr1; ++k) {
+                xi_m[k] = -INFINITY;
+                xi_s[k] = 0.0;
+            }
+            Bv[(long long)(T - 1) * N + i] = 0.0;
+            // l[:,T-1] - sum_value[T-1]  (LHMM.py:486-500); sum_value[T-1] == Q
+            G[(long long)(T - 1) * N + i] = a - qnew;
+        }
+        {
+            double *cur = ((T - 1) & 1) ? vec1 : vec0;
+            __syncthreads();   // everyone is done reading the forward vectors
+            cur[i] = act ? 0.0 : -INFINITY;
+            __syncthreads();
+        }
+        for (int t = T - 2; t >= 0; --t) {
+            const double *nxt = ((t + 1) & 1) ? vec1 : vec0;
+            double *cur = (t & 1) ? vec1 : vec0;
+            double l = -INFINITY;
+            if (act) {
+                const double *bn = B + (long long)(t + 1) * N;
+                double m = -INFINITY;
+                for (int k = sr0; k < sr1; ++k) {
+                    const int j = col_idx[k];
+                    m = fmax(m, csr_val[k] + bn[j] + nxt[j]);
+                }
+                double r = m;
+                if (!isinf(m)) {
+                    double s = 0.0;
+                    for (int k = sr0; k < sr1; ++k) {
+                        const int j = col_idx[k];
+                        s += exp(csr_val[k] + bn[j] + nxt[j] - m);
+                    }
+                    r = m + log(s);
+                }
+                bcur = r;
+                if (final_pass) {
+                    const double at = A_[(long long)t * N + i];
+                    // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
+                    for (int k = sr0; k < sr1; ++k) {
+                        const int j = col_idx[k];
+                        const double v = ((at + csr_val[k]) + bn[j]) + nxt[j];
+                        const double om = xi_m[k];
+                        if (v > om) {
+                            xi_s[k] = xi_s[k] * exp(om - v) + 1.0;   // exp(-inf) = 0 on first hit
+                            xi_m[k] = v;
+                        } else if (v > -INFINITY) {
+                            xi_s[k] += exp(v - om);
+                        }
+                    }
+                    l = at + r;
+                    if (l > gm) {
+                        gs = gs * exp(gm - l) + 1.0;
+                        gm = l;
+                    } else if (l > -INFINITY) {
+                        gs += exp(l - gm);
+                    }
+                    Bv[(long long)t * N + i] = r;
+                }
+            }
+            cur[i] = act ? bcur : -INFINITY;
+            if (final_pass) {
+                const double norm = block_lse(l, red, slot);   // sum_value[t] (LHMM.py:488)
+                if (act) G[(long long)t * N + i] = l - norm;
+            }
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- pi (LHMM.py:447-452,470-471)
+        if (!fix_pi) {
+            const double a0 = act ? A_[i] : -INFINITY;
+            const double p0 = a0 + ((T > 1) ? bcur : 0.0);
+            const double n0 = block_lse(act ? p0 : -INFINITY, red, slot);
+            // the reference stores pi = exp(.) and takes np.log of it again on the next pass
+            const double pv = exp(p0 - n0);
+            __syncthreads();
+            lpi[i] = act ? log(pv) : -INFINITY;
+            if (final_pass && act) pi_out[d.vec_off + i] = pv;
+            __syncthreads();
+        } else if (final_pass && act) {
+            pi_out[d.vec_off + i] = exp(lpi[i]);
+        }
+        if (final_pass) {
+            if (act) {
+                gamma_out[d.vec_off + i] = (gs > 0.0) ? gm + log(gs) : -INFINITY;
+                for (int k = sr0; k < sr1; ++k)
+                    ksai[d.mat_off + (long long)i * N + col_idx[k]] = (xi_s[k] > 0.0) ? xi_m[k] + log(xi_s[k]) : -INFINITY;
+            }
+            if (i == 0) {
+                logp[blockIdx.x] = qnew;
+                npass_out[blockIdx.x] = npass;
+                for (int k = npass; k < PCL_MAX_PASS; ++k) qtrace[(long long)blockIdx.x * PCL_MAX_PASS + k] = NAN;
+            }
+            break;
+        }
+        q = qnew;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Viterbi (LHMM.py:546-609).  Bit-exact in float64: adds in the reference's order
+// (p_i + ln A_ij) -> max with first-index tie-break -> + prob[j,t].
+// ------------------------------------------------------------------------------------------------
+__global__ void hmm_viterbi_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                   const int *__restrict__ col_ptr, const int *__restrict__ row_idx,
+                                   const double *__restrict__ csc_val, const double *__restrict__ logpi,
+                                   unsigned short *__restrict__ bp, int32_t *__restrict__ path,
+                                   double *__restrict__ point, int end_state_back) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ Red red;
+    __shared__ int s_end, s_stale;
+    const UttDesc d = utts[blockIdx.x];
+    const int N = d.N, T = d.T;
+    const int NP = blockDim.x;
+    double *vec0 = smem, *vec1 = smem + NP;
+    const int i = threadIdx.x;
+    const bool act = i < N;
+    const double *B = Bt + d.b_off;
+    unsigned short *BP = bp + d.b_off;
+    int pc0 = 0, pc1 = 0;
+    if (act) {
+        pc0 = col_ptr[d.ptr_off + i] + d.nnz_off;
+        pc1 = col_ptr[d.ptr_off + i + 1] + d.nnz_off;
+    }
+    double p = -INFINITY;
+    if (act) p = logpi[d.vec_off + i] + B[i];   // LHMM.py:571
+    vec0[i] = p;
+    if (i == 0) s_stale = 0;
+    __syncthreads();
+    for (int t = 1; t < T; ++t) {
+        const double *prev = (t & 1) ? vec0 : vec1;
+        double *cur = (t & 1) ? vec1 : vec0;
+        if (act) {
+            // max over ALL source states of prev[i'] + ln A[i',j]; non-stored entries are -inf, and
+            // the first index equal to the max is index 0 when the max is -inf (LHMM.py:577-583).
+            double best = -INFINITY;
+            int arg = 0;
+            for (int k = pc0; k < pc1; ++k) {
+                const double v = prev[row_idx[k]] + csc_val[k];
+                if (v > best) {
+                    best = v;
+                    arg = row_idx[k];
+                }
+            }
+            BP[(long long)t * N + i] = (unsigned short)arg;
+            if (i == N - 1 && t == T - 1) s_stale = arg;   // quirk Q9: stale max_index of the last inner loop
+            p = best + B[(long long)t * N + i];             // LHMM.py:584
+        }
+        cur[i] = p;
+        __syncthreads();
+    }
+    // end state: first argmax of the final scores (LHMM.py:591-593) or of the last 4 (:587-589)
+    {
+        double v = act ? p : -INFINITY;
+        if (end_state_back && act && i < N - 4) v = -INFINITY;
+        int slot = 0;
+        const double m = block_max(v, red, slot);
+        // lowest index attaining the max; NaN never occurs on this path
+        int cand = (act && v == m && !(end_state_back && i < N - 4)) ? i : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if ((threadIdx.x & 63) == 0) red.ibuf[0][threadIdx.x >> 6] = cand;
+        __syncthreads();
+        if (i == 0) {
+            int e = 0x7fffffff;
+            for (int k = 0; k < (int)(blockDim.x >> 6); ++k) e = min(e, red.ibuf[0][k]);
+            if (e == 0x7fffffff) e = end_state_back ? max(N - 4, 0) : 0;
+            s_end = e;
+        }
+        __syncthreads();
+    }
+    if (i == 0) {
+        const double *fin = ((T - 1) & 1) ? vec1 : vec0;
+        point[blockIdx.x] = fin[s_end];
+        int cur = end_state_back ? s_stale : s_end;
+        int32_t *P = path + d.path_off;
+        for (int t = T - 1; t >= 0; --t) {       // LHMM.py:596-599
+            P[t] = cur;
+            cur = (t > 0) ? (int)BP[(long long)t * N + cur] : 0;
+        }
+    }
+}
+
+}  // namespace
+
+int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold) {
+    const int NP = (b->Nmax + 63) / 64 * 64;
+    if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);
+    const size_t shm = (size_t)3 * NP * sizeof(double);
+    pcl_timer_begin(ctx, "fb");
+    hipLaunchKernelGGL(hmm_fb_kernel, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
+                       b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
+                       b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
+    pcl_timer_end(ctx, "fb");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back) {
+    const int NP = (b->Nmax + 63) / 64 * 64;
+    if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);
+    if (b->Nmax > 65535) PCL_FAIL(ctx, PCL_ERR_INVALID, "too many states for 16-bit back-pointers");
+    const size_t shm = (size_t)2 * NP * sizeof(double);
+    pcl_timer_begin(ctx, "viterbi");
+    hipLaunchKernelGGL(hmm_viterbi_kernel, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->col_ptr,
+                       b->row_idx, b->csc_val, b->logpi, b->bp, b->path, b->point, end_state_back);
+    pcl_timer_end(ctx, "viterbi");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}

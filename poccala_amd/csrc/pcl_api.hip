@@ -1,0 +1,641 @@
+// pcl_api.hip -- host side of the C-ABI declared in include/poccala_hip.h.
+// Owns device memory, builds the state-major scoring work lists and the sparse transition
+// structure, and launches the kernels in gmm_score.hip / hmm_dp.hip / gmm_accumulate.hip.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "pcl_internal.h"
+
+static std::string g_init_error;
+
+void pcl_set_error(pcl_ctx *ctx, const char *msg) {
+    if (ctx) ctx->err = msg;
+    else g_init_error = msg;
+}
+
+// ---------------------------------------------------------------- timers (HIP events on ctx->stream)
+void pcl_timer_begin(pcl_ctx *ctx, const char *which) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    hipEventRecord(a, ctx->stream);
+    ctx->timers[which].ev.push_back({a, b});
+}
+void pcl_timer_end(pcl_ctx *ctx, const char *which) {
+    auto &t = ctx->timers[which];
+    if (!t.ev.empty()) hipEventRecord(t.ev.back().second, ctx->stream);
+}
+
+template <typename T>
+static int dev_alloc(pcl_ctx *ctx, T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) PCL_FAIL(ctx, PCL_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    return PCL_OK;
+}
+template <typename T>
+static void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+#define TRY(x)                    \
+    do {                          \
+        int _r = (x);             \
+        if (_r != PCL_OK) return _r; \
+    } while (0)
+
+extern "C" {
+
+// ================================================================ context
+int pcl_init(int device, pcl_ctx **out) {
+    if (!out) PCL_FAIL(nullptr, PCL_ERR_INVALID, "pcl_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        PCL_FAIL(nullptr, PCL_ERR_HIP, "pcl_init: no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) PCL_FAIL(nullptr, PCL_ERR_INVALID, "pcl_init: device %d out of range [0,%d)", device, n);
+    pcl_ctx *ctx = new pcl_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
+        delete ctx;
+        return PCL_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
+    *out = ctx;
+    return PCL_OK;
+}
+
+static void free_model(pcl_ctx *ctx) {
+    dev_free(ctx->params32);
+    dev_free(ctx->params64);
+    dev_free(ctx->mean32);
+    dev_free(ctx->mean64);
+    dev_free(ctx->stats);
+    ctx->st_acc = ctx->st_alpha = ctx->st_mean = ctx->st_cov = nullptr;
+    ctx->J = ctx->M = ctx->Mpad = 0;
+}
+
+int pcl_destroy(pcl_ctx *ctx) {
+    if (!ctx) return PCL_OK;
+    hipSetDevice(ctx->device);
+    pcl_comm_destroy(ctx);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->timers)
+        for (auto &p : kv.second.ev) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+    free_model(ctx);
+    dev_free(ctx->frames32);
+    dev_free(ctx->frames64);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PCL_OK;
+}
+
+const char *pcl_last_error(pcl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int pcl_sync(pcl_ctx *ctx) {
+    if (!ctx) return PCL_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_device_info(pcl_ctx *ctx, char *name, int cap, int *cus, size_t *hbm_bytes) {
+    if (!ctx) return PCL_ERR_INVALID;
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && cap > 0) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return PCL_OK;
+}
+
+int pcl_kernel_time(pcl_ctx *ctx, const char *which, float *total_ms, int *launches) {
+    if (!ctx || !which) return PCL_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float tot = 0.f;
+    int n = 0;
+    auto it = ctx->timers.find(which);
+    if (it != ctx->timers.end()) {
+        for (auto &p : it->second.ev) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                tot += ms;
+                ++n;
+            }
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        it->second.ev.clear();
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return PCL_OK;
+}
+
+// ================================================================ model
+static int device_dim(int D) {
+    if (D == 13 || D == 26 || D == 39) return D;
+    const int opts[] = {8, 16, 24, 32, 40, 48, 64};
+    for (int o : opts)
+        if (D <= o) return o;
+    return -1;
+}
+
+int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, const double *var, const double *weight,
+                     int flags) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (J <= 0 || M <= 0 || D <= 0 || !mean || !var || !weight) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: bad shape J=%d M=%d D=%d", J, M, D);
+    const int Dd = device_dim(D);
+    if (Dd < 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: feature dimension %d > 64 is not supported", D);
+    if (ctx->F > 0 && ctx->Dhost != D)
+        PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->Dhost, D);  // DataDimensionError, Clustering.py:749-751
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    free_model(ctx);
+    const int Mpad = (M + 3) / 4 * 4;
+    const int row = (2 * Dd + 1 + 3) / 4 * 4;
+    const size_t np = (size_t)J * Mpad * row, nm = (size_t)J * Mpad * Dd;
+    std::vector<double> p64(np, 0.0), m64(nm, 0.0);
+    const double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
+    for (int j = 0; j < J; ++j) {
+        for (int m = 0; m < Mpad; ++m) {
+            double *pr = &p64[((size_t)j * Mpad + m) * row];
+            if (m >= M) {
+                pr[2 * Dd] = -INFINITY;  // padded mixture: contributes exp2(-inf) = 0
+                continue;
+            }
+            const double *mu = mean + ((size_t)j * M + m) * D;
+            const double *vr = var + ((size_t)j * M + m) * D;
+            double sumvar = 0.0, sumlog = 0.0;
+            for (int d = 0; d < D; ++d) {
+                if (!(vr[d] > 0.0)) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: variance[%d,%d,%d] = %g is not positive", j, m, d, vr[d]);
+                const double s = sqrt(LOG2E / (2.0 * vr[d]));
+                pr[2 * d] = s;
+                pr[2 * d + 1] = -mu[d] * s;
+                sumvar += vr[d];
+                sumlog += log(vr[d]);
+                m64[((size_t)j * Mpad + m) * Dd + d] = mu[d];
+            }
+            const double w = weight[(size_t)j * M + m];
+            // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var);  textbook form only on request
+            const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
+            pr[2 * Dd] = LOG2E * (log(w) - 0.5 * D * LOG_2PI - 0.5 * tail);
+        }
+    }
+    std::vector<float> p32(np), m32(nm);
+    for (size_t i = 0; i < np; ++i) p32[i] = (float)p64[i];
+    for (size_t i = 0; i < nm; ++i) m32[i] = (float)m64[i];
+    TRY(dev_alloc(ctx, &ctx->params32, np));
+    TRY(dev_alloc(ctx, &ctx->params64, np));
+    TRY(dev_alloc(ctx, &ctx->mean32, nm));
+    TRY(dev_alloc(ctx, &ctx->mean64, nm));
+    HIPCHK(ctx, hipMemcpy(ctx->params32, p32.data(), np * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->params64, p64.data(), np * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->mean32, m32.data(), nm * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
+    ctx->J = J;
+    ctx->M = M;
+    ctx->Mpad = Mpad;
+    ctx->D = Dd;
+    ctx->Dhost = D;
+    ctx->row = row;
+    ctx->model_flags = flags;
+    // statistics: [acc J*Mpad | alpha J | mean J*Mpad*Dd | cov J*Mpad*Dd]
+    ctx->stats_len = (size_t)J * Mpad + J + 2 * nm;
+    TRY(dev_alloc(ctx, &ctx->stats, ctx->stats_len));
+    ctx->st_acc = ctx->stats;
+    ctx->st_alpha = ctx->st_acc + (size_t)J * Mpad;
+    ctx->st_mean = ctx->st_alpha + J;
+    ctx->st_cov = ctx->st_mean + nm;
+    HIPCHK(ctx, hipMemset(ctx->stats, 0, ctx->stats_len * sizeof(double)));
+    return PCL_OK;
+}
+
+// ================================================================ frames
+int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dtype) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (F <= 0 || D <= 0 || !frames) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_upload: bad shape F=%lld D=%d", (long long)F, D);
+    if (ctx->J > 0 && ctx->Dhost != D)
+        PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", D, ctx->Dhost);  // DataDimensionError, Clustering.py:749-751
+    const int Dd = device_dim(D);
+    if (Dd < 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_upload: feature dimension %d > 64 is not supported", D);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    dev_free(ctx->frames32);
+    dev_free(ctx->frames64);
+    const size_t n = (size_t)F * Dd;
+    std::vector<float> f32(n, 0.f);
+    std::vector<double> f64(n, 0.0);
+    for (int64_t f = 0; f < F; ++f)
+        for (int d = 0; d < D; ++d) {
+            const double v = (dtype == PCL_F64) ? ((const double *)frames)[f * D + d] : (double)((const float *)frames)[f * D + d];
+            f64[f * Dd + d] = v;
+            f32[f * Dd + d] = (float)v;
+        }
+    TRY(dev_alloc(ctx, &ctx->frames32, n));
+    TRY(dev_alloc(ctx, &ctx->frames64, n));
+    HIPCHK(ctx, hipMemcpy(ctx->frames32, f32.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->frames64, f64.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    ctx->F = F;
+    ctx->FD = Dd;
+    if (ctx->J == 0) ctx->Dhost = D;
+    return PCL_OK;
+}
+
+// ================================================================ batch
+int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, const int64_t *frame_begin, pcl_batch **out) {
+    if (!ctx || !out) return PCL_ERR_INVALID;
+    *out = nullptr;
+    if (U <= 0 || !N || !T) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: bad arguments (U=%d)", U);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pcl_batch *b = new pcl_batch();
+    b->ctx = ctx;
+    b->U = U;
+    b->utt.resize(U);
+    long long bo = 0, mo = 0, vo = 0, po = 0, to = 0;
+    for (int u = 0; u < U; ++u) {
+        if (N[u] < 1 || T[u] < 1) {
+            delete b;
+            PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: utterance %d has N=%d T=%d", u, N[u], T[u]);
+        }
+        if (frame_begin && (frame_begin[u] < 0 || frame_begin[u] + T[u] > ctx->F)) {
+            delete b;
+            PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: utterance %d frames [%lld,%lld) outside the uploaded %lld frames", u,
+                     (long long)frame_begin[u], (long long)frame_begin[u] + T[u], (long long)ctx->F);
+        }
+        UttDesc &d = b->utt[u];
+        d.b_off = bo;
+        d.mat_off = mo;
+        d.frame0 = frame_begin ? frame_begin[u] : -1;
+        d.T = T[u];
+        d.N = N[u];
+        d.vec_off = (int)vo;
+        d.ptr_off = (int)po;
+        d.nnz_off = 0;
+        d.path_off = (int)to;
+        bo += (long long)N[u] * T[u];
+        mo += (long long)N[u] * N[u];
+        vo += N[u];
+        po += N[u] + 1;
+        to += T[u];
+        b->Nmax = std::max(b->Nmax, (int)N[u]);
+        b->Tmax = std::max(b->Tmax, (int)T[u]);
+    }
+    b->sumNT = bo;
+    b->sumNN = mo;
+    b->sumN = vo;
+    b->sumT = to;
+    if (vo > 0x7fffffffLL || to > 0x7fffffffLL) {
+        delete b;
+        PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: batch too large");
+    }
+    int r = PCL_OK;
+    auto A = [&](int rr) { if (r == PCL_OK) r = rr; };
+    A(dev_alloc(ctx, &b->d_utt, (size_t)U));
+    A(dev_alloc(ctx, &b->Bt, (size_t)bo));
+    A(dev_alloc(ctx, &b->logpi, (size_t)vo));
+    A(dev_alloc(ctx, &b->d_row_state, (size_t)vo));
+    if (r != PCL_OK) {
+        pcl_batch_destroy(b);
+        return r;
+    }
+    *out = b;
+    return PCL_OK;
+}
+
+int pcl_batch_destroy(pcl_batch *b) {
+    if (!b) return PCL_OK;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    pcl_accumulate_release(b);
+    dev_free(b->d_utt); dev_free(b->Bt); dev_free(b->alpha); dev_free(b->beta); dev_free(b->lgam);
+    dev_free(b->logpi); dev_free(b->pi_out); dev_free(b->gamma_out); dev_free(b->ksai);
+    dev_free(b->logp); dev_free(b->qtrace); dev_free(b->point); dev_free(b->npass); dev_free(b->path);
+    dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
+    dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
+    dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
+    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->tmp);
+    delete b;
+    return PCL_OK;
+}
+
+int pcl_batch_set_transitions(pcl_batch *b, const double *logA, const double *logpi) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!logA || !logpi) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_transitions: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // sparse structure: an entry is stored unless ln A == -inf
+    std::vector<int> row_ptr((size_t)b->sumN + b->U), col_ptr((size_t)b->sumN + b->U);
+    std::vector<int> col_idx, row_idx;
+    std::vector<double> csr_val, csc_val;
+    b->max_outdeg = b->max_indeg = 0;
+    for (int u = 0; u < b->U; ++u) {
+        UttDesc &d = b->utt[u];
+        const int N = d.N;
+        const double *A = logA + d.mat_off;
+        d.nnz_off = (int)col_idx.size();
+        int cnt = 0;
+        for (int i = 0; i < N; ++i) {
+            row_ptr[d.ptr_off + i] = cnt;
+            for (int j = 0; j < N; ++j) {
+                const double v = A[(size_t)i * N + j];
+                if (!(v == -INFINITY)) {
+                    col_idx.push_back(j);
+                    csr_val.push_back(v);
+                    ++cnt;
+                }
+            }
+            b->max_outdeg = std::max(b->max_outdeg, cnt - row_ptr[d.ptr_off + i]);
+        }
+        row_ptr[d.ptr_off + N] = cnt;
+        int cc = 0;
+        for (int j = 0; j < N; ++j) {
+            col_ptr[d.ptr_off + j] = cc;
+            for (int i = 0; i < N; ++i) {
+                const double v = A[(size_t)i * N + j];
+                if (!(v == -INFINITY)) {
+                    row_idx.push_back(i);
+                    csc_val.push_back(v);
+                    ++cc;
+                }
+            }
+            b->max_indeg = std::max(b->max_indeg, cc - col_ptr[d.ptr_off + j]);
+        }
+        col_ptr[d.ptr_off + N] = cc;
+        if (col_idx.size() > 0x7fffffffULL) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_transitions: too many transitions");
+    }
+    b->nnz = (long long)col_idx.size();
+    dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
+    dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
+    dev_free(b->xi_m); dev_free(b->xi_s);
+    const size_t nz = (size_t)b->nnz, np = row_ptr.size();
+    TRY(dev_alloc(ctx, &b->row_ptr, np));
+    TRY(dev_alloc(ctx, &b->col_ptr, np));
+    TRY(dev_alloc(ctx, &b->col_idx, nz));
+    TRY(dev_alloc(ctx, &b->row_idx, nz));
+    TRY(dev_alloc(ctx, &b->csr_val, nz));
+    TRY(dev_alloc(ctx, &b->csc_val, nz));
+    TRY(dev_alloc(ctx, &b->xi_m, nz));
+    TRY(dev_alloc(ctx, &b->xi_s, nz));
+    HIPCHK(ctx, hipMemcpy(b->row_ptr, row_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->col_ptr, col_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
+    if (nz) {
+        HIPCHK(ctx, hipMemcpy(b->col_idx, col_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(b->row_idx, row_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(b->csr_val, csr_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(b->csc_val, csc_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(ctx, hipMemcpy(b->logpi, logpi, (size_t)b->sumN * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    b->have_trans = true;
+    b->have_fb = b->have_vit = false;
+    return PCL_OK;
+}
+
+int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!row_state) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: NULL argument");
+    if (ctx->J == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_set_states: upload a model first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    b->row_state.assign(row_state, row_state + b->sumN);
+    // count segments per state
+    std::vector<int> count(ctx->J, 0);
+    for (int u = 0; u < b->U; ++u) {
+        const UttDesc &d = b->utt[u];
+        for (int n = 0; n < d.N; ++n) {
+            const int st = row_state[d.vec_off + n];
+            if (st >= ctx->J || st < PCL_ROW_EXIT) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: utterance %d row %d has state %d outside [0,%d)", u, n, st, ctx->J);
+            if (st >= 0) {
+                if (d.frame0 < 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_set_states: batch was created without frame_begin");
+                ++count[st];
+            }
+        }
+    }
+    std::vector<int> start(ctx->J + 1, 0);
+    for (int j = 0; j < ctx->J; ++j) start[j + 1] = start[j] + count[j];
+    b->n_segs = start[ctx->J];
+    b->segs.assign(b->n_segs, ScoreSeg());
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    std::vector<long long> vtot(ctx->J, 0);
+    for (int u = 0; u < b->U; ++u) {
+        const UttDesc &d = b->utt[u];
+        for (int n = 0; n < d.N; ++n) {
+            const int st = row_state[d.vec_off + n];
+            if (st < 0) continue;
+            ScoreSeg &s = b->segs[fill[st]++];
+            s.frame0 = d.frame0;
+            s.out0 = d.b_off + n;
+            s.len = d.T;
+            s.out_stride = d.N;
+            if (vtot[st] + d.T > 0x7fffffffLL) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: state %d has too many frames", st);
+            s.vstart = (int)vtot[st];
+            s.pad = st;
+            vtot[st] += d.T;
+        }
+    }
+    b->work_states.clear();
+    b->state_seg_lo.clear();
+    b->state_seg_hi.clear();
+    for (int j = 0; j < ctx->J; ++j)
+        if (count[j]) {
+            b->work_states.push_back(j);
+            b->state_seg_lo.push_back(start[j]);
+            b->state_seg_hi.push_back(start[j + 1]);
+        }
+    dev_free(b->d_segs);
+    dev_free(b->d_tiles);
+    b->tile_frames = 0;
+    TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
+    if (b->n_segs) HIPCHK(ctx, hipMemcpy(b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    b->have_states = true;
+    return PCL_OK;
+}
+
+static int ensure_tmp(pcl_batch *b) {
+    if (!b->tmp) TRY(dev_alloc(b->ctx, &b->tmp, (size_t)b->sumNT));
+    return PCL_OK;
+}
+
+int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!B) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_emissions: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TRY(ensure_tmp(b));
+    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpyAsync(b->tmp, B, (size_t)b->sumNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TRY(pcl_launch_transpose(ctx, b, b->tmp, b->Bt, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    b->have_B = true;
+    b->have_fb = b->have_vit = false;
+    return PCL_OK;
+}
+
+static int build_tiles(pcl_batch *b, int precision) {
+    pcl_ctx *ctx = b->ctx;
+    const int tf = pcl_score_tile_frames(ctx->D, precision);
+    if (b->d_tiles && b->tile_frames == tf) return PCL_OK;
+    std::vector<ScoreTile> tiles;
+    for (size_t k = 0; k < b->work_states.size(); ++k) {
+        const int lo = b->state_seg_lo[k], hi = b->state_seg_hi[k];
+        const long long tot = (long long)b->segs[hi - 1].vstart + b->segs[hi - 1].len;
+        for (long long v = 0; v < tot; v += tf) tiles.push_back(ScoreTile{b->work_states[k], lo, hi, (int)v});
+    }
+    dev_free(b->d_tiles);
+    b->n_tiles = (int)tiles.size();
+    b->tile_frames = tf;
+    TRY(dev_alloc(ctx, &b->d_tiles, tiles.size()));
+    if (!tiles.empty()) HIPCHK(ctx, hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(ScoreTile), hipMemcpyHostToDevice));
+    return PCL_OK;
+}
+
+int pcl_batch_score(pcl_batch *b, int precision) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_score: precision %d", precision);
+    if (ctx->J == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: no model uploaded");
+    if (ctx->F == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: no frames uploaded");
+    if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: pcl_batch_set_states was not called");
+    if (ctx->FD != ctx->D) PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension does not match model dimension %d", ctx->Dhost);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TRY(build_tiles(b, precision));
+    TRY(pcl_launch_fill_virtual_rows(ctx, b));
+    TRY(pcl_launch_score(ctx, b, precision));
+    b->have_B = true;
+    b->have_fb = b->have_vit = false;
+    return PCL_OK;
+}
+
+int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_forward_backward: no transitions set");
+    if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_forward_backward: no emissions (score or set_emissions first)");  // LHMM.py:69
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!b->alpha) {
+        TRY(dev_alloc(ctx, &b->alpha, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->beta, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->lgam, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->pi_out, (size_t)b->sumN));
+        TRY(dev_alloc(ctx, &b->gamma_out, (size_t)b->sumN));
+        TRY(dev_alloc(ctx, &b->ksai, (size_t)b->sumNN));
+        TRY(dev_alloc(ctx, &b->logp, (size_t)b->U));
+        TRY(dev_alloc(ctx, &b->qtrace, (size_t)b->U * PCL_MAX_PASS));
+        TRY(dev_alloc(ctx, &b->npass, (size_t)b->U));
+    }
+    TRY(pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold));
+    b->have_fb = true;
+    return PCL_OK;
+}
+
+int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no transitions set");
+    if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no emissions (score or set_emissions first)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!b->bp) {
+        TRY(dev_alloc(ctx, &b->bp, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->path, (size_t)b->sumT));
+        TRY(dev_alloc(ctx, &b->point, (size_t)b->U));
+    }
+    TRY(pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0));
+    b->have_vit = true;
+    return PCL_OK;
+}
+
+int pcl_batch_get(pcl_batch *b, int what, void *host) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!host) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_get: NULL host buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double *mat = nullptr;
+    switch (what) {
+        case PCL_GET_B:
+            if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: no emissions yet");
+            mat = b->Bt;
+            break;
+        case PCL_GET_ALPHA: mat = b->alpha; break;
+        case PCL_GET_BETA: mat = b->beta; break;
+        case PCL_GET_LGAMMA: mat = b->lgam; break;
+        default: break;
+    }
+    if (what >= PCL_GET_ALPHA && what <= PCL_GET_QTRACE && !b->have_fb) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: run pcl_batch_forward_backward first");
+    if ((what == PCL_GET_PATH || what == PCL_GET_POINT) && !b->have_vit) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: run pcl_batch_viterbi first");
+    if (mat) {
+        TRY(ensure_tmp(b));
+        TRY(pcl_launch_transpose(ctx, b, mat, b->tmp, 0));
+        HIPCHK(ctx, hipMemcpyAsync(host, b->tmp, (size_t)b->sumNT * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return PCL_OK;
+    }
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (what) {
+        case PCL_GET_KSAI: src = b->ksai; bytes = (size_t)b->sumNN * 8; break;
+        case PCL_GET_GAMMA: src = b->gamma_out; bytes = (size_t)b->sumN * 8; break;
+        case PCL_GET_PI: src = b->pi_out; bytes = (size_t)b->sumN * 8; break;
+        case PCL_GET_LOGP: src = b->logp; bytes = (size_t)b->U * 8; break;
+        case PCL_GET_NPASS: src = b->npass; bytes = (size_t)b->U * 4; break;
+        case PCL_GET_QTRACE: src = b->qtrace; bytes = (size_t)b->U * PCL_MAX_PASS * 8; break;
+        case PCL_GET_PATH: src = b->path; bytes = (size_t)b->sumT * 4; break;
+        case PCL_GET_POINT: src = b->point; bytes = (size_t)b->U * 8; break;
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_get: unknown selector %d", what);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+// ================================================================ E-step statistics
+int pcl_stats_zero(pcl_ctx *ctx) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_zero: no model uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->stats, 0, ctx->stats_len * sizeof(double), ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_batch_accumulate(pcl_batch *b, int precision) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate: precision %d", precision);
+    if (!b->have_fb) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: run pcl_batch_forward_backward first");
+    if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return pcl_launch_accumulate(ctx, b, precision);
+}
+
+int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_download: no model uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<double> h(ctx->stats_len);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->stats, ctx->stats_len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int J = ctx->J, M = ctx->M, Mp = ctx->Mpad, D = ctx->Dhost, Dd = ctx->D;
+    const double *a = h.data(), *al = a + (size_t)J * Mp, *me = al + J, *co = me + (size_t)J * Mp * Dd;
+    for (int j = 0; j < J; ++j) {
+        if (alpha_acc) alpha_acc[j] = al[j];
+        for (int m = 0; m < M; ++m) {
+            if (acc) acc[(size_t)j * M + m] = a[(size_t)j * Mp + m];
+            for (int d = 0; d < D; ++d) {
+                if (mean_acc) mean_acc[((size_t)j * M + m) * D + d] = me[((size_t)j * Mp + m) * Dd + d];
+                if (cov_acc) cov_acc[((size_t)j * M + m) * D + d] = co[((size_t)j * Mp + m) * Dd + d];
+            }
+        }
+    }
+    return PCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// Internal structures shared by the C-ABI host code and the HIP kernels of libpoccala_hip.so.
+// Target: gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/poccala_hip.h"
+
+// ---------------------------------------------------------------- device-side descriptors
+// One scoring segment = one (utterance, emitting row): `len` consecutive frames starting at frame
+// row `frame0`, written to out[out0 + t*out_stride].  Segments are sorted by GMM state; `vstart`
+// is the segment's offset inside the state's virtual concatenation of frames (H4, state-major).
+struct ScoreSeg {
+    long long frame0;
+    long long out0;
+    int len;
+    int out_stride;
+    int vstart;
+    int pad;
+};
+// One workgroup of the scoring kernel: frames [vstart, vstart+tile) of `state`'s concatenation.
+struct ScoreTile {
+    int state;
+    int seg_lo, seg_hi;  // the state's segments are segs[seg_lo, seg_hi)
+    int vstart;
+};
+// One sentence HMM (time-major device matrices: element (t, n) at b_off + t*N + n).
+struct UttDesc {
+    long long b_off;    // into Bt / alpha / beta / lgam
+    long long mat_off;  // into the ragged dense (N,N) xi output
+    long long frame0;   // first frame row (or -1)
+    int T, N;
+    int vec_off;   // into ragged (N,) vectors
+    int ptr_off;   // into row_ptr / col_ptr (N+1 entries per utterance)
+    int nnz_off;   // into CSR / CSC entry arrays
+    int path_off;  // into ragged (T,) vectors
+};
+
+// ---------------------------------------------------------------- host-side objects
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+
+struct pcl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int cus = 0;
+    // model (device)
+    int J = 0, M = 0, Mpad = 0, D = 0, Dhost = 0, row = 0;  // D = device (padded) feature dimension
+    int model_flags = 0;
+    float *params32 = nullptr;   // J * Mpad * row : [s_0 c_0 s_1 c_1 ... const2]  (log2 domain)
+    double *params64 = nullptr;  // same layout, float64
+    float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
+    double *mean64 = nullptr;
+    // frames (device)
+    int64_t F = 0;
+    int FD = 0;
+    float *frames32 = nullptr;
+    double *frames64 = nullptr;
+    // E-step statistics (device, float64, linear domain)
+    double *stats = nullptr;  // one allocation: [acc J*Mpad | alpha J | mean J*Mpad*D | cov J*Mpad*D]
+    size_t stats_len = 0;
+    double *st_acc = nullptr, *st_alpha = nullptr, *st_mean = nullptr, *st_cov = nullptr;
+    // RCCL
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+    std::map<std::string, KernelTimer> timers;
+};
+
+struct pcl_batch {
+    pcl_ctx *ctx = nullptr;
+    int U = 0, Nmax = 0, Tmax = 0;
+    long long sumNT = 0, sumN = 0, sumT = 0, sumNN = 0;
+    std::vector<UttDesc> utt;  // host copy
+    std::vector<int32_t> row_state;
+    bool have_trans = false, have_states = false, have_B = false, have_fb = false, have_vit = false;
+    int max_outdeg = 0, max_indeg = 0;
+    long long nnz = 0;
+    // device
+    UttDesc *d_utt = nullptr;
+    double *Bt = nullptr, *alpha = nullptr, *beta = nullptr, *lgam = nullptr;
+    double *logpi = nullptr, *pi_out = nullptr, *gamma_out = nullptr, *ksai = nullptr;
+    double *logp = nullptr, *qtrace = nullptr, *point = nullptr;
+    int32_t *npass = nullptr, *path = nullptr;
+    int *row_ptr = nullptr, *col_idx = nullptr;   // CSR (successors)
+    double *csr_val = nullptr;
+    int *col_ptr = nullptr, *row_idx = nullptr;   // CSC (predecessors, ascending source index)
+    double *csc_val = nullptr;
+    double *xi_m = nullptr, *xi_s = nullptr;      // per CSR entry online-LSE state
+    unsigned short *bp = nullptr;                 // Viterbi back-pointers, time-major (t, n)
+    int32_t *d_row_state = nullptr;
+    // scoring work lists
+    ScoreSeg *d_segs = nullptr;
+    std::vector<ScoreSeg> segs;              // host copy, sorted by state
+    std::vector<int> state_seg_lo, state_seg_hi;  // per state with work: segment range
+    std::vector<int> work_states;
+    ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with
+    int n_segs = 0, n_tiles = 0, tile_frames = 0;
+    double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
+    // accumulate work lists (per state: list of segments with lgam/B offsets) reuse d_segs
+};
+
+// ---------------------------------------------------------------- error helpers
+#define PCL_FAIL(ctx, code, ...)                         \
+    do {                                                 \
+        char _b[512];                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);           \
+        pcl_set_error((ctx), _b);                        \
+        return (code);                                   \
+    } while (0)
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) PCL_FAIL(ctx, PCL_ERR_HIP, "%s: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+void pcl_set_error(pcl_ctx *ctx, const char *msg);
+void pcl_timer_begin(pcl_ctx *ctx, const char *which);
+void pcl_timer_end(pcl_ctx *ctx, const char *which);
+
+// ---------------------------------------------------------------- kernel launchers (one per .hip file)
+int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision);
+int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b);
+int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold);
+int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back);
+int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
+void pcl_accumulate_release(pcl_batch *b);
+int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
+int pcl_score_tile_frames(int D, int precision);

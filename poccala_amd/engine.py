@@ -1,0 +1,274 @@
+"""Batched host API over the C-ABI (include/poccala_hip.h).
+
+`Engine` owns one GPU context (model + frame matrix + E-step statistics); `Batch` is a set of
+sentence-level HMMs processed together.  The drop-in classes in StatisticalModel/ and
+AcousticModel/ call these with batch size 1; bench.py and the batched entry points
+(`score_labels`, `estep_labels`, `align_labels`) call them with whole corpus shards.
+
+Reference call stacks replaced:
+  (B) AcousticModel.multi_embedded_training_1  AcousticModel/AcousticModel.py:884-916
+  (C) AcousticModel.multi_process_data         AcousticModel/AcousticModel.py:723-768
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GET, PCL_F32, PCL_F64, PCL_MAX_PASS, PCL_ROW_ENTRY, PCL_ROW_EXIT, PoccalaHipError, as_c, ptr
+
+
+class Engine(object):
+    """One GPU: `Engine(device)`.  Raises if libpoccala_hip.so is missing or no GPU is present."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.pcl_init(int(device), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.pcl_last_error(None)
+            self._ctx = None
+            raise PoccalaHipError(rc, (msg or b'pcl_init failed').decode())
+        self.device = int(device)
+        self.J = self.M = self.D = 0
+        self.F = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise PoccalaHipError(rc, self._lib.pcl_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.pcl_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self._lib.pcl_sync(self._ctx))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        mem = C.c_size_t()
+        self._check(self._lib.pcl_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
+        return dict(name=name.value.decode(), cus=cus.value, hbm_bytes=mem.value)
+
+    def kernel_time(self, which):
+        """(total_ms, launches) of a kernel group since the last query (HIP events on the ctx stream)."""
+        ms = C.c_float()
+        n = C.c_int()
+        self._check(self._lib.pcl_kernel_time(self._ctx, which.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ model / frames
+    def load_model(self, mean, var, weight, logdet=False):
+        """mean, var (J,M,D) -- var is the DIAGONAL of the reference's (M,D,D) covariance (util.py:23);
+        weight (J,M).  `logdet=True` swaps quirk Q1's constant for the textbook one (not parity)."""
+        mean = as_c(mean, np.float64)
+        var = as_c(var, np.float64)
+        weight = as_c(weight, np.float64)
+        if mean.ndim != 3 or var.shape != mean.shape or weight.shape != mean.shape[:2]:
+            raise ValueError('model shapes: mean %s var %s weight %s' % (mean.shape, var.shape, weight.shape))
+        J, M, D = mean.shape
+        self._check(self._lib.pcl_model_upload(self._ctx, J, M, D, ptr(mean), ptr(var), ptr(weight),
+                                               1 if logdet else 0))
+        self.J, self.M, self.D = J, M, D
+
+    def load_frames(self, frames):
+        """(F,D) float32 or float64 MFCC rows of every utterance of the shard, concatenated."""
+        frames = np.asarray(frames)
+        if frames.ndim != 2:
+            raise ValueError('frames must be (F,D)')
+        if frames.dtype == np.float32:
+            f, dt = as_c(frames, np.float32), PCL_F32
+        else:
+            f, dt = as_c(frames, np.float64), PCL_F64
+        self._check(self._lib.pcl_frames_upload(self._ctx, f.shape[0], f.shape[1], ptr(f), dt))
+        self.F = f.shape[0]
+
+    def batch(self, N, T, frame_begin=None):
+        return Batch(self, N, T, frame_begin)
+
+    # ------------------------------------------------------------------ E-step statistics
+    def stats_zero(self):
+        self._check(self._lib.pcl_stats_zero(self._ctx))
+
+    def stats_download(self):
+        """Linear-domain sums: acc (J,M), alpha_acc (J,), mean_acc (J,M,D), cov_acc (J,M,D)."""
+        acc = np.empty((self.J, self.M))
+        al = np.empty((self.J,))
+        me = np.empty((self.J, self.M, self.D))
+        co = np.empty((self.J, self.M, self.D))
+        self._check(self._lib.pcl_stats_download(self._ctx, ptr(acc), ptr(al), ptr(me), ptr(co)))
+        return dict(acc=acc, alpha_acc=al, mean_acc=me, cov_acc=co)
+
+    # ------------------------------------------------------------------ RCCL
+    def comm_unique_id(self):
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = self._lib.pcl_comm_unique_id(ptr(buf))
+        if rc != 0:
+            raise PoccalaHipError(rc, self._lib.pcl_last_error(None).decode())
+        return buf.tobytes()
+
+    def comm_init(self, rank, nranks, unique_id):
+        buf = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        self._check(self._lib.pcl_comm_init(self._ctx, int(rank), int(nranks), ptr(buf)))
+
+    def stats_allreduce(self):
+        self._check(self._lib.pcl_stats_allreduce(self._ctx))
+
+
+class Batch(object):
+    """U sentence HMMs.  N[u] states, T[u] frames; matrices cross the boundary in the reference's
+    (N,T) float64 layout, one array per utterance."""
+
+    def __init__(self, engine, N, T, frame_begin=None):
+        self.eng = engine
+        self._lib = engine._lib
+        self.N = as_c(N, np.int32).reshape(-1)
+        self.T = as_c(T, np.int32).reshape(-1)
+        if self.N.shape != self.T.shape or self.N.size == 0:
+            raise ValueError('N and T must be equal-length, non-empty')
+        self.U = int(self.N.size)
+        fb = None if frame_begin is None else as_c(frame_begin, np.int64).reshape(-1)
+        self._b = C.c_void_p()
+        engine._check(self._lib.pcl_batch_create(engine._ctx, self.U, ptr(self.N), ptr(self.T), ptr(fb),
+                                                 C.byref(self._b)))
+        n64, t64 = self.N.astype(np.int64), self.T.astype(np.int64)
+        self._nt_off = np.concatenate([[0], np.cumsum(n64 * t64)])
+        self._nn_off = np.concatenate([[0], np.cumsum(n64 * n64)])
+        self._n_off = np.concatenate([[0], np.cumsum(n64)])
+        self._t_off = np.concatenate([[0], np.cumsum(t64)])
+
+    def close(self):
+        if getattr(self, '_b', None):
+            self._lib.pcl_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        self.eng._check(rc)
+
+    def _ragged(self, arrays, shape_of, dtype=np.float64):
+        out = []
+        for u, a in enumerate(arrays):
+            a = np.asarray(a, dtype=dtype)
+            if a.shape != shape_of(u):
+                raise ValueError('utterance %d: expected shape %s, got %s' % (u, shape_of(u), a.shape))
+            out.append(a.reshape(-1))
+        if len(out) != self.U:
+            raise ValueError('expected %d arrays, got %d' % (self.U, len(out)))
+        return np.ascontiguousarray(np.concatenate(out), dtype=dtype)
+
+    # ------------------------------------------------------------------ inputs
+    def set_transitions(self, logA, logpi):
+        """logA[u] (N,N) = np.log(transmat), logpi[u] (N,) = np.log(pi) -- logged by the caller so that
+        Viterbi sees bit-identical operands (LHMM.py:571,577)."""
+        a = self._ragged(logA, lambda u: (self.N[u], self.N[u]))
+        p = self._ragged(logpi, lambda u: (self.N[u],))
+        self._check(self._lib.pcl_batch_set_transitions(self._b, ptr(a), ptr(p)))
+
+    def set_states(self, row_state):
+        s = self._ragged(row_state, lambda u: (self.N[u],), dtype=np.int32)
+        self._check(self._lib.pcl_batch_set_states(self._b, ptr(s)))
+
+    def set_emissions(self, B):
+        b = self._ragged(B, lambda u: (self.N[u], self.T[u]))
+        self._check(self._lib.pcl_batch_set_emissions(self._b, ptr(b)))
+
+    # ------------------------------------------------------------------ kernels
+    def score(self, precision=PCL_F32):
+        self._check(self._lib.pcl_batch_score(self._b, int(precision)))
+
+    def forward_backward(self, fix_pi=False, threshold=0.64):
+        self._check(self._lib.pcl_batch_forward_backward(self._b, 1 if fix_pi else 0, float(threshold)))
+
+    def viterbi(self, end_state_back=False):
+        self._check(self._lib.pcl_batch_viterbi(self._b, 1 if end_state_back else 0))
+
+    def accumulate(self, precision=PCL_F32):
+        self._check(self._lib.pcl_batch_accumulate(self._b, int(precision)))
+
+    # ------------------------------------------------------------------ outputs
+    def get(self, what):
+        """List of per-utterance arrays (or a (U,...) array for per-utterance scalars)."""
+        code = GET[what]
+        if what in ('B', 'alpha', 'beta', 'lgamma'):
+            flat = np.empty(int(self._nt_off[-1]))
+            self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))
+            return [flat[self._nt_off[u]:self._nt_off[u + 1]].reshape(self.N[u], self.T[u]) for u in range(self.U)]
+        if what == 'ksai':
+            flat = np.empty(int(self._nn_off[-1]))
+            self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))
+            return [flat[self._nn_off[u]:self._nn_off[u + 1]].reshape(self.N[u], self.N[u]) for u in range(self.U)]
+        if what in ('gamma', 'pi'):
+            flat = np.empty(int(self._n_off[-1]))
+            self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))
+            return [flat[self._n_off[u]:self._n_off[u + 1]] for u in range(self.U)]
+        if what == 'path':
+            flat = np.empty(int(self._t_off[-1]), dtype=np.int32)
+            self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))
+            return [flat[self._t_off[u]:self._t_off[u + 1]] for u in range(self.U)]
+        if what in ('logp', 'point'):
+            out = np.empty(self.U)
+        elif what == 'npass':
+            out = np.empty(self.U, dtype=np.int32)
+        elif what == 'qtrace':
+            out = np.empty((self.U, PCL_MAX_PASS))
+        else:
+            raise KeyError(what)
+        self._check(self._lib.pcl_batch_get(self._b, code, ptr(out)))
+        return out
+
+
+# ---------------------------------------------------------------------- sentence HMM construction
+def embedded_structure(n_units, unit_trans, s=5):
+    """Host part of AcousticModel.embedded (AcousticModel/AcousticModel.py:957-1014) for one label:
+    the (N,N) transition matrix and the uniform 1/N pi.  unit_trans: list of (S,S) matrices, one
+    per label position.  The emission rows are laid out by `embedded_row_states`."""
+    e = s - 2
+    n = e * n_units + 2
+    a = np.zeros((n, n))
+    a[:s - 1, :s] = unit_trans[0][:-1]
+    for i in range(n_units):
+        lo = i * e + 1
+        a[lo:lo + e, lo - 1:lo - 1 + s] = unit_trans[i][1:-1]
+    pi = np.ones(n) / n
+    return a, pi
+
+
+def embedded_row_states(unit_state_ids, s=5):
+    """Row -> GMM state id map of the sentence HMM: entry row, each unit's S-2 emitting states,
+    exit row (AcousticModel.py:990-1001).  unit_state_ids: (L, S-2) global GMM state ids."""
+    ids = np.asarray(unit_state_ids, dtype=np.int32).reshape(-1)
+    return np.concatenate([[PCL_ROW_ENTRY], ids, [PCL_ROW_EXIT]]).astype(np.int32)
+
+
+def make_sentence_batch(engine, unit_ids, T, frame_begin, unit_trans, s=5):
+    """Build the batch for a list of labels.  unit_ids[u]: sequence of unit indices (label of
+    utterance u); unit i owns GMM states i*(S-2) .. i*(S-2)+S-3 of the uploaded model and the
+    transition matrix unit_trans[i] (S,S).  Returns (batch, N)."""
+    e = s - 2
+    n = np.array([e * len(l) + 2 for l in unit_ids], dtype=np.int32)
+    b = engine.batch(n, T, frame_begin)
+    log_a, log_pi, rows = [], [], []
+    with np.errstate(divide='ignore'):
+        for lab in unit_ids:
+            lab = np.asarray(lab, dtype=np.int64)
+            a, pi = embedded_structure(len(lab), [unit_trans[i] for i in lab], s)
+            log_a.append(np.log(a))
+            log_pi.append(np.log(pi))
+            rows.append(embedded_row_states(lab[:, None] * e + np.arange(e)[None, :], s))
+    b.set_transitions(log_a, log_pi)
+    b.set_states(rows)
+    return b, n

@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (BASELINE.json north_star): log-likelihoods and gamma/xi occupancies within 1e-4 relative
+for the float32 scoring path, Viterbi state sequences bit-exact.  The float64 path (PCL_F64) is held
+to 1e-9.  All DP state is float64 in both modes.
+"""
+import numpy as np
+import pytest
+
+from oracle import poccala_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+S = 5
+F32_RTOL = 1e-4      # the north-star bound
+F32_LOGLIK_ATOL = 2e-4   # absolute bound on ln b_j(o_t) (|ln b| ~ 50..150 -> ~2e-6 relative)
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from poccala_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def fin_close(got, ref, rtol, atol=0.0):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------ scoring (A1/A4/A6)
+def small_problem(seed, units=4, M=8, D=13, U=5, T=40, L=3, ragged=True):
+    from poccala_amd import synth
+    mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
+    frames, lens, begin = synth.make_frames(U, T, D, seed=seed + 1, ragged=ragged)
+    labels = synth.make_labels(U, L, units, seed=seed + 2)
+    return mean, var, w, trans, frames, lens, begin, labels
+
+
+def oracle_model(mean, var, w, trans):
+    e = S - 2
+    return {u: dict(trans=trans[u], gmms=[(mean[u * e + k], var[u * e + k], w[u * e + k]) for k in range(e)])
+            for u in range(len(trans))}
+
+
+@pytest.mark.parametrize('M,D', [(8, 13), (5, 39), (256, 39), (7, 20), (3, 50)])
+@pytest.mark.parametrize('prec', ['f32', 'f64'])
+def test_score_matches_oracle(eng, M, D, prec):
+    from poccala_amd import PCL_F32, PCL_F64
+    from poccala_amd.engine import make_sentence_batch
+    mean, var, w, trans, frames, lens, begin, labels = small_problem(11 + M + D, M=M, D=D)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32 if prec == 'f32' else PCL_F64)
+    got = b.get('B')
+    model = oracle_model(mean, var, w, trans)
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, _, ref, _ = po.score_label(x, list(lab), model)
+        assert np.all(got[u][0] == 0.0) and np.all(np.isneginf(got[u][-1]))     # A5 virtual rows
+        if prec == 'f32':
+            fin_close(got[u], ref, rtol=0, atol=F32_LOGLIK_ATOL)
+        else:
+            fin_close(got[u], ref, rtol=1e-12)
+    b.close()
+
+
+def test_score_golden_unit_hmm(eng, golden):
+    """G3: the reference's own cal_observation_pro output for a C1-shaped unit HMM."""
+    from poccala_amd import PCL_F32, PCL_F64
+    g = golden('G3_unit_B')
+    mean = np.stack([g['mean_%d' % k] for k in range(3)])
+    var = np.stack([g['var_%d' % k] for k in range(3)])
+    w = np.stack([g['w_%d' % k] for k in range(3)])
+    eng.load_model(mean, var, w)
+    eng.load_frames(g['x'])
+    b = eng.batch([5], [300], [0])
+    b.set_states([np.array([-1, 0, 1, 2, -2], dtype=np.int32)])
+    b.score(PCL_F64)
+    fin_close(b.get('B')[0], g['B'], rtol=1e-12)
+    b.score(PCL_F32)
+    fin_close(b.get('B')[0], g['B'], rtol=0, atol=F32_LOGLIK_ATOL)
+    b.close()
+
+
+def test_score_zero_weight_and_padding(eng):
+    """A mixture with weight 0 contributes ln 0 = -inf (Clustering.py:757) and must not poison the LSE;
+    M = 5 also exercises the padded mixtures."""
+    from poccala_amd import PCL_F32
+    rng = np.random.default_rng(5)
+    mean = rng.standard_normal((1, 5, 13))
+    var = rng.uniform(0.5, 2, (1, 5, 13))
+    w = np.array([[0.5, 0.0, 0.25, 0.25, 0.0]])
+    x = rng.standard_normal((70, 13))
+    eng.load_model(mean, var, w)
+    eng.load_frames(x)
+    b = eng.batch([3], [70], [0])
+    b.set_states([np.array([-1, 0, -2], dtype=np.int32)])
+    b.score(PCL_F32)
+    ref = po.gmm_point(x, mean[0], var[0], w[0])
+    np.testing.assert_allclose(b.get('B')[0][1], ref, atol=F32_LOGLIK_ATOL)
+    b.close()
+
+
+def test_dimension_mismatch_raises(eng):
+    """DataDimensionError of the reference (Clustering.py:749-751) -> PCL_ERR_INVALID."""
+    from poccala_amd import PoccalaHipError
+    rng = np.random.default_rng(0)
+    eng.load_model(rng.standard_normal((3, 4, 13)), np.ones((3, 4, 13)), np.ones((3, 4)) / 4)
+    with pytest.raises(PoccalaHipError):
+        eng.load_frames(rng.standard_normal((10, 12)))
+    eng.load_frames(rng.standard_normal((10, 13)))
+
+
+# ------------------------------------------------------------------ Baum-Welch (A8..A12) vs golden
+BW_CASES = ['G6_small_fix0', 'G6_small_fix1', 'G6_small_fix2', 'G6_small_fix3', 'G6_small_fix4',
+            'G6_small_fix6', 'G8_floor', 'G6_n62_fix0', 'G6_n62_fix3']
+
+
+@pytest.mark.parametrize('case', BW_CASES)
+def test_forward_backward_golden(eng, golden, case):
+    g = golden(case)
+    fix = int(g['fix_code'])
+    A, B, pi = g['emb_A'], g['emb_B'], g['emb_pi']
+    n, t = B.shape
+    b = eng.batch([n], [t])
+    with np.errstate(divide='ignore'):
+        b.set_transitions([np.log(A)], [np.log(pi)])
+    b.set_emissions([B])
+    b.forward_backward(fix_pi=bool(fix & 1))
+    assert int(b.get('npass')[0]) == int(g['bw_n_pass'])
+    q = b.get('qtrace')[0]
+    np.testing.assert_allclose(q[:int(g['bw_n_pass']) - 1], g['bw_q_trace'][1:], atol=2e-6)
+    np.testing.assert_allclose(b.get('logp')[0], float(g['bw_logp']), rtol=1e-12)
+    np.testing.assert_allclose(b.get('pi')[0], g['bw_pi'], rtol=1e-9, atol=1e-300)
+    fin_close(b.get('ksai')[0], g['bw_ksai'], rtol=1e-10)
+    fin_close(b.get('gamma')[0], g['bw_gamma'], rtol=1e-10)
+    fin_close(b.get('B')[0], B, rtol=0)
+    if 'bw_alpha' in g.files:
+        fin_close(b.get('alpha')[0], g['bw_alpha'], rtol=1e-10)
+        fin_close(b.get('beta')[0], g['bw_beta'], rtol=1e-10)
+        l = g['bw_alpha'] + g['bw_beta']
+        ref_lg = l - po.lse(l, axis=0)[None, :]
+        fin_close(b.get('lgamma')[0], ref_lg, rtol=1e-9, atol=1e-9)
+    b.close()
+
+
+def test_forward_backward_dense_and_multiwave(eng):
+    """A dense transition matrix (every state reachable) and N > 64 (several wavefronts per HMM)."""
+    rng = np.random.default_rng(77)
+    cases = [(7, 30), (130, 25), (64, 12), (65, 9)]
+    As, pis, Bs = [], [], []
+    for n, t in cases:
+        As.append(rng.dirichlet(np.ones(n), size=n))
+        pis.append(rng.dirichlet(np.ones(n)))
+        Bs.append(rng.standard_normal((n, t)) * 3 - 30)
+    b = eng.batch([c[0] for c in cases], [c[1] for c in cases])
+    b.set_transitions([np.log(a) for a in As], [np.log(p) for p in pis])
+    b.set_emissions(Bs)
+    for fix_pi in (False, True):
+        b.forward_backward(fix_pi=fix_pi)
+        al, be, ks, ga, pi, lp, npass = (b.get(k) for k in ('alpha', 'beta', 'ksai', 'gamma', 'pi', 'logp', 'npass'))
+        for u in range(len(cases)):
+            ref = po.baum_welch(As[u], pis[u], [Bs[u]], fix_code=1 if fix_pi else 0)
+            assert int(npass[u]) == ref['n_pass']
+            fin_close(al[u], ref['alpha'][0], rtol=1e-10)
+            fin_close(be[u], ref['beta'][0], rtol=1e-10)
+            fin_close(ks[u], ref['ksai'], rtol=1e-10)
+            fin_close(ga[u], ref['gamma'], rtol=1e-10)
+            np.testing.assert_allclose(pi[u], ref['pi'], rtol=1e-9, atol=1e-300)
+            np.testing.assert_allclose(lp[u], ref['logp'][0], rtol=1e-12)
+    b.close()
+
+
+# ------------------------------------------------------------------ Viterbi (A14), bit-exact
+def run_viterbi(eng, A, pi, prob, esb=False):
+    n, t = prob.shape
+    b = eng.batch([n], [t])
+    with np.errstate(divide='ignore'):
+        b.set_transitions([np.log(A)], [np.log(pi)])
+    b.set_emissions([prob])
+    b.viterbi(end_state_back=esb)
+    out = float(b.get('point')[0]), b.get('path')[0].astype(np.float64)
+    b.close()
+    return out
+
+
+def test_viterbi_golden_bit_exact(eng, golden):
+    g = golden('G5_viterbi')
+    for tag in ('dense', 'tie', 'lr'):
+        point, path = run_viterbi(eng, g[tag + '_A'], g[tag + '_pi'], g[tag + '_prob'])
+        assert np.array_equal(path, g[tag + '_path']), tag
+        assert point == float(g[tag + '_point']), tag
+    point, path = run_viterbi(eng, g['tie_A'], g['tie_pi'], g['t1_prob'])
+    assert np.array_equal(path, g['t1_path']) and point == float(g['t1_point'])
+    point, path = run_viterbi(eng, g['lr_A'], g['lr_pi'], g['lr_prob'], esb=True)      # quirk Q9
+    assert np.array_equal(path, g['lr_esb_path']) and point == float(g['lr_esb_point'])
+
+
+@pytest.mark.parametrize('case', BW_CASES)
+def test_viterbi_sentence_hmm_golden(eng, golden, case):
+    g = golden(case)
+    point, path = run_viterbi(eng, g['emb_A'], g['emb_pi'], g['emb_B'])
+    assert np.array_equal(path, g['vit_path'])
+    assert point == float(g['vit_point'])
+
+
+def test_viterbi_batch_matches_oracle_bit_exact(eng):
+    rng = np.random.default_rng(9)
+    cases = [(62, 300), (5, 1), (122, 77), (8, 40), (200, 15)]
+    As, pis, Bs = [], [], []
+    for n, t in cases:
+        a = rng.dirichlet(np.ones(n), size=n)
+        a[rng.random((n, n)) < 0.5] = 0.0                    # sparse, some all-zero columns possible
+        As.append(a)
+        pis.append(rng.dirichlet(np.ones(n)))
+        Bs.append(np.round(rng.standard_normal((n, t)) * 4, 1) - 20)   # coarse values -> frequent ties
+    b = eng.batch([c[0] for c in cases], [c[1] for c in cases])
+    with np.errstate(divide='ignore'):
+        b.set_transitions([np.log(a) for a in As], [np.log(p) for p in pis])
+    b.set_emissions(Bs)
+    b.viterbi()
+    pts, paths = b.get('point'), b.get('path')
+    for u in range(len(cases)):
+        rp, rpath = po.viterbi(As[u], pis[u], Bs[u])
+        assert np.array_equal(paths[u].astype(np.float64), rpath), u
+        assert pts[u] == rp or (np.isneginf(pts[u]) and np.isneginf(rp))
+    b.close()
+
+
+# ------------------------------------------------------------------ end-to-end E-step and alignment vs oracle
+@pytest.mark.parametrize('prec', ['f32', 'f64'])
+def test_estep_end_to_end(eng, prec):
+    from poccala_amd import PCL_F32, PCL_F64
+    from poccala_amd.engine import make_sentence_batch
+    P = PCL_F32 if prec == 'f32' else PCL_F64
+    mean, var, w, trans, frames, lens, begin, labels = small_problem(301, units=5, M=16, D=39, U=6, T=60, L=4)
+    labels[0][1] = labels[0][0]                      # a repeated unit inside one label
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(P)
+    b.forward_backward(fix_pi=False)
+    eng.stats_zero()
+    b.accumulate(P)
+    st = eng.stats_download()
+    model = oracle_model(mean, var, w, trans)
+    J, M, D = mean.shape
+    ref = dict(acc=np.zeros((J, M)), alpha_acc=np.zeros(J), mean_acc=np.zeros((J, M, D)), cov_acc=np.zeros((J, M, D)))
+    lp, ks, ga, lg = b.get('logp'), b.get('ksai'), b.get('gamma'), b.get('lgamma')
+    rt = F32_RTOL if prec == 'f32' else 1e-9
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        bw, accs, _ = po.estep_utterance(x, list(lab), model)
+        np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=rt)
+        # occupancies: normalised posteriors in the linear domain
+        l = bw['alpha'][0] + bw['beta'][0]
+        ref_g = np.exp(l - po.lse(l, axis=0)[None, :])
+        np.testing.assert_allclose(np.exp(lg[u]), ref_g, rtol=rt, atol=1e-7 if prec == 'f32' else 1e-12)
+        # un-normalised xi/gamma (log domain, quirk Q5): compare relative to P(O)
+        fk = np.isfinite(bw['ksai'])
+        assert np.array_equal(np.isfinite(ks[u]), fk)
+        np.testing.assert_allclose(np.exp(ks[u][fk] - lp[u]), np.exp(bw['ksai'][fk] - bw['logp'][0]), rtol=rt, atol=1e-7 if prec == 'f32' else 1e-12)
+        np.testing.assert_allclose(np.exp(ga[u][1:-1] - lp[u]), np.exp(bw['gamma'][1:-1] - bw['logp'][0]), rtol=rt, atol=1e-7 if prec == 'f32' else 1e-12)
+        for pos, unit in enumerate(lab):
+            for k in range(S - 2):
+                j = unit * (S - 2) + k
+                a = accs[pos].gmm[k]
+                ref['acc'][j] += np.exp(a['acc'])
+                ref['alpha_acc'][j] += np.exp(a['alpha_acc'])
+                ref['mean_acc'][j] += np.exp(a['mean_acc'])
+                ref['cov_acc'][j] += np.exp(a['cov_acc'])
+    for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+        scale = np.abs(ref[key]).max()
+        np.testing.assert_allclose(st[key], ref[key], rtol=2 * rt, atol=scale * (1e-6 if prec == 'f32' else 1e-13), err_msg=key)
+    b.close()
+
+
+def test_alignment_end_to_end(eng):
+    """Forced alignment (call stack C).  With float64 scoring the path equals the oracle's; with
+    float32 scoring near-ties may flip so only the agreement rate is asserted."""
+    from poccala_amd import PCL_F32, PCL_F64
+    from poccala_amd.engine import make_sentence_batch
+    mean, var, w, trans, frames, lens, begin, labels = small_problem(401, units=6, M=16, D=39, U=8, T=90, L=5)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    model = oracle_model(mean, var, w, trans)
+    refs = []
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        refs.append(po.align_utterance(x, list(lab), model))
+    b.score(PCL_F64)
+    b.viterbi()
+    for u in range(len(labels)):
+        assert np.array_equal(b.get('path')[u].astype(np.float64), refs[u][1])
+        np.testing.assert_allclose(b.get('point')[u], refs[u][0], rtol=1e-12)
+    b.score(PCL_F32)
+    b.viterbi()
+    agree = np.mean(np.concatenate([b.get('path')[u] == refs[u][1] for u in range(len(labels))]))
+    assert agree >= 0.99
+    b.close()
+
+
+# ------------------------------------------------------------------ BASELINE config C2 at full size: properties
+def test_c2_full_size_properties(eng):
+    """configs[1]: 128 utterances x 300 frames, 39-dim, 256-mix, 50 units x 3 states.  Size-independent
+    properties of the E-step: sum_j gamma_t(j) = 1; LSE(alpha_{T-1}) = LSE(ln pi + B_0
+    + beta_0); Viterbi score <= forward score; sum over mixtures of the statistics equals alpha_acc;
+    plus a spot check of some utterances against the oracle."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.engine import make_sentence_batch
+    c = synth.CONFIGS['C2']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'])
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'])
+    labels = synth.make_labels(c['U'], c['L'], c['units'])
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    b.forward_backward(fix_pi=True)       # pi fixed: alpha_0 uses the caller's pi, so the identity below holds
+    lg, al, be, B, lp = (b.get(k) for k in ('lgamma', 'alpha', 'beta', 'B', 'logp'))
+    for u in range(0, c['U'], 7):
+        np.testing.assert_allclose(po.lse(lg[u], axis=0), 0.0, atol=1e-9)
+        lhs = po.lse(al[u][:, -1])
+        rhs = po.lse(np.log(1.0 / n[u]) + B[u][:, 0] + be[u][:, 0])
+        np.testing.assert_allclose(lhs, rhs, rtol=1e-10)
+        np.testing.assert_allclose(lhs, lp[u], rtol=1e-12)
+    b.viterbi()
+    assert np.all(b.get('point') <= lp + 1e-9)
+    paths = b.get('path')
+    for u in range(0, c['U'], 11):
+        assert np.all(np.diff(paths[u]) >= 0)                      # left-to-right topology
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    st = eng.stats_download()
+    np.testing.assert_allclose(st['acc'].sum(axis=1), st['alpha_acc'], rtol=1e-4)
+    total_gamma = sum(np.exp(lg[u][1:-1]).sum() for u in range(c['U']))
+    np.testing.assert_allclose(st['alpha_acc'].sum(), total_gamma, rtol=1e-6)
+    # spot check two utterances against the oracle (scoring 60 x 300 x 256 Gaussians each)
+    model = oracle_model(mean, var, w, trans)
+    for u in (3, 77):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, a, bref, pi = po.score_label(x, list(labels[u]), model)
+        fin_close(B[u], bref, rtol=0, atol=F32_LOGLIK_ATOL)
+        bw = po.baum_welch(a, pi, [bref], fix_code=1)
+        np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=F32_RTOL)
+    b.close()
