@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpoccala_hip.so')
+LIB_PATH = os.environ.get('POCCALA_HIP_LIB', os.path.join(_HERE, 'libpoccala_hip.so'))   # override: kernel A/B builds
 
 PCL_F32, PCL_F64 = 0, 1
 PCL_MODEL_Q1_SUMVAR, PCL_MODEL_LOGDET = 0, 1

@@ -142,11 +142,17 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     const bool live = m < Mpad;
     const real *p = params + ((size_t)j * Mpad + (live ? m : 0)) * ROW;
 
-    real s[D], c[D], S1[D], S2[D];
+    // f32: the 2D scoring parameters stay in VGPRs for the whole pass.  f64 (parity mode) re-reads them
+    // (L1-resident, 632 B per lane): with them resident the kernel needs > 256 VGPRs per lane and hipcc's
+    // AGPR spill code for 64-bit values returned doubles with damaged low words (2^-20 relative errors).
+    constexpr bool PREG = sizeof(real) == 4;
+    real s[PREG ? D : 1], c[PREG ? D : 1], S1[D], S2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        s[d] = p[2 * d];
-        c[d] = p[2 * d + 1];
+        if (PREG) {
+            s[d] = p[2 * d];
+            c[d] = p[2 * d + 1];
+        }
         S1[d] = 0;
         S2[d] = 0;
     }
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
             real q = 0;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                y[d] = Fast<real>::fma(x[d], s[d], c[d]);
+                y[d] = PREG ? Fast<real>::fma(x[d], s[d], c[d]) : Fast<real>::fma(x[d], p[2 * d], p[2 * d + 1]);
                 q = Fast<real>::fma(y[d], y[d], q);
             }
             const real g = Fast<real>::exp2((k2 - q) + cf[f]);   // gamma_t(j,m)  (Clustering.py:660-661)
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
         const real *mu = means + jm * D;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const double sd = (double)s[d];
+            const double sd = (double)(PREG ? s[d] : p[2 * d]);
             if (sd > 0.0) {
                 // sum g (o + bias) = sum g (o - mu) + (mu + bias) sum g    (Clustering.py:669-672)
                 st_mean[jm * D + d] += (double)S1[d] / sd + ((double)mu[d] + bias) * a0;

@@ -19,6 +19,8 @@
 //     rescaled once per group of G mixtures: (1 + 1/G) v_exp_f32 per Gaussian, no cross-lane traffic.
 //   * result  ln b = ln2 * (max + log2(sum))  is finished in float64 and written to the time-major
 //     emission matrix consumed by the DP kernels.
+#include <stdlib.h>
+
 #include "pcl_internal.h"
 
 namespace {
@@ -28,7 +30,10 @@ constexpr int WG = 256;  // 4 waves
 #define PCL_GROUP 4
 #endif
 #ifndef PCL_R32
-#define PCL_R32 4
+#define PCL_R32 3   // measured on MI355X: R=3 (3 waves/SIMD) 64.3 TF vs R=4 (2 waves/SIMD) 52.8, R=5 54.7
+#endif
+#ifndef PCL_CH32
+#define PCL_CH32 64   // mixtures per LDS chunk (f32)
 #endif
 constexpr int GROUP = PCL_GROUP;  // mixtures per LSE rescale (Mpad is a multiple of 4 >= this)
 
@@ -150,6 +155,115 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: parameters through the scalar data path instead of LDS.  The per-mixture (s_d, c_d) pairs are
+// wave-uniform, so they are fetched with s_load into SGPR pairs and fed to v_pk_fma_f32 through
+// op_sel:  y.xy = x.xy * S.lo + S.hi  reads ONE SGPR pair (one constant-bus operand) and two VGPRs,
+// and handles two frames per instruction.  Measured on MI355X (tools/ubench_valu.hip) this form
+// issues at 121-132 TFLOP/s against 95-105 for v_fma_f32 with VGPR operands.  No LDS, no barriers:
+// every wave streams the state's parameter block on its own; the block is L2-resident.
+// ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma_sgpr_pair(f2 x, f2 sc) {
+    f2 y;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(y) : "v"(x), "s"(sc));
+    return y;
+}
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) {
+    f2 y;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
+    return y;
+}
+
+template <int D, int RP /* frame PAIRS per lane */>
+__global__ __launch_bounds__(WG, 2) void gmm_score_kernel_v2(const float *__restrict__ frames,
+                                                             const float *__restrict__ params, int Mpad,
+                                                             const ScoreTile *__restrict__ tiles,
+                                                             const ScoreSeg *__restrict__ segs,
+                                                             double *__restrict__ out) {
+    constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
+    constexpr int R = 2 * RP;
+    const ScoreTile tile = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
+    if (tile.vstart + wave * R * 64 >= vend) return;   // whole wave past the end of the state's frames
+
+    f2 x[RP][D];
+    long long oidx[R];
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int v = tile.vstart + (wave * R + r) * 64 + lane;
+        valid[r] = v < vend;
+        if (!valid[r]) v = tile.vstart;
+        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        }
+        const ScoreSeg sg = segs[lo];
+        const long long t = v - sg.vstart;
+        const float *fp = frames + (sg.frame0 + t) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[r >> 1][d][r & 1] = fp[d];
+        oidx[r] = sg.out0 + t * (long long)sg.out_stride;
+    }
+    float mx[R], sm[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mx[r] = -1.0e30f;
+        sm[r] = 0.f;
+    }
+    const float *pbase = params + (size_t)tile.state * Mpad * ROW;
+    for (int m = 0; m < Mpad; m += GROUP) {
+        float v[GROUP][R];
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            const f2 *prow = reinterpret_cast<const f2 *>(pbase + (size_t)(m + g) * ROW);   // wave-uniform
+            f2 q[RP];
+#pragma unroll
+            for (int rp = 0; rp < RP; ++rp) q[rp] = f2{0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const f2 sc = prow[d];
+#pragma unroll
+                for (int rp = 0; rp < RP; ++rp) {
+                    const f2 y = pk_fma_sgpr_pair(x[rp][d], sc);
+                    q[rp] = pk_fma(y, y, q[rp]);
+                }
+            }
+            const float k2 = pbase[(size_t)(m + g) * ROW + 2 * D];
+#pragma unroll
+            for (int rp = 0; rp < RP; ++rp) {
+                v[g][2 * rp] = k2 - q[rp].x;
+                v[g][2 * rp + 1] = k2 - q[rp].y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float gm = v[0][r];
+#pragma unroll
+            for (int g = 1; g < GROUP; ++g) gm = __builtin_fmaxf(gm, v[g][r]);
+            const float nm = __builtin_fmaxf(mx[r], gm);
+            float acc = sm[r] * __builtin_amdgcn_exp2f(mx[r] - nm);
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g) acc += __builtin_amdgcn_exp2f(v[g][r] - nm);
+            sm[r] = acc;
+            mx[r] = nm;
+        }
+    }
+    constexpr double LN2 = 0.693147180559945309417232121458;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (valid[r]) {
+            const double res = (sm[r] > 0) ? LN2 * ((double)mx[r] + ::log2((double)sm[r])) : -INFINITY;
+            out[oidx[r]] = res;
+        }
+    }
+}
+
 // rows of the sentence HMMs that are not GMM states: entry -> 0, exit -> -inf
 __global__ void fill_virtual_rows_kernel(const UttDesc *__restrict__ utt, const int32_t *__restrict__ row_state,
                                          double *__restrict__ Bt, int U) {
@@ -181,6 +295,12 @@ __global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *
             dst[d.b_off + e] = src[d.b_off + (long long)t * d.N + n];
         }
     }
+}
+
+template <int D>
+void launch_score_v2(pcl_ctx *ctx, pcl_batch *b) {
+    hipLaunchKernelGGL((gmm_score_kernel_v2<D, 2>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, ctx->params32,
+                       ctx->Mpad, b->d_tiles, b->d_segs, b->Bt);
 }
 
 template <int D, int R, int CH, typename real>
@@ -218,9 +338,12 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision) {
     if (b->n_tiles == 0) return PCL_OK;
     const int D = ctx->D;
     pcl_timer_begin(ctx, "score");
-    if (precision == PCL_F32) {
+    static const int variant = getenv("PCL_SCORE_VARIANT") ? atoi(getenv("PCL_SCORE_VARIANT")) : 1;
+    if (precision == PCL_F32 && variant == 2 && (D == 39 || D == 13)) {
+        if (D == 39) launch_score_v2<39>(ctx, b); else launch_score_v2<13>(ctx, b);
+    } else if (precision == PCL_F32) {
         switch (D) {
-#define CASE32(DD) case DD: launch_score_t<DD, r32(DD), 64, float>(ctx, b, ctx->frames32, ctx->params32); break;
+#define CASE32(DD) case DD: launch_score_t<DD, r32(DD), PCL_CH32, float>(ctx, b, ctx->frames32, ctx->params32); break;
             CASE32(13) CASE32(26) CASE32(39)
             CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40) CASE32(48) CASE32(64)
 #undef CASE32

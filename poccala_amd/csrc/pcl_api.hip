@@ -156,8 +156,6 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     if (J <= 0 || M <= 0 || D <= 0 || !mean || !var || !weight) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: bad shape J=%d M=%d D=%d", J, M, D);
     const int Dd = device_dim(D);
     if (Dd < 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: feature dimension %d > 64 is not supported", D);
-    if (ctx->F > 0 && ctx->Dhost != D)
-        PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->Dhost, D);  // DataDimensionError, Clustering.py:749-751
     HIPCHK(ctx, hipSetDevice(ctx->device));
     free_model(ctx);
     const int Mpad = (M + 3) / 4 * 4;
@@ -223,8 +221,6 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
 int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dtype) {
     if (!ctx) return PCL_ERR_INVALID;
     if (F <= 0 || D <= 0 || !frames) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_upload: bad shape F=%lld D=%d", (long long)F, D);
-    if (ctx->J > 0 && ctx->Dhost != D)
-        PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", D, ctx->Dhost);  // DataDimensionError, Clustering.py:749-751
     const int Dd = device_dim(D);
     if (Dd < 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_upload: feature dimension %d > 64 is not supported", D);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -245,7 +241,7 @@ int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dt
     HIPCHK(ctx, hipMemcpy(ctx->frames64, f64.data(), n * sizeof(double), hipMemcpyHostToDevice));
     ctx->F = F;
     ctx->FD = Dd;
-    if (ctx->J == 0) ctx->Dhost = D;
+    ctx->FDhost = D;
     return PCL_OK;
 }
 
@@ -506,7 +502,8 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     if (ctx->J == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: no model uploaded");
     if (ctx->F == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: no frames uploaded");
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: pcl_batch_set_states was not called");
-    if (ctx->FD != ctx->D) PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension does not match model dimension %d", ctx->Dhost);
+    if (ctx->FDhost != ctx->Dhost)  // DataDimensionError, Clustering.py:749-751
+        PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));

@@ -59,7 +59,7 @@ struct pcl_ctx {
     double *mean64 = nullptr;
     // frames (device)
     int64_t F = 0;
-    int FD = 0;
+    int FD = 0, FDhost = 0;
     float *frames32 = nullptr;
     double *frames64 = nullptr;
     // E-step statistics (device, float64, linear domain)

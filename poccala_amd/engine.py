@@ -10,6 +10,7 @@ Reference call stacks replaced:
   (C) AcousticModel.multi_process_data         AcousticModel/AcousticModel.py:723-768
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -31,6 +32,7 @@ class Engine(object):
         self.device = int(device)
         self.J = self.M = self.D = 0
         self.F = 0
+        self._batches = []   # weak refs to live batches: destroyed before the context
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -39,6 +41,11 @@ class Engine(object):
 
     def close(self):
         if getattr(self, '_ctx', None):
+            for ref in list(self._batches):
+                b = ref()
+                if b is not None:
+                    b.close()
+            self._batches = []
             self._lib.pcl_destroy(self._ctx)
             self._ctx = None
 
@@ -139,6 +146,7 @@ class Batch(object):
         self._b = C.c_void_p()
         engine._check(self._lib.pcl_batch_create(engine._ctx, self.U, ptr(self.N), ptr(self.T), ptr(fb),
                                                  C.byref(self._b)))
+        engine._batches.append(weakref.ref(self))
         n64, t64 = self.N.astype(np.int64), self.T.astype(np.int64)
         self._nt_off = np.concatenate([[0], np.cumsum(n64 * t64)])
         self._nn_off = np.concatenate([[0], np.cumsum(n64 * n64)])
@@ -147,7 +155,8 @@ class Batch(object):
 
     def close(self):
         if getattr(self, '_b', None):
-            self._lib.pcl_batch_destroy(self._b)
+            if getattr(self.eng, '_ctx', None):       # the context frees its batches when it closes
+                self._lib.pcl_batch_destroy(self._b)
             self._b = None
 
     def __del__(self):

@@ -108,12 +108,17 @@ def test_score_zero_weight_and_padding(eng):
 
 
 def test_dimension_mismatch_raises(eng):
-    """DataDimensionError of the reference (Clustering.py:749-751) -> PCL_ERR_INVALID."""
+    """DataDimensionError of the reference (raised by GMM.point, Clustering.py:749-751) -> PCL_ERR_INVALID
+    from the scoring call."""
     from poccala_amd import PoccalaHipError
     rng = np.random.default_rng(0)
-    eng.load_model(rng.standard_normal((3, 4, 13)), np.ones((3, 4, 13)), np.ones((3, 4)) / 4)
-    with pytest.raises(PoccalaHipError):
-        eng.load_frames(rng.standard_normal((10, 12)))
+    eng.load_model(rng.standard_normal((1, 4, 13)), np.ones((1, 4, 13)), np.ones((1, 4)) / 4)
+    eng.load_frames(rng.standard_normal((10, 12)))
+    b = eng.batch([3], [10], [0])
+    b.set_states([np.array([-1, 0, -2], dtype=np.int32)])
+    with pytest.raises(PoccalaHipError, match='dimension'):
+        b.score()
+    b.close()
     eng.load_frames(rng.standard_normal((10, 13)))
 
 

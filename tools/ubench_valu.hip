@@ -10,7 +10,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #define ITERS 4096
 
 template <int MODE>
-__global__ void k(float *out, float a, float b) {
+__global__ void k(float *out, float a, float b, unsigned long long *clk = nullptr) {
+    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
     float acc[16];
     float2v acc2[8];
 #pragma unroll
@@ -34,6 +35,30 @@ __global__ void k(float *out, float a, float b) {
         } else if (MODE == 3) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(acc[i]));
+        } else if (MODE == 5) {
+            // the scoring kernel's mix: y = x*S.lo + S.hi (sgpr pair) ; q = y*y + q, 8 independent chains
+            float2v y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(y[i]) : "v"(acc2[i]), "s"(ab));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc2[i]) : "v"(y[i]));
+        } else if (MODE == 6) {
+            // same mix, parameters in a VGPR pair (LDS-broadcast form)
+            float2v y[8];
+            float2v abv = {a, b};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(y[i]) : "v"(acc2[i]), "v"(abv));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc2[i]) : "v"(y[i]));
+        } else if (MODE == 7) {
+            // same mix with plain v_fma_f32 (what the compiler emits for the LDS kernel)
+            float y[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y[i]) : "v"(acc[i]), "v"(a), "v"(b));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(acc[i]) : "v"(y[i]));
         } else if (MODE == 4) {
             // v_fma_f32 with one SGPR operand
 #pragma unroll
@@ -41,6 +66,10 @@ __global__ void k(float *out, float a, float b) {
         }
     }
     float s = 0;
+    if (clk && threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i];
 #pragma unroll
@@ -59,7 +88,9 @@ void run(const char *name, int waves_per_simd, double flop_per_lane_iter, float 
     k<MODE><<<grid, block>>>(out, 0.999f, 1e-3f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) k<MODE><<<grid, block>>>(out, 0.999f, 1e-3f);
+    static unsigned long long *clk = nullptr;
+    if (!clk) hipMalloc(&clk, 2 * 4096 * sizeof(unsigned long long));
+    for (int r = 0; r < 5; ++r) k<MODE><<<grid, block>>>(out, 0.999f, 1e-3f, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -67,9 +98,13 @@ void run(const char *name, int waves_per_simd, double flop_per_lane_iter, float 
     ms /= 5;
     double lanes = (double)grid.x * 256;
     double tf = lanes * ITERS * flop_per_lane_iter / (ms * 1e-3) / 1e12;
-    double instr_per_clk_simd = (double)ITERS * (MODE == 1 || MODE == 2 ? 8 : 16) * waves_per_simd / (ms * 1e-3 * 2.4e9);
-    printf("%-34s waves/SIMD=%d  %.3f ms  %.1f TFLOP/s  wave-instr/clk/SIMD(@2.4GHz)=%.3f\n", name, waves_per_simd, ms, tf,
-           instr_per_clk_simd);
+    unsigned long long h[2];
+    hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+    double ghz = (double)h[0] / ((double)h[1] * 10.0);   // s_memrealtime ticks at 100 MHz
+    int ninstr = (MODE == 1 || MODE == 2) ? 8 : (MODE == 5 || MODE == 6) ? 16 : (MODE == 7) ? 32 : 16;
+    double instr_per_clk_simd = (double)ITERS * ninstr * waves_per_simd / (ms * 1e-3 * ghz * 1e9);
+    printf("%-36s waves/SIMD=%d  %.3f ms  %6.1f TFLOP/s  clock %.2f GHz  wave-instr/clk/SIMD=%.3f\n", name, waves_per_simd, ms, tf,
+           ghz, instr_per_clk_simd);
 }
 
 int main() {
@@ -92,6 +127,9 @@ int main() {
         run<1>("v_pk_fma_f32 (vgpr pairs)", w, 8 * 4, out);
         run<2>("v_pk_fma_f32 (sgpr pair, op_sel)", w, 8 * 4, out);
         run<3>("v_exp_f32", w, 16, out);
+        run<5>("mix pk: y=x*S+S (sgpr) ; q+=y*y", w, 16 * 4, out);
+        run<6>("mix pk: y=x*P+P (vgpr) ; q+=y*y", w, 16 * 4, out);
+        run<7>("mix v_fma: y=x*s+c ; q+=y*y", w, 32 * 2, out);
     }
     return 0;
 }
