@@ -116,6 +116,10 @@ int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state);
  * == LHMM(probmat=[B]) (LHMM.py:75) and the `prob` argument of LHMM.viterbi (LHMM.py:547). */
 int pcl_batch_set_emissions(pcl_batch *b, const double *B);
 
+/* Posteriors given by the caller (ragged (N_u,T_u) row-major f64, ln gamma_t(i)) instead of computed by
+ * pcl_batch_forward_backward == the l_value argument of Clustering.GMM.update_acc (Clustering.py:653). */
+int pcl_batch_set_posteriors(pcl_batch *b, const double *lgamma);
+
 /* A1+A4+A5+A6: fill every row of every emission matrix:  ln b_j(o_t) = LSE_m[ln w_m + N(o_t; mu_m, var_m)]
  * == LHMM.cal_observation_pro (LHMM.py:163-187) -> Clustering.GMM.point (Clustering.py:740-767)
  *    -> util.gaussian_function (util.py:20-31), batched state-major over the whole batch. */

@@ -1,0 +1,206 @@
+"""Drop-in for the hot-path part of AcousticModel/AcousticModel.py.
+
+Mirrored (starred): `embedded` :957-1014, `viterbi` :1016-1027, `discriminate`
+:937-955, `VirtualState` :1029-1043, plus `init_unit` :164-226 / `init_parameter` :228-240 so that a
+per-utterance E-step or alignment can be written exactly as the reference's workers write it
+(`multi_embedded_training_1` :884-916, `multi_process_data` :723-768).  Batched equivalents that keep
+everything on the GPU are `estep_batch` / `align_batch`.  Orchestration (Pool fan-out, file walking,
+flat start, audio) is out of scope.
+"""
+import os
+
+import numpy as np
+
+from ..Exceptions import NullLog
+from .._lib import PCL_F32, PCL_F64
+from ..engine import make_sentence_batch
+from ..runtime import default_engine
+from ..StatisticalModel.Clustering import Clustering
+from ..StatisticalModel.DataInitialization import DataInitialization
+from ..StatisticalModel.LHMM import LHMM
+from ..StatisticalModel.util import matrix_log_sum_exp
+
+
+class AcousticModel(DataInitialization):
+    def __init__(self, log=None, unit_type='XIF_tone', mode=0, processes=None, job_id=0, console=True, state_num=5,
+                 mix_level=1, dct_num=13, delta_1=True, delta_2=True, parameters_path=None):
+        super().__init__()
+        self.log = log if log is not None else NullLog()
+        self.__unit_type = unit_type
+        self.__state_num = state_num
+        self.__mix_level = mix_level
+        self.__vector_size = dct_num * (3 if delta_2 else 2 if delta_1 else 1)     # AcousticModel.py:84-88
+        self.__address = parameters_path or os.environ.get('parameters_file_path', '.')
+        self.__loaded_units = []
+        self.processes = processes or 1
+
+    loaded_units = property(lambda self: self.__loaded_units)
+    statenum = property(lambda self: self.__state_num)
+
+    def load_unit(self, unit_file):
+        """Unit inventory file: line 1 description, then comma-separated units (AcousticModel.py:151-161)."""
+        with open(unit_file) as f:
+            f.readline()
+            for line in f:
+                self.__loaded_units.extend(u for u in line.strip('\n').split(',') if u)
+
+    # ------------------------------------------------------------------ unit HMMs
+    def init_unit(self, unit, new_log=True, fix_code=0):
+        """5-state left-right unit HMM: entry / S-2 GMM states / exit, flat-start transitions
+        (AcousticModel.py:164-226)."""
+        s = self.__state_num
+        states = {i: unit for i in range(s)}
+        transmat = np.zeros((s, s))
+        transmat[0][1] = 1.
+        for j in range(1, s - 1):
+            transmat[j][j] = 0.5
+            transmat[j][j + 1] = 0.5
+        gmm = [Clustering.GMM(self.log, dimension=self.__vector_size, mix_level=self.__mix_level, gmm_id=k)
+               for k in range(s - 2)]
+        prof = [AcousticModel.VirtualState(1.)] + gmm + [AcousticModel.VirtualState(0.)]
+        return LHMM(states, s, self.log, transmat=transmat, profunc=prof, fix_code=fix_code)
+
+    def unit_path(self, unit):
+        return '%s/%s/%s' % (self.__address, self.__unit_type, unit)
+
+    def init_parameter(self, unit, hmm):
+        hmm.init_parameter(self.unit_path(unit))
+        for i in range(1, self.__state_num - 1):
+            hmm.profunction[i].init_parameter(self.unit_path(unit))
+
+    def save_parameter(self, unit, hmm):
+        os.makedirs(self.unit_path(unit), exist_ok=True)
+        hmm.save_parameter(self.unit_path(unit))
+        for i in range(1, self.__state_num - 1):
+            hmm.profunction[i].save_parameter(self.unit_path(unit))
+
+    def save_acc(self, unit, hmm):
+        os.makedirs(self.unit_path(unit), exist_ok=True)
+        hmm.save_acc(self.unit_path(unit))
+        for i in range(1, self.__state_num - 1):
+            hmm.profunction[i].save_acc(self.unit_path(unit))
+
+    # ------------------------------------------------------------------ A7 embedded (AcousticModel.py:957-1014)
+    def embedded(self, label, hmm_list, data_index, alter=15):
+        s = self.__state_num
+        e = s - 2
+        n = e * len(hmm_list) + 2
+
+        def embedded_states():
+            names = [label[0]]
+            for u in label:
+                names.extend([u] * e)
+            names.append(label[len(label) - 1])
+            return dict(enumerate(names))
+
+        def embedded_transmat():
+            a = np.zeros((n, n))
+            a[:s - 1, :s] = hmm_list[0].transmat[:-1]
+            for i in range(len(label)):
+                lo = i * e + 1
+                a[lo:lo + e, lo - 1:lo - 1 + s] = hmm_list[i].transmat[1:-1]
+            return a
+
+        def embedded_prob():
+            rows = [hmm_list[0].B_p[data_index][0:-1]]
+            for i in range(1, len(label)):
+                rows.append(hmm_list[i].B_p[data_index][1:-1, :])
+            rows.append(hmm_list[len(label) - 1].B_p[data_index][-1:, :])
+            return np.concatenate(rows, axis=0)
+
+        def embedded_pi():
+            return np.ones((n,)) / n
+
+        funcs = [embedded_states, embedded_transmat, embedded_prob, embedded_pi]
+        return [funcs[k]() for k in range(4) if 2 ** (3 - k) & alter]
+
+    # ------------------------------------------------------------------ A14 wrappers
+    def viterbi(self, complex_states, complex_transmat, complex_prob, complex_pi):
+        return LHMM.viterbi(self.log, complex_states, complex_transmat, complex_prob, complex_pi, convert=True,
+                            show_mark_state=True)
+
+    @staticmethod
+    def discriminate(unit, sequence):
+        """Frame indices labelled `unit`, split into contiguous runs (AcousticModel.py:937-955)."""
+        loc = np.where(np.asarray(sequence) == unit)[0]
+        if len(loc) == 0:
+            return []
+        return np.split(loc, np.where(np.diff(loc) != 1)[0] + 1)
+
+    class VirtualState(object):
+        """Constant-score pdf of the non-emitting entry/exit states (AcousticModel.py:1029-1043)."""
+
+        def __init__(self, p=0.):
+            self.__p = p
+
+        def point(self, x, log=False, standard=False, record=False):
+            if log:
+                with np.errstate(divide='ignore'):
+                    return np.log(self.__p)
+            return self.__p
+
+    # ------------------------------------------------------------------ batched, GPU-resident equivalents
+    def _model_arrays(self, unit_hmms):
+        units = sorted(unit_hmms)
+        idx = {u: i for i, u in enumerate(units)}
+        arrs = [unit_hmms[u].profunction[1 + k].model_arrays() for u in units for k in range(self.__state_num - 2)]
+        trans = [np.asarray(unit_hmms[u].transmat, dtype=np.float64) for u in units]
+        return units, idx, (np.stack([a[0] for a in arrs]), np.stack([a[1] for a in arrs]), np.stack([a[2] for a in arrs])), trans
+
+    def _sentence_batch(self, labels, data_list, unit_hmms, engine):
+        units, idx, (mean, var, w), trans = self._model_arrays(unit_hmms)
+        engine.load_model(mean, var, w)
+        lens = np.array([len(d) for d in data_list], dtype=np.int32)
+        begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+        engine.load_frames(np.concatenate([np.asarray(d) for d in data_list], axis=0))
+        unit_ids = [np.array([idx[u] for u in lab]) for lab in labels]
+        b, n = make_sentence_batch(engine, unit_ids, lens, begin, trans, self.__state_num)
+        return b, n, units, idx
+
+    def align_batch(self, labels, data_list, unit_hmms, precision=PCL_F64, engine=None):
+        """Forced alignment of many utterances at once (call stack C, AcousticModel.py:723-768):
+        returns [(point, unit-name sequence)] like AcousticModel.viterbi does per utterance."""
+        engine = engine or default_engine()
+        b, n, units, idx = self._sentence_batch(labels, data_list, unit_hmms, engine)
+        b.score(precision)
+        b.viterbi()
+        pts, paths = b.get('point'), b.get('path')
+        b.close()
+        e = self.__state_num - 2
+        out = []
+        for u, lab in enumerate(labels):
+            names = np.array([lab[0]] + [x for x in lab for _ in range(e)] + [lab[-1]])
+            out.append((float(pts[u]), names[paths[u]]))
+        return out
+
+    def estep_batch(self, labels, data_list, unit_hmms, fix_code=0, precision=PCL_F32, engine=None):
+        """E-step of many utterances at once (call stack B, AcousticModel.py:884-916).  Returns
+        (stats, hmm_acc): `stats` = linear-domain GMM statistics per state (engine.stats_download,
+        states ordered unit-major over sorted(unit_hmms)); `hmm_acc[unit]` = (ksai_acc (S-2,S),
+        gamma_acc (S-2,)) log-domain, merged over every occurrence as LHMM.add_acc does."""
+        engine = engine or default_engine()
+        s = self.__state_num
+        e = s - 2
+        b, n, units, idx = self._sentence_batch(labels, data_list, unit_hmms, engine)
+        b.score(precision)
+        b.forward_backward(fix_pi=bool(fix_code & 1))
+        stats = None
+        if not fix_code & 2:
+            engine.stats_zero()
+            b.accumulate(precision)
+            stats = engine.stats_download()
+        hmm_acc = {}
+        if not fix_code & 4:
+            ks, ga = b.get('ksai'), b.get('gamma')
+            parts = {u: ([], []) for u in units}
+            for uu, lab in enumerate(labels):
+                kv, gv = ks[uu][1:-1, :], ga[uu][1:-1]
+                for pos, unit in enumerate(lab):
+                    parts[unit][0].append(kv[pos * e:(pos + 1) * e, pos * e:pos * e + s])
+                    parts[unit][1].append(gv[pos * e:(pos + 1) * e].reshape(1, -1))
+            for unit, (kl, gl) in parts.items():
+                if kl:
+                    hmm_acc[unit] = (matrix_log_sum_exp(kl, axis_x=e), matrix_log_sum_exp(gl, axis_x=1).reshape(-1))
+        logp = b.get('logp')
+        b.close()
+        return stats, hmm_acc, logp

@@ -33,6 +33,7 @@ PROTOTYPES = {
     'pcl_batch_set_transitions': (_i, [_vp, _vp, _vp]),
     'pcl_batch_set_states': (_i, [_vp, _vp]),
     'pcl_batch_set_emissions': (_i, [_vp, _vp]),
+    'pcl_batch_set_posteriors': (_i, [_vp, _vp]),
     'pcl_batch_score': (_i, [_vp, _i]),
     'pcl_batch_forward_backward': (_i, [_vp, _i, _d]),
     'pcl_batch_viterbi': (_i, [_vp, _i]),

@@ -477,6 +477,21 @@ int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
     return PCL_OK;
 }
 
+int pcl_batch_set_posteriors(pcl_batch *b, const double *lgamma) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!lgamma) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_posteriors: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TRY(ensure_tmp(b));
+    if (!b->lgam) TRY(dev_alloc(ctx, &b->lgam, (size_t)b->sumNT));
+    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpyAsync(b->tmp, lgamma, (size_t)b->sumNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TRY(pcl_launch_transpose(ctx, b, b->tmp, b->lgam, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    b->have_post = true;
+    return PCL_OK;
+}
+
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
     const int tf = pcl_score_tile_frames(ctx->D, precision);
@@ -522,7 +537,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
     if (!b->alpha) {
         TRY(dev_alloc(ctx, &b->alpha, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->beta, (size_t)b->sumNT));
-        TRY(dev_alloc(ctx, &b->lgam, (size_t)b->sumNT));
+        if (!b->lgam) TRY(dev_alloc(ctx, &b->lgam, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->pi_out, (size_t)b->sumN));
         TRY(dev_alloc(ctx, &b->gamma_out, (size_t)b->sumN));
         TRY(dev_alloc(ctx, &b->ksai, (size_t)b->sumNN));
@@ -532,6 +547,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
     }
     TRY(pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold));
     b->have_fb = true;
+    b->have_post = true;
     return PCL_OK;
 }
 
@@ -607,7 +623,8 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
     if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate: precision %d", precision);
-    if (!b->have_fb) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: run pcl_batch_forward_backward first");
+    if (!b->have_post) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: run pcl_batch_forward_backward (or set_posteriors) first");
+    if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no emissions");
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return pcl_launch_accumulate(ctx, b, precision);

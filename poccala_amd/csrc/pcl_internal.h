@@ -78,7 +78,7 @@ struct pcl_batch {
     long long sumNT = 0, sumN = 0, sumT = 0, sumNN = 0;
     std::vector<UttDesc> utt;  // host copy
     std::vector<int32_t> row_state;
-    bool have_trans = false, have_states = false, have_B = false, have_fb = false, have_vit = false;
+    bool have_trans = false, have_states = false, have_B = false, have_fb = false, have_vit = false, have_post = false;
     int max_outdeg = 0, max_indeg = 0;
     long long nnz = 0;
     // device

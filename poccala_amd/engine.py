@@ -195,6 +195,11 @@ class Batch(object):
         b = self._ragged(B, lambda u: (self.N[u], self.T[u]))
         self._check(self._lib.pcl_batch_set_emissions(self._b, ptr(b)))
 
+    def set_posteriors(self, lgamma):
+        """ln gamma_t(i) per utterance (N,T), for accumulate() without a forward-backward on this batch."""
+        g = self._ragged(lgamma, lambda u: (self.N[u], self.T[u]))
+        self._check(self._lib.pcl_batch_set_posteriors(self._b, ptr(g)))
+
     # ------------------------------------------------------------------ kernels
     def score(self, precision=PCL_F32):
         self._check(self._lib.pcl_batch_score(self._b, int(precision)))

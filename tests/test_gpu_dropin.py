@@ -1,0 +1,182 @@
+"""The drop-in classes (poccala_amd.StatisticalModel / poccala_amd.AcousticModel) driven exactly the way
+the reference's worker drives its own classes (multi_embedded_training_1, AcousticModel.py:884-916), and
+compared with what the reference produced for the same inputs (golden G4..G9)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+S = 5
+CASES = ['G6_small_fix0', 'G6_small_fix1', 'G6_small_fix2', 'G6_small_fix3', 'G6_small_fix4', 'G6_small_fix6',
+         'G8_floor', 'G6_n62_fix0']
+
+
+class RecLog(object):
+    def __init__(self):
+        self.msgs = []
+
+    def note(self, content, cls='i', show_console=True):
+        self.msgs.append((cls, content))
+
+
+def fin_close(got, ref, rtol, atol=0.0):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=rtol, atol=atol)
+
+
+def build_units(g):
+    """Unit HMMs from the fixture, one instance per label position (as init_unit + init_parameter do)."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    from poccala_amd.StatisticalModel.LHMM import LHMM
+    names = [str(u) for u in g['unit_names']]
+    label = [str(u) for u in g['label']]
+    hmm_list = []
+    for u in label:
+        ui = names.index(u)
+        gmms = []
+        for k in range(S - 2):
+            var = g['var_%d_%d' % (ui, k)]
+            cov = np.array([np.diag(v) for v in var])                       # (M,D,D) as the reference stores it
+            gmms.append(Clustering.GMM(RecLog(), dimension=var.shape[1], mix_level=var.shape[0],
+                                       alpha=g['w_%d_%d' % (ui, k)].copy(), mean=g['mean_%d_%d' % (ui, k)].copy(),
+                                       covariance=cov, gmm_id=k))
+        prof = [AcousticModel.VirtualState(1.)] + gmms + [AcousticModel.VirtualState(0.)]
+        hmm_list.append(LHMM({i: u for i in range(S)}, S, RecLog(), transmat=g['trans_%d' % ui].copy(), profunc=prof))
+    return label, hmm_list
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_worker_flow_matches_reference(golden, case):
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd.StatisticalModel.LHMM import LHMM
+    g = golden(case)
+    fix = int(g['fix_code'])
+    x = g['x']
+    t = len(x)
+    label, hmm_list = build_units(g)
+    am = AcousticModel(RecLog(), 'XIF_tone', state_num=S)
+    # --- the reference worker, line for line in meaning (AcousticModel.py:897-910)
+    for hmm in hmm_list:
+        hmm.cal_observation_pro([x], [t])
+        hmm.clear_data()
+    states, A, B, pi = am.embedded(label, hmm_list, 0, 15)
+    fin_close(B, g['emb_B'], rtol=1e-12)
+    np.testing.assert_allclose(A, g['emb_A'], rtol=0)
+    assert [states[i] for i in range(len(states))] == [str(s) for s in g['emb_states']]
+    # alignment (AcousticModel.py:750)
+    point, seq = am.viterbi(states, A, B, pi)
+    assert np.array_equal(np.asarray(seq).astype(str), g['vit_path_conv'].astype(str))
+    np.testing.assert_allclose(point, float(g['vit_point_conv']), rtol=1e-12)
+    for u in set(label):
+        runs = AcousticModel.discriminate(u, seq)
+        assert len(runs) == int(g['disc_%s_n' % u])
+        for ri, r in enumerate(runs):
+            assert np.array_equal(r, g['disc_%s_%d' % (u, ri)])
+    # E-step (AcousticModel.py:906-910)
+    elog = RecLog()
+    embed = LHMM(states, S, elog, transmat=A, probmat=[B], pi=pi, hmm_list=hmm_list, fix_code=fix)
+    embed.add_data([x])
+    embed.add_T([t])
+    embed.baulm_welch(show_q=False)
+    assert embed.n_pass == int(g['bw_n_pass'])
+    np.testing.assert_allclose(embed.q_trace[1:], g['bw_q_trace'][1:], atol=2e-6)
+    np.testing.assert_allclose(embed.pi, g['bw_pi'], rtol=1e-9, atol=1e-300)
+    for pos, h in enumerate(hmm_list):
+        fin_close(h.ksai_acc, g['ksai_acc_%d' % pos], rtol=1e-10)
+        fin_close(h.gamma_acc, g['gamma_acc_%d' % pos], rtol=1e-10)
+        for k in range(S - 2):
+            gm = h.profunction[1 + k]
+            fin_close(gm.acc, g['acc_%d_%d' % (pos, k)], rtol=1e-8)
+            fin_close(np.float64(gm.alpha_acc), g['alpha_acc_%d_%d' % (pos, k)], rtol=1e-10)
+            fin_close(gm.mean_acc, g['mean_acc_%d_%d' % (pos, k)], rtol=1e-8)
+            fin_close(np.array(gm._GMM__covariance_acc), g['cov_acc_%d_%d' % (pos, k)], rtol=1e-8)
+    # M-step (multi_embedded_training_2 -> LHMM.update_param, AcousticModel.py:918-935)
+    for pos, h in enumerate(hmm_list):
+        h.fix_code = fix
+        h.update_param(c_covariance=float(g['c_covariance']))
+        np.testing.assert_allclose(h.transmat, g['new_trans_%d' % pos], rtol=1e-9, atol=1e-300)
+        for k in range(S - 2):
+            gm = h.profunction[1 + k]
+            np.testing.assert_allclose(gm.alpha, g['new_w_%d_%d' % (pos, k)], rtol=1e-8)
+            np.testing.assert_allclose(gm.mean, g['new_mean_%d_%d' % (pos, k)], rtol=1e-6, atol=1e-8)
+            got_var = np.array([np.diagonal(c) for c in gm.covariance])
+            np.testing.assert_allclose(got_var, g['new_var_%d_%d' % (pos, k)], rtol=1e-7)
+
+
+def test_model_tree_round_trip_matches_reference_layout(golden, tmp_path):
+    """T3 / G9: the directory tree written by save_parameter / save_acc has the reference's files, dtypes
+    and shapes, and loads back."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    g = golden('G6_small_fix0')
+    label, hmm_list = build_units(g)
+    x = g['x']
+    am = AcousticModel(RecLog(), 'XIF_tone', state_num=S, mix_level=4, parameters_path=str(tmp_path))
+    am.save_parameter('b', hmm_list[0])
+    am.save_acc('b', hmm_list[0])
+    listing = []
+    root = am.unit_path('b')
+    for r, dirs, files in os.walk(root):
+        dirs.sort()
+        for f in sorted(files):
+            rel = os.path.relpath(os.path.join(r, f), root)
+            if f.endswith('.npy'):
+                arr = np.load(os.path.join(r, f))
+                parts = rel.rsplit('_', 1)
+                if parts[-1][:-4].isdigit():
+                    rel = parts[0] + '_<ts>.npy'
+                listing.append('%s|%s|%s' % (rel, arr.dtype, 'x'.join(map(str, arr.shape))))
+    ref = [s for s in (str(v) for v in golden('G9_layout')['listing']) if '|text|' not in s]
+    assert sorted(listing) == sorted(ref)
+    fresh = am.init_unit('b')
+    am.init_parameter('b', fresh)
+    np.testing.assert_array_equal(fresh.transmat, hmm_list[0].transmat)
+    np.testing.assert_array_equal(fresh.profunction[2].mean, hmm_list[0].profunction[2].mean)
+    fresh.cal_observation_pro([x], [len(x)])
+    hmm_list[0].cal_observation_pro([x], [len(x)])
+    fin_close(fresh.B_p[0], hmm_list[0].B_p[0], rtol=0)
+
+
+def test_gmm_point_single_frame_and_dimension_error(golden):
+    from poccala_amd.Exceptions import DataDimensionError
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    from poccala_amd.StatisticalModel.util import gaussian_function
+    g = golden('G2_gmm_point')
+    key = '8_39'
+    gm = Clustering.GMM(RecLog(), dimension=39, mix_level=8, alpha=g['w_' + key], mean=g['mean_' + key],
+                        covariance=np.array([np.diag(v) for v in g['var_' + key]]))
+    for t in (0, 5):
+        np.testing.assert_allclose(gm.point(g['x_' + key][t], log=True, record=True), g['out_' + key][t], rtol=1e-12)
+    with pytest.raises(DataDimensionError):
+        gm.point(g['x_' + key][0][:38], log=True)
+    g1 = golden('G1_util')
+    out = gaussian_function(g1['gauss_y_39'][2], g1['gauss_mean_39'][2], np.diag(g1['gauss_var_39'][2]), 39, log=True)
+    np.testing.assert_allclose(out, g1['gauss_out_39'][2], rtol=1e-12)
+
+
+def test_batched_estep_equals_per_utterance_dropin(golden):
+    """AcousticModel.estep_batch (everything resident on the GPU) gives the statistics that the
+    per-utterance drop-in flow accumulates."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd import PCL_F64
+    g = golden('G6_small_fix0')
+    label, hmm_list = build_units(g)
+    am = AcousticModel(RecLog(), 'XIF_tone', state_num=S, mix_level=4)
+    unit_hmms = {u: hmm_list[label.index(u)] for u in set(label)}
+    stats, hmm_acc, logp = am.estep_batch([label], [g['x']], unit_hmms, fix_code=0, precision=PCL_F64)
+    np.testing.assert_allclose(logp[0], float(g['bw_logp']), rtol=1e-10)
+    units = sorted(unit_hmms)
+    for unit in units:
+        pos_list = [p for p, u in enumerate(label) if u == unit]
+        ref_k = np.logaddexp.reduce([g['ksai_acc_%d' % p] for p in pos_list])
+        fin_close(hmm_acc[unit][0], ref_k, rtol=1e-9)
+        for k in range(S - 2):
+            j = units.index(unit) * (S - 2) + k
+            ref = sum(np.exp(g['acc_%d_%d' % (p, k)]) for p in pos_list)
+            np.testing.assert_allclose(stats['acc'][j], ref, rtol=1e-8)
+            refm = sum(np.exp(g['mean_acc_%d_%d' % (p, k)]) for p in pos_list)
+            np.testing.assert_allclose(stats['mean_acc'][j], refm, rtol=1e-8)
