@@ -13,8 +13,10 @@ belongs to the accumulate stage, measured separately under "extra").
 
 Inputs (frames, model, batch descriptors) are resident in HBM before the timed region.  Timing:
 barrier + device sync on both sides of exactly K steps, MAX over ranks; rank 0 prints ONE JSON line.
-Multi-GPU: one process per GPU (torch.distributed.run), torch.distributed (gloo) is used only for the
-barrier / max / unique-id broadcast; the GPU work goes through libpoccala_hip.so and RCCL.
+Multi-GPU: one process per GPU (launched by torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from
+the env).  The barrier / max / RCCL-id broadcast go over a small TCP control plane
+(poccala_amd.distributed.Control) so that the GPU processes never import torch, whose wheel bundles a second
+HIP runtime; the GPU work goes through libpoccala_hip.so and RCCL.
 """
 import argparse
 import json
@@ -130,20 +132,17 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
         args.gpus = world
 
-    # The HIP library first (so /opt/rocm's runtime is the one in the process), torch (gloo) second.
     from poccala_amd import Engine, PCL_F32, PCL_F64, synth
     from poccala_amd.engine import make_sentence_batch
     eng = Engine(local)
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+    # control plane: a few tiny host-side exchanges over TCP (poccala_amd.distributed.Control), no torch in
+    # the GPU processes; the statistics themselves travel over RCCL inside the library.
+    from poccala_amd.distributed import Control
+    use_dist = world > 1 or bool(os.environ.get('POCCALA_FORCE_DIST'))   # FORCE: exercise RCCL at world 1
+    ctl = Control(rank, world)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        ctl.barrier()
 
     P = PCL_F32 if args.precision == 'f32' else PCL_F64
     cfg = dict(synth.CONFIGS[args.workload])
@@ -156,11 +155,8 @@ def main():
     eng.load_model(mean, var, w)
     eng.load_frames(frames)
     batch, n_states = make_sentence_batch(eng, labels, lens, begin, trans)
-    if world > 1:
-        import torch
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
+    if use_dist:
+        eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
     t_setup = time.perf_counter() - t_setup
 
     def step():
@@ -181,11 +177,7 @@ def main():
     elapsed = time.perf_counter() - t0
     score_ms, score_n = eng.kernel_time('score')
     fb_ms, fb_n = eng.kernel_time('fb')
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = ctl.allreduce_max(elapsed)
 
     frames_per_rank = int(lens.sum())
     total_frames = frames_per_rank * world
@@ -267,9 +259,9 @@ def main():
             out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value']}
         print(json.dumps(out))
     batch.close()
-    if world > 1:
+    if use_dist:
         eng._lib.pcl_comm_destroy(eng._ctx)
-        dist.destroy_process_group()
+    ctl.close()
     eng.close()
 
 

@@ -1,0 +1,115 @@
+"""world_size-2 gloo tests (CPU) of the host side of the multi-GPU path: sharding, the log-domain
+all-reduce of the HMM accumulators, and that sharded E-step statistics sum to the unsharded ones.
+The per-rank compute here is the oracle (test infrastructure); on the GPU box the same host code
+drives libpoccala_hip.so and RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from poccala_amd.distributed import shard_range
+
+
+def test_shard_range_partitions_everything():
+    for n in (1, 7, 8, 1024, 8191):
+        for world in (1, 2, 3, 8):
+            got = [shard_range(n, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(got[r][1] == got[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in got]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import poccala_oracle as po
+    from poccala_amd import synth
+    from poccala_amd.distributed import allreduce_logsumexp, allreduce_sum_host, shard_range
+    units, M, D, U, T, L = 3, 4, 5, 6, 30, 2
+    mean, var, w, trans = synth.make_model(units, M, D, seed=5)
+    frames, lens, begin = synth.make_frames(U, T, D, seed=6)
+    labels = synth.make_labels(U, L, units, seed=7)
+    model = {u: dict(trans=trans[u], gmms=[(mean[u * 3 + k], var[u * 3 + k], w[u * 3 + k]) for k in range(3)]) for u in range(units)}
+
+    def stats_for(utts):
+        acc = np.zeros((units * 3, M))
+        ks = np.full((units, 3, 5), -np.inf)
+        for u in utts:
+            x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+            bw, accs, _ = po.estep_utterance(x, list(labels[u]), model)
+            for pos, unit in enumerate(labels[u]):
+                ks[unit] = np.logaddexp(ks[unit], accs[pos].ksai_acc)
+                for k in range(3):
+                    acc[unit * 3 + k] += np.exp(accs[pos].gmm[k]['acc'])
+        return acc, ks
+    lo, hi = shard_range(U, rank, world)
+    acc, ks = stats_for(range(lo, hi))
+    acc_all = allreduce_sum_host(acc, dist)          # stands in for pcl_stats_allreduce (RCCL) on the GPU box
+    ks_all = allreduce_logsumexp(ks, dist)
+    if rank == 0:
+        ref_acc, ref_ks = stats_for(range(U))
+        q.put((np.allclose(acc_all, ref_acc, rtol=1e-12), np.array_equal(np.isneginf(ks_all), np.isneginf(ref_ks)),
+               np.allclose(ks_all[np.isfinite(ref_ks)], ref_ks[np.isfinite(ref_ks)], rtol=1e-12)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_estep_statistics_sum_to_unsharded_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == (True, True, True)
+
+
+def _ctl_worker(rank, world, port, q):
+    from poccala_amd.distributed import Control
+    ctl = Control(rank, world, addr='127.0.0.1', port=port)
+    ctl.barrier()
+    got = ctl.allgather({'r': rank})
+    uid = ctl.broadcast(b'x' * 128 if rank == 0 else None, src=0)
+    mx = ctl.allreduce_max(1.5 + rank)
+    a = np.array([[-np.inf, -3.0 - rank], [2.0 * rank, -np.inf if rank else 0.5]])
+    lse = ctl.allreduce_logsumexp(a)
+    sm = ctl.allreduce_sum(np.ones(3) * (rank + 1))
+    ctl.barrier()
+    ctl.close()
+    if rank == 0:
+        q.put((got, uid, mx, lse, sm))
+
+
+def test_tcp_control_plane_world2():
+    """The torch-free control plane bench.py uses between GPU ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, uid, mx, lse, sm = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [{'r': 0}, {'r': 1}] and uid == b'x' * 128 and mx == 2.5
+    ref = np.array([[-np.inf, np.logaddexp(-3.0, -4.0)], [np.logaddexp(0.0, 2.0), 0.5]])
+    assert np.isneginf(lse[0, 0])
+    np.testing.assert_allclose(lse[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-14)
+    np.testing.assert_allclose(sm, 3.0)
