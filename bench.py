@@ -185,6 +185,9 @@ def main():
 
     # dominant kernel: gmm_score.  Algorithmic FLOP per launch = scored (frame, state) pairs x M x (3D+4)
     # (SURVEY.md section 8d); the emitting rows of an utterance are N-2.
+    score_variant = int(os.environ.get('PCL_SCORE_VARIANT', '3'))
+    score_kernel_name = ('gmm_score_kernel<39,2,32,double>' if P == PCL_F64 else
+                         'gmm_score_mfma_kernel<39,2>' if score_variant == 3 else 'gmm_score_kernel<39,3,64,float>')
     pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
     flop_per_launch = pairs * cfg['M'] * (3 * cfg['D'] + 4)
     score_avg_ms = score_ms / max(score_n, 1)
@@ -195,11 +198,14 @@ def main():
     roofline = dict(bound='mfma', achieved=achieved, peak=FP32_VECTOR_PEAK_TFLOPS, unit='TFLOP/s',
                     frac=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
                     traffic=args.traffic_bytes,
-                    kernel='gmm_score_kernel<39,4,64,float>' if P == PCL_F32 else 'gmm_score_kernel<39,2,32,double>',
+                    kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
-                    note='FP32 VALU kernel, no MFMA by design (diagonal Gaussians are not a dense contraction at f32 '
-                         'accuracy); peak = 157.3 TFLOP/s which is both the FP32 vector and the FP32-input MFMA peak',
+                    note='quadratic form of the diagonal Gaussians on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32: exact f32 '
+                         'FMA chain, no reduced precision), log-sum-exp on the VALU; achieved = ALGORITHMIC flops M(3D+4) per '
+                         '(frame,state) pair / kernel time; the kernel executes 2(2D+2) MFMA flops per Gaussian; peak = 157.3 '
+                         'TFLOP/s dense f32 MFMA (= f32 vector peak)' if score_variant == 3 and P == PCL_F32 else
+                         'FP32 VALU kernel (PCL_SCORE_VARIANT=1) / f64 parity mode; peak = 157.3 TFLOP/s f32',
                     hbm_algorithmic_bytes_per_launch=alg_bytes,
                     hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_n else None,
                     fb_kernel_avg_ms=fb_ms / max(fb_n, 1))

@@ -338,7 +338,7 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision) {
     if (b->n_tiles == 0) return PCL_OK;
     const int D = ctx->D;
     pcl_timer_begin(ctx, "score");
-    static const int variant = getenv("PCL_SCORE_VARIANT") ? atoi(getenv("PCL_SCORE_VARIANT")) : 1;
+    const int variant = ctx->score_variant;
     if (precision == PCL_F32 && variant == 2 && (D == 39 || D == 13)) {
         if (D == 39) launch_score_v2<39>(ctx, b); else launch_score_v2<13>(ctx, b);
     } else if (precision == PCL_F32) {

@@ -3,6 +3,7 @@
 // structure, and launches the kernels in gmm_score.hip / hmm_dp.hip / gmm_accumulate.hip.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -68,6 +69,8 @@ int pcl_init(int device, pcl_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
+    const char *var = getenv("PCL_SCORE_VARIANT");   // kernel A/B: 1 VALU+LDS, 2 VALU+SGPR pk_fma, 3 f32 MFMA (default)
+    ctx->score_variant = var ? atoi(var) : 3;
     *out = ctx;
     return PCL_OK;
 }
@@ -77,6 +80,8 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->params64);
     dev_free(ctx->mean32);
     dev_free(ctx->mean64);
+    dev_free(ctx->pm32);
+    dev_free(ctx->centers32);
     dev_free(ctx->stats);
     ctx->st_acc = ctx->st_alpha = ctx->st_mean = ctx->st_cov = nullptr;
     ctx->J = ctx->M = ctx->Mpad = 0;
@@ -199,6 +204,43 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     HIPCHK(ctx, hipMemcpy(ctx->params64, p64.data(), np * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->mean32, m32.data(), nm * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
+    // ---- MFMA scoring layout (gmm_score_mfma.hip): expansion of the exponent around a per-state centre
+    {
+        const int Mp32 = (M + 31) / 32 * 32, nmt = Mp32 / 32, KS = Dd + 1, KS4 = (KS + 3) / 4;
+        const size_t npm = (size_t)J * nmt * KS4 * 64 * 4;
+        std::vector<float> pm(npm, 0.f), cen((size_t)J * Dd, 0.f);
+        for (int j = 0; j < J; ++j) {
+            std::vector<double> c(Dd, 0.0);
+            for (int m = 0; m < M; ++m)
+                for (int d = 0; d < D; ++d) c[d] += mean[((size_t)j * M + m) * D + d];
+            for (int d = 0; d < D; ++d) {
+                c[d] = (double)(float)(c[d] / M);   // the kernel subtracts the f32 value: expand around exactly that
+                cen[(size_t)j * Dd + d] = (float)c[d];
+            }
+            for (int m = 0; m < Mp32; ++m) {
+                const int mt = m >> 5, cl = m & 31;
+                float *base = &pm[(((size_t)j * nmt + mt) * KS4) * 64 * 4];
+                auto put = [&](int s, int half, double v) { base[((size_t)(s >> 2) * 64 + (half * 32 + cl)) * 4 + (s & 3)] = (float)v; };
+                if (m >= M) {
+                    put(Dd, 0, -INFINITY);   // padded mixture: k' = -inf
+                    continue;
+                }
+                double kq = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    const double vr = var[((size_t)j * M + m) * D + d], dm = mean[((size_t)j * M + m) * D + d] - c[d];
+                    put(d, 0, -LOG2E / (2.0 * vr));
+                    put(d, 1, LOG2E * dm / vr);
+                    kq += dm * dm / (2.0 * vr);
+                }
+                put(Dd, 0, p64[((size_t)j * Mpad + m) * row + 2 * Dd] - LOG2E * kq);
+            }
+        }
+        TRY(dev_alloc(ctx, &ctx->pm32, npm));
+        TRY(dev_alloc(ctx, &ctx->centers32, cen.size()));
+        HIPCHK(ctx, hipMemcpy(ctx->pm32, pm.data(), npm * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->centers32, cen.data(), cen.size() * sizeof(float), hipMemcpyHostToDevice));
+        ctx->Mpad32 = Mp32;
+    }
     ctx->J = J;
     ctx->M = M;
     ctx->Mpad = Mpad;
@@ -494,7 +536,8 @@ int pcl_batch_set_posteriors(pcl_batch *b, const double *lgamma) {
 
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
-    const int tf = pcl_score_tile_frames(ctx->D, precision);
+    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D);
+    const int tf = mfma ? pcl_score_mfma_tile_frames() : pcl_score_tile_frames(ctx->D, precision);
     if (b->d_tiles && b->tile_frames == tf) return PCL_OK;
     std::vector<ScoreTile> tiles;
     for (size_t k = 0; k < b->work_states.size(); ++k) {
@@ -522,7 +565,8 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
-    TRY(pcl_launch_score(ctx, b, precision));
+    if (precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D)) TRY(pcl_launch_score_mfma(ctx, b));
+    else TRY(pcl_launch_score(ctx, b, precision));
     b->have_B = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;

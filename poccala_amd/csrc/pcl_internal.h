@@ -55,6 +55,10 @@ struct pcl_ctx {
     int model_flags = 0;
     float *params32 = nullptr;   // J * Mpad * row : [s_0 c_0 s_1 c_1 ... const2]  (log2 domain)
     double *params64 = nullptr;  // same layout, float64
+    float *pm32 = nullptr;       // MFMA scoring layout: [J][Mpad32/32][KS4][64 lanes][4], see gmm_score_mfma.hip
+    float *centers32 = nullptr;  // J * D per-state expansion centres c_j
+    int Mpad32 = 0;              // M rounded up to a multiple of 32
+    int score_variant = 0;       // 1 = VALU/LDS, 2 = VALU/SGPR pk_fma, 3 = f32 MFMA
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
     double *mean64 = nullptr;
     // frames (device)
@@ -132,3 +136,6 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
 void pcl_accumulate_release(pcl_batch *b);
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
 int pcl_score_tile_frames(int D, int precision);
+int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b);
+int pcl_score_mfma_tile_frames();
+bool pcl_score_mfma_supported(int D);
