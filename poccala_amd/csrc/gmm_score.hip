@@ -66,6 +66,7 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
     const ScoreTile tile = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
     const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
 
     real x[R][D];
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel_v2(const float *__rest
     const ScoreTile tile = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
     const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
     if (tile.vstart + wave * R * 64 >= vend) return;   // whole wave past the end of the state's frames
 

@@ -29,11 +29,20 @@
 namespace {
 
 constexpr int WG = 256;
+#ifndef PCL_MFMA_NT
+#define PCL_MFMA_NT 2      // frame column tiles (32 frames) per wave
+#endif
+#ifndef PCL_MFMA_MINW
+#define PCL_MFMA_MINW 2    // __launch_bounds__ waves per SIMD
+#endif
+#ifndef PCL_MFMA_PIPE
+#define PCL_MFMA_PIPE 0    // 1: log-sum-exp of m-tile i-1 is issued behind the MFMAs of m-tile i
+#endif
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 template <int D, int NT>
-__global__ __launch_bounds__(WG, 2) void gmm_score_mfma_kernel(const float *__restrict__ frames,
+__global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const float *__restrict__ frames,
                                                                const float *__restrict__ pm,
                                                                const float *__restrict__ centers, int n_mtiles,
                                                                const ScoreTile *__restrict__ tiles,
@@ -46,6 +55,7 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_mfma_kernel(const float *__re
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5;
     const int col = lane & 31;
+    if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
     const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
     if (tile.vstart + wave * NT * 32 >= vend) return;   // whole wave past the end of the state's frames
 
@@ -91,6 +101,25 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_mfma_kernel(const float *__re
 #pragma unroll
     for (int q = 0; q < KS4; ++q) a[q] = pa[q * 64];
 
+    auto lse_update = [&](const f16v &t, int c) {
+        float gm = t[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, t[r]);
+        const float nm = __builtin_fmaxf(mx[c], gm);
+        float s = sm[c] * __builtin_amdgcn_exp2f(mx[c] - nm);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(t[r] - nm);
+        sm[c] = s;
+        mx[c] = nm;
+    };
+#if PCL_MFMA_PIPE
+    f16v prev[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[c][r] = -INFINITY;   // contributes exp2(-inf) = 0
+    }
+#endif
     for (int mt = 0; mt < n_mtiles; ++mt) {
         // prefetch the next m-tile's A operand (the last iteration re-reads the current tile)
         const f4v *pn = pa + (size_t)(mt + 1 < n_mtiles ? mt + 1 : mt) * (KS4 * 64);
@@ -111,21 +140,23 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_mfma_kernel(const float *__re
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s >> 2][s & 3], xb[c][s], acc[c], 0, 0, 0);
         }
         // online log-sum-exp over this lane's 16 mixtures of each frame column (log2 domain)
+#if PCL_MFMA_PIPE
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
-            float gm = acc[c][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
-            const float nm = __builtin_fmaxf(mx[c], gm);
-            float s = sm[c] * __builtin_amdgcn_exp2f(mx[c] - nm);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r] - nm);
-            sm[c] = s;
-            mx[c] = nm;
+            lse_update(prev[c], c);
+            prev[c] = acc[c];
         }
+#else
+#pragma unroll
+        for (int c = 0; c < NT; ++c) lse_update(acc[c], c);
+#endif
 #pragma unroll
         for (int q = 0; q < KS4; ++q) a[q] = an[q];
     }
+#if PCL_MFMA_PIPE
+#pragma unroll
+    for (int c = 0; c < NT; ++c) lse_update(prev[c], c);
+#endif
 
     constexpr double LN2 = 0.693147180559945309417232121458;
 #pragma unroll
@@ -142,13 +173,13 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_mfma_kernel(const float *__re
 
 template <int D>
 void launch_t(pcl_ctx *ctx, pcl_batch *b) {
-    hipLaunchKernelGGL((gmm_score_mfma_kernel<D, 2>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, ctx->pm32,
+    hipLaunchKernelGGL((gmm_score_mfma_kernel<D, PCL_MFMA_NT>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, ctx->pm32,
                        ctx->centers32, ctx->Mpad32 / 32, b->d_tiles, b->d_segs, b->Bt);
 }
 
 }  // namespace
 
-int pcl_score_mfma_tile_frames() { return WG / 64 * 2 * 32; }
+int pcl_score_mfma_tile_frames() { return WG / 64 * PCL_MFMA_NT * 32; }
 
 bool pcl_score_mfma_supported(int D) { return D == 39 || D == 13 || D == 26; }
 

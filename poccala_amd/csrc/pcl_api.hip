@@ -539,12 +539,28 @@ static int build_tiles(pcl_batch *b, int precision) {
     const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D);
     const int tf = mfma ? pcl_score_mfma_tile_frames() : pcl_score_tile_frames(ctx->D, precision);
     if (b->d_tiles && b->tile_frames == tf) return PCL_OK;
-    std::vector<ScoreTile> tiles;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, observed,
+    // speed only), so all tiles of one state are placed at block indices with the same residue mod 8:
+    // the state's parameter block is then fetched into ONE XCD's L2 instead of eight.  Shorter queues
+    // are padded with empty tiles (seg_lo == seg_hi), which exit immediately.
+    constexpr int NXCD = 8;
+    std::vector<ScoreTile> queue[NXCD];
+    std::vector<long long> load(NXCD, 0);
     for (size_t k = 0; k < b->work_states.size(); ++k) {
         const int lo = b->state_seg_lo[k], hi = b->state_seg_hi[k];
         const long long tot = (long long)b->segs[hi - 1].vstart + b->segs[hi - 1].len;
-        for (long long v = 0; v < tot; v += tf) tiles.push_back(ScoreTile{b->work_states[k], lo, hi, (int)v});
+        int g = 0;
+        for (int x = 1; x < NXCD; ++x)
+            if (load[x] < load[g]) g = x;          // least-loaded XCD queue
+        for (long long v = 0; v < tot; v += tf) queue[g].push_back(ScoreTile{b->work_states[k], lo, hi, (int)v});
+        load[g] += (tot + tf - 1) / tf;
     }
+    size_t depth = 0;
+    for (int x = 0; x < NXCD; ++x) depth = std::max(depth, queue[x].size());
+    std::vector<ScoreTile> tiles;
+    tiles.reserve(depth * NXCD);
+    for (size_t q = 0; q < depth; ++q)
+        for (int x = 0; x < NXCD; ++x) tiles.push_back(q < queue[x].size() ? queue[x][q] : ScoreTile{0, 0, 0, 0});
     dev_free(b->d_tiles);
     b->n_tiles = (int)tiles.size();
     b->tile_frames = tf;

@@ -1,0 +1,17 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/v
+build() { # name flags
+  (cd poccala_amd/csrc && for f in pcl_api gmm_score gmm_score_mfma hmm_dp gmm_accumulate pcl_comm; do
+     if [ $f = gmm_score_mfma ] || [ ! -f ../../gpurun_out/v/$f.o ]; then hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $2 -c $f.hip -o ../../gpurun_out/v/$f.o 2>/dev/null; fi; done
+   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_out/v/lib_$1.so ../../gpurun_out/v/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib)
+}
+run() { POCCALA_HIP_LIB=$GRAFT_REPO_ROOT/gpurun_out/v/lib_$1.so PCL_SCORE_VARIANT=3 CHECK=1 timeout 120 python tools/score_bench.py 512 2048 50 2>&1 | tail -2 >> gpurun_out/mfma_ab.log; }
+rm -f gpurun_out/mfma_ab.log gpurun_out/v/*
+build base ""; run base
+build nt3 "-DPCL_MFMA_NT=3"; run nt3
+build nt1 "-DPCL_MFMA_NT=1"; run nt1
+build pipe "-DPCL_MFMA_PIPE=1"; run pipe
+build nt3pipe "-DPCL_MFMA_NT=3 -DPCL_MFMA_PIPE=1"; run nt3pipe
+build nt4 "-DPCL_MFMA_NT=4 -DPCL_MFMA_MINW=1"; run nt4
+build minw3 "-DPCL_MFMA_MINW=3"; run minw3
+cat gpurun_out/mfma_ab.log
