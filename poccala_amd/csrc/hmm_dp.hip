@@ -76,7 +76,15 @@ __device__ __forceinline__ double block_lse(double v, Red &red, int &slot) {
 
 // ------------------------------------------------------------------------------------------------
 // Baum-Welch pass loop for one utterance per workgroup.
+//   KREG > 0: every state has at most KREG predecessors and successors (a sentence HMM built by
+//             AcousticModel.embedded has 2): the transition lists and the xi accumulators live in
+//             registers and nothing but the emission / alpha rows is read from memory in the loops.
+//   KREG = 0: general sparse lists in global memory (dense or wide transition matrices).
+// The recursion is a T-long dependent chain with one wave per SIMD at the bench's batch size, so the
+// loops are software pipelined: the emission (and alpha) row of step t+1 is requested before step t
+// is computed.  Backward exchanges  w_j = b_j(o_{t+1}) + beta_{t+1}(j)  through LDS.
 // ------------------------------------------------------------------------------------------------
+template <int KREG>
 __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
                               const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                               const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
@@ -86,6 +94,7 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
                               double *__restrict__ xi_s, double *__restrict__ ksai, double *__restrict__ gamma_out,
                               double *__restrict__ pi_out, double *__restrict__ logp, double *__restrict__ qtrace,
                               int32_t *__restrict__ npass_out, int fix_pi, double threshold) {
+    constexpr int KR = KREG > 0 ? KREG : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Red red;
     const UttDesc d = utts[blockIdx.x];
@@ -103,13 +112,25 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
     double *Bv = beta + d.b_off;
     double *G = lgam + d.b_off;
 
-    // this lane's predecessor (CSC) and successor (CSR) ranges
+    // this lane's predecessor (CSC) and successor (CSR) lists
     int pc0 = 0, pc1 = 0, sr0 = 0, sr1 = 0;
     if (act) {
         pc0 = col_ptr[d.ptr_off + i] + d.nnz_off;
         pc1 = col_ptr[d.ptr_off + i + 1] + d.nnz_off;
         sr0 = row_ptr[d.ptr_off + i] + d.nnz_off;
         sr1 = row_ptr[d.ptr_off + i + 1] + d.nnz_off;
+    }
+    const int npred = pc1 - pc0, nsucc = sr1 - sr0;
+    int pidx[KR], sidx[KR];
+    double pval[KR], sval[KR], xm[KR], xs[KR];
+    if (KREG > 0) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            pidx[k] = (k < npred) ? row_idx[pc0 + k] : 0;
+            pval[k] = (k < npred) ? csc_val[pc0 + k] : -INFINITY;
+            sidx[k] = (k < nsucc) ? col_idx[sr0 + k] : 0;
+            sval[k] = (k < nsucc) ? csr_val[sr0 + k] : -INFINITY;
+        }
     }
     lpi[i] = act ? logpi_in[d.vec_off + i] : -INFINITY;
     // dense xi output starts at -inf (LHMM.py:404: ln 0 entries stay -inf)
@@ -121,25 +142,47 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
     for (;;) {
         // ---------------------------------------------------------------- forward (LHMM.py:335-351)
         double a = -INFINITY;
+        double bcur_t = act ? B[i] : 0.0;                               // emission of step t, prefetched
         if (act) {
-            a = lpi[i] + B[i];
+            a = lpi[i] + bcur_t;
             A_[i] = a;
         }
         vec0[i] = a;
+        double bnext_t = (act && T > 1) ? B[(long long)N + i] : 0.0;
         __syncthreads();
         for (int t = 1; t < T; ++t) {
             const double *prev = (t & 1) ? vec0 : vec1;
             double *cur = (t & 1) ? vec1 : vec0;
+            bcur_t = bnext_t;
+            if (act && t + 1 < T) bnext_t = B[(long long)(t + 1) * N + i];   // in flight during this step
             if (act) {
-                double m = -INFINITY;
-                for (int k = pc0; k < pc1; ++k) m = fmax(m, prev[row_idx[k]] + csc_val[k]);
-                double r = m;
-                if (!isinf(m)) {
-                    double s = 0.0;
-                    for (int k = pc0; k < pc1; ++k) s += exp(prev[row_idx[k]] + csc_val[k] - m);
-                    r = m + log(s);
+                double r;
+                if (KREG > 0) {
+                    double v[KR];
+                    double m = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) {
+                        v[k] = prev[pidx[k]] + pval[k];
+                        m = fmax(m, v[k]);
+                    }
+                    r = m;
+                    if (!isinf(m)) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) s += exp(v[k] - m);   // padded entries: exp(-inf) = 0
+                        r = m + log(s);
+                    }
+                } else {
+                    double m = -INFINITY;
+                    for (int k = pc0; k < pc1; ++k) m = fmax(m, prev[row_idx[k]] + csc_val[k]);
+                    r = m;
+                    if (!isinf(m)) {
+                        double s = 0.0;
+                        for (int k = pc0; k < pc1; ++k) s += exp(prev[row_idx[k]] + csc_val[k] - m);
+                        r = m + log(s);
+                    }
                 }
-                a = r + B[(long long)t * N + i];
+                a = r + bcur_t;
                 A_[(long long)t * N + i] = a;
             }
             cur[i] = a;
@@ -160,59 +203,98 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
         }
 
         // ---------------------------------------------------------------- backward (LHMM.py:353-366)
-        // beta_{T-1} = 0 for every state (quirk Q8)
-        double bcur = 0.0;
+        // beta_{T-1} = 0 for every state (quirk Q8).  The vector exchanged through LDS is
+        //   w_j = b_j(o_{t+1}) + beta_{t+1}(j).
+        double bcur = 0.0;                 // beta_t(i) of the step just computed
         double gm = -INFINITY, gs = 0.0;   // online LSE for gamma_i over t < T-1 (LHMM.py:442-445)
         if (final_pass && act) {
-            for (int k = sr0; k < sr1; ++k) {
-                xi_m[k] = -INFINITY;
-                xi_s[k] = 0.0;
+            if (KREG > 0) {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    xm[k] = -INFINITY;
+                    xs[k] = 0.0;
+                }
+            } else {
+                for (int k = sr0; k < sr1; ++k) {
+                    xi_m[k] = -INFINITY;
+                    xi_s[k] = 0.0;
+                }
             }
             Bv[(long long)(T - 1) * N + i] = 0.0;
             // l[:,T-1] - sum_value[T-1]  (LHMM.py:486-500); sum_value[T-1] == Q
             G[(long long)(T - 1) * N + i] = a - qnew;
         }
+        __syncthreads();   // everyone is done reading the forward vectors
         {
             double *cur = ((T - 1) & 1) ? vec1 : vec0;
-            __syncthreads();   // everyone is done reading the forward vectors
-            cur[i] = act ? 0.0 : -INFINITY;
-            __syncthreads();
+            cur[i] = act ? B[(long long)(T - 1) * N + i] + 0.0 : -INFINITY;   // w at t+1 = T-1
         }
+        double at_next = (final_pass && act && T > 1) ? A_[(long long)(T - 2) * N + i] : 0.0;   // alpha_t, prefetched
+        double b_t = (act && T > 1) ? B[(long long)(T - 2) * N + i] : 0.0;                     // b_i(o_t), for w of the next step
+        __syncthreads();
         for (int t = T - 2; t >= 0; --t) {
             const double *nxt = ((t + 1) & 1) ? vec1 : vec0;
             double *cur = (t & 1) ? vec1 : vec0;
+            const double at = at_next, bt = b_t;
+            if (act && t > 0) {
+                b_t = B[(long long)(t - 1) * N + i];
+                if (final_pass) at_next = A_[(long long)(t - 1) * N + i];
+            }
             double l = -INFINITY;
             if (act) {
-                const double *bn = B + (long long)(t + 1) * N;
-                double m = -INFINITY;
-                for (int k = sr0; k < sr1; ++k) {
-                    const int j = col_idx[k];
-                    m = fmax(m, csr_val[k] + bn[j] + nxt[j]);
-                }
-                double r = m;
-                if (!isinf(m)) {
-                    double s = 0.0;
-                    for (int k = sr0; k < sr1; ++k) {
-                        const int j = col_idx[k];
-                        s += exp(csr_val[k] + bn[j] + nxt[j] - m);
+                double r;
+                if (KREG > 0) {
+                    double v[KR];
+                    double m = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) {
+                        v[k] = sval[k] + nxt[sidx[k]];
+                        m = fmax(m, v[k]);
                     }
-                    r = m + log(s);
+                    r = m;
+                    if (!isinf(m)) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) s += exp(v[k] - m);
+                        r = m + log(s);
+                    }
+                    if (final_pass) {
+                        // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) {
+                            const double x = at + v[k];
+                            if (x > xm[k]) {
+                                xs[k] = xs[k] * exp(xm[k] - x) + 1.0;   // exp(-inf) = 0 on the first hit
+                                xm[k] = x;
+                            } else if (x > -INFINITY) {
+                                xs[k] += exp(x - xm[k]);
+                            }
+                        }
+                    }
+                } else {
+                    double m = -INFINITY;
+                    for (int k = sr0; k < sr1; ++k) m = fmax(m, csr_val[k] + nxt[col_idx[k]]);
+                    r = m;
+                    if (!isinf(m)) {
+                        double s = 0.0;
+                        for (int k = sr0; k < sr1; ++k) s += exp(csr_val[k] + nxt[col_idx[k]] - m);
+                        r = m + log(s);
+                    }
+                    if (final_pass) {
+                        for (int k = sr0; k < sr1; ++k) {
+                            const double x = at + (csr_val[k] + nxt[col_idx[k]]);
+                            const double om = xi_m[k];
+                            if (x > om) {
+                                xi_s[k] = xi_s[k] * exp(om - x) + 1.0;
+                                xi_m[k] = x;
+                            } else if (x > -INFINITY) {
+                                xi_s[k] += exp(x - om);
+                            }
+                        }
+                    }
                 }
                 bcur = r;
                 if (final_pass) {
-                    const double at = A_[(long long)t * N + i];
-                    // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
-                    for (int k = sr0; k < sr1; ++k) {
-                        const int j = col_idx[k];
-                        const double v = ((at + csr_val[k]) + bn[j]) + nxt[j];
-                        const double om = xi_m[k];
-                        if (v > om) {
-                            xi_s[k] = xi_s[k] * exp(om - v) + 1.0;   // exp(-inf) = 0 on first hit
-                            xi_m[k] = v;
-                        } else if (v > -INFINITY) {
-                            xi_s[k] += exp(v - om);
-                        }
-                    }
                     l = at + r;
                     if (l > gm) {
                         gs = gs * exp(gm - l) + 1.0;
@@ -223,7 +305,7 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
                     Bv[(long long)t * N + i] = r;
                 }
             }
-            cur[i] = act ? bcur : -INFINITY;
+            cur[i] = act ? bt + bcur : -INFINITY;            // w_i for step t-1
             if (final_pass) {
                 const double norm = block_lse(l, red, slot);   // sum_value[t] (LHMM.py:488)
                 if (act) G[(long long)t * N + i] = l - norm;
@@ -247,8 +329,14 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
         if (final_pass) {
             if (act) {
                 gamma_out[d.vec_off + i] = (gs > 0.0) ? gm + log(gs) : -INFINITY;
-                for (int k = sr0; k < sr1; ++k)
-                    ksai[d.mat_off + (long long)i * N + col_idx[k]] = (xi_s[k] > 0.0) ? xi_m[k] + log(xi_s[k]) : -INFINITY;
+                if (KREG > 0) {
+#pragma unroll
+                    for (int k = 0; k < KR; ++k)
+                        if (k < nsucc) ksai[d.mat_off + (long long)i * N + sidx[k]] = (xs[k] > 0.0) ? xm[k] + log(xs[k]) : -INFINITY;
+                } else {
+                    for (int k = sr0; k < sr1; ++k)
+                        ksai[d.mat_off + (long long)i * N + col_idx[k]] = (xi_s[k] > 0.0) ? xi_m[k] + log(xi_s[k]) : -INFINITY;
+                }
             }
             if (i == 0) {
                 logp[blockIdx.x] = qnew;
@@ -352,9 +440,14 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);
     const size_t shm = (size_t)3 * NP * sizeof(double);
     pcl_timer_begin(ctx, "fb");
-    hipLaunchKernelGGL(hmm_fb_kernel, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
-                       b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
-                       b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
+    if (b->max_indeg <= 2 && b->max_outdeg <= 2)
+        hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
+                           b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
+                           b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
+    else
+        hipLaunchKernelGGL(hmm_fb_kernel<0>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
+                           b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
+                           b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
     pcl_timer_end(ctx, "fb");
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
