@@ -224,6 +224,159 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA form of the accumulate pass (f32).  Both halves of the E-step statistics are dense contractions:
+//   (1) v[f,m] + cf[f]  = Xe[f,:] . P[:,m]        (the scoring GEMM of gmm_score_mfma.hip, K = 2D+2, with the
+//                                                  per-frame coefficient cf riding in the spare K slot)
+//   (2) S[m,:]         += sum_f g[f,m] Xe[f,:]     g = exp2(v + cf)  -- raw moments about the state centre:
+//                                                  columns [x'^2_d, x'_d | 1] give S2, S1, S0
+// Orientation: MFMA (1) is computed as D1[frame rows][mixture cols], so a lane holds, for ITS mixture
+// column, 16 frame rows per register set; register r of D1, used directly as the A operand of MFMA (2),
+// supplies the k-pair (frame row(r), frame row(r)+4) with the mixture on the lane -- no data movement
+// between the two products.  The frame tile Xe (32 frames x 80 features) is staged once in LDS by the
+// workgroup and read by MFMA (1) frame-major and by MFMA (2) feature-major (stride 97: conflict free).
+// A wave owns one 32-mixture tile of one state: its 40 parameter registers and its 48 moment
+// accumulators stay resident while the workgroup walks the state's frame list.
+// Flush: cov = S2 - 2 d S1 + d^2 S0, mean = S1 + (c + bias) S0 with d = mu - c, in float64.
+// ------------------------------------------------------------------------------------------------
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int AW = 8;        // waves (32-mixture tiles) per workgroup
+constexpr int XSTR = 97;     // LDS row stride of the frame tile (floats)
+
+template <int D>
+__global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
+    const float *__restrict__ frames, const float *__restrict__ pm, const float *__restrict__ centers,
+    const double *__restrict__ means64, int M, int Mpad, int n_mtiles, int n_states, const int *__restrict__ work_states,
+    const int *__restrict__ seg_lo, const int *__restrict__ seg_hi, const long long *__restrict__ off,
+    const ActiveFrame *__restrict__ list, double bias, double *__restrict__ st_acc, double *__restrict__ st_alpha,
+    double *__restrict__ st_mean, double *__restrict__ st_cov) {
+    constexpr int KS = D + 1, KS4 = (KS + 3) / 4;
+    constexpr int NCOL = 2 * D + 1;            // useful moment columns: 2D features + the constant
+    __shared__ __attribute__((aligned(16))) float xe[2][32 * XSTR];
+    __shared__ double red[AW];
+
+    // XCD-aware mapping: the 8 slices of one state sit on block indices with equal residue mod 8
+    const int nslice = (n_mtiles + AW - 1) / AW;
+    const int b = blockIdx.x;
+    int w, slice;
+    if (nslice == 8) {
+        w = (b & 7) + 8 * (b >> 6);
+        slice = (b >> 3) & 7;
+    } else {
+        w = b / nslice;
+        slice = b - w * nslice;
+    }
+    if (w >= n_states) return;
+    const int j = work_states[w];
+    const long long beg = off[seg_lo[w]], end = off[seg_hi[w]];
+    if (beg == end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int mt = slice * AW + wave;
+    const bool live = mt < n_mtiles;
+    const float *cen = centers + (size_t)j * D;
+
+    // parameters of this wave's m-tile: the scoring layout [m-tile][KS4][64][4] (spare slot = 1 carries cf)
+    float pb[KS4 * 4];
+    {
+        const float4 *pa = reinterpret_cast<const float4 *>(pm) + ((size_t)j * n_mtiles + (live ? mt : 0)) * (KS4 * 64) + lane;
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) {
+            const float4 t = pa[q * 64];
+            pb[4 * q] = t.x; pb[4 * q + 1] = t.y; pb[4 * q + 2] = t.z; pb[4 * q + 3] = t.w;
+        }
+    }
+    f16v S[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[ct][r] = 0.f;
+    double galpha = 0.0;
+    constexpr double LOG2E = 1.4426950408889634074;
+
+    auto stage = [&](int buf, long long f0) {
+        const int nf = (int)min(32LL, end - f0);
+        float *x = xe[buf];
+        for (int e = threadIdx.x; e < 32 * D; e += AW * 64) {
+            const int f = e / D, d = e - f * D;
+            float v = 0.f;
+            if (f < nf) v = frames[list[f0 + f].frame * D + d] - cen[d];
+            x[f * XSTR + 2 * d] = v * v;
+            x[f * XSTR + 2 * d + 1] = v;
+        }
+        if (threadIdx.x < 32) {
+            const int f = threadIdx.x;
+            float c = -INFINITY;                          // padding frame: g = exp2(-inf) = 0
+            if (f < nf) {
+                const ActiveFrame a = list[f0 + f];
+                c = (float)(a.coef * LOG2E);
+                if (slice == 0) galpha += exp(a.lg);
+            }
+            x[f * XSTR + 2 * D] = 1.f;
+            x[f * XSTR + 2 * D + 1] = c;
+            for (int k = 2 * D + 2; k < XSTR; ++k) x[f * XSTR + k] = 0.f;
+        }
+    };
+
+    stage(0, beg);
+    __syncthreads();
+    int buf = 0;
+    for (long long f0 = beg; f0 < end; f0 += 32) {
+        if (f0 + 32 < end) stage(buf ^ 1, f0 + 32);      // next tile, other buffer
+        if (live) {
+            const float *x = xe[buf];
+            // (1) D1[frame][mixture] = Xe . P   (log2 domain, + cf)
+            f16v d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[col * XSTR + 2 * s + half], pb[s], d1, 0, 0, 0);
+            // posteriors gamma_t(j,m)   (Clustering.py:660-661)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] = __builtin_amdgcn_exp2f(d1[r]);
+            // (2) S[mixture][feature] += g^T . Xe ; register r of d1 = frames (row(r), row(r)+4)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int fr = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    S[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[r], x[fr * XSTR + ct * 32 + col], S[ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- flush: lane (col) = feature column of tile ct, register r = mixture row
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float s0 = __shfl(S[2][r], (lane & 32) + (2 * D - 64), 64);     // column 2D (the constant) lives in tile 2
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int cidx = ct * 32 + col;
+                const float s1 = __shfl_xor(S[ct][r], 1, 64);                      // odd neighbour: x' column of the same d
+                if (m < M && !(cidx & 1) && cidx < 2 * D) {
+                    const int d = cidx >> 1;
+                    const size_t o = ((size_t)j * Mpad + m) * D + d;
+                    const double c = (double)cen[d], dl = means64[o] - c;
+                    const double S0 = (double)s0, S1 = (double)s1, S2 = (double)S[ct][r];
+                    st_mean[o] += S1 + (c + bias) * S0;                            // Clustering.py:669-672
+                    st_cov[o] += S2 - 2.0 * dl * S1 + dl * dl * S0;                // Clustering.py:674-678
+                }
+                if (m < M && cidx == 2 * D) st_acc[(size_t)j * Mpad + m] += (double)S[ct][r];   // Clustering.py:665
+            }
+        }
+    }
+    if (slice == 0) {
+        double v = (threadIdx.x < 32) ? galpha : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) st_alpha[j] += v;                                    // Clustering.py:667
+    }
+}
+
 struct AccWork {
     int *cnt = nullptr;
     long long *off = nullptr;
@@ -303,7 +456,17 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
                        w.off, w.list);
     const int D = ctx->D;
-    if (precision == PCL_F32) {
+    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && (D == 39 || D == 26 || D == 13);
+    if (mfma) {
+        const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = (int)b->work_states.size();
+        const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
+#define LAUNCH_MFMA(DD)                                                                                                   \
+    hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
+                       ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, w.work_states, w.seg_lo, w.seg_hi, w.off,   \
+                       w.list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
+        if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
+#undef LAUNCH_MFMA
+    } else if (precision == PCL_F32) {
         switch (D) {
 #define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, w, ctx->frames32, ctx->params32, ctx->mean32); break;
             CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)

@@ -233,6 +233,7 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
                     kq += dm * dm / (2.0 * vr);
                 }
                 put(Dd, 0, p64[((size_t)j * Mpad + m) * row + 2 * Dd] - LOG2E * kq);
+                put(Dd, 1, 1.0);   // spare K slot: scoring multiplies it by 0, the accumulate kernel by cf[f]
             }
         }
         TRY(dev_alloc(ctx, &ctx->pm32, npm));
