@@ -5,7 +5,13 @@
 //   -> Clustering.GMM.point(log=True)  StatisticalModel/Clustering.py:740-767
 //   -> util.gaussian_function(log=True) StatisticalModel/util.py:20-31   (quirk Q1 constant)
 //
-// Mapping (MI355X-first, VALU bound, no MFMA -- see DESIGN.md):
+// This is the VALU formulation: the float64 parity mode always uses it, the float32 mode uses it for
+// feature dimensions the MFMA kernel (gmm_score_mfma.hip) has no instantiation for, or on request
+// (PCL_SCORE_VARIANT=1).  A third variant that fed the parameters through SGPR pairs into
+// v_pk_fma_f32 op_sel measured slower with compiler-scheduled scalar loads (profiles/r01_score_variants.txt)
+// and was removed.
+//
+// Mapping (VALU bound, no MFMA -- see DESIGN.md):
 //   * state-major batching: a workgroup scores TILE frames of ONE GMM state, gathered from all
 //     utterances of the batch that contain the state, so the state's M x (2D+1) parameter block is
 //     streamed through LDS once per TILE frames.
@@ -156,116 +162,6 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// v2: parameters through the scalar data path instead of LDS.  The per-mixture (s_d, c_d) pairs are
-// wave-uniform, so they are fetched with s_load into SGPR pairs and fed to v_pk_fma_f32 through
-// op_sel:  y.xy = x.xy * S.lo + S.hi  reads ONE SGPR pair (one constant-bus operand) and two VGPRs,
-// and handles two frames per instruction.  Measured on MI355X (tools/ubench_valu.hip) this form
-// issues at 121-132 TFLOP/s against 95-105 for v_fma_f32 with VGPR operands.  No LDS, no barriers:
-// every wave streams the state's parameter block on its own; the block is L2-resident.
-// ------------------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 pk_fma_sgpr_pair(f2 x, f2 sc) {
-    f2 y;
-    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(y) : "v"(x), "s"(sc));
-    return y;
-}
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) {
-    f2 y;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c));
-    return y;
-}
-
-template <int D, int RP /* frame PAIRS per lane */>
-__global__ __launch_bounds__(WG, 2) void gmm_score_kernel_v2(const float *__restrict__ frames,
-                                                             const float *__restrict__ params, int Mpad,
-                                                             const ScoreTile *__restrict__ tiles,
-                                                             const ScoreSeg *__restrict__ segs,
-                                                             double *__restrict__ out) {
-    constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
-    constexpr int R = 2 * RP;
-    const ScoreTile tile = tiles[blockIdx.x];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
-    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
-    if (tile.vstart + wave * R * 64 >= vend) return;   // whole wave past the end of the state's frames
-
-    f2 x[RP][D];
-    long long oidx[R];
-    bool valid[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int v = tile.vstart + (wave * R + r) * 64 + lane;
-        valid[r] = v < vend;
-        if (!valid[r]) v = tile.vstart;
-        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
-        }
-        const ScoreSeg sg = segs[lo];
-        const long long t = v - sg.vstart;
-        const float *fp = frames + (sg.frame0 + t) * D;
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[r >> 1][d][r & 1] = fp[d];
-        oidx[r] = sg.out0 + t * (long long)sg.out_stride;
-    }
-    float mx[R], sm[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        mx[r] = -1.0e30f;
-        sm[r] = 0.f;
-    }
-    const float *pbase = params + (size_t)tile.state * Mpad * ROW;
-    for (int m = 0; m < Mpad; m += GROUP) {
-        float v[GROUP][R];
-#pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-            const f2 *prow = reinterpret_cast<const f2 *>(pbase + (size_t)(m + g) * ROW);   // wave-uniform
-            f2 q[RP];
-#pragma unroll
-            for (int rp = 0; rp < RP; ++rp) q[rp] = f2{0.f, 0.f};
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const f2 sc = prow[d];
-#pragma unroll
-                for (int rp = 0; rp < RP; ++rp) {
-                    const f2 y = pk_fma_sgpr_pair(x[rp][d], sc);
-                    q[rp] = pk_fma(y, y, q[rp]);
-                }
-            }
-            const float k2 = pbase[(size_t)(m + g) * ROW + 2 * D];
-#pragma unroll
-            for (int rp = 0; rp < RP; ++rp) {
-                v[g][2 * rp] = k2 - q[rp].x;
-                v[g][2 * rp + 1] = k2 - q[rp].y;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float gm = v[0][r];
-#pragma unroll
-            for (int g = 1; g < GROUP; ++g) gm = __builtin_fmaxf(gm, v[g][r]);
-            const float nm = __builtin_fmaxf(mx[r], gm);
-            float acc = sm[r] * __builtin_amdgcn_exp2f(mx[r] - nm);
-#pragma unroll
-            for (int g = 0; g < GROUP; ++g) acc += __builtin_amdgcn_exp2f(v[g][r] - nm);
-            sm[r] = acc;
-            mx[r] = nm;
-        }
-    }
-    constexpr double LN2 = 0.693147180559945309417232121458;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (valid[r]) {
-            const double res = (sm[r] > 0) ? LN2 * ((double)mx[r] + ::log2((double)sm[r])) : -INFINITY;
-            out[oidx[r]] = res;
-        }
-    }
-}
-
 // rows of the sentence HMMs that are not GMM states: entry -> 0, exit -> -inf
 __global__ void fill_virtual_rows_kernel(const UttDesc *__restrict__ utt, const int32_t *__restrict__ row_state,
                                          double *__restrict__ Bt, int U) {
@@ -297,12 +193,6 @@ __global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *
             dst[d.b_off + e] = src[d.b_off + (long long)t * d.N + n];
         }
     }
-}
-
-template <int D>
-void launch_score_v2(pcl_ctx *ctx, pcl_batch *b) {
-    hipLaunchKernelGGL((gmm_score_kernel_v2<D, 2>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, ctx->params32,
-                       ctx->Mpad, b->d_tiles, b->d_segs, b->Bt);
 }
 
 template <int D, int R, int CH, typename real>
@@ -340,10 +230,7 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision) {
     if (b->n_tiles == 0) return PCL_OK;
     const int D = ctx->D;
     pcl_timer_begin(ctx, "score");
-    const int variant = ctx->score_variant;
-    if (precision == PCL_F32 && variant == 2 && (D == 39 || D == 13)) {
-        if (D == 39) launch_score_v2<39>(ctx, b); else launch_score_v2<13>(ctx, b);
-    } else if (precision == PCL_F32) {
+    if (precision == PCL_F32) {
         switch (D) {
 #define CASE32(DD) case DD: launch_score_t<DD, r32(DD), PCL_CH32, float>(ctx, b, ctx->frames32, ctx->params32); break;
             CASE32(13) CASE32(26) CASE32(39)

@@ -35,6 +35,9 @@ constexpr int WG = 256;
 #ifndef PCL_MFMA_MINW
 #define PCL_MFMA_MINW 2    // __launch_bounds__ waves per SIMD
 #endif
+#ifndef PCL_MFMA_LSE
+#define PCL_MFMA_LSE 1     // 1: reference-shifted log-sum-exp (the shift rides in the spare K slot of the MFMA)
+#endif
 #ifndef PCL_MFMA_PIPE
 #define PCL_MFMA_PIPE 0    // 1: log-sum-exp of m-tile i-1 is issued behind the MFMAs of m-tile i
 #endif
@@ -101,6 +104,65 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
 #pragma unroll
     for (int q = 0; q < KS4; ++q) a[q] = pa[q * 64];
 
+#if PCL_MFMA_LSE
+    // Reference-shifted log-sum-exp.  The K dimension has one spare slot (2D+1 features in 2D+2): the
+    // parameter side holds 1 there and the frame side holds -ref[frame], so the matrix pipe delivers
+    // v - ref and the VALU only has to do  s += exp2(v - ref)  (one v_exp_f32 + one add per Gaussian, no
+    // subtract, no per-tile rescale).  ref is a true maximum seen earlier for that frame, so the largest
+    // term is >= 1 and nothing underflows; it is raised only when some value exceeds it by > 2^64
+    // (wave-uniform slow path, always taken on the first m-tile).  Both half-waves of a frame column share
+    // one ref, so their partial sums simply add at the end.
+    float ref[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) ref[c] = 0.f;
+    for (int mt = 0; mt < n_mtiles; ++mt) {
+        const f4v *pn = pa + (size_t)(mt + 1 < n_mtiles ? mt + 1 : mt) * (KS4 * 64);
+        f4v an[KS4];
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) an[q] = pn[q * 64];
+        f16v acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s >> 2][s & 3], xb[c][s], acc[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            float gm = acc[c][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
+            if (mt == 0 || __any(gm > 64.f)) {
+                const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));   // max over the frame's 32 mixtures
+                if ((mt == 0 || gp > 0.f) && gp > -INFINITY) {
+                    sm[c] = (mt == 0) ? 0.f : sm[c] * __builtin_amdgcn_exp2f(-gp);   // first tile: gp << 0, 0 * exp2(-gp) would be 0 * inf
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] -= gp;
+                    ref[c] += gp;
+                    if (half) xb[c][D] = -ref[c];
+                }
+            }
+            float s = sm[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
+            sm[c] = s;
+        }
+#pragma unroll
+        for (int q = 0; q < KS4; ++q) a[q] = an[q];
+    }
+    constexpr double LN2R = 0.693147180559945309417232121458;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
+        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2R * ((double)ref[c] + ::log2(S)) : -INFINITY;
+    }
+    return;
+#else
     auto lse_update = [&](const f16v &t, int c) {
         float gm = t[0];
 #pragma unroll
@@ -158,6 +220,7 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
     for (int c = 0; c < NT; ++c) lse_update(prev[c], c);
 #endif
 
+#endif
     constexpr double LN2 = 0.693147180559945309417232121458;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {

@@ -69,7 +69,7 @@ int pcl_init(int device, pcl_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
-    const char *var = getenv("PCL_SCORE_VARIANT");   // kernel A/B: 1 VALU+LDS, 2 VALU+SGPR pk_fma, 3 f32 MFMA (default)
+    const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
     ctx->score_variant = var ? atoi(var) : 3;
     *out = ctx;
     return PCL_OK;

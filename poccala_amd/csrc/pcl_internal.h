@@ -58,7 +58,7 @@ struct pcl_ctx {
     float *pm32 = nullptr;       // MFMA scoring layout: [J][Mpad32/32][KS4][64 lanes][4], see gmm_score_mfma.hip
     float *centers32 = nullptr;  // J * D per-state expansion centres c_j
     int Mpad32 = 0;              // M rounded up to a multiple of 32
-    int score_variant = 0;       // 1 = VALU/LDS, 2 = VALU/SGPR pk_fma, 3 = f32 MFMA
+    int score_variant = 0;       // 1 = VALU/LDS, 3 = f32 MFMA (default)
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
     double *mean64 = nullptr;
     // frames (device)

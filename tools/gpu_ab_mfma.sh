@@ -7,11 +7,5 @@ build() { # name flags
 }
 run() { POCCALA_HIP_LIB=$GRAFT_REPO_ROOT/gpurun_out/v/lib_$1.so PCL_SCORE_VARIANT=3 CHECK=1 timeout 120 python tools/score_bench.py 512 2048 50 2>&1 | tail -2 >> gpurun_out/mfma_ab.log; }
 rm -f gpurun_out/mfma_ab.log gpurun_out/v/*
-build base ""; run base
-build nt3 "-DPCL_MFMA_NT=3"; run nt3
-build nt1 "-DPCL_MFMA_NT=1"; run nt1
-build pipe "-DPCL_MFMA_PIPE=1"; run pipe
-build nt3pipe "-DPCL_MFMA_NT=3 -DPCL_MFMA_PIPE=1"; run nt3pipe
-build nt4 "-DPCL_MFMA_NT=4 -DPCL_MFMA_MINW=1"; run nt4
-build minw3 "-DPCL_MFMA_MINW=3"; run minw3
+for v in "$@"; do name=$(echo "$v" | tr -d ' =-' | tr -c 'A-Za-z0-9\n' '_'); build "x$name" "$v"; run "x$name"; done
 cat gpurun_out/mfma_ab.log
