@@ -152,6 +152,13 @@ int pcl_batch_accumulate(pcl_batch *b, int precision);
 /* J*M, J, J*M*D, J*M*D doubles */
 int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc);
 
+/* A15: Clustering.GMM.update_param (Clustering.py:682-693) for every state, on the device, from the resident
+ * (all-reduced) statistics: w = acc/alpha_acc, mu = mean_acc/acc - bias, var = max(cov_acc/acc, c_covariance);
+ * then every scoring layout is rebuilt, so the next E-step can start without leaving the GPU.
+ * pcl_model_download returns the float64 master copy (J*M*D, J*M*D, J*M; NULL pointers are skipped). */
+int pcl_mstep(pcl_ctx *ctx, double c_covariance);
+int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight);
+
 /* ----------------------------------------------------------------- multi-GPU (RCCL over xGMI)
  * Replaces the reference's file-based accumulator merge (LHMM.py:256-290, Clustering.py:314-367).
  * id_bytes is a 128-byte ncclUniqueId made by rank 0 and distributed by the caller. */

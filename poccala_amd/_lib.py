@@ -41,6 +41,8 @@ PROTOTYPES = {
     'pcl_stats_zero': (_i, [_vp]),
     'pcl_batch_accumulate': (_i, [_vp, _i]),
     'pcl_stats_download': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'pcl_mstep': (_i, [_vp, _d]),
+    'pcl_model_download': (_i, [_vp, _vp, _vp, _vp]),
     'pcl_comm_unique_id': (_i, [_vp]),
     'pcl_comm_init': (_i, [_vp, _i, _i, _vp]),
     'pcl_stats_allreduce': (_i, [_vp]),

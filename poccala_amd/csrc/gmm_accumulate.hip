@@ -251,9 +251,8 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
     const ActiveFrame *__restrict__ list, double bias, double *__restrict__ st_acc, double *__restrict__ st_alpha,
     double *__restrict__ st_mean, double *__restrict__ st_cov) {
     constexpr int KS = D + 1, KS4 = (KS + 3) / 4;
-    constexpr int NCOL = 2 * D + 1;            // useful moment columns: 2D features + the constant
+    constexpr int NCT = (2 * D + 1 + 31) / 32;   // 32-column tiles covering the 2D feature columns + the constant
     __shared__ __attribute__((aligned(16))) float xe[2][32 * XSTR];
-    __shared__ double red[AW];
 
     // XCD-aware mapping: the 8 slices of one state sit on block indices with equal residue mod 8
     const int nslice = (n_mtiles + AW - 1) / AW;
@@ -285,9 +284,9 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
             pb[4 * q] = t.x; pb[4 * q + 1] = t.y; pb[4 * q + 2] = t.z; pb[4 * q + 3] = t.w;
         }
     }
-    f16v S[3];
+    f16v S[NCT];
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[ct][r] = 0.f;
     double galpha = 0.0;
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int fr = (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
+                for (int ct = 0; ct < NCT; ++ct)
                     S[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[r], x[fr * XSTR + ct * 32 + col], S[ct], 0, 0, 0);
             }
         }
@@ -352,9 +351,9 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float s0 = __shfl(S[2][r], (lane & 32) + (2 * D - 64), 64);     // column 2D (the constant) lives in tile 2
+            const float s0 = __shfl(S[(2 * D) >> 5][r], (lane & 32) + ((2 * D) & 31), 64);   // column 2D = the constant feature
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) {
+            for (int ct = 0; ct < NCT; ++ct) {
                 const int cidx = ct * 32 + col;
                 const float s1 = __shfl_xor(S[ct][r], 1, 64);                      // odd neighbour: x' column of the same d
                 if (m < M && !(cidx & 1) && cidx < 2 * D) {

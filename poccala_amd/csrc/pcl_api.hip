@@ -80,6 +80,8 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->params64);
     dev_free(ctx->mean32);
     dev_free(ctx->mean64);
+    dev_free(ctx->var64);
+    dev_free(ctx->w64);
     dev_free(ctx->pm32);
     dev_free(ctx->centers32);
     dev_free(ctx->stats);
@@ -165,90 +167,42 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     free_model(ctx);
     const int Mpad = (M + 3) / 4 * 4;
     const int row = (2 * Dd + 1 + 3) / 4 * 4;
-    const size_t np = (size_t)J * Mpad * row, nm = (size_t)J * Mpad * Dd;
-    std::vector<double> p64(np, 0.0), m64(nm, 0.0);
-    const double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
-    for (int j = 0; j < J; ++j) {
-        for (int m = 0; m < Mpad; ++m) {
-            double *pr = &p64[((size_t)j * Mpad + m) * row];
-            if (m >= M) {
-                pr[2 * Dd] = -INFINITY;  // padded mixture: contributes exp2(-inf) = 0
-                continue;
-            }
-            const double *mu = mean + ((size_t)j * M + m) * D;
-            const double *vr = var + ((size_t)j * M + m) * D;
-            double sumvar = 0.0, sumlog = 0.0;
+    const int Mp32 = (M + 31) / 32 * 32, KS4 = (Dd + 1 + 3) / 4;
+    const size_t np = (size_t)J * Mpad * row, nm = (size_t)J * Mpad * Dd, nw = (size_t)J * Mpad;
+    const size_t npm = (size_t)J * (Mp32 / 32) * KS4 * 64 * 4;
+    // float64 master copy in the padded device layout; every derived layout is built on the device
+    std::vector<double> m64(nm, 0.0), v64(nm, 1.0), w64(nw, 0.0);
+    for (int j = 0; j < J; ++j)
+        for (int m = 0; m < M; ++m) {
+            w64[(size_t)j * Mpad + m] = weight[(size_t)j * M + m];
             for (int d = 0; d < D; ++d) {
-                if (!(vr[d] > 0.0)) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: variance[%d,%d,%d] = %g is not positive", j, m, d, vr[d]);
-                const double s = sqrt(LOG2E / (2.0 * vr[d]));
-                pr[2 * d] = s;
-                pr[2 * d + 1] = -mu[d] * s;
-                sumvar += vr[d];
-                sumlog += log(vr[d]);
-                m64[((size_t)j * Mpad + m) * Dd + d] = mu[d];
+                const double vr = var[((size_t)j * M + m) * D + d];
+                if (!(vr > 0.0)) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_model_upload: variance[%d,%d,%d] = %g is not positive", j, m, d, vr);
+                m64[((size_t)j * Mpad + m) * Dd + d] = mean[((size_t)j * M + m) * D + d];
+                v64[((size_t)j * Mpad + m) * Dd + d] = vr;
             }
-            const double w = weight[(size_t)j * M + m];
-            // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var);  textbook form only on request
-            const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
-            pr[2 * Dd] = LOG2E * (log(w) - 0.5 * D * LOG_2PI - 0.5 * tail);
         }
-    }
-    std::vector<float> p32(np), m32(nm);
-    for (size_t i = 0; i < np; ++i) p32[i] = (float)p64[i];
-    for (size_t i = 0; i < nm; ++i) m32[i] = (float)m64[i];
     TRY(dev_alloc(ctx, &ctx->params32, np));
     TRY(dev_alloc(ctx, &ctx->params64, np));
     TRY(dev_alloc(ctx, &ctx->mean32, nm));
     TRY(dev_alloc(ctx, &ctx->mean64, nm));
-    HIPCHK(ctx, hipMemcpy(ctx->params32, p32.data(), np * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->params64, p64.data(), np * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->mean32, m32.data(), nm * sizeof(float), hipMemcpyHostToDevice));
+    TRY(dev_alloc(ctx, &ctx->var64, nm));
+    TRY(dev_alloc(ctx, &ctx->w64, nw));
+    TRY(dev_alloc(ctx, &ctx->pm32, npm));
+    TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
-    // ---- MFMA scoring layout (gmm_score_mfma.hip): expansion of the exponent around a per-state centre
-    {
-        const int Mp32 = (M + 31) / 32 * 32, nmt = Mp32 / 32, KS = Dd + 1, KS4 = (KS + 3) / 4;
-        const size_t npm = (size_t)J * nmt * KS4 * 64 * 4;
-        std::vector<float> pm(npm, 0.f), cen((size_t)J * Dd, 0.f);
-        for (int j = 0; j < J; ++j) {
-            std::vector<double> c(Dd, 0.0);
-            for (int m = 0; m < M; ++m)
-                for (int d = 0; d < D; ++d) c[d] += mean[((size_t)j * M + m) * D + d];
-            for (int d = 0; d < D; ++d) {
-                c[d] = (double)(float)(c[d] / M);   // the kernel subtracts the f32 value: expand around exactly that
-                cen[(size_t)j * Dd + d] = (float)c[d];
-            }
-            for (int m = 0; m < Mp32; ++m) {
-                const int mt = m >> 5, cl = m & 31;
-                float *base = &pm[(((size_t)j * nmt + mt) * KS4) * 64 * 4];
-                auto put = [&](int s, int half, double v) { base[((size_t)(s >> 2) * 64 + (half * 32 + cl)) * 4 + (s & 3)] = (float)v; };
-                if (m >= M) {
-                    put(Dd, 0, -INFINITY);   // padded mixture: k' = -inf
-                    continue;
-                }
-                double kq = 0.0;
-                for (int d = 0; d < D; ++d) {
-                    const double vr = var[((size_t)j * M + m) * D + d], dm = mean[((size_t)j * M + m) * D + d] - c[d];
-                    put(d, 0, -LOG2E / (2.0 * vr));
-                    put(d, 1, LOG2E * dm / vr);
-                    kq += dm * dm / (2.0 * vr);
-                }
-                put(Dd, 0, p64[((size_t)j * Mpad + m) * row + 2 * Dd] - LOG2E * kq);
-                put(Dd, 1, 1.0);   // spare K slot: scoring multiplies it by 0, the accumulate kernel by cf[f]
-            }
-        }
-        TRY(dev_alloc(ctx, &ctx->pm32, npm));
-        TRY(dev_alloc(ctx, &ctx->centers32, cen.size()));
-        HIPCHK(ctx, hipMemcpy(ctx->pm32, pm.data(), npm * sizeof(float), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(ctx->centers32, cen.data(), cen.size() * sizeof(float), hipMemcpyHostToDevice));
-        ctx->Mpad32 = Mp32;
-    }
+    HIPCHK(ctx, hipMemcpy(ctx->var64, v64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->w64, w64.data(), nw * sizeof(double), hipMemcpyHostToDevice));
     ctx->J = J;
     ctx->M = M;
     ctx->Mpad = Mpad;
+    ctx->Mpad32 = Mp32;
     ctx->D = Dd;
     ctx->Dhost = D;
     ctx->row = row;
     ctx->model_flags = flags;
+    TRY(pcl_launch_derive(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     // statistics: [acc J*Mpad | alpha J | mean J*Mpad*Dd | cov J*Mpad*Dd]
     ctx->stats_len = (size_t)J * Mpad + J + 2 * nm;
     TRY(dev_alloc(ctx, &ctx->stats, ctx->stats_len));
@@ -689,6 +643,35 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return pcl_launch_accumulate(ctx, b, precision);
+}
+
+int pcl_mstep(pcl_ctx *ctx, double c_covariance) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_mstep: no model uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return pcl_launch_mstep(ctx, c_covariance);
+}
+
+int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!ctx->mean64) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_model_download: no model uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->J * ctx->M * ctx->Dhost;
+    double *tmp = nullptr;
+    TRY(dev_alloc(ctx, &tmp, n));
+    int r = PCL_OK;
+    const double *srcs[3] = {ctx->mean64, ctx->var64, ctx->w64};
+    double *dsts[3] = {mean, var, weight};
+    for (int k = 0; k < 3 && r == PCL_OK; ++k) {
+        if (!dsts[k]) continue;
+        const int inner = (k == 2) ? 1 : ctx->Dhost;
+        r = pcl_launch_pack(ctx, srcs[k], inner, tmp);
+        if (r == PCL_OK && hipMemcpyAsync(dsts[k], tmp, (size_t)ctx->J * ctx->M * inner * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = PCL_ERR_HIP;
+        if (r == PCL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = PCL_ERR_HIP;
+    }
+    dev_free(tmp);
+    if (r != PCL_OK && ctx->err.empty()) pcl_set_error(ctx, "pcl_model_download: copy failed");
+    return r;
 }
 
 int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc) {

@@ -60,7 +60,8 @@ struct pcl_ctx {
     int Mpad32 = 0;              // M rounded up to a multiple of 32
     int score_variant = 0;       // 1 = VALU/LDS, 3 = f32 MFMA (default)
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
-    double *mean64 = nullptr;
+    double *mean64 = nullptr;    // float64 master copy of the model: mean, var (J*Mpad*D), weight (J*Mpad)
+    double *var64 = nullptr, *w64 = nullptr;
     // frames (device)
     int64_t F = 0;
     int FD = 0, FDhost = 0;
@@ -139,3 +140,6 @@ int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
+int pcl_launch_derive(pcl_ctx *ctx);
+int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
+int pcl_launch_pack(pcl_ctx *ctx, const double *src, int inner, double *dst);

@@ -114,6 +114,18 @@ class Engine(object):
         self._check(self._lib.pcl_stats_download(self._ctx, ptr(acc), ptr(al), ptr(me), ptr(co)))
         return dict(acc=acc, alpha_acc=al, mean_acc=me, cov_acc=co)
 
+    def mstep(self, c_covariance=1e-3):
+        """GMM.update_param for every state on the device (Clustering.py:682-693); rebuilds the scoring layouts."""
+        self._check(self._lib.pcl_mstep(self._ctx, float(c_covariance)))
+
+    def model_download(self):
+        """(mean (J,M,D), var (J,M,D), weight (J,M)) float64 master copy."""
+        mean = np.empty((self.J, self.M, self.D))
+        var = np.empty((self.J, self.M, self.D))
+        w = np.empty((self.J, self.M))
+        self._check(self._lib.pcl_model_download(self._ctx, ptr(mean), ptr(var), ptr(w)))
+        return mean, var, w
+
     # ------------------------------------------------------------------ RCCL
     def comm_unique_id(self):
         buf = np.zeros(128, dtype=np.uint8)

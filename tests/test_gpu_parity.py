@@ -356,3 +356,58 @@ def test_c2_full_size_properties(eng):
         bw = po.baum_welch(a, pi, [bref], fix_code=1)
         np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=F32_RTOL)
     b.close()
+
+
+# ------------------------------------------------------------------ A15 on the device: one EM iteration
+@pytest.mark.parametrize('prec', ['f32', 'f64'])
+def test_em_iteration_on_device(eng, prec):
+    """E-step -> device M-step (pcl_mstep) -> model download, against the oracle's E-step + update_param merged
+    over label positions; then a second E-step runs on the re-derived layouts and must score what the oracle
+    scores with the new parameters."""
+    from poccala_amd import PCL_F32, PCL_F64
+    from poccala_amd.engine import make_sentence_batch
+    P = PCL_F32 if prec == 'f32' else PCL_F64
+    rt = 2e-4 if prec == 'f32' else 1e-8
+    mean, var, w, trans, frames, lens, begin, labels = small_problem(501, units=3, M=6, D=13, U=12, T=80, L=3)
+    eng.load_model(mean, var, w)
+    m0, v0, w0 = eng.model_download()
+    np.testing.assert_array_equal(m0, mean)
+    np.testing.assert_array_equal(v0, var)
+    np.testing.assert_array_equal(w0, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(P)
+    b.forward_backward()
+    eng.stats_zero()
+    b.accumulate(P)
+    eng.mstep(c_covariance=1e-3)
+    nm, nv, nw = eng.model_download()
+    # oracle: per-position log accumulators merged per state, then Clustering.GMM.update_param
+    model = oracle_model(mean, var, w, trans)
+    J, M, D = mean.shape
+    merged = [dict(acc=np.full(M, -np.inf), alpha_acc=-np.inf, mean_acc=np.full((M, D), -np.inf), cov_acc=np.full((M, D), -np.inf))
+              for _ in range(J)]
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, accs, _ = po.estep_utterance(x, list(lab), model)
+        for pos, unit in enumerate(lab):
+            for k in range(S - 2):
+                mj, a = merged[unit * (S - 2) + k], accs[pos].gmm[k]
+                mj['acc'] = np.logaddexp(mj['acc'], a['acc'])
+                mj['alpha_acc'] = np.logaddexp(mj['alpha_acc'], a['alpha_acc'])
+                mj['mean_acc'] = np.logaddexp(mj['mean_acc'], a['mean_acc'])
+                mj['cov_acc'] = np.logaddexp(mj['cov_acc'], a['cov_acc'])
+    used = sorted(set(int(u) * (S - 2) + k for lab in labels for u in lab for k in range(S - 2)))
+    for j in used:
+        rw, rm, rv = po.gmm_update_param(merged[j], c_covariance=1e-3)
+        np.testing.assert_allclose(nw[j], rw, rtol=rt)
+        np.testing.assert_allclose(nm[j], rm, rtol=rt, atol=rt)
+        np.testing.assert_allclose(nv[j], rv, rtol=10 * rt)
+    # second E-step on the re-derived device layouts
+    b.score(P)
+    B2 = b.get('B')
+    model2 = {u: dict(trans=trans[u], gmms=[(nm[u * 3 + k], nv[u * 3 + k], nw[u * 3 + k]) for k in range(3)]) for u in range(len(trans))}
+    x = frames[begin[0]:begin[0] + lens[0]].astype(np.float64)
+    _, _, ref, _ = po.score_label(x, list(labels[0]), model2)
+    fin_close(B2[0], ref, rtol=0, atol=F32_LOGLIK_ATOL if prec == 'f32' else 1e-9)
+    b.close()
