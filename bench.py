@@ -233,8 +233,21 @@ def main():
         acc_ms, acc_n = eng.kernel_time('accumulate')
         ar_ms, ar_n = eng.kernel_time('allreduce')
         vit_ms, _ = eng.kernel_time('viterbi')
+        # M-step on the device (A15) and the PCIe legs the timed region excludes
+        t1 = time.perf_counter()
+        eng.mstep(1e-3)
+        eng.sync()
+        t_mstep = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        eng.load_frames(frames)
+        t_h2d = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        batch.get('logp'); batch.get('gamma'); batch.get('ksai_nz')
+        t_d2h = time.perf_counter() - t1
         extra = dict(viterbi_frames_per_s_per_gpu=frames_per_rank / t_vit, viterbi_kernel_ms=vit_ms,
-                     estep_frames_per_s=total_frames / t_estep, accumulate_ms=acc_ms, allreduce_ms=ar_ms,
+                     estep_frames_per_s=total_frames / t_estep, estep_ms=t_estep * 1e3, accumulate_ms=acc_ms, allreduce_ms=ar_ms,
+                     mstep_ms=t_mstep * 1e3, frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
+                     pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),
                      setup_s=t_setup)
 
     cpu = None

@@ -68,7 +68,9 @@ typedef enum {
     PCL_GET_NPASS = 8,   /* Baum-Welch passes run, (U,) int32 (quirk Q6)                                     */
     PCL_GET_QTRACE = 9,  /* Q after each pass, (U, PCL_MAX_PASS) f64, unused = NaN                            */
     PCL_GET_PATH = 10,   /* Viterbi state indices, ragged (T_u,) int32          == LHMM.viterbi mark_state   */
-    PCL_GET_POINT = 11   /* Viterbi score, (U,) f64                             == LHMM.viterbi point        */
+    PCL_GET_POINT = 11,  /* Viterbi score, (U,) f64                             == LHMM.viterbi point        */
+    PCL_GET_KSAI_NZ = 12 /* ln xi of the stored transitions only (ln A > -inf), row-major order per utterance, f64;
+                            a sentence HMM has ~2N of them instead of N*N                                     */
 } pcl_get_what;
 #define PCL_MAX_PASS 16
 

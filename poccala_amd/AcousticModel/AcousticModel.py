@@ -191,10 +191,12 @@ class AcousticModel(DataInitialization):
             stats = engine.stats_download()
         hmm_acc = {}
         if not fix_code & 4:
-            ks, ga = b.get('ksai'), b.get('gamma')
+            nz, ga = b.get('ksai_nz'), b.get('gamma')          # only the stored transitions cross PCIe
             parts = {u: ([], []) for u in units}
             for uu, lab in enumerate(labels):
-                kv, gv = ks[uu][1:-1, :], ga[uu][1:-1]
+                dense = np.full((n[uu], n[uu]), -np.inf)
+                dense[b.nz_index[uu]] = nz[uu]
+                kv, gv = dense[1:-1, :], ga[uu][1:-1]
                 for pos, unit in enumerate(lab):
                     parts[unit][0].append(kv[pos * e:(pos + 1) * e, pos * e:pos * e + s])
                     parts[unit][1].append(gv[pos * e:(pos + 1) * e].reshape(1, -1))

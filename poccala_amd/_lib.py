@@ -15,7 +15,7 @@ PCL_F32, PCL_F64 = 0, 1
 PCL_MODEL_Q1_SUMVAR, PCL_MODEL_LOGDET = 0, 1
 PCL_ROW_ENTRY, PCL_ROW_EXIT = -1, -2
 PCL_MAX_PASS = 16
-GET = dict(B=0, alpha=1, beta=2, lgamma=3, ksai=4, gamma=5, pi=6, logp=7, npass=8, qtrace=9, path=10, point=11)
+GET = dict(B=0, alpha=1, beta=2, lgamma=3, ksai=4, gamma=5, pi=6, logp=7, npass=8, qtrace=9, path=10, point=11, ksai_nz=12)
 
 # every symbol include/poccala_hip.h declares: (restype, argtypes)
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double

@@ -433,7 +433,22 @@ __global__ void hmm_viterbi_kernel(const UttDesc *__restrict__ utts, const doubl
     }
 }
 
+// dense ragged (N,N) xi -> values of the stored transitions in CSR (row-major) order
+__global__ void ksai_gather_kernel(const UttDesc *__restrict__ utts, const int *__restrict__ row_ptr,
+                                   const int *__restrict__ col_idx, const double *__restrict__ ksai, double *__restrict__ dst) {
+    const UttDesc d = utts[blockIdx.x];
+    for (int i = threadIdx.x; i < d.N; i += blockDim.x)
+        for (int k = row_ptr[d.ptr_off + i]; k < row_ptr[d.ptr_off + i + 1]; ++k)
+            dst[d.nnz_off + k] = ksai[d.mat_off + (long long)i * d.N + col_idx[d.nnz_off + k]];
+}
+
 }  // namespace
+
+int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst) {
+    hipLaunchKernelGGL(ksai_gather_kernel, dim3(b->U), dim3(64), 0, ctx->stream, b->d_utt, b->row_ptr, b->col_idx, b->ksai, dst);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
 
 int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold) {
     const int NP = (b->Nmax + 63) / 64 * 64;

@@ -117,7 +117,21 @@ __global__ void pack_kernel(const double *__restrict__ src, int J, int M, int Mp
     dst[gid] = src[((size_t)j * Mpad + m) * D + d];
 }
 
+// element-type conversion of the frame matrix: d64 -> f32 (dst32) or f32 -> d64 (dst64)
+__global__ void cast_kernel(const double *__restrict__ src64, float *__restrict__ f32, double *__restrict__ dst64, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (dst64) dst64[i] = (double)f32[i];
+        else f32[i] = (float)src64[i];
+    }
+}
+
 }  // namespace
+
+int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n) {
+    hipLaunchKernelGGL(cast_kernel, dim3(2048), dim3(256), 0, ctx->stream, src64, f32, dst64, n);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
 
 int pcl_launch_derive(pcl_ctx *ctx) {
     hipLaunchKernelGGL(centers_kernel, dim3(ctx->J), dim3(64), 0, ctx->stream, ctx->mean64, ctx->M, ctx->Mpad, ctx->D, ctx->centers32);

@@ -224,18 +224,25 @@ int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dt
     dev_free(ctx->frames32);
     dev_free(ctx->frames64);
     const size_t n = (size_t)F * Dd;
-    std::vector<float> f32(n, 0.f);
-    std::vector<double> f64(n, 0.0);
-    for (int64_t f = 0; f < F; ++f)
-        for (int d = 0; d < D; ++d) {
-            const double v = (dtype == PCL_F64) ? ((const double *)frames)[f * D + d] : (double)((const float *)frames)[f * D + d];
-            f64[f * Dd + d] = v;
-            f32[f * Dd + d] = (float)v;
-        }
+    // Direct PCIe copy in the host element type (padded on the host only when D has no exact kernel);
+    // the other precision is derived on the device: f32 now (every mode reads it), f64 lazily (parity mode).
+    const size_t esz = (dtype == PCL_F64) ? sizeof(double) : sizeof(float);
+    const void *src = frames;
+    std::vector<char> padded;
+    if (Dd != D) {
+        padded.assign(n * esz, 0);
+        for (int64_t f = 0; f < F; ++f) memcpy(&padded[(size_t)f * Dd * esz], (const char *)frames + (size_t)f * D * esz, (size_t)D * esz);
+        src = padded.data();
+    }
     TRY(dev_alloc(ctx, &ctx->frames32, n));
-    TRY(dev_alloc(ctx, &ctx->frames64, n));
-    HIPCHK(ctx, hipMemcpy(ctx->frames32, f32.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(ctx->frames64, f64.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    if (dtype == PCL_F64) {
+        TRY(dev_alloc(ctx, &ctx->frames64, n));
+        HIPCHK(ctx, hipMemcpy(ctx->frames64, src, n * esz, hipMemcpyHostToDevice));
+        TRY(pcl_launch_cast(ctx, ctx->frames64, ctx->frames32, nullptr, n));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpy(ctx->frames32, src, n * esz, hipMemcpyHostToDevice));
+    }
     ctx->F = F;
     ctx->FD = Dd;
     ctx->FDhost = D;
@@ -489,6 +496,13 @@ int pcl_batch_set_posteriors(pcl_batch *b, const double *lgamma) {
     return PCL_OK;
 }
 
+static int ensure_frames64(pcl_ctx *ctx) {
+    if (ctx->frames64 || !ctx->frames32) return PCL_OK;
+    const size_t n = (size_t)ctx->F * ctx->FD;
+    TRY(dev_alloc(ctx, &ctx->frames64, n));
+    return pcl_launch_cast(ctx, nullptr, ctx->frames32, ctx->frames64, n);   // float -> double is exact
+}
+
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
     const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D);
@@ -534,6 +548,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     if (ctx->FDhost != ctx->Dhost)  // DataDimensionError, Clustering.py:749-751
         PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (precision == PCL_F64) TRY(ensure_frames64(ctx));
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
     if (precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D)) TRY(pcl_launch_score_mfma(ctx, b));
@@ -598,7 +613,7 @@ int pcl_batch_get(pcl_batch *b, int what, void *host) {
         case PCL_GET_LGAMMA: mat = b->lgam; break;
         default: break;
     }
-    if (what >= PCL_GET_ALPHA && what <= PCL_GET_QTRACE && !b->have_fb) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: run pcl_batch_forward_backward first");
+    if (((what >= PCL_GET_ALPHA && what <= PCL_GET_QTRACE) || what == PCL_GET_KSAI_NZ) && !b->have_fb) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: run pcl_batch_forward_backward first");
     if ((what == PCL_GET_PATH || what == PCL_GET_POINT) && !b->have_vit) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: run pcl_batch_viterbi first");
     if (mat) {
         TRY(ensure_tmp(b));
@@ -611,6 +626,11 @@ int pcl_batch_get(pcl_batch *b, int what, void *host) {
     size_t bytes = 0;
     switch (what) {
         case PCL_GET_KSAI: src = b->ksai; bytes = (size_t)b->sumNN * 8; break;
+        case PCL_GET_KSAI_NZ:
+            TRY(ensure_tmp(b));
+            TRY(pcl_launch_ksai_gather(ctx, b, b->tmp));
+            src = b->tmp; bytes = (size_t)b->nnz * 8;
+            break;
         case PCL_GET_GAMMA: src = b->gamma_out; bytes = (size_t)b->sumN * 8; break;
         case PCL_GET_PI: src = b->pi_out; bytes = (size_t)b->sumN * 8; break;
         case PCL_GET_LOGP: src = b->logp; bytes = (size_t)b->U * 8; break;
@@ -642,6 +662,7 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no emissions");
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (precision == PCL_F64) TRY(ensure_frames64(ctx));
     return pcl_launch_accumulate(ctx, b, precision);
 }
 

@@ -133,6 +133,7 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision);
 int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b);
 int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold);
 int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back);
+int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst);
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
 void pcl_accumulate_release(pcl_batch *b);
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
@@ -141,5 +142,6 @@ int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);
+int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
 int pcl_launch_pack(pcl_ctx *ctx, const double *src, int inner, double *dst);

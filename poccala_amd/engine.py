@@ -164,6 +164,8 @@ class Batch(object):
         self._nn_off = np.concatenate([[0], np.cumsum(n64 * n64)])
         self._n_off = np.concatenate([[0], np.cumsum(n64)])
         self._t_off = np.concatenate([[0], np.cumsum(t64)])
+        self._nnz_off = None
+        self.nz_index = None
 
     def close(self):
         if getattr(self, '_b', None):
@@ -197,6 +199,9 @@ class Batch(object):
         Viterbi sees bit-identical operands (LHMM.py:571,577)."""
         a = self._ragged(logA, lambda u: (self.N[u], self.N[u]))
         p = self._ragged(logpi, lambda u: (self.N[u],))
+        # stored transitions (ln A > -inf) per utterance, row-major: the order of get('ksai_nz')
+        self.nz_index = [np.nonzero(~np.isneginf(np.asarray(m, dtype=np.float64))) for m in logA]
+        self._nnz_off = np.concatenate([[0], np.cumsum([len(ix[0]) for ix in self.nz_index])])
         self._check(self._lib.pcl_batch_set_transitions(self._b, ptr(a), ptr(p)))
 
     def set_states(self, row_state):
@@ -237,6 +242,12 @@ class Batch(object):
             flat = np.empty(int(self._nn_off[-1]))
             self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))
             return [flat[self._nn_off[u]:self._nn_off[u + 1]].reshape(self.N[u], self.N[u]) for u in range(self.U)]
+        if what == 'ksai_nz':
+            if self._nnz_off is None:
+                raise RuntimeError('set_transitions first')
+            flat = np.empty(int(self._nnz_off[-1]))
+            self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))
+            return [flat[self._nnz_off[u]:self._nnz_off[u + 1]] for u in range(self.U)]
         if what in ('gamma', 'pi'):
             flat = np.empty(int(self._n_off[-1]))
             self._check(self._lib.pcl_batch_get(self._b, code, ptr(flat)))

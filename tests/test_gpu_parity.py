@@ -170,7 +170,9 @@ def test_forward_backward_dense_and_multiwave(eng):
     for fix_pi in (False, True):
         b.forward_backward(fix_pi=fix_pi)
         al, be, ks, ga, pi, lp, npass = (b.get(k) for k in ('alpha', 'beta', 'ksai', 'gamma', 'pi', 'logp', 'npass'))
+        nz = b.get('ksai_nz')
         for u in range(len(cases)):
+            np.testing.assert_array_equal(nz[u], ks[u][b.nz_index[u]])      # sparse download == dense entries
             ref = po.baum_welch(As[u], pis[u], [Bs[u]], fix_code=1 if fix_pi else 0)
             assert int(npass[u]) == ref['n_pass']
             fin_close(al[u], ref['alpha'][0], rtol=1e-10)
