@@ -321,7 +321,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
-    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->tmp);
+    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
     return PCL_OK;
 }
@@ -374,7 +374,7 @@ int pcl_batch_set_transitions(pcl_batch *b, const double *logA, const double *lo
     b->nnz = (long long)col_idx.size();
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
-    dev_free(b->xi_m); dev_free(b->xi_s);
+    dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->nz_tmp);
     const size_t nz = (size_t)b->nnz, np = row_ptr.size();
     TRY(dev_alloc(ctx, &b->row_ptr, np));
     TRY(dev_alloc(ctx, &b->col_ptr, np));
@@ -627,9 +627,9 @@ int pcl_batch_get(pcl_batch *b, int what, void *host) {
     switch (what) {
         case PCL_GET_KSAI: src = b->ksai; bytes = (size_t)b->sumNN * 8; break;
         case PCL_GET_KSAI_NZ:
-            TRY(ensure_tmp(b));
-            TRY(pcl_launch_ksai_gather(ctx, b, b->tmp));
-            src = b->tmp; bytes = (size_t)b->nnz * 8;
+            if (!b->nz_tmp) TRY(dev_alloc(ctx, &b->nz_tmp, (size_t)b->nnz));
+            TRY(pcl_launch_ksai_gather(ctx, b, b->nz_tmp));
+            src = b->nz_tmp; bytes = (size_t)b->nnz * 8;
             break;
         case PCL_GET_GAMMA: src = b->gamma_out; bytes = (size_t)b->sumN * 8; break;
         case PCL_GET_PI: src = b->pi_out; bytes = (size_t)b->sumN * 8; break;

@@ -107,6 +107,7 @@ struct pcl_batch {
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with
     int n_segs = 0, n_tiles = 0, tile_frames = 0;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
+    double *nz_tmp = nullptr;                // nnz staging buffer for the sparse xi download
     // accumulate work lists (per state: list of segments with lgam/B offsets) reuse d_segs
 };
 
