@@ -26,84 +26,107 @@ __global__ void centers_kernel(const double *__restrict__ mean64, int M, int Mpa
     }
 }
 
-// one thread per (state, mixture) of the padded grids
-__global__ void derive_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
-                              const double *__restrict__ w64, const float *__restrict__ centers, int J, int M, int Mpad,
-                              int Mpad32, int D, int Dhost, int row, int flags, float *__restrict__ params32,
-                              double *__restrict__ params64, float *__restrict__ mean32, float *__restrict__ pm32) {
-    const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const int mmax = Mpad32 > Mpad ? Mpad32 : Mpad;
-    if (gid >= (long long)J * mmax) return;
-    const int j = (int)(gid / mmax), m = (int)(gid % mmax);
-    const int KS = D + 1, KS4 = (KS + 3) / 4, nmt = Mpad32 / 32;
-    const bool real_m = m < M;
-    double k2 = -INFINITY;
-    if (m < Mpad) {
-        double *p64 = params64 + ((size_t)j * Mpad + m) * row;
-        float *p32 = params32 + ((size_t)j * Mpad + m) * row;
-        double sumvar = 0.0, sumlog = 0.0;
-        for (int d = 0; d < D; ++d) {
-            double s = 0.0, c = 0.0, mu = 0.0;
-            if (real_m && d < Dhost) {
-                const size_t o = ((size_t)j * Mpad + m) * D + d;
-                mu = mean64[o];
-                const double vr = var64[o];
-                s = sqrt(LOG2E / (2.0 * vr));
-                c = -mu * s;
-                sumvar += vr;
-                sumlog += log(vr);
-            }
-            p64[2 * d] = s; p64[2 * d + 1] = c;
-            p32[2 * d] = (float)s; p32[2 * d + 1] = (float)c;
-            mean32[((size_t)j * Mpad + m) * D + d] = (float)mu;
+// one workgroup per (state, 32-mixture tile): the tile's mean/var rows are staged in LDS with coalesced
+// loads and every output layout is written with contiguous 8/16-byte stores
+__global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
+                                                     const double *__restrict__ w64, const float *__restrict__ centers, int M,
+                                                     int Mpad, int Mpad32, int D, int Dhost, int row, int flags,
+                                                     float *__restrict__ params32, double *__restrict__ params64,
+                                                     float *__restrict__ mean32, float *__restrict__ pm32) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
+    const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
+    double *mu = sh, *vr = sh + 32 * D, *k2s = vr + 32 * D, *kqs = k2s + 32;
+    float *cen = reinterpret_cast<float *>(kqs + 32);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 32 * D; e += 256) {
+        const int m = m0 + e / D;
+        const bool ok = m < M && (e % D) < Dhost;
+        mu[e] = ok ? mean64[((size_t)j * Mpad + m0) * D + e] : 0.0;
+        vr[e] = ok ? var64[((size_t)j * Mpad + m0) * D + e] : 1.0;
+    }
+    for (int d = tid; d < D; d += 256) cen[d] = centers[(size_t)j * D + d];
+    __syncthreads();
+    if (tid < 32) {
+        const int m = m0 + tid;
+        double sumvar = 0.0, sumlog = 0.0, kq = 0.0;
+        for (int d = 0; d < Dhost; ++d) {
+            const double v = vr[tid * D + d], dm = mu[tid * D + d] - (double)cen[d];
+            sumvar += v;
+            sumlog += log(v);
+            kq += dm * dm / (2.0 * v);
         }
-        if (real_m) {
+        double k2 = -INFINITY;
+        if (m < M) {
             // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var); textbook log-determinant only on request
             const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
             k2 = LOG2E * (log(w64[(size_t)j * Mpad + m]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
         }
-        p64[2 * D] = k2; p32[2 * D] = (float)k2;
-        for (int k = 2 * D + 1; k < row; ++k) { p64[k] = 0.0; p32[k] = 0.f; }
+        k2s[tid] = k2;
+        kqs[tid] = LOG2E * kq;
     }
-    if (m < Mpad32 && pm32) {
-        const int mt = m >> 5, cl = m & 31;
-        float *base = pm32 + (((size_t)j * nmt + mt) * KS4) * 64 * 4;
-        double kq = 0.0;
-        for (int s = 0; s < KS4 * 4; ++s) {
-            double a = 0.0, b = 0.0;
-            if (real_m && s < Dhost) {
-                const size_t o = ((size_t)j * Mpad + m) * D + s;
-                const double vr = var64[o], dm = mean64[o] - (double)centers[(size_t)j * D + s];
-                a = -LOG2E / (2.0 * vr);
-                b = LOG2E * dm / vr;
-                kq += dm * dm / (2.0 * vr);
+    __syncthreads();
+    // VALU scoring rows [s_d c_d ... k2 pad] and the f32 means (only mixtures inside the Mpad grid)
+    for (int e = tid; e < 32 * D; e += 256) {
+        const int ml = e / D, d = e - ml * D, m = m0 + ml;
+        if (m >= Mpad) continue;
+        const bool ok = m < M && d < Dhost;
+        const double s = ok ? sqrt(LOG2E / (2.0 * vr[e])) : 0.0, c = ok ? -mu[e] * s : 0.0;
+        const size_t o = ((size_t)j * Mpad + m) * row + 2 * d;
+        *reinterpret_cast<double2 *>(params64 + o) = make_double2(s, c);
+        *reinterpret_cast<float2 *>(params32 + o) = make_float2((float)s, (float)c);
+        mean32[((size_t)j * Mpad + m) * D + d] = ok ? (float)mu[e] : 0.f;
+    }
+    for (int e = tid; e < 32 * (row - 2 * D); e += 256) {
+        const int ml = e / (row - 2 * D), k = 2 * D + e % (row - 2 * D), m = m0 + ml;
+        if (m >= Mpad) continue;
+        const double v = (k == 2 * D) ? k2s[ml] : 0.0;
+        params64[((size_t)j * Mpad + m) * row + k] = v;
+        params32[((size_t)j * Mpad + m) * row + k] = (float)v;
+    }
+    // MFMA layout [KS4][64 lanes][4]: lane = half * 32 + mixture, element = k-step 4q + e
+    float4 *pt = reinterpret_cast<float4 *>(pm32) + ((size_t)j * nmt + mt) * (KS4 * 64);
+    for (int e = tid; e < KS4 * 64; e += 256) {
+        const int q = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
+        const bool real_m = (m0 + cl) < M;
+        float v[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int s = 4 * q + x;
+            float val = 0.f;
+            if (s < D) {
+                if (real_m && s < Dhost) {
+                    const double var = vr[cl * D + s], dm = mu[cl * D + s] - (double)cen[s];
+                    val = half ? (float)(LOG2E * dm / var) : (float)(-LOG2E / (2.0 * var));
+                }
+            } else if (s == D) {
+                // the constant pair: k' on the low half-wave, 1 in the spare slot (multiplied by 0 in plain
+                // scoring, by -ref / cf in the kernels that use the slot)
+                val = half ? 1.f : (real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY);
             }
-            base[((size_t)(s >> 2) * 64 + cl) * 4 + (s & 3)] = (float)a;
-            base[((size_t)(s >> 2) * 64 + 32 + cl) * 4 + (s & 3)] = (float)b;
+            v[x] = val;
         }
-        // the constant pair (k-step D): k' on the low half-wave, 1 in the spare slot (it multiplies 0 in the
-        // scoring kernel, -ref / cf in the kernels that use the slot)
-        base[((size_t)(D >> 2) * 64 + cl) * 4 + (D & 3)] = real_m ? (float)(k2 - LOG2E * kq) : -INFINITY;
-        base[((size_t)(D >> 2) * 64 + 32 + cl) * 4 + (D & 3)] = 1.f;
+        pt[e] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
-// Clustering.GMM.update_param for every (state, mixture)
+// Clustering.GMM.update_param, one thread per (state, mixture, dim)
 __global__ void mstep_kernel(const double *__restrict__ st_acc, const double *__restrict__ st_alpha,
                              const double *__restrict__ st_mean, const double *__restrict__ st_cov, int J, int M, int Mpad,
                              int D, int Dhost, double bias, double floor_var, double *__restrict__ mean64,
                              double *__restrict__ var64, double *__restrict__ w64) {
-    const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (gid >= (long long)J * M) return;
-    const int j = (int)(gid / M), m = (int)(gid % M);
-    const size_t jm = (size_t)j * Mpad + m;
-    const double a = st_acc[jm];
-    w64[jm] = a / st_alpha[j];                                   // Clustering.py:685
-    for (int d = 0; d < Dhost; ++d) {
-        mean64[jm * D + d] = st_mean[jm * D + d] / a - bias;     // :686
-        double c = st_cov[jm * D + d] / a;                       // :688
+    const long long total = (long long)J * Mpad * D;
+    for (long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const int d = (int)(gid % D);
+        const long long jm = gid / D;
+        const int m = (int)(jm % Mpad), j = (int)(jm / Mpad);
+        if (m >= M || d >= Dhost) continue;
+        const double a = st_acc[jm];
+        if (d == 0) w64[jm] = a / st_alpha[j];                   // Clustering.py:685
+        mean64[gid] = st_mean[gid] / a - bias;                   // :686
+        double c = st_cov[gid] / a;                              // :688
         if (c < floor_var) c = floor_var;                        // :689-692
-        var64[jm * D + d] = c;
+        var64[gid] = c;
     }
 }
 
@@ -135,19 +158,17 @@ int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64
 
 int pcl_launch_derive(pcl_ctx *ctx) {
     hipLaunchKernelGGL(centers_kernel, dim3(ctx->J), dim3(64), 0, ctx->stream, ctx->mean64, ctx->M, ctx->Mpad, ctx->D, ctx->centers32);
-    const int mmax = ctx->Mpad32 > ctx->Mpad ? ctx->Mpad32 : ctx->Mpad;
-    const long long n = (long long)ctx->J * mmax;
-    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64,
-                       ctx->centers32, ctx->J, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
+    const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)ctx->D * sizeof(float);
+    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
+                       ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }
 
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var) {
-    const long long n = (long long)ctx->J * ctx->M;
     pcl_timer_begin(ctx, "mstep");
-    hipLaunchKernelGGL(mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->st_acc, ctx->st_alpha, ctx->st_mean,
+    hipLaunchKernelGGL(mstep_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_acc, ctx->st_alpha, ctx->st_mean,
                        ctx->st_cov, ctx->J, ctx->M, ctx->Mpad, ctx->D, ctx->Dhost, 100.0, floor_var, ctx->mean64, ctx->var64, ctx->w64);
     int r = pcl_launch_derive(ctx);
     pcl_timer_end(ctx, "mstep");
