@@ -413,3 +413,69 @@ def test_em_iteration_on_device(eng, prec):
     _, _, ref, _ = po.score_label(x, list(labels[0]), model2)
     fin_close(B2[0], ref, rtol=0, atol=F32_LOGLIK_ATOL if prec == 'f32' else 1e-9)
     b.close()
+
+
+# ------------------------------------------------------------------ BASELINE config C3 at full size: forced alignment
+def test_c3_full_size_alignment_properties(eng):
+    """configs[2]: 1024 utterances x ~300 frames (ragged here), 39-dim, 2048-mix, Viterbi forced alignment.
+    Properties: every path is monotone in a left-right sentence HMM and starts in the entry state; the
+    Viterbi score never exceeds the forward score; re-running Viterbi in the oracle on the SAME emissions
+    reproduces the device path bit for bit (the contract of LHMM.viterbi); the emissions of
+    sampled utterances match the oracle."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.engine import make_sentence_batch, embedded_structure
+    c = synth.CONFIGS['C3']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'])
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], ragged=True)
+    labels = synth.make_labels(c['U'], c['L'], c['units'])
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    b.viterbi()
+    b.forward_backward(fix_pi=True)
+    pts, paths, lp = b.get('point'), b.get('path'), b.get('logp')
+    assert np.all(pts <= lp + 1e-9)
+    for u in range(c['U']):
+        assert paths[u][0] == 0 and np.all(np.diff(paths[u]) >= 0) and np.all(np.diff(paths[u]) <= 1)
+    B = b.get('B')
+    model = oracle_model(mean, var, w, trans)
+    for u in (0, 511, 1023):
+        a, pi = embedded_structure(len(labels[u]), [trans[i] for i in labels[u]])
+        rp, rpath = po.viterbi(a, pi, B[u])
+        assert np.array_equal(paths[u].astype(np.float64), rpath) and rp == pts[u]
+    x = frames[begin[5]:begin[5] + lens[5]].astype(np.float64)
+    ref = po.gmm_point(x, *model[int(labels[5][3])]['gmms'][1])
+    np.testing.assert_allclose(B[5][1 + 3 * 3 + 1], ref, atol=F32_LOGLIK_ATOL)
+    b.close()
+
+
+def test_uneven_states_and_tiny_batches(eng):
+    """State lists of very different lengths (padding tiles of the XCD-aware order), a state used by a single
+    short utterance, T = 1 and T = 2 utterances."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.engine import make_sentence_batch
+    mean, var, w, trans = synth.make_model(11, 40, 39, seed=21)
+    lens = np.array([1, 2, 700, 3, 65, 64, 63, 257, 300, 5], dtype=np.int32)
+    begin = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
+    rng = np.random.default_rng(3)
+    frames = rng.standard_normal((int(lens.sum()), 39)).astype(np.float32)
+    labels = [np.array([0]), np.array([1, 0]), np.array([0, 0, 0, 2]), np.array([10]), np.array([3, 4]),
+              np.array([0, 5]), np.array([6]), np.array([0, 7, 0]), np.array([8, 9, 0]), np.array([0])]
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    B = b.get('B')
+    model = oracle_model(mean, var, w, trans)
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, _, ref, _ = po.score_label(x, list(lab), model)
+        fin_close(B[u], ref, rtol=0, atol=F32_LOGLIK_ATOL)
+    b.viterbi()
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, a, _, pi = po.score_label(x, list(lab), model)
+        rp, rpath = po.viterbi(a, pi, B[u])
+        assert np.array_equal(b.get('path')[u].astype(np.float64), rpath)
+    b.close()
