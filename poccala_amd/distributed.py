@@ -127,13 +127,14 @@ class Control(object):
                 for k in range(32):
                     try:
                         s = socket.create_connection((addr, base + k), timeout=2.0)
-                        s.settimeout(timeout)
+                        s.settimeout(5.0)                   # a foreign service on this port must not stall us
                         _send(s, (_MAGIC, self.rank))
                         if _recv(s) == _MAGIC:
+                            s.settimeout(timeout)
                             self.hub = s
                             break
                         s.close()
-                    except (OSError, ConnectionError, pickle.UnpicklingError, struct.error):
+                    except (OSError, ConnectionError, pickle.UnpicklingError, struct.error, EOFError, ValueError):
                         continue
                 if self.hub is None:
                     if time.time() > deadline:
