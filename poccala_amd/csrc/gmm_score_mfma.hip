@@ -19,8 +19,8 @@
 //   B (frames):     lane l holds X[f0 + (l&31)][2s + (l>>5)]  ->  lanes 0-31 carry x'^2 (1 at s = D),
 //                   lanes 32-63 carry x' (0 at s = D).  Resident in VGPRs for the whole kernel.
 //   D: lane l, reg r = mixture row (r&3) + 8 (r>>2) + 4 (l>>5) of frame column l&31: a lane owns 16 of the
-//      32 mixture values of ONE frame, so the log-sum-exp over mixtures is 16 values per lane per m-tile
-//      (one rescale per 16 -> 17/16 v_exp_f32 per Gaussian) and the two half-waves are merged once at the end.
+//      32 mixture values of ONE frame, so the log-sum-exp over mixtures is per lane (reference-shifted,
+//      see the loop) and the two half-waves are merged once at the end.
 // A wave owns NT = 2 column tiles (64 frames); 4 waves per workgroup; 2 waves per SIMD.
 #include <stdlib.h>
 
@@ -35,14 +35,9 @@ constexpr int WG = 256;
 #ifndef PCL_MFMA_MINW
 #define PCL_MFMA_MINW 2    // __launch_bounds__ waves per SIMD
 #endif
-#ifndef PCL_MFMA_LSE
-#define PCL_MFMA_LSE 1     // 1: reference-shifted log-sum-exp (the shift rides in the spare K slot of the MFMA)
-#endif
-#ifndef PCL_MFMA_PIPE
-#define PCL_MFMA_PIPE 0    // 1: log-sum-exp of m-tile i-1 is issued behind the MFMAs of m-tile i
-#endif
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 template <int D, int NT>
 __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const float *__restrict__ frames,
@@ -60,7 +55,7 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
     const int col = lane & 31;
     if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
     const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
-    if (tile.vstart + wave * NT * 32 >= vend) return;   // whole wave past the end of the state's frames
+    const bool wave_active = tile.vstart + wave * NT * 32 < vend;   // a wave past the end still helps staging
 
     // ---- B operand: this lane's frames, centred, squared on the low half-wave
     float xb[NT][KS4 * 4];
@@ -91,35 +86,35 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
         oidx[c] = sg.out0 + t * (long long)sg.out_stride;
     }
 
-    float mx[NT], sm[NT];
+    float sm[NT], ref[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-        mx[c] = -1.0e30f;
         sm[c] = 0.f;
+        ref[c] = 0.f;
     }
 
-    // parameters of this state: [m-tile][KS4][64 lanes][4] floats
-    const f4v *pa = reinterpret_cast<const f4v *>(pm) + (size_t)tile.state * n_mtiles * (KS4 * 64) + lane;
-    f4v a[KS4];
-#pragma unroll
-    for (int q = 0; q < KS4; ++q) a[q] = pa[q * 64];
+    // parameters of this state: [m-tile][KS4][64 lanes][4] floats, staged per m-tile in LDS by LDS-DMA
+    // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR destination) and shared by the 4 waves.
+    __shared__ __attribute__((aligned(16))) float abuf[2][KS4 * 64 * 4];
+    const float *pstate = pm + (size_t)tile.state * n_mtiles * (KS4 * 64 * 4);
+    auto dma = [&](int buf, int mt) {
+        const float *src = pstate + (size_t)mt * (KS4 * 64 * 4);
+        for (int p = wave; p < KS4; p += WG / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)&abuf[buf][p * 256], 16, 0, 0);
+    };
 
-#if PCL_MFMA_LSE
     // Reference-shifted log-sum-exp.  The K dimension has one spare slot (2D+1 features in 2D+2): the
     // parameter side holds 1 there and the frame side holds -ref[frame], so the matrix pipe delivers
-    // v - ref and the VALU only has to do  s += exp2(v - ref)  (one v_exp_f32 + one add per Gaussian, no
-    // subtract, no per-tile rescale).  ref is a true maximum seen earlier for that frame, so the largest
-    // term is >= 1 and nothing underflows; it is raised only when some value exceeds it by > 2^64
-    // (wave-uniform slow path, always taken on the first m-tile).  Both half-waves of a frame column share
-    // one ref, so their partial sums simply add at the end.
-    float ref[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) ref[c] = 0.f;
-    for (int mt = 0; mt < n_mtiles; ++mt) {
-        const f4v *pn = pa + (size_t)(mt + 1 < n_mtiles ? mt + 1 : mt) * (KS4 * 64);
-        f4v an[KS4];
-#pragma unroll
-        for (int q = 0; q < KS4; ++q) an[q] = pn[q * 64];
+    // v - ref and the VALU only does  s += sum_r exp2(v_r - ref): 16 v_exp_f32 and a packed add tree per
+    // 16 Gaussians -- no subtract, no max, no per-tile rescale.  (Every VALU instruction issued on a SIMD
+    // costs matrix-pipe time: SQ_VALU_MFMA_BUSY_CYCLES showed the pipe 82 % busy at 1.3 VALU per MFMA.)
+    // ref is a true maximum seen earlier for that frame, so the largest term is >= 1 and nothing
+    // underflows.  It is raised on a wave-uniform slow path, taken on the first m-tile and whenever a sum
+    // overflows f32 (a value more than ~2^127 above ref): that path recomputes the tile's sum from the
+    // still-live accumulators with the usual max-rescale.  Both half-waves of a frame column share one
+    // ref, so their partial sums simply add at the end.
+    auto process = [&](const f4v (&av)[KS4], int mt) {
         f16v acc[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
@@ -130,107 +125,58 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
             for (int c = 0; c < NT; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s >> 2][s & 3], xb[c][s], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], xb[c][s], acc[c], 0, 0, 0);
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
-            float gm = acc[c][0];
+            f2v e[8];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
-            if (mt == 0 || __any(gm > 64.f)) {
+            for (int r = 0; r < 8; ++r) e[r] = f2v{__builtin_amdgcn_exp2f(acc[c][2 * r]), __builtin_amdgcn_exp2f(acc[c][2 * r + 1])};
+            const f2v t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
+            const f2v t = t0 + t1;
+            const float snew = sm[c] + (t.x + t.y);
+            if (mt == 0 || __any(!(snew < 3.0e38f))) {
+                float gm = acc[c][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
                 const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));   // max over the frame's 32 mixtures
+                float s = sm[c];
                 if ((mt == 0 || gp > 0.f) && gp > -INFINITY) {
-                    sm[c] = (mt == 0) ? 0.f : sm[c] * __builtin_amdgcn_exp2f(-gp);   // first tile: gp << 0, 0 * exp2(-gp) would be 0 * inf
+                    s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);   // first tile: gp << 0, 0 * exp2(-gp) would be 0 * inf
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[c][r] -= gp;
                     ref[c] += gp;
                     if (half) xb[c][D] = -ref[c];
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
+                sm[c] = s;
+            } else {
+                sm[c] = snew;
             }
-            float s = sm[c];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
-            sm[c] = s;
         }
-#pragma unroll
-        for (int q = 0; q < KS4; ++q) a[q] = an[q];
-    }
-    constexpr double LN2R = 0.693147180559945309417232121458;
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
-        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2R * ((double)ref[c] + ::log2(S)) : -INFINITY;
-    }
-    return;
-#else
-    auto lse_update = [&](const f16v &t, int c) {
-        float gm = t[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, t[r]);
-        const float nm = __builtin_fmaxf(mx[c], gm);
-        float s = sm[c] * __builtin_amdgcn_exp2f(mx[c] - nm);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(t[r] - nm);
-        sm[c] = s;
-        mx[c] = nm;
     };
-#if PCL_MFMA_PIPE
-    f16v prev[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) prev[c][r] = -INFINITY;   // contributes exp2(-inf) = 0
-    }
-#endif
+    // One barrier per m-tile.  The DMA of tile i+1 is issued right after the barrier that publishes tile i
+    // and has a whole tile of MFMAs (5120 cycles) to land; hipcc cannot sink it the way it sinks ordinary
+    // global loads (it sank a register prefetch to just in front of the MFMAs that use it, exposing the L2
+    // latency on every tile).
+    dma(0, 0);
     for (int mt = 0; mt < n_mtiles; ++mt) {
-        // prefetch the next m-tile's A operand (the last iteration re-reads the current tile)
-        const f4v *pn = pa + (size_t)(mt + 1 < n_mtiles ? mt + 1 : mt) * (KS4 * 64);
-        f4v an[KS4];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile mt have landed
+        __syncthreads();                                    // everyone's pieces have; buffer (mt+1)&1 is free
+        if (mt + 1 < n_mtiles) dma((mt + 1) & 1, mt + 1);
+        if (wave_active) {
+            f4v a[KS4];
 #pragma unroll
-        for (int q = 0; q < KS4; ++q) an[q] = pn[q * 64];
-
-        f16v acc[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+            for (int q = 0; q < KS4; ++q) a[q] = *reinterpret_cast<const f4v *>(&abuf[mt & 1][(q * 64 + lane) * 4]);
+            process(a, mt);
         }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-#pragma unroll
-            for (int c = 0; c < NT; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s >> 2][s & 3], xb[c][s], acc[c], 0, 0, 0);
-        }
-        // online log-sum-exp over this lane's 16 mixtures of each frame column (log2 domain)
-#if PCL_MFMA_PIPE
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            lse_update(prev[c], c);
-            prev[c] = acc[c];
-        }
-#else
-#pragma unroll
-        for (int c = 0; c < NT; ++c) lse_update(acc[c], c);
-#endif
-#pragma unroll
-        for (int q = 0; q < KS4; ++q) a[q] = an[q];
     }
-#if PCL_MFMA_PIPE
-#pragma unroll
-    for (int c = 0; c < NT; ++c) lse_update(prev[c], c);
-#endif
-
-#endif
     constexpr double LN2 = 0.693147180559945309417232121458;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-        // merge the two half-waves (mixture rows 4h..4h+3 mod 8 of every m-tile)
-        const float m2 = __shfl_xor(mx[c], 32, 64);
-        const float s2 = __shfl_xor(sm[c], 32, 64);
-        const float M = __builtin_fmaxf(mx[c], m2);
-        const double S = (double)sm[c] * (double)__builtin_amdgcn_exp2f(mx[c] - M) +
-                         (double)s2 * (double)__builtin_amdgcn_exp2f(m2 - M);
-        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2 * ((double)M + ::log2(S)) : -INFINITY;
+        const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
+        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2 * ((double)ref[c] + ::log2(S)) : -INFINITY;
     }
 }
 
