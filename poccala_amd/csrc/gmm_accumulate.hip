@@ -292,35 +292,73 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
     double galpha = 0.0;
     constexpr double LOG2E = 1.4426950408889634074;
 
-    auto stage = [&](int buf, long long f0) {
-        const int nf = (int)min(32LL, end - f0);
+    // Staging is split (issue early / write late): the gather loads of tile i+1 are issued into registers
+    // BEFORE the MFMAs of tile i and written to the other LDS buffer AFTER them, so their latency (two
+    // dependent loads: list entry -> frame row) is covered by 88 MFMAs instead of being exposed per tile.
+    constexpr int NE = (32 * D + AW * 64 - 1) / (AW * 64);   // feature elements per thread per tile
+    float xv[NE];
+    long long fidx[NE];                                      // frame rows of the tile after next (one more stage ahead)
+    float cfv = -INFINITY, cfn = -INFINITY;
+    double lgv = -INFINITY, lgn = -INFINITY;
+    auto stage_index = [&](long long f0) {                   // level 1 of the gather: list entries
+        const int nf = (f0 < end) ? (int)min(32LL, end - f0) : 0;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * AW * 64;
+            const int f = e / D;
+            fidx[k] = (e < 32 * D && f < nf) ? list[f0 + f].frame : -1;
+        }
+        cfn = -INFINITY;                                     // padding frame: g = exp2(-inf) = 0
+        lgn = -INFINITY;
+        if (threadIdx.x < nf) {
+            const ActiveFrame a = list[f0 + threadIdx.x];
+            cfn = (float)(a.coef * LOG2E);
+            lgn = a.lg;
+        }
+    };
+    auto stage_load = [&]() {                                // level 2: frame rows, from the indices loaded a tile ago
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * AW * 64;
+            const int d = e % D;
+            xv[k] = (fidx[k] >= 0) ? frames[fidx[k] * D + d] - cen[d] : 0.f;
+        }
+        cfv = cfn;
+        lgv = lgn;
+    };
+    auto stage_store = [&](int buf) {
         float *x = xe[buf];
-        for (int e = threadIdx.x; e < 32 * D; e += AW * 64) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * AW * 64;
             const int f = e / D, d = e - f * D;
-            float v = 0.f;
-            if (f < nf) v = frames[list[f0 + f].frame * D + d] - cen[d];
-            x[f * XSTR + 2 * d] = v * v;
-            x[f * XSTR + 2 * d + 1] = v;
+            if (e < 32 * D) {
+                x[f * XSTR + 2 * d] = xv[k] * xv[k];
+                x[f * XSTR + 2 * d + 1] = xv[k];
+            }
         }
         if (threadIdx.x < 32) {
             const int f = threadIdx.x;
-            float c = -INFINITY;                          // padding frame: g = exp2(-inf) = 0
-            if (f < nf) {
-                const ActiveFrame a = list[f0 + f];
-                c = (float)(a.coef * LOG2E);
-                if (slice == 0) galpha += exp(a.lg);
-            }
+            if (slice == 0 && lgv > -INFINITY) galpha += exp(lgv);
             x[f * XSTR + 2 * D] = 1.f;
-            x[f * XSTR + 2 * D + 1] = c;
+            x[f * XSTR + 2 * D + 1] = cfv;
             for (int k = 2 * D + 2; k < XSTR; ++k) x[f * XSTR + k] = 0.f;
         }
     };
 
-    stage(0, beg);
+    stage_index(beg);
+    stage_load();
+    stage_store(0);
+    stage_index(beg + 32);
     __syncthreads();
     int buf = 0;
     for (long long f0 = beg; f0 < end; f0 += 32) {
-        if (f0 + 32 < end) stage(buf ^ 1, f0 + 32);      // next tile, other buffer
+        const bool more = f0 + 32 < end;
+        if (more) {
+            stage_load();                                // tile i+1: frame rows in flight during the MFMAs below
+            stage_index(f0 + 64);                        // tile i+2: list entries
+        }
+        __builtin_amdgcn_sched_barrier(0);               // keep the loads in front of the matrix work
         if (live) {
             const float *x = xe[buf];
             // (1) D1[frame][mixture] = Xe . P   (log2 domain, + cf)
@@ -342,6 +380,8 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
                     S[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[r], x[fr * XSTR + ct * 32 + col], S[ct], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage_store(buf ^ 1);                  // nobody reads buf^1 until the barrier below
         __syncthreads();
         buf ^= 1;
     }
