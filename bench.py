@@ -45,7 +45,8 @@ def parse():
     p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
     p.add_argument('--traffic-bytes', type=float, default=None,
-                   help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass (profiles/)')
+                   help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass; default: the figure '
+                        'committed in profiles/r01_bench_summary.txt (FETCH_SIZE + WRITE_SIZE passes, tools/gpu_profile.sh)')
     return p.parse_args()
 
 
@@ -195,9 +196,17 @@ def main():
     # algorithmic HBM bytes per scoring launch: frames read once per scored state row (4D) is an upper
     # bound served from L2; the honest algorithmic figure is frames once + parameters once + B written once
     alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + pairs * 8
+    traffic = args.traffic_bytes
+    if traffic is None and args.workload == 'C4shard' and not args.utts and P == PCL_F32 and score_variant == 3:
+        try:   # PMC counters cannot be read from inside the run: use the committed separate-pass measurement
+            for line in open(os.path.join(ROOT, 'profiles', 'r01_bench_summary.txt')):
+                if line.startswith('traffic_bytes for bench.py'):
+                    traffic = float(line.split(':')[1])
+        except OSError:
+            pass
     roofline = dict(bound='mfma', achieved=achieved, peak=FP32_VECTOR_PEAK_TFLOPS, unit='TFLOP/s',
                     frac=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
-                    traffic=args.traffic_bytes,
+                    traffic=traffic, traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_bench_summary.txt), per launch',
                     kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
