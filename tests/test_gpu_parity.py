@@ -479,3 +479,49 @@ def test_uneven_states_and_tiny_batches(eng):
         rp, rpath = po.viterbi(a, pi, B[u])
         assert np.array_equal(b.get('path')[u].astype(np.float64), rpath)
     b.close()
+
+
+# ------------------------------------------------------------------ multi-GPU semantics on one GPU
+def test_sharded_estep_equals_unsharded_and_rccl_world1(eng):
+    """SURVEY section 4, multi-GPU tier without 8 GPUs: the utterances are split into 1/2/4 shards the way
+    bench.py / shard_range assign them to ranks, every shard runs its own E-step, and the shard statistics are
+    summed (what the RCCL all-reduce does).  The sums must equal the unsharded statistics.  Also: RCCL
+    initialised at world size 1 leaves the statistics untouched."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.distributed import shard_range
+    from poccala_amd.engine import make_sentence_batch
+    mean, var, w, trans = synth.make_model(6, 64, 39, seed=31)
+    frames, lens, begin = synth.make_frames(24, 120, 39, seed=32, ragged=True)
+    labels = synth.make_labels(24, 6, 6, seed=33)
+    eng.load_model(mean, var, w)
+
+    def estep(utts):
+        f0, f1 = int(begin[utts[0]]), int(begin[utts[-1]] + lens[utts[-1]])
+        eng.load_frames(frames[f0:f1])
+        b, _ = make_sentence_batch(eng, [labels[u] for u in utts], lens[utts], begin[utts] - f0, trans)
+        b.score(PCL_F32)
+        b.forward_backward()
+        b.accumulate(PCL_F32)                       # adds into the resident statistics
+        lp = b.get('logp').copy()
+        b.close()
+        return lp
+    eng.stats_zero()
+    lp_all = estep(np.arange(24))
+    ref = eng.stats_download()
+    for world in (2, 4):
+        eng.stats_zero()
+        lps = []
+        for rank in range(world):
+            lo, hi = shard_range(24, rank, world)
+            lps.append(estep(np.arange(lo, hi)))
+        got = eng.stats_download()
+        np.testing.assert_array_equal(np.concatenate(lps), lp_all)          # per-utterance results do not depend on the batch
+        for k in ref:
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-5, atol=1e-5 * np.abs(ref[k]).max(), err_msg='%s world %d' % (k, world))
+    # RCCL at world size 1: init, all-reduce, destroy
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    eng.stats_allreduce()
+    after = eng.stats_download()
+    for k in ref:
+        np.testing.assert_array_equal(after[k], got[k])
+    eng._lib.pcl_comm_destroy(eng._ctx)

@@ -7,7 +7,7 @@ import socket
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
+import multiprocessing as mp     # torch is imported only inside the spawned gloo workers, never in the pytest process
 
 from poccala_amd.distributed import shard_range
 
