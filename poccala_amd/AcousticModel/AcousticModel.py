@@ -206,3 +206,47 @@ class AcousticModel(DataInitialization):
         logp = b.get('logp')
         b.close()
         return stats, hmm_acc, logp
+
+    # ------------------------------------------------------------------ what follows the two workers in the reference
+    def segment_batch(self, labels, data_list, unit_hmms, precision=PCL_F64, engine=None):
+        """Alignment -> per-unit data segments for many utterances (the loop at AcousticModel.py:758-764:
+        discriminate + __save_data): returns {unit: [frame blocks]} where each block is the (n,D) slice of one
+        contiguous run of that unit, in utterance order; an utterance whose path misses a label unit is
+        dropped, as the reference does (:754-757)."""
+        out = {}
+        dropped = []
+        for u, (point, names) in enumerate(self.align_batch(labels, data_list, unit_hmms, precision, engine)):
+            if len(set(names)) < len(set(labels[u])):
+                dropped.append(u)
+                continue
+            data = np.asarray(data_list[u])
+            for unit in set(labels[u]):
+                for loc in AcousticModel.discriminate(unit, names):
+                    out.setdefault(unit, []).append(data[loc])
+        return out, dropped
+
+    def save_batch_acc(self, stats, hmm_acc, unit_hmms):
+        """Write the result of `estep_batch` as reference-format accumulator files (log domain, float64,
+        SURVEY T3): <unit>/HMM/{ksai-acc,gamma-acc}/..., <unit>/GMM_k/{acc,alpha-acc,mean-acc,covariance-acc}/...
+        so that the reference's multi_embedded_training_2 (AcousticModel.py:918-935) can merge them."""
+        units = sorted(unit_hmms)
+        e = self.__state_num - 2
+        for ui, unit in enumerate(units):
+            hmm = unit_hmms[unit]
+            touched = False
+            if unit in hmm_acc:
+                hmm.add_acc(hmm_acc[unit][0], hmm_acc[unit][1])
+                touched = True
+            if stats is not None:
+                with np.errstate(divide='ignore'):
+                    for k in range(e):
+                        j = ui * e + k
+                        if stats['alpha_acc'][j] > 0:
+                            g = hmm.profunction[1 + k]
+                            g.acc = np.log(stats['acc'][j])
+                            g.alpha_acc = float(np.log(stats['alpha_acc'][j]))
+                            g.mean_acc = np.log(stats['mean_acc'][j])
+                            g.covariance_acc = list(np.log(stats['cov_acc'][j]))
+                            touched = True
+            if touched:
+                self.save_acc(unit, hmm)

@@ -180,3 +180,31 @@ def test_batched_estep_equals_per_utterance_dropin(golden):
             np.testing.assert_allclose(stats['acc'][j], ref, rtol=1e-8)
             refm = sum(np.exp(g['mean_acc_%d_%d' % (p, k)]) for p in pos_list)
             np.testing.assert_allclose(stats['mean_acc'][j], refm, rtol=1e-8)
+
+
+def test_segment_batch_and_accumulator_files(golden, tmp_path):
+    """The steps after the two workers: alignment -> per-unit segments (AcousticModel.py:758-764) and the
+    reference-format accumulator files a reference multi_embedded_training_2 could merge."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd import PCL_F64
+    g = golden('G6_small_fix0')
+    label, hmm_list = build_units(g)
+    am = AcousticModel(RecLog(), 'XIF_tone', state_num=S, mix_level=4, dct_num=13, delta_1=False, delta_2=False,
+                       parameters_path=str(tmp_path))
+    unit_hmms = {u: hmm_list[label.index(u)] for u in set(label)}
+    segs, dropped = am.segment_batch([label], [g['x']], unit_hmms, precision=PCL_F64)
+    assert dropped == []
+    for u in set(label):
+        assert len(segs[u]) == int(g['disc_%s_n' % u])
+        for ri, blk in enumerate(segs[u]):
+            np.testing.assert_array_equal(blk, g['x'][g['disc_%s_%d' % (u, ri)]])
+    stats, hmm_acc, _ = am.estep_batch([label], [g['x']], unit_hmms, fix_code=0, precision=PCL_F64)
+    am.save_batch_acc(stats, hmm_acc, unit_hmms)
+    fresh = am.init_unit('b')
+    fresh.init_acc(am.unit_path('b'))
+    for k in range(S - 2):
+        fresh.profunction[1 + k].init_acc(am.unit_path('b'))
+    pos = [p for p, u in enumerate(label) if u == 'b']
+    fin_close(fresh.ksai_acc, np.logaddexp.reduce([g['ksai_acc_%d' % p] for p in pos]), rtol=1e-9)
+    fin_close(fresh.profunction[1].acc, np.logaddexp.reduce([g['acc_%d_0' % p] for p in pos]), rtol=1e-8, atol=1e-10)
+    fin_close(fresh.profunction[2].mean_acc, np.logaddexp.reduce([g['mean_acc_%d_1' % p] for p in pos]), rtol=1e-8, atol=1e-10)
