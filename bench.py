@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CPU_SAMPLE_FRAMES = 64            # frames per utterance in the CPU baseline sample (about 20-30 s of CPU work per leg)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
 HBM_PEAK_GBS = 8000.0
 
@@ -71,6 +72,29 @@ def _cpu_vectorised_utt(args):
     return time.perf_counter() - t0
 
 
+def _cpu_gemm_utt(args):
+    """Informational third figure: the same log-likelihoods through the expanded quadratic form as ONE float64
+    GEMM per state on the host BLAS (single thread per worker) + the vectorised forward-backward.  This is not
+    the reference's arithmetic (it is the formulation the GPU kernel uses); it shows what an optimised CPU
+    implementation of the same mathematics would do on these cores."""
+    from threadpoolctl import threadpool_limits
+    from oracle import poccala_oracle as po
+    x, gmms_per_row, a, pi = args
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        xe = np.concatenate([x * x, x, np.ones((x.shape[0], 1))], axis=1)             # (T, 2D+1)
+        rows = [np.zeros(x.shape[0])]
+        for (mean, var, w) in gmms_per_row:
+            d = mean.shape[1]
+            with np.errstate(divide='ignore'):
+                k = np.log(w) - d / 2.0 * po.LOG_2PI - 0.5 * var.sum(1) - 0.5 * (mean * mean / var).sum(1)
+            p = np.concatenate([-0.5 / var, mean / var, k[:, None]], axis=1)           # (M, 2D+1)
+            rows.append(po.lse(xe @ p.T, axis=1))
+        rows.append(np.full(x.shape[0], -np.inf))
+        po.baum_welch(a, pi, [np.array(rows)])
+        return time.perf_counter() - t0
+
+
 def _cpu_faithful_sample(args):
     """The reference's own loop nest (per frame x per mixture NumPy calls; per-(t,j) LSE) on a tiny
     sample: `nf` frames of scoring for every row + one full forward/backward lattice."""
@@ -101,7 +125,7 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
     n_utt = min(cores, len(labels))
     for u in range(n_utt):
         lab = labels[u]
-        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        x = frames[begin[u]:begin[u] + min(int(lens[u]), CPU_SAMPLE_FRAMES)].astype(np.float64)   # bounded sample
         gm = [(mean[i * e + k], var[i * e + k], w[i * e + k]) for i in lab for k in range(e)]
         a, pi = embedded_structure(len(lab), [trans[i] for i in lab])
         jobs_v.append((x, gm, a, pi))
@@ -111,12 +135,18 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
         pool.map(_cpu_vectorised_utt, jobs_v, chunksize=1)
         wall = time.perf_counter() - t0
         per_frame = pool.map(_cpu_faithful_sample, jobs_f, chunksize=1)
+        t0 = time.perf_counter()
+        pool.map(_cpu_gemm_utt, jobs_v, chunksize=1)
+        wall_gemm = time.perf_counter() - t0
     frames_done = int(sum(len(j[0]) for j in jobs_v))
     vec = frames_done / wall
     faithful = len(per_frame) / float(np.mean(per_frame)) if n_utt == cores else cores / float(np.mean(per_frame))
     return dict(value=vec, unit='frames/s', cores=min(cores, n_utt), kind='port',
-                sample='%d utterances x %d frames (one per core, multiprocessing), vectorised float64 NumPy oracle: '
-                       'score %d label states x %d mixtures + 3-pass forward-backward' % (n_utt, int(lens[0]), len(jobs_v[0][1]), cfg['M']),
+                sample='first %d frames of %d utterances (one utterance per core, multiprocessing), vectorised float64 NumPy oracle: '
+                       'score %d label states x %d mixtures + 3-pass forward-backward' % (len(jobs_v[0][0]), n_utt, len(jobs_v[0][1]), cfg['M']),
+                gemm_value=frames_done / wall_gemm,
+                gemm_sample='same sample, expanded quadratic form as one float64 BLAS GEMM per state (1 thread per worker): an '
+                            'optimised CPU formulation, not the reference arithmetic',
                 faithful_value=faithful,
                 faithful_sample='reference loop nest (per frame x per mixture NumPy calls, per-(t,j) LSE): 1 frame x %d states '
                                 'of scoring + one faithful forward/backward lattice per core, scaled to frames/s over %d cores' % (len(jobs_v[0][1]), cores))
@@ -135,11 +165,12 @@ def main():
 
     from poccala_amd import Engine, PCL_F32, PCL_F64, synth
     from poccala_amd.engine import make_sentence_batch
-    eng = Engine(local)
+    eng = Engine(int(os.environ.get('POCCALA_DEVICE', local)))   # override only for single-GPU rehearsals of the N > 1 path
     # control plane: a few tiny host-side exchanges over TCP (poccala_amd.distributed.Control), no torch in
     # the GPU processes; the statistics themselves travel over RCCL inside the library.
     from poccala_amd.distributed import Control
-    use_dist = world > 1 or bool(os.environ.get('POCCALA_FORCE_DIST'))   # FORCE: exercise RCCL at world 1
+    use_dist = (world > 1 or bool(os.environ.get('POCCALA_FORCE_DIST'))) and not os.environ.get('POCCALA_NO_RCCL')
+    # FORCE_DIST: exercise RCCL at world 1; NO_RCCL: rehearse the N > 1 control flow with all ranks on one GPU
     ctl = Control(rank, world)
 
     def barrier():
@@ -284,7 +315,8 @@ def main():
         if extra:
             out['extra'] = extra
         if cpu:
-            out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value']}
+            out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value'],
+                                   'vs_blas_gemm_formulation': value / cpu['gemm_value']}
         print(json.dumps(out))
     batch.close()
     if use_dist:

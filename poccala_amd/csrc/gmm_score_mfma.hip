@@ -127,6 +127,11 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
             for (int c = 0; c < NT; ++c)
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s >> 2][s & 3], xb[c][s], acc[c], 0, 0, 0);
         }
+#ifdef PCL_DIAG_NOLSE
+#pragma unroll
+        for (int c = 0; c < NT; ++c) sm[c] += acc[c][0] + acc[c][15];   // diagnostic build: no log-sum-exp work (wrong results)
+        return;
+#endif
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             f2v e[8];

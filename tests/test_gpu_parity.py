@@ -525,3 +525,29 @@ def test_sharded_estep_equals_unsharded_and_rccl_world1(eng):
     for k in ref:
         np.testing.assert_array_equal(after[k], got[k])
     eng._lib.pcl_comm_destroy(eng._ctx)
+
+
+# ------------------------------------------------------------------ BASELINE config C5 shape: all-state scoring for decoding
+def test_c5_all_state_scoring(eng):
+    """configs[4] scores EVERY GMM state of the XIF_tone inventory (183 units -> J = 549) for every frame
+    (the decoder has no label).  Here: J = 549, D = 39, a reduced mixture count and 4 short utterances; every
+    row of every emission matrix against the oracle.  The rows of an utterance are then all J states."""
+    from poccala_amd import PCL_F32, synth
+    units, M, D = 183, 24, 39
+    mean, var, w, _ = synth.make_model(units, M, D, seed=51)
+    frames, lens, begin = synth.make_frames(4, 45, D, seed=52, ragged=True)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    J = units * 3
+    b = eng.batch([J + 2] * 4, lens, begin)
+    rows = np.concatenate([[-1], np.arange(J), [-2]]).astype(np.int32)
+    b.set_states([rows] * 4)
+    b.score(PCL_F32)
+    B = b.get('B')
+    for u in range(4):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        for j in (0, 1, 274, 547, 548):
+            np.testing.assert_allclose(B[u][1 + j], po.gmm_point(x, mean[j], var[j], w[j]), atol=F32_LOGLIK_ATOL)
+        assert np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1]))
+    # the A16 recursion (Decoder.Token.viterbi, parity unpinned) over one word HMM = plain Viterbi scores on those rows
+    b.close()
