@@ -161,6 +161,19 @@ int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mea
 int pcl_mstep(pcl_ctx *ctx, double c_covariance);
 int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight);
 
+/* ----------------------------------------------------------------- MFCC front-end (next row f4: the step before the path)
+ * AudioProcessing.MFCC.mfcc (StatisticalModel/AudioProcessing.py:416-448) for U signals at once, float64:
+ * pre-emphasis 0.98 (:184), framing sampletime/overlap (:201), per-FRAME window factor (:228, as the reference
+ * computes it), |rFFT_nfft| (:250), mel filter bank + frame energy (:279), ln + DCT (:347), c0 <- ln(energy)
+ * (flags bit0), deltas / delta-deltas over +-2 frames (flags bit1 / bit2, :401).  signal = concatenated samples,
+ * sig_off[U+1]; twiddle_cos/sin[nfft], mel_response[filterbanks][nfft/2+1] and dct_matrix[rank][filterbanks] are
+ * built by the caller (poccala_amd/StatisticalModel/AudioProcessing.py) so the reference's filter and DCT
+ * conventions are defined in one place.  out: out_rows x (rank * {1,2,3}) row-major, out_rows = total frames. */
+int pcl_mfcc(pcl_ctx *ctx, int U, const double *signal, const int64_t *sig_off, int framerate, double sampletime,
+             double overlap, int nfft, int filterbanks, int rank, int flags, const double *twiddle_cos,
+             const double *twiddle_sin, const double *mel_response, const double *dct_matrix, double *out,
+             int64_t out_rows);
+
 /* ----------------------------------------------------------------- multi-GPU (RCCL over xGMI)
  * Replaces the reference's file-based accumulator merge (LHMM.py:256-290, Clustering.py:314-367).
  * id_bytes is a 128-byte ncclUniqueId made by rank 0 and distributed by the caller. */
