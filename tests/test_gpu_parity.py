@@ -551,3 +551,43 @@ def test_c5_all_state_scoring(eng):
         assert np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1]))
     # the A16 recursion (Decoder.Token.viterbi, parity unpinned) over one word HMM = plain Viterbi scores on those rows
     b.close()
+
+
+# ------------------------------------------------------------------ error behaviour of the C-ABI
+def test_cabi_error_codes(eng):
+    """Every misuse returns a negative pcl_status with a message; nothing crashes, nothing falls back."""
+    from poccala_amd import PoccalaHipError
+    rng = np.random.default_rng(0)
+    with pytest.raises(PoccalaHipError, match='not positive'):
+        eng.load_model(rng.standard_normal((1, 2, 13)), np.zeros((1, 2, 13)), np.ones((1, 2)) / 2)
+    with pytest.raises(PoccalaHipError, match='> 64'):
+        eng.load_model(rng.standard_normal((1, 2, 70)), np.ones((1, 2, 70)), np.ones((1, 2)) / 2)
+    eng.load_model(rng.standard_normal((2, 2, 13)), np.ones((2, 2, 13)), np.ones((2, 2)) / 2)
+    eng.load_frames(rng.standard_normal((20, 13)))
+    with pytest.raises(PoccalaHipError, match='outside the uploaded'):
+        eng.batch([3], [30], [0])
+    b = eng.batch([3], [20], [0])
+    with pytest.raises(PoccalaHipError, match='set_states'):
+        b.score()
+    with pytest.raises(PoccalaHipError, match='outside'):
+        b.set_states([np.array([-1, 5, -2], dtype=np.int32)])
+    with pytest.raises(PoccalaHipError, match='no transitions'):
+        b.forward_backward()
+    a = np.array([[0, 1, 0], [0, .5, .5], [0, 0, 0.]])
+    with np.errstate(divide='ignore'):
+        b.set_transitions([np.log(a)], [np.log(np.ones(3) / 3)])
+    with pytest.raises(PoccalaHipError, match='no emissions'):       # LHMM.py:69: profunc or probmat is required
+        b.forward_backward()
+    with pytest.raises(PoccalaHipError, match='forward_backward first'):
+        b.get('alpha')
+    with pytest.raises(PoccalaHipError, match='viterbi first'):
+        b.get('path')
+    with pytest.raises(ValueError):
+        b.set_emissions([np.zeros((3, 19))])
+    b.set_states([np.array([-1, 1, -2], dtype=np.int32)])
+    b.score()
+    b.forward_backward()
+    assert np.isfinite(b.get('logp')[0])
+    b.close()
+    with pytest.raises(PoccalaHipError, match='has N=0'):
+        eng.batch([0], [5])

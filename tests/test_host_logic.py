@@ -1,0 +1,101 @@
+"""Host-side logic of the product package that needs no GPU: sentence-HMM construction (A7), discriminate,
+the log-sum-exp helpers that merge per-unit accumulators, the MFCC filter/DCT matrices, sharding."""
+import numpy as np
+import pytest
+
+from oracle import mfcc_oracle as mo
+from oracle import poccala_oracle as po
+
+CASES = ['G6_small_fix0', 'G6_small_fix1', 'G6_n62_fix0', 'G8_floor']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_embedded_structure_matches_reference(golden, case):
+    """engine.embedded_structure / embedded_row_states == AcousticModel.embedded's A, pi and row layout (G4)."""
+    from poccala_amd.engine import embedded_row_states, embedded_structure
+    g = golden(case)
+    names = [str(u) for u in g['unit_names']]
+    label = [str(u) for u in g['label']]
+    trans = [g['trans_%d' % names.index(u)] for u in label]
+    a, pi = embedded_structure(len(label), trans)
+    np.testing.assert_array_equal(a, g['emb_A'])
+    np.testing.assert_array_equal(pi, g['emb_pi'])
+    ids = np.array([[names.index(u) * 3 + k for k in range(3)] for u in label])
+    rows = embedded_row_states(ids)
+    assert rows[0] == -1 and rows[-1] == -2 and len(rows) == len(g['emb_states'])
+    unit_of_row = [str(g['emb_states'][0])] + [names[r // 3] for r in rows[1:-1]] + [str(g['emb_states'][-1])]
+    assert unit_of_row == [str(s) for s in g['emb_states']]
+
+
+def test_dropin_embedded_and_discriminate_on_cpu(golden):
+    """AcousticModel.embedded (with stand-in unit HMMs) and discriminate need no GPU."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    g = golden('G6_small_fix0')
+    names = [str(u) for u in g['unit_names']]
+    label = [str(u) for u in g['label']]
+
+    class Unit(object):
+        def __init__(self, trans, b):
+            self.transmat, self.B_p = trans, [b]
+    e = 3
+    units = []
+    for pos, u in enumerate(label):
+        b = np.vstack([np.zeros((1, g['emb_B'].shape[1])), g['emb_B'][1 + pos * e:1 + (pos + 1) * e], np.full((1, g['emb_B'].shape[1]), -np.inf)])
+        units.append(Unit(g['trans_%d' % names.index(u)], b))
+    am = AcousticModel(None, 'XIF_tone', state_num=5)
+    states, a, b, pi = am.embedded(label, units, 0, 15)
+    np.testing.assert_array_equal(a, g['emb_A'])
+    np.testing.assert_array_equal(b, g['emb_B'])
+    assert [states[i] for i in range(len(states))] == [str(s) for s in g['emb_states']]
+    assert am.embedded(label, units, 0, 4)[0].shape == a.shape        # alter bitmask: transmat only
+    seq = g['vit_path_conv'].astype(str)
+    for u in set(label):
+        runs = AcousticModel.discriminate(u, seq)
+        assert len(runs) == int(g['disc_%s_n' % u])
+        for ri, r in enumerate(runs):
+            np.testing.assert_array_equal(r, g['disc_%s_%d' % (u, ri)])
+    assert AcousticModel.VirtualState(1.).point(None, log=True) == 0.0
+    assert np.isneginf(AcousticModel.VirtualState(0.).point(None, log=True))
+
+
+def test_host_lse_helpers_match_reference(golden):
+    from poccala_amd.StatisticalModel.util import log_sum_exp, matrix_log_sum_exp
+    g = golden('G1_util')
+    for i in range(5):
+        ref, got = g['lse_out_%d' % i], log_sum_exp(g['lse_in_%d' % i])
+        assert (got == ref) if np.isinf(ref) else abs(got - ref) <= 1e-12 * abs(ref)
+    np.testing.assert_allclose(log_sum_exp(g['lse_vec_in'], vector=True), g['lse_vec_out'], rtol=1e-12)
+    np.testing.assert_allclose(matrix_log_sum_exp(list(g['mlse_in']), 4), g['mlse_out_full'], rtol=1e-12)
+    np.testing.assert_allclose(matrix_log_sum_exp(list(g['mlse_in']), 3), g['mlse_out_3'], rtol=1e-12)
+
+
+def test_mfcc_host_matrices_match_oracle():
+    from poccala_amd.StatisticalModel.AudioProcessing import dct_basis, frame_count, mel_filter_matrix
+    for rate in (8000, 16000, 44100):
+        np.testing.assert_allclose(mel_filter_matrix(rate), mo.mel_response(rate), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(dct_basis(26, 13), mo.dct_matrix(26, 13), rtol=1e-14)
+    for n in (400, 401, 599, 600, 9000):
+        assert frame_count(n, 16000) == mo.frame_geometry(n, 16000)[2]
+
+
+def test_gmm_dropin_parameter_files_without_gpu(tmp_path):
+    """save/init of parameters and accumulators (T3) are pure file logic."""
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    rng = np.random.default_rng(0)
+    g = Clustering.GMM(None, dimension=5, mix_level=3, alpha=rng.dirichlet(np.ones(3)), mean=rng.standard_normal((3, 5)),
+                       covariance=np.array([np.diag(v) for v in rng.uniform(0.5, 2, (3, 5))]), gmm_id=1)
+    g.acc = np.log(rng.uniform(0.1, 1, 3))
+    g.alpha_acc = 0.3
+    g.mean_acc = rng.standard_normal((3, 5))
+    g.covariance_acc = list(rng.standard_normal((3, 5)))
+    g.save_parameter(str(tmp_path))
+    g.save_acc(str(tmp_path))
+    g.save_acc(str(tmp_path))                               # same second: must not overwrite (the reference's race)
+    h = Clustering.GMM(None, dimension=5, mix_level=3, gmm_id=1)
+    h.init_parameter(str(tmp_path))
+    np.testing.assert_array_equal(h.mean, g.mean)
+    np.testing.assert_array_equal(h.diag_variance(), g.diag_variance())
+    h.init_acc(str(tmp_path))
+    np.testing.assert_allclose(h.acc, g.acc + np.log(2), rtol=1e-12)           # two identical files merged
+    np.testing.assert_allclose(h.alpha_acc, 0.3 + np.log(2), rtol=1e-12)
+    assert h.covariance_acc == 100.0                        # the reference's getter returns the bias (T2)
