@@ -14,8 +14,11 @@
  *   - The caller owns every host buffer (C-contiguous NumPy arrays).  The library
  *     owns all device memory (inside pcl_ctx / pcl_batch).
  *   - One pcl_ctx = one GPU = one HIP stream.  Calls on a ctx are serialised by the
- *     caller (one process or thread per GPU).  Every function is synchronous at
- *     return unless it says "asynchronous" (then pcl_sync() completes it).
+ *     caller (one process or thread per GPU).  Uploads, downloads (pcl_batch_get,
+ *     pcl_*_download) and pcl_stats_allreduce are synchronous at return.  The compute
+ *     calls -- pcl_batch_score / _forward_backward / _viterbi / _accumulate,
+ *     pcl_stats_zero, pcl_mstep -- are ASYNCHRONOUS: they enqueue kernels on the ctx
+ *     stream in call order and return; pcl_sync() or any download completes them.
  *   - Host-side matrices use the REFERENCE layout: (N,T) row-major emission /
  *     alpha / beta matrices, float64, log domain, -inf for impossible.
  *   - log A and log pi are passed ALREADY LOGGED by the caller (np.log), because
