@@ -28,7 +28,10 @@
 
 namespace {
 
-constexpr int WG = 256;
+#ifndef PCL_MFMA_WG
+#define PCL_MFMA_WG 256     // threads per workgroup = 64 x (waves sharing one LDS copy of the A tile)
+#endif
+constexpr int WG = PCL_MFMA_WG;
 #ifndef PCL_MFMA_NT
 #define PCL_MFMA_NT 2      // frame column tiles (32 frames) per wave
 #endif
