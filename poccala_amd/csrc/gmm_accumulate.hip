@@ -240,10 +240,14 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
 // Flush: cov = S2 - 2 d S1 + d^2 S0, mean = S1 + (c + bias) S0 with d = mu - c, in float64.
 // ------------------------------------------------------------------------------------------------
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4x __attribute__((ext_vector_type(4)));
+#ifndef PCL_ACC_T16
+#define PCL_ACC_T16 1      // 1: 16x16x4 MFMA tiles (80 moment columns), 0: 32x32x2 (96 with padding)
+#endif
 constexpr int AW = 8;        // waves (32-mixture tiles) per workgroup
-constexpr int XSTR = 97;     // LDS row stride of the frame tile (floats)
+constexpr int XSTR = PCL_ACC_T16 ? 98 : 97;   // LDS row stride of the frame tile (floats): odd multiples avoid bank conflicts of the frame-major reads
 
-template <int D>
+template <int D, bool T16>
 __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
     const float *__restrict__ frames, const float *__restrict__ pm, const float *__restrict__ centers,
     const double *__restrict__ means64, int M, int Mpad, int n_mtiles, int n_states, const int *__restrict__ work_states,
@@ -274,9 +278,23 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
     const bool live = mt < n_mtiles;
     const float *cen = centers + (size_t)j * D;
 
-    // parameters of this wave's m-tile: the scoring layout [m-tile][KS4][64][4] (spare slot = 1 carries cf)
-    float pb[KS4 * 4];
-    {
+    // parameters of this wave's m-tile, from the scoring layout [m-tile][KS4][64][4] (spare slot = 1 carries cf)
+    //   T16 = false: 32x32x2 products, the layout is used as it is (lane = half * 32 + mixture)
+    //   T16 = true : 16x16x4 products (no padding columns in the moment product: 5 x 16 = 80 instead of 3 x 32 = 96):
+    //                lane l needs P[kappa = 4 s + (l >> 4)][mixture ms * 16 + (l & 15)], kappa = 2 * pair + half
+    constexpr int K16 = (2 * D + 2 + 3) / 4;          // k-steps of 4
+    constexpr int NCT16 = (2 * D + 1 + 15) / 16;      // 16-column tiles of the moment product
+    float pb[T16 ? 2 * K16 : KS4 * 4];
+    if constexpr (T16) {
+        const float *base = pm + ((size_t)j * n_mtiles + (live ? mt : 0)) * (KS4 * 64 * 4);
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int s = 0; s < K16; ++s) {
+                const int kappa = 4 * s + (lane >> 4), pair = kappa >> 1, hf = kappa & 1, cl = ms * 16 + (lane & 15);
+                pb[ms * K16 + s] = (pair < KS4 * 4) ? base[((size_t)(pair >> 2) * 64 + hf * 32 + cl) * 4 + (pair & 3)] : 0.f;
+            }
+    } else {
         const float4 *pa = reinterpret_cast<const float4 *>(pm) + ((size_t)j * n_mtiles + (live ? mt : 0)) * (KS4 * 64) + lane;
 #pragma unroll
         for (int q = 0; q < KS4; ++q) {
@@ -284,11 +302,19 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
             pb[4 * q] = t.x; pb[4 * q + 1] = t.y; pb[4 * q + 2] = t.z; pb[4 * q + 3] = t.w;
         }
     }
-    f16v S[NCT];
+    f16v S[T16 ? 1 : NCT];
+    f4x S16[T16 ? 2 : 1][T16 ? NCT16 : 1];
+    if constexpr (T16) {
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+        for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[ct][r] = 0.f;
+            for (int ct = 0; ct < NCT16; ++ct) S16[ms][ct] = f4x{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[ct][r] = 0.f;
+    }
     double galpha = 0.0;
     constexpr double LOG2E = 1.4426950408889634074;
 
@@ -361,23 +387,62 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);               // keep the loads in front of the matrix work
         if (live) {
             const float *x = xe[buf];
-            // (1) D1[frame][mixture] = Xe . P   (log2 domain, + cf)
-            f16v d1;
+            if constexpr (T16) {
+                const int l15 = lane & 15, kk = lane >> 4;
+                // (1) D1[ft][ms][frame 4 kk + reg][mixture l15] = Xe . P, four independent 16x16 chains
+                f4x d1[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1[r] = 0.f;
+                for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[col * XSTR + 2 * s + half], pb[s], d1, 0, 0, 0);
-            // posteriors gamma_t(j,m)   (Clustering.py:660-661)
+                    for (int ms = 0; ms < 2; ++ms) d1[ft][ms] = f4x{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1[r] = __builtin_amdgcn_exp2f(d1[r]);
-            // (2) S[mixture][feature] += g^T . Xe ; register r of d1 = frames (row(r), row(r)+4)
+                for (int s = 0; s < K16; ++s) {
+                    const float a0 = x[l15 * XSTR + 4 * s + kk], a1 = x[(16 + l15) * XSTR + 4 * s + kk];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int fr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    for (int ms = 0; ms < 2; ++ms) {
+                        d1[0][ms] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, pb[ms * K16 + s], d1[0][ms], 0, 0, 0);
+                        d1[1][ms] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, pb[ms * K16 + s], d1[1][ms], 0, 0, 0);
+                    }
+                }
+                // posteriors gamma_t(j,m)   (Clustering.py:660-661)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                    S[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[r], x[fr * XSTR + ct * 32 + col], S[ct], 0, 0, 0);
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d1[ft][ms][r] = __builtin_amdgcn_exp2f(d1[ft][ms][r]);
+                // (2) S[ms][ct][mixture][feature] += g^T . Xe ; register r of d1 = frames 4 kk + r (k = kk)
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int fr = ft * 16 + 4 * kk + r;
+#pragma unroll
+                        for (int ct = 0; ct < NCT16; ++ct) {
+                            const float bx = x[fr * XSTR + ct * 16 + l15];
+                            S16[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[ft][0][r], bx, S16[0][ct], 0, 0, 0);
+                            S16[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[ft][1][r], bx, S16[1][ct], 0, 0, 0);
+                        }
+                    }
+            } else {
+                // (1) D1[frame][mixture] = Xe . P   (log2 domain, + cf)
+                f16v d1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[col * XSTR + 2 * s + half], pb[s], d1, 0, 0, 0);
+                // posteriors gamma_t(j,m)   (Clustering.py:660-661)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] = __builtin_amdgcn_exp2f(d1[r]);
+                // (2) S[mixture][feature] += g^T . Xe ; register r of d1 = frames (row(r), row(r)+4)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int fr = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+                        S[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[r], x[fr * XSTR + ct * 32 + col], S[ct], 0, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -386,25 +451,42 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
         buf ^= 1;
     }
 
-    // ---- flush: lane (col) = feature column of tile ct, register r = mixture row
+    // ---- flush: lane = feature column, register = mixture row; cov = S2 - 2 d S1 + d^2 S0, mean = S1 + (c + bias) S0
+    auto flush_one = [&](int m, int cidx, float s0, float s1, float s2v) {
+        if (m < M && !(cidx & 1) && cidx < 2 * D) {
+            const int d = cidx >> 1;
+            const size_t o = ((size_t)j * Mpad + m) * D + d;
+            const double c = (double)cen[d], dl = means64[o] - c;
+            const double S0 = (double)s0, S1 = (double)s1, S2 = (double)s2v;
+            st_mean[o] += S1 + (c + bias) * S0;                            // Clustering.py:669-672
+            st_cov[o] += S2 - 2.0 * dl * S1 + dl * dl * S0;                // Clustering.py:674-678
+        }
+        if (m < M && cidx == 2 * D) st_acc[(size_t)j * Mpad + m] += (double)s2v;   // Clustering.py:665
+    };
     if (live) {
+        if constexpr (T16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float s0 = __shfl(S[(2 * D) >> 5][r], (lane & 32) + ((2 * D) & 31), 64);   // column 2D = the constant feature
+            for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cidx = ct * 32 + col;
-                const float s1 = __shfl_xor(S[ct][r], 1, 64);                      // odd neighbour: x' column of the same d
-                if (m < M && !(cidx & 1) && cidx < 2 * D) {
-                    const int d = cidx >> 1;
-                    const size_t o = ((size_t)j * Mpad + m) * D + d;
-                    const double c = (double)cen[d], dl = means64[o] - c;
-                    const double S0 = (double)s0, S1 = (double)s1, S2 = (double)S[ct][r];
-                    st_mean[o] += S1 + (c + bias) * S0;                            // Clustering.py:669-672
-                    st_cov[o] += S2 - 2.0 * dl * S1 + dl * dl * S0;                // Clustering.py:674-678
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 32 + ms * 16 + 4 * (lane >> 4) + r;
+                    const float s0 = __shfl(S16[ms][(2 * D) >> 4][r], (lane & 48) + ((2 * D) & 15), 64);
+#pragma unroll
+                    for (int ct = 0; ct < NCT16; ++ct) {
+                        const float s1 = __shfl_xor(S16[ms][ct][r], 1, 64);
+                        flush_one(m, ct * 16 + (lane & 15), s0, s1, S16[ms][ct][r]);
+                    }
                 }
-                if (m < M && cidx == 2 * D) st_acc[(size_t)j * Mpad + m] += (double)S[ct][r];   // Clustering.py:665
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float s0 = __shfl(S[(2 * D) >> 5][r], (lane & 32) + ((2 * D) & 31), 64);   // column 2D = the constant feature
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const float s1 = __shfl_xor(S[ct][r], 1, 64);                      // odd neighbour: x' column of the same d
+                    flush_one(m, ct * 32 + col, s0, s1, S[ct][r]);
+                }
             }
         }
     }
@@ -500,7 +582,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = (int)b->work_states.size();
         const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
 #define LAUNCH_MFMA(DD)                                                                                                   \
-    hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
+    hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD, PCL_ACC_T16 != 0>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
                        ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, w.work_states, w.seg_lo, w.seg_hi, w.off,   \
                        w.list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
         if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
