@@ -31,12 +31,6 @@ namespace {
 constexpr int WG = 256;
 constexpr int FC = 32;  // frames per LDS chunk
 
-struct ActiveFrame {
-    long long frame;  // row of the frame matrix
-    double coef;      // ln gamma_t(j) - ln b_j(o_t)
-    double lg;        // ln gamma_t(j)
-};
-
 // one wave per segment: number of frames whose posterior survives
 __global__ void acc_count_kernel(const ScoreSeg *__restrict__ segs, int n_segs, const double *__restrict__ lgam,
                                  double thr, int *__restrict__ cnt) {
@@ -498,72 +492,63 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
     }
 }
 
-struct AccWork {
-    int *cnt = nullptr;
-    long long *off = nullptr;
-    ActiveFrame *list = nullptr;
-    int *work_states = nullptr, *seg_lo = nullptr, *seg_hi = nullptr;
-    size_t cap_list = 0, cap_segs = 0, cap_states = 0;
-};
-std::map<pcl_batch *, AccWork> g_work;   // freed with the batch (pcl_accumulate_release)
-
 template <int D, typename real, int MINW>
-void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const AccWork &w, const real *frames, const real *params,
-                  const real *means) {
+void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const real *means) {
     dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)b->work_states.size());
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
-                       ctx->Mpad, w.work_states, w.seg_lo, w.seg_hi, w.off, w.list, 100.0, ctx->st_acc, ctx->st_alpha,
-                       ctx->st_mean, ctx->st_cov);
+                       ctx->Mpad, b->d_work_states, b->d_seg_lo, b->d_seg_hi, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
+                       ctx->st_alpha, ctx->st_mean, ctx->st_cov);
 }
 
 }  // namespace
 
 void pcl_accumulate_release(pcl_batch *b) {
-    auto it = g_work.find(b);
-    if (it == g_work.end()) return;
-    AccWork &w = it->second;
-    if (w.cnt) (void)hipFree(w.cnt);
-    if (w.off) (void)hipFree(w.off);
-    if (w.list) (void)hipFree(w.list);
-    if (w.work_states) (void)hipFree(w.work_states);
-    if (w.seg_lo) (void)hipFree(w.seg_lo);
-    if (w.seg_hi) (void)hipFree(w.seg_hi);
-    g_work.erase(it);
+    if (b->acc_cnt) (void)hipFree(b->acc_cnt);
+    if (b->acc_off) (void)hipFree(b->acc_off);
+    if (b->acc_list) (void)hipFree(b->acc_list);
+    if (b->d_work_states) (void)hipFree(b->d_work_states);
+    if (b->d_seg_lo) (void)hipFree(b->d_seg_lo);
+    if (b->d_seg_hi) (void)hipFree(b->d_seg_hi);
+    b->acc_cnt = nullptr; b->acc_off = nullptr; b->acc_list = nullptr;
+    b->d_work_states = b->d_seg_lo = b->d_seg_hi = nullptr;
+    b->acc_cap_list = b->acc_cap_segs = b->acc_cap_states = 0;
 }
 
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     if (b->n_segs == 0) return PCL_OK;
-    AccWork &w = g_work[b];
     size_t cap = 0;
     for (size_t k = 0; k < b->work_states.size(); ++k) {
         const ScoreSeg &last = b->segs[b->state_seg_hi[k] - 1];
         cap += (size_t)last.vstart + last.len;
     }
-    if (w.cap_segs < (size_t)b->n_segs + 1) {
-        if (w.cnt) (void)hipFree(w.cnt);
-        if (w.off) (void)hipFree(w.off);
-        HIPCHK(ctx, hipMalloc((void **)&w.cnt, ((size_t)b->n_segs + 1) * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void **)&w.off, ((size_t)b->n_segs + 1) * sizeof(long long)));
-        w.cap_segs = (size_t)b->n_segs + 1;
+    if (b->acc_cap_segs < (size_t)b->n_segs + 1) {
+        if (b->acc_cnt) (void)hipFree(b->acc_cnt);
+        if (b->acc_off) (void)hipFree(b->acc_off);
+        b->acc_cnt = nullptr; b->acc_off = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&b->acc_cnt, ((size_t)b->n_segs + 1) * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void **)&b->acc_off, ((size_t)b->n_segs + 1) * sizeof(long long)));
+        b->acc_cap_segs = (size_t)b->n_segs + 1;
     }
-    if (w.cap_list < cap) {
-        if (w.list) (void)hipFree(w.list);
-        HIPCHK(ctx, hipMalloc((void **)&w.list, cap * sizeof(ActiveFrame)));
-        w.cap_list = cap;
+    if (b->acc_cap_list < cap) {
+        if (b->acc_list) (void)hipFree(b->acc_list);
+        b->acc_list = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&b->acc_list, cap * sizeof(ActiveFrame)));
+        b->acc_cap_list = cap;
     }
     const size_t ns = b->work_states.size();
-    if (w.cap_states < ns) {
-        if (w.work_states) (void)hipFree(w.work_states);
-        if (w.seg_lo) (void)hipFree(w.seg_lo);
-        if (w.seg_hi) (void)hipFree(w.seg_hi);
-        HIPCHK(ctx, hipMalloc((void **)&w.work_states, ns * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void **)&w.seg_lo, ns * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void **)&w.seg_hi, ns * sizeof(int)));
-        w.cap_states = ns;
+    if (b->acc_cap_states < ns) {
+        if (b->d_work_states) (void)hipFree(b->d_work_states);
+        if (b->d_seg_lo) (void)hipFree(b->d_seg_lo);
+        if (b->d_seg_hi) (void)hipFree(b->d_seg_hi);
+        b->d_work_states = b->d_seg_lo = b->d_seg_hi = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&b->d_work_states, ns * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void **)&b->d_seg_lo, ns * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void **)&b->d_seg_hi, ns * sizeof(int)));
+        b->acc_cap_states = ns;
     }
-    HIPCHK(ctx, hipMemcpyAsync(w.work_states, b->work_states.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(w.seg_lo, b->state_seg_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(w.seg_hi, b->state_seg_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_work_states, b->work_states.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_lo, b->state_seg_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_hi, b->state_seg_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 
     // a frame survives unless every gamma_t(j,m) <= gamma_t(j) underflows to exactly 0 in the
     // kernel's arithmetic (f32: 2^-149, f64: 2^-1074)
@@ -572,10 +557,10 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     pcl_timer_begin(ctx, "accumulate");
     const int wpb = 4;
     dim3 gseg((b->n_segs + wpb - 1) / wpb);
-    hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, w.cnt);
-    hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.cnt, b->n_segs, w.off);
+    hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, b->acc_cnt);
+    hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
     hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
-                       w.off, w.list);
+                       b->acc_off, b->acc_list);
     const int D = ctx->D;
     const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && (D == 39 || D == 26 || D == 13);
     if (mfma) {
@@ -583,23 +568,23 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
 #define LAUNCH_MFMA(DD)                                                                                                   \
     hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD, PCL_ACC_T16 != 0>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
-                       ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, w.work_states, w.seg_lo, w.seg_hi, w.off,   \
-                       w.list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
+                       ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, b->d_work_states, b->d_seg_lo, b->d_seg_hi,   \
+                       b->acc_off, b->acc_list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
         if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
 #undef LAUNCH_MFMA
     } else if (precision == PCL_F32) {
         switch (D) {
-#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, w, ctx->frames32, ctx->params32, ctx->mean32); break;
+#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32); break;
             CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)
 #undef CASE32
-#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, w, ctx->frames32, ctx->params32, ctx->mean32); break;
+#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32); break;
             CASE32W(48) CASE32W(64)
 #undef CASE32W
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 accumulate kernel for padded D=%d", D);
         }
     } else {
         switch (D) {
-#define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, w, ctx->frames64, ctx->params64, ctx->mean64); break;
+#define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, ctx->frames64, ctx->params64, ctx->mean64); break;
             CASE64(13) CASE64(26) CASE64(39) CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
 #undef CASE64
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 accumulate kernel for padded D=%d", D);

@@ -40,6 +40,13 @@ struct UttDesc {
     int path_off;  // into ragged (T,) vectors
 };
 
+// One surviving (frame, state) pair of the accumulate pass.
+struct ActiveFrame {
+    long long frame;  // row of the frame matrix
+    double coef;      // ln gamma_t(j) - ln b_j(o_t)
+    double lg;        // ln gamma_t(j)
+};
+
 // ---------------------------------------------------------------- host-side objects
 struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -108,7 +115,12 @@ struct pcl_batch {
     int n_segs = 0, n_tiles = 0, tile_frames = 0;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
     double *nz_tmp = nullptr;                // nnz staging buffer for the sparse xi download
-    // accumulate work lists (per state: list of segments with lgam/B offsets) reuse d_segs
+    // accumulate work lists (gmm_accumulate.hip): per-segment counts / offsets, per-state active-frame lists
+    int *acc_cnt = nullptr;
+    long long *acc_off = nullptr;
+    ActiveFrame *acc_list = nullptr;
+    int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
+    size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
 };
 
 // ---------------------------------------------------------------- error helpers
