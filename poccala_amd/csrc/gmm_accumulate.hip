@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
             const int f = e / D, d = e - f * D;
             xs[f * XS + d] = frames[list[f0 + f].frame * D + d];
         }
-        if (threadIdx.x < nf) {
+        if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cf[threadIdx.x] = (real)(a.coef * LOG2E);
             if (blockIdx.x == 0) galpha += exp(a.lg);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
         }
         cfn = -INFINITY;                                     // padding frame: g = exp2(-inf) = 0
         lgn = -INFINITY;
-        if (threadIdx.x < nf) {
+        if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cfn = (float)(a.coef * LOG2E);
             lgn = a.lg;

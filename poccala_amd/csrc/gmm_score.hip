@@ -164,7 +164,7 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
 
 // rows of the sentence HMMs that are not GMM states: entry -> 0, exit -> -inf
 __global__ void fill_virtual_rows_kernel(const UttDesc *__restrict__ utt, const int32_t *__restrict__ row_state,
-                                         double *__restrict__ Bt, int U) {
+                                         double *__restrict__ Bt) {
     const int u = blockIdx.y;
     const UttDesc d = utt[u];
     const long long total = (long long)d.T * d.N;
@@ -214,7 +214,7 @@ int pcl_score_tile_frames(int D, int precision) {
 
 int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b) {
     dim3 grid(8, b->U);
-    hipLaunchKernelGGL(fill_virtual_rows_kernel, grid, dim3(256), 0, ctx->stream, b->d_utt, b->d_row_state, b->Bt, b->U);
+    hipLaunchKernelGGL(fill_virtual_rows_kernel, grid, dim3(256), 0, ctx->stream, b->d_utt, b->d_row_state, b->Bt);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

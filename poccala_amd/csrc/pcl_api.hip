@@ -7,7 +7,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <mutex>
 
 #include "pcl_internal.h"
 
