@@ -177,11 +177,12 @@ class LHMM(DataInitialization):
             q, qs = -np.inf, []
             while True:
                 qs.append(q)
-                res = self._device_pass(_np_log(self.__pi), True, np.inf)
+                res = self._device_pass(_np_log(self.__pi).reshape(-1), True, np.inf)
                 self.__ksai = matrix_log_sum_exp(res['ksai'], axis_x=self.__hmm_size)
                 self.__gamma = matrix_log_sum_exp([g.reshape(1, -1) for g in res['gamma']], axis_x=1).reshape(-1)
                 if not fix_pi:
-                    self.__pi = np.exp(matrix_log_sum_exp([lg[:, 0].reshape(1, -1) for lg in res['lgamma']], axis_x=1)).reshape(-1)
+                    # (1,N) and un-normalised (sums to the number of utterances), exactly as LHMM.py:465-466 leaves it
+                    self.__pi = np.exp(matrix_log_sum_exp([lg[:, 0].reshape(1, -1) for lg in res['lgamma']], axis_x=1))
                 q_new = log_sum_exp(np.concatenate([a[:, -1] for a in res['alpha']]))       # LHMM.py:417-422
                 if q_new - q > 0.64:                                                        # LHMM.py:539
                     q = q_new

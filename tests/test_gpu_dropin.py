@@ -208,3 +208,26 @@ def test_segment_batch_and_accumulator_files(golden, tmp_path):
     fin_close(fresh.ksai_acc, np.logaddexp.reduce([g['ksai_acc_%d' % p] for p in pos]), rtol=1e-9)
     fin_close(fresh.profunction[1].acc, np.logaddexp.reduce([g['acc_%d_0' % p] for p in pos]), rtol=1e-8, atol=1e-10)
     fin_close(fresh.profunction[2].mean_acc, np.logaddexp.reduce([g['mean_acc_%d_1' % p] for p in pos]), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('tag', ['free', 'pifixed'])
+def test_lhmm_with_several_utterances(golden, tag):
+    """datasize > 1: the host-driven pass loop of the drop-in LHMM (one device pass per iteration, merge as
+    LHMM.py:454-466) against the reference's own run (G11)."""
+    from poccala_amd.StatisticalModel.LHMM import LHMM
+    g = golden('G11_multi_utterance')
+    n = 8
+    bs = [g['B%d_%s' % (k, tag)].copy() for k in range(3)]
+    fix = 1 if tag == 'pifixed' else 0
+    unit = LHMM({i: 'u' for i in range(n)}, n, RecLog(), transmat=g['A_' + tag].copy(), probmat=[np.zeros((n, 1))], fix_code=6)
+    h = LHMM({i: 'u' for i in range(n)}, n, RecLog(), transmat=g['A_' + tag].copy(), probmat=bs, pi=g['pi0_' + tag].copy(),
+             hmm_list=[unit], fix_code=fix | 2)
+    h.add_data([np.zeros((b.shape[1], 1)) for b in bs])
+    h.add_T([b.shape[1] for b in bs])
+    h.baulm_welch()
+    assert h.n_pass == int(g['n_pass_' + tag])
+    np.testing.assert_allclose(h.q_trace[1:], g['q_trace_' + tag][1:], atol=2e-6)
+    assert np.shape(h.pi) == np.shape(g['pi_' + tag])
+    np.testing.assert_allclose(h.pi, g['pi_' + tag], rtol=1e-9, atol=1e-300)
+    fin_close(unit.ksai_acc, g['ksai_acc_' + tag], rtol=1e-10)
+    fin_close(unit.gamma_acc, g['gamma_acc_' + tag], rtol=1e-10)

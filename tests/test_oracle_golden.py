@@ -209,3 +209,28 @@ def test_g9_layout(golden):
     assert 'GMM_0/GMM_covariance.npy|float64|4x13x13' in listing     # full matrices, quirk Q2
     assert 'GMM_2/covariance-acc/GMM_covariance_acc_<ts>.npy|float64|4x13' in listing
     assert 'HMM/ksai-acc/ksai_acc_<ts>.npy|float64|3x5' in listing
+
+
+@pytest.mark.parametrize('tag', ['free', 'pifixed'])
+def test_g11_multi_utterance_lhmm(golden, tag):
+    """An LHMM holding three utterances: merged xi/gamma/pi and Q over all utterances (LHMM.py:412-422,454-466)."""
+    g = golden('G11_multi_utterance')
+    bs = [g['B%d_%s' % (k, tag)] for k in range(3)]
+    fix = 1 if tag == 'pifixed' else 0
+    bw = po.baum_welch(g['A_' + tag], g['pi0_' + tag], bs, fix_code=fix)
+    assert bw['n_pass'] == int(g['n_pass_' + tag])
+    np.testing.assert_allclose(bw['q_trace'][1:], g['q_trace_' + tag][1:], atol=2e-6)
+    close(np.ravel(bw['pi']), np.ravel(g['pi_' + tag]), atol=1e-300)   # the reference's pi becomes (1,N) here and sums to 3
+    for name in ('ksai', 'gamma'):
+        ref = g['%s_%s' % (name, tag)]
+        assert np.array_equal(np.isneginf(bw[name]), np.isneginf(ref))
+        close(bw[name][np.isfinite(ref)], ref[np.isfinite(ref)])
+    for k in range(3):
+        ref = g['alpha%d_%s' % (k, tag)]
+        close(bw['alpha'][k][np.isfinite(ref)], ref[np.isfinite(ref)])
+    # update_acc adds the MERGED statistics once per utterance (LHMM.py:484-496)
+    ua = po.UnitAcc(8, [])
+    po.update_acc(bw, bs, [None] * 3, [ua], [[]], fix_code=fix | 2, s=8)
+    ref = g['ksai_acc_' + tag]
+    close(ua.ksai_acc[np.isfinite(ref)], ref[np.isfinite(ref)])
+    close(ua.gamma_acc, g['gamma_acc_' + tag])
