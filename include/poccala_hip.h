@@ -164,6 +164,13 @@ int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mea
 int pcl_mstep(pcl_ctx *ctx, double c_covariance);
 int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight);
 
+/* Numerical guard of the f32 matrix-core path.  The MFMA kernels evaluate the Gaussian exponent in a form expanded
+ * around a per-state centre c_j; its f32 rounding error grows with cond[j] = max_m log2(e) * sum_d (mu_jmd - c_jd)^2 /
+ * (2 var_jmd) (about 5e-7 * cond nats).  States with cond[j] > *cond_max (default 96, env PCL_MFMA_COND_MAX) are scored
+ * and accumulated by the direct-form (x-mu)^2 kernels instead, so util.py:78-88's result keeps its 1e-4 tolerance on
+ * any model.  cond: J floats (may be NULL); cond_max: 1 float (may be NULL).  Recomputed by upload and by pcl_mstep. */
+int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
+
 /* ----------------------------------------------------------------- MFCC front-end (next row f4: the step before the path)
  * AudioProcessing.MFCC.mfcc (StatisticalModel/AudioProcessing.py:416-448) for U signals at once, float64:
  * pre-emphasis 0.98 (:184), framing sampletime/overlap (:201), per-FRAME window factor (:228, as the reference

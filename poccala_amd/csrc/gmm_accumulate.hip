@@ -493,10 +493,11 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
 }
 
 template <int D, typename real, int MINW>
-void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const real *means) {
-    dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)b->work_states.size());
+void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const real *means, int first, int count) {
+    if (count == 0) return;
+    dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)count);
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
-                       ctx->Mpad, b->d_work_states, b->d_seg_lo, b->d_seg_hi, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
+                       ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
                        ctx->st_alpha, ctx->st_mean, ctx->st_cov);
 }
 
@@ -546,9 +547,26 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         HIPCHK(ctx, hipMalloc((void **)&b->d_seg_hi, ns * sizeof(int)));
         b->acc_cap_states = ns;
     }
-    HIPCHK(ctx, hipMemcpyAsync(b->d_work_states, b->work_states.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_lo, b->state_seg_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_hi, b->state_seg_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    // MFMA mode: well-conditioned states first (MFMA kernel), then the ill-conditioned ones (direct-form VALU kernel)
+    const int D = ctx->D;
+    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && (D == 39 || D == 26 || D == 13);
+    b->acc_ws.clear(); b->acc_lo.clear(); b->acc_hi.clear();
+    int n_good = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t k = 0; k < ns; ++k) {
+            const bool bad = mfma && pcl_state_uses_valu(ctx, b->work_states[k]);
+            if (bad != (pass == 1)) continue;
+            b->acc_ws.push_back(b->work_states[k]);
+            b->acc_lo.push_back(b->state_seg_lo[k]);
+            b->acc_hi.push_back(b->state_seg_hi[k]);
+            n_good += pass == 0;
+        }
+    const int n_bad = (int)ns - n_good;
+    // the staging vectors live in the batch: the copies below are asynchronous from pageable memory only until the
+    // call returns on this runtime, but keeping them alive costs nothing
+    HIPCHK(ctx, hipMemcpyAsync(b->d_work_states, b->acc_ws.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_lo, b->acc_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_hi, b->acc_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 
     // a frame survives unless every gamma_t(j,m) <= gamma_t(j) underflows to exactly 0 in the
     // kernel's arithmetic (f32: 2^-149, f64: 2^-1074)
@@ -561,10 +579,8 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
     hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
                        b->acc_off, b->acc_list);
-    const int D = ctx->D;
-    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && (D == 39 || D == 26 || D == 13);
-    if (mfma) {
-        const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = (int)b->work_states.size();
+    if (mfma && n_good > 0) {
+        const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = n_good;
         const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
 #define LAUNCH_MFMA(DD)                                                                                                   \
     hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD, PCL_ACC_T16 != 0>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
@@ -572,19 +588,21 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
                        b->acc_off, b->acc_list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
         if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
 #undef LAUNCH_MFMA
-    } else if (precision == PCL_F32) {
+    }
+    if (precision == PCL_F32) {
+        const int first = mfma ? n_good : 0, count = mfma ? n_bad : (int)ns;
         switch (D) {
-#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32); break;
+#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count); break;
             CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)
 #undef CASE32
-#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32); break;
+#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count); break;
             CASE32W(48) CASE32W(64)
 #undef CASE32W
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 accumulate kernel for padded D=%d", D);
         }
     } else {
         switch (D) {
-#define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, ctx->frames64, ctx->params64, ctx->mean64); break;
+#define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, ctx->frames64, ctx->params64, ctx->mean64, 0, (int)ns); break;
             CASE64(13) CASE64(26) CASE64(39) CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
 #undef CASE64
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 accumulate kernel for padded D=%d", D);

@@ -196,9 +196,9 @@ __global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *
 }
 
 template <int D, int R, int CH, typename real>
-void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params) {
-    hipLaunchKernelGGL((gmm_score_kernel<D, R, CH, real>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, frames, params,
-                       ctx->Mpad, b->d_tiles, b->d_segs, b->Bt);
+void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const ScoreTile *tiles, int n_tiles) {
+    hipLaunchKernelGGL((gmm_score_kernel<D, R, CH, real>), dim3(n_tiles), dim3(WG), 0, ctx->stream, frames, params,
+                       ctx->Mpad, tiles, b->d_segs, b->Bt);
 }
 
 // frames per lane for each (D, precision); the tile is WG * R frames.  x[R][D] must stay in VGPRs
@@ -226,13 +226,14 @@ int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *
     return PCL_OK;
 }
 
-int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision) {
-    if (b->n_tiles == 0) return PCL_OK;
+int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile *tiles, int n_tiles) {
+    if (n_tiles == 0) return PCL_OK;
     const int D = ctx->D;
-    pcl_timer_begin(ctx, "score");
+    const char *tname = (tiles == b->d_tiles_v) ? "score_direct" : "score";   // the ill-conditioned remainder is timed apart
+    pcl_timer_begin(ctx, tname);
     if (precision == PCL_F32) {
         switch (D) {
-#define CASE32(DD) case DD: launch_score_t<DD, r32(DD), PCL_CH32, float>(ctx, b, ctx->frames32, ctx->params32); break;
+#define CASE32(DD) case DD: launch_score_t<DD, r32(DD), PCL_CH32, float>(ctx, b, ctx->frames32, ctx->params32, tiles, n_tiles); break;
             CASE32(13) CASE32(26) CASE32(39)
             CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40) CASE32(48) CASE32(64)
 #undef CASE32
@@ -240,14 +241,14 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision) {
         }
     } else {
         switch (D) {
-#define CASE64(DD) case DD: launch_score_t<DD, r64(DD), 32, double>(ctx, b, ctx->frames64, ctx->params64); break;
+#define CASE64(DD) case DD: launch_score_t<DD, r64(DD), 32, double>(ctx, b, ctx->frames64, ctx->params64, tiles, n_tiles); break;
             CASE64(13) CASE64(26) CASE64(39)
             CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
 #undef CASE64
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 scoring kernel for padded D=%d", D);
         }
     }
-    pcl_timer_end(ctx, "score");
+    pcl_timer_end(ctx, tname);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

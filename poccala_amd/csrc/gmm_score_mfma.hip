@@ -189,9 +189,9 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
 }
 
 template <int D>
-void launch_t(pcl_ctx *ctx, pcl_batch *b) {
-    hipLaunchKernelGGL((gmm_score_mfma_kernel<D, PCL_MFMA_NT>), dim3(b->n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, ctx->pm32,
-                       ctx->centers32, ctx->Mpad32 / 32, b->d_tiles, b->d_segs, b->Bt);
+void launch_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    hipLaunchKernelGGL((gmm_score_mfma_kernel<D, PCL_MFMA_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, ctx->pm32,
+                       ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs, b->Bt);
 }
 
 }  // namespace
@@ -200,13 +200,13 @@ int pcl_score_mfma_tile_frames() { return WG / 64 * PCL_MFMA_NT * 32; }
 
 bool pcl_score_mfma_supported(int D) { return D == 39 || D == 13 || D == 26; }
 
-int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b) {
-    if (b->n_tiles == 0) return PCL_OK;
+int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    if (n_tiles == 0) return PCL_OK;
     pcl_timer_begin(ctx, "score");
     switch (ctx->D) {
-        case 39: launch_t<39>(ctx, b); break;
-        case 26: launch_t<26>(ctx, b); break;
-        case 13: launch_t<13>(ctx, b); break;
+        case 39: launch_t<39>(ctx, b, tiles, n_tiles); break;
+        case 26: launch_t<26>(ctx, b, tiles, n_tiles); break;
+        case 13: launch_t<13>(ctx, b, tiles, n_tiles); break;
         default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no MFMA scoring kernel for D=%d", ctx->D);
     }
     pcl_timer_end(ctx, "score");

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      const double *__restrict__ w64, const float *__restrict__ centers, int M,
                                                      int Mpad, int Mpad32, int D, int Dhost, int row, int flags,
                                                      float *__restrict__ params32, double *__restrict__ params64,
-                                                     float *__restrict__ mean32, float *__restrict__ pm32) {
+                                                     float *__restrict__ mean32, float *__restrict__ pm32,
+                                                     float *__restrict__ cond) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
@@ -64,6 +65,9 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
         k2s[tid] = k2;
         kqs[tid] = LOG2E * kq;
+        // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats order
+        // like their bit patterns, so an integer atomicMax works)
+        if (m < M) atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
     }
     __syncthreads();
     // VALU scoring rows [s_d c_d ... k2 pad] and the f32 means (only mixtures inside the Mpad grid)
@@ -159,10 +163,16 @@ int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64
 int pcl_launch_derive(pcl_ctx *ctx) {
     hipLaunchKernelGGL(centers_kernel, dim3(ctx->J), dim3(64), 0, ctx->stream, ctx->mean64, ctx->M, ctx->Mpad, ctx->D, ctx->centers32);
     const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)ctx->D * sizeof(float);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
-                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32);
+                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, ctx->d_cond);
     HIPCHK(ctx, hipGetLastError());
+    // the per-state conditioning decides which kernel scores a state: bring it to the host (J floats)
+    ctx->cond.resize(ctx->J);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cond.data(), ctx->d_cond, (size_t)ctx->J * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ++ctx->model_gen;
     return PCL_OK;
 }
 

@@ -70,6 +70,7 @@ int pcl_init(int device, pcl_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
     const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
     ctx->score_variant = var ? atoi(var) : 3;
+    if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
     *out = ctx;
     return PCL_OK;
 }
@@ -83,6 +84,7 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->w64);
     dev_free(ctx->pm32);
     dev_free(ctx->centers32);
+    dev_free(ctx->d_cond);
     dev_free(ctx->stats);
     ctx->st_acc = ctx->st_alpha = ctx->st_mean = ctx->st_cov = nullptr;
     ctx->J = ctx->M = ctx->Mpad = 0;
@@ -189,6 +191,7 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->w64, nw));
     TRY(dev_alloc(ctx, &ctx->pm32, npm));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
+    TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->var64, v64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->w64, w64.data(), nw * sizeof(double), hipMemcpyHostToDevice));
@@ -320,7 +323,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
-    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->tmp); dev_free(b->nz_tmp);
+    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
     return PCL_OK;
 }
@@ -451,6 +454,7 @@ int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state) {
         }
     dev_free(b->d_segs);
     dev_free(b->d_tiles);
+    dev_free(b->d_tiles_v);
     b->tile_frames = 0;
     TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
     if (b->n_segs) HIPCHK(ctx, hipMemcpy(b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg), hipMemcpyHostToDevice));
@@ -502,19 +506,15 @@ static int ensure_frames64(pcl_ctx *ctx) {
     return pcl_launch_cast(ctx, nullptr, ctx->frames32, ctx->frames64, n);   // float -> double is exact
 }
 
-static int build_tiles(pcl_batch *b, int precision) {
-    pcl_ctx *ctx = b->ctx;
-    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D);
-    const int tf = mfma ? pcl_score_mfma_tile_frames() : pcl_score_tile_frames(ctx->D, precision);
-    if (b->d_tiles && b->tile_frames == tf) return PCL_OK;
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, observed,
-    // speed only), so all tiles of one state are placed at block indices with the same residue mod 8:
-    // the state's parameter block is then fetched into ONE XCD's L2 instead of eight.  Shorter queues
-    // are padded with empty tiles (seg_lo == seg_hi), which exit immediately.
+// XCD-aware tile order for a subset of the batch's states: workgroups are dealt round-robin over the 8 XCDs
+// (block b -> XCD b % 8, observed, speed only), so all tiles of one state are placed at block indices with the
+// same residue mod 8: the state's parameter block is then fetched into ONE XCD's L2 instead of eight.
+// Shorter queues are padded with empty tiles (seg_lo == seg_hi), which exit immediately.
+static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<size_t> &which, int tf) {
     constexpr int NXCD = 8;
     std::vector<ScoreTile> queue[NXCD];
     std::vector<long long> load(NXCD, 0);
-    for (size_t k = 0; k < b->work_states.size(); ++k) {
+    for (size_t k : which) {
         const int lo = b->state_seg_lo[k], hi = b->state_seg_hi[k];
         const long long tot = (long long)b->segs[hi - 1].vstart + b->segs[hi - 1].len;
         int g = 0;
@@ -529,11 +529,31 @@ static int build_tiles(pcl_batch *b, int precision) {
     tiles.reserve(depth * NXCD);
     for (size_t q = 0; q < depth; ++q)
         for (int x = 0; x < NXCD; ++x) tiles.push_back(q < queue[x].size() ? queue[x][q] : ScoreTile{0, 0, 0, 0});
+    return tiles;
+}
+
+static int build_tiles(pcl_batch *b, int precision) {
+    pcl_ctx *ctx = b->ctx;
+    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D);
+    const int tf = mfma ? pcl_score_mfma_tile_frames() : pcl_score_tile_frames(ctx->D, precision);
+    if (b->d_tiles && b->tile_frames == tf && b->tile_gen == ctx->model_gen) return PCL_OK;
+    // MFMA mode: states whose centred expansion is ill conditioned go to the direct-form VALU kernel
+    std::vector<size_t> good, bad;
+    for (size_t k = 0; k < b->work_states.size(); ++k) (mfma && pcl_state_uses_valu(ctx, b->work_states[k]) ? bad : good).push_back(k);
+    const std::vector<ScoreTile> tiles = make_tiles(b, good, tf);
+    const std::vector<ScoreTile> tiles_v = bad.empty() ? std::vector<ScoreTile>() : make_tiles(b, bad, pcl_score_tile_frames(ctx->D, PCL_F32));
     dev_free(b->d_tiles);
+    dev_free(b->d_tiles_v);
     b->n_tiles = (int)tiles.size();
+    b->n_tiles_v = (int)tiles_v.size();
     b->tile_frames = tf;
+    b->tile_gen = ctx->model_gen;
     TRY(dev_alloc(ctx, &b->d_tiles, tiles.size()));
     if (!tiles.empty()) HIPCHK(ctx, hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(ScoreTile), hipMemcpyHostToDevice));
+    if (!tiles_v.empty()) {
+        TRY(dev_alloc(ctx, &b->d_tiles_v, tiles_v.size()));
+        HIPCHK(ctx, hipMemcpy(b->d_tiles_v, tiles_v.data(), tiles_v.size() * sizeof(ScoreTile), hipMemcpyHostToDevice));
+    }
     return PCL_OK;
 }
 
@@ -550,8 +570,12 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     if (precision == PCL_F64) TRY(ensure_frames64(ctx));
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
-    if (precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D)) TRY(pcl_launch_score_mfma(ctx, b));
-    else TRY(pcl_launch_score(ctx, b, precision));
+    if (precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D)) {
+        TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
+        TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
+    } else {
+        TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));
+    }
     b->have_B = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;
@@ -670,6 +694,14 @@ int pcl_mstep(pcl_ctx *ctx, double c_covariance) {
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_mstep: no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return pcl_launch_mstep(ctx, c_covariance);
+}
+
+int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (ctx->cond.empty()) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_model_conditioning: no model uploaded");
+    if (cond) memcpy(cond, ctx->cond.data(), ctx->cond.size() * sizeof(float));
+    if (cond_max) *cond_max = ctx->cond_max;
+    return PCL_OK;
 }
 
 int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight) {

@@ -66,6 +66,13 @@ struct pcl_ctx {
     float *centers32 = nullptr;  // J * D per-state expansion centres c_j
     int Mpad32 = 0;              // M rounded up to a multiple of 32
     int score_variant = 0;       // 1 = VALU/LDS, 3 = f32 MFMA (default)
+    // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
+    // the magnitude of the terms that cancel in it.  States above cond_max are scored / accumulated by the
+    // direct-form VALU kernels instead (f32 error of the expansion ~ 5e-7 * cond nats).
+    float *d_cond = nullptr;
+    std::vector<float> cond;
+    float cond_max = 96.f;
+    int model_gen = 0;           // bumped whenever the layouts (and cond) are re-derived
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
     double *mean64 = nullptr;    // float64 master copy of the model: mean, var (J*Mpad*D), weight (J*Mpad)
     double *var64 = nullptr, *w64 = nullptr;
@@ -111,8 +118,10 @@ struct pcl_batch {
     std::vector<ScoreSeg> segs;              // host copy, sorted by state
     std::vector<int> state_seg_lo, state_seg_hi;  // per state with work: segment range
     std::vector<int> work_states;
-    ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with
-    int n_segs = 0, n_tiles = 0, tile_frames = 0;
+    ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
+    std::vector<int> acc_ws, acc_lo, acc_hi; // accumulate's state order (well-conditioned first)
+    ScoreTile *d_tiles_v = nullptr;          // MFMA mode only: tiles of ill-conditioned states for the VALU kernel
+    int n_segs = 0, n_tiles = 0, n_tiles_v = 0, tile_frames = 0, tile_gen = -1;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
     double *nz_tmp = nullptr;                // nnz staging buffer for the sparse xi download
     // accumulate work lists (gmm_accumulate.hip): per-segment counts / offsets, per-state active-frame lists
@@ -142,7 +151,7 @@ void pcl_timer_begin(pcl_ctx *ctx, const char *which);
 void pcl_timer_end(pcl_ctx *ctx, const char *which);
 
 // ---------------------------------------------------------------- kernel launchers (one per .hip file)
-int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision);
+int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile *tiles, int n_tiles);
 int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b);
 int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold);
 int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back);
@@ -151,10 +160,11 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
 void pcl_accumulate_release(pcl_batch *b);
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
 int pcl_score_tile_frames(int D, int precision);
-int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b);
+int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);
+inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) { return !ctx->cond.empty() && ctx->cond[j] > ctx->cond_max; }
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
 int pcl_launch_pack(pcl_ctx *ctx, const double *src, int inner, double *dst);

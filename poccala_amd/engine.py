@@ -126,6 +126,14 @@ class Engine(object):
         self._check(self._lib.pcl_model_download(self._ctx, ptr(mean), ptr(var), ptr(w)))
         return mean, var, w
 
+    def model_conditioning(self):
+        """(cond (J,) float32, cond_max): conditioning of the centred expansion per state; states above cond_max
+        are scored and accumulated by the direct-form kernels instead of the matrix-core ones."""
+        cond = np.empty(self.J, dtype=np.float32)
+        cmax = np.empty(1, dtype=np.float32)
+        self._check(self._lib.pcl_model_conditioning(self._ctx, ptr(cond), ptr(cmax)))
+        return cond, float(cmax[0])
+
     # ------------------------------------------------------------------ RCCL
     def comm_unique_id(self):
         buf = np.zeros(128, dtype=np.uint8)

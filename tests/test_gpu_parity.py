@@ -591,3 +591,95 @@ def test_cabi_error_codes(eng):
     b.close()
     with pytest.raises(PoccalaHipError, match='has N=0'):
         eng.batch([0], [5])
+
+
+# ------------------------------------------------------------------ ill-conditioned states leave the matrix-core path
+def mixed_conditioning_model(seed, units=3, M=64, D=39):
+    """Every unit's middle state is hard for the centred f32 expansion (means spread over 5 sigma, small variances,
+    a common offset of 60); the other states look like the bench model."""
+    from poccala_amd import synth
+    rng = np.random.default_rng(seed)
+    mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
+    bad = np.arange(1, mean.shape[0], S - 2)
+    mean[bad] = rng.standard_normal((len(bad), M, D)) * 5.0 + 60.0
+    var[bad] = rng.uniform(0.05, 0.5, (len(bad), M, D))
+    return mean, var, w, trans, bad
+
+
+def test_ill_conditioned_states_use_direct_form(eng):
+    from poccala_amd import PCL_F32
+    from poccala_amd.engine import make_sentence_batch
+    rng = np.random.default_rng(77)
+    mean, var, w, trans, bad = mixed_conditioning_model(901)
+    J, M, D = mean.shape
+    eng.load_model(mean, var, w)
+    cond, cmax = eng.model_conditioning()
+    good = np.setdiff1d(np.arange(J), bad)
+    assert (cond[bad] > cmax).all() and (cond[good] <= cmax).all()
+    # frames drawn from the states themselves so that the scores are the ones training would see
+    T = 120
+    st = rng.integers(0, J, T)
+    comp = rng.integers(0, M, T)
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((T, D))).astype(np.float32)
+    eng.load_frames(x)
+    b = eng.batch([J + 2], [T], [0])
+    b.set_states([np.concatenate([[-1], np.arange(J), [-2]]).astype(np.int32)])
+    b.score(PCL_F32)
+    got = b.get('B')[0][1:-1]
+    ref = np.stack([po.gmm_point(x.astype(np.float64), mean[j], var[j], w[j]) for j in range(J)])
+    err = np.abs(got - ref)
+    own = np.zeros_like(err, dtype=bool)
+    own[st, np.arange(T)] = True                      # the (state, frame) pairs that carry posterior mass
+    assert err[own].max() < F32_LOGLIK_ATOL
+    np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)
+    b.close()
+
+    # E-step statistics with both kernels contributing to one statistics buffer; every utterance is sampled from
+    # its own label's states (4 frames per state), so that the posteriors are not decided by far-tail scores
+    U, L, PER = 4, 3, 4
+    labels = [list(rng.integers(0, len(trans), L)) for _ in range(U)]
+    TU = L * (S - 2) * PER
+    lens = np.full(U, TU, dtype=np.int64)
+    begin = np.arange(U, dtype=np.int64) * TU
+    st = np.concatenate([np.repeat([unit * (S - 2) + k for unit in lab for k in range(S - 2)], PER) for lab in labels])
+    comp = rng.integers(0, M, len(st))
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((len(st), D))).astype(np.float32)
+    eng.load_frames(x)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    b.forward_backward(fix_pi=False)
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    stt = eng.stats_download()
+    model = oracle_model(mean, var, w, trans)
+    refs = dict(acc=np.zeros((J, M)), alpha_acc=np.zeros(J), mean_acc=np.zeros((J, M, D)), cov_acc=np.zeros((J, M, D)))
+    lp = b.get('logp')
+    for u, lab in enumerate(labels):
+        xx = x[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        bw, accs, _ = po.estep_utterance(xx, list(lab), model)
+        np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=F32_RTOL)
+        for pos, unit in enumerate(lab):
+            for k in range(S - 2):
+                j = unit * (S - 2) + k
+                a = accs[pos].gmm[k]
+                for key in refs:
+                    refs[key][j] += np.exp(a[key])
+    for key in refs:
+        scale = np.abs(refs[key]).max()
+        np.testing.assert_allclose(stt[key], refs[key], rtol=2 * F32_RTOL, atol=scale * 1e-6, err_msg=key)
+
+    # an M-step changes the conditioning; the same batch must pick the new split up
+    eng.mstep(1e-3)
+    cond2, _ = eng.model_conditioning()
+    assert not np.array_equal(cond, cond2)
+    m2, v2, w2 = eng.model_download()
+    b.score(PCL_F32)
+    Bm = b.get('B')
+    rows = np.concatenate([[s for unit in labels[0] for s in range(unit * (S - 2), unit * (S - 2) + S - 2)]])
+    xx = x[:TU].astype(np.float64)
+    for r, j in enumerate(rows):
+        if not np.isfinite(w2[j]).all() or (w2[j] <= 0).any():
+            continue
+        refj = po.gmm_point(xx, m2[j], v2[j], w2[j])
+        np.testing.assert_allclose(Bm[0][r + 1], refj, rtol=5e-6, atol=F32_LOGLIK_ATOL)
+    b.close()
