@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 CPU_SAMPLE_FRAMES = 64            # frames per utterance in the CPU baseline sample (about 20-30 s of CPU work per leg)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
+BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -217,9 +218,25 @@ def main():
 
     # dominant kernel: gmm_score.  Algorithmic FLOP per launch = scored (frame, state) pairs x M x (3D+4)
     # (SURVEY.md section 8d); the emitting rows of an utterance are N-2.
-    score_variant = int(os.environ.get('PCL_SCORE_VARIANT', '3'))
-    score_kernel_name = ('gmm_score_kernel<39,2,32,double>' if P == PCL_F64 else
-                         'gmm_score_mfma_kernel<39,2>' if score_variant == 3 else 'gmm_score_kernel<39,3,64,float>')
+    score_variant = int(os.environ.get('PCL_SCORE_VARIANT', '4'))
+    if P == PCL_F64:
+        score_variant = 0
+    # per scoring kernel: name, the peak its arithmetic is priced against, and what that peak means
+    KERNELS = {
+        0: ('gmm_score_kernel<39,2,32,double>', FP32_VECTOR_PEAK_TFLOPS / 2, 'f64 parity mode on the VALU (78.6 TFLOP/s f64 vector peak)'),
+        1: ('gmm_score_kernel<39,3,64,float>', FP32_VECTOR_PEAK_TFLOPS, 'f32 VALU kernel (PCL_SCORE_VARIANT=1); peak = 157.3 TFLOP/s f32 vector'),
+        3: ('gmm_score_mfma_kernel<39,2>', FP32_VECTOR_PEAK_TFLOPS,
+            'quadratic form on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3); peak = 157.3 TFLOP/s '
+            'dense f32 MFMA (= f32 vector peak)'),
+        4: ('gmm_score_split_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 6,
+            'quadratic form of the diagonal Gaussians as an f32-ACCURATE contraction on the bf16 matrix pipe: every f32 operand '
+            'is the exact sum of three bf16 pieces and six of the nine cross products are kept (dropped terms < 2^-24 relative; '
+            'measured error vs float64 at or below the exact f32 FMA chain, same parity tolerances), f32 accumulate, '
+            'log-sum-exp on the VALU.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; peak = '
+            '2516.6 TFLOP/s dense bf16 MFMA / 6 products per f32-accurate product = 419.4 (the f32-input MFMA peak is 157.3); '
+            'the kernel executes 6 x 2(2D+2) = 960 bf16 MFMA flops per Gaussian: see executed_bf16_tflops'),
+    }
+    score_kernel_name, score_peak, score_note = KERNELS.get(score_variant, KERNELS[1])
     pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
     flop_per_launch = pairs * cfg['M'] * (3 * cfg['D'] + 4)
     score_avg_ms = score_ms / max(score_n, 1)
@@ -228,24 +245,22 @@ def main():
     # bound served from L2; the honest algorithmic figure is frames once + parameters once + B written once
     alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + pairs * 8
     traffic = args.traffic_bytes
-    if traffic is None and args.workload == 'C4shard' and not args.utts and P == PCL_F32 and score_variant == 3:
+    if traffic is None and args.workload == 'C4shard' and not args.utts and P == PCL_F32 and score_variant == 4:
         try:   # PMC counters cannot be read from inside the run: use the committed separate-pass measurement
             for line in open(os.path.join(ROOT, 'profiles', 'r01_bench_summary.txt')):
                 if line.startswith('traffic_bytes for bench.py'):
                     traffic = float(line.split(':')[1])
         except OSError:
             pass
-    roofline = dict(bound='mfma', achieved=achieved, peak=FP32_VECTOR_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
+    roofline = dict(bound='mfma', achieved=achieved, peak=score_peak, unit='TFLOP/s',
+                    frac=(achieved / score_peak) if achieved else None,
                     traffic=traffic, traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_bench_summary.txt), per launch',
                     kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
-                    note='quadratic form of the diagonal Gaussians on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32: exact f32 '
-                         'FMA chain, no reduced precision), log-sum-exp on the VALU; achieved = ALGORITHMIC flops M(3D+4) per '
-                         '(frame,state) pair / kernel time; the kernel executes 2(2D+2) MFMA flops per Gaussian; peak = 157.3 '
-                         'TFLOP/s dense f32 MFMA (= f32 vector peak)' if score_variant == 3 and P == PCL_F32 else
-                         'FP32 VALU kernel (PCL_SCORE_VARIANT=1) / f64 parity mode; peak = 157.3 TFLOP/s f32',
+                    executed_bf16_tflops=(pairs * cfg['M'] * 6 * 2 * (2 * cfg['D'] + 2) / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant == 4 else None,
+                    frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
+                    note=score_note,
                     hbm_algorithmic_bytes_per_launch=alg_bytes,
                     hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_n else None,
                     fb_kernel_avg_ms=fb_ms / max(fb_n, 1))
@@ -307,7 +322,7 @@ def main():
                                    % (args.workload, cfg['U'], cfg['T'], cfg['D'], cfg['M'], cfg['units'], cfg['units'] * 3, cfg['L'],
                                       3 * cfg['L'] + 2, 3 * cfg['L']),
                        'utterances_total': cfg['U'] * world, 'frames_per_step_total': total_frames,
-                       'arithmetic': 'f32 Gaussian scoring, f64 dynamic programming' if P == PCL_F32 else 'f64',
+                       'arithmetic': 'f32 Gaussian scoring (f32-accurate split-bf16 products, f32 accumulate), f64 dynamic programming' if P == PCL_F32 else 'f64',
                        'device': info['name'], 'cus': info['cus']},
             'roofline': roofline,
             'cpu_baseline': cpu,

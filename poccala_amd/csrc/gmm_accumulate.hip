@@ -549,7 +549,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     }
     // MFMA mode: well-conditioned states first (MFMA kernel), then the ill-conditioned ones (direct-form VALU kernel)
     const int D = ctx->D;
-    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && (D == 39 || D == 26 || D == 13);
+    const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && (D == 39 || D == 26 || D == 13);
     b->acc_ws.clear(); b->acc_lo.clear(); b->acc_hi.clear();
     int n_good = 0;
     for (int pass = 0; pass < 2; ++pass)

@@ -1,0 +1,226 @@
+// gmm_score_split.hip -- GMM scoring with f32-accurate products on the bf16 matrix pipe (gfx950).
+//
+// Same reference rows as gmm_score.hip (A1/A4/A6: util.py:20-31, Clustering.py:740-767, LHMM.py:163-187) and the
+// same contraction as gmm_score_mfma.hip:
+//     v[f,m] = k'_m + sum_d ( a_md x'_fd^2 + b_md x'_fd ) - ref_f,      x' = x - c_j.
+//
+// Why not the f32-input MFMA.  On gfx950 v_mfma_f32_32x32x2_f32 runs at the VALU's rate (64 FLOP/clk/SIMD) AND
+// blocks the VALU while it runs (tools/ubench_hybrid.hip: a v_fma wave beside an f32-MFMA wave makes ~5 % progress),
+// so that kernel is bounded by 157 TFLOP/s minus its own log-sum-exp.  The bf16 pipe is 16x faster and a separate
+// pipe.  Every f32 number is EXACTLY the sum of three bf16 numbers (3 x 8 significand bits, round-to-nearest
+// residuals), and a bf16 x bf16 product is exact in f32, so
+//     a x = (a1 + a2 + a3)(x1 + x2 + x3) = a1x1 + (a1x2 + a2x1) + (a1x3 + a2x2 + a3x1) + O(2^-24 |a x|)
+// with f32 accumulation: six bf16 MFMAs per K-step instead of one f32 MFMA, 6/16 of the matrix-pipe time, and
+// the dropped cross terms are below f32's own rounding.  Measured against float64 (tools/ubench_split.hip, sum of
+// |terms| = 205): this scheme 1.8e-5, the exact f32 FMA chain 3.5e-5 (fewer, wider partial sums) -- it is not a
+// reduced-precision path, and the parity tests hold it to the same tolerances.
+//
+// Mapping (v_mfma_f32_32x32x16_bf16: D[32 mixtures x 32 frames] += A[32 x 16] B[16 x 32]).  K-step s, lane l
+// (r = l&31, h = l>>5), element j = feature d = 8s + j of the side h selects:
+//   B (frames):     h = 0: x'_d^2 (1 at d = D),  h = 1: x'_d (-ref at d = D)   -- VGPR-resident, 3 pieces
+//   A (parameters): h = 0: a_md   (k'_m at d = D), h = 1: b_md (1 at d = D)    -- layout [m-tile][piece][s][64][8],
+//                   staged per m-tile in LDS by LDS-DMA (double buffered) and shared by the 4 waves.
+// Pass order a3x1, a2x2, a2x1, a1x3, a1x2, a1x1: the small terms first, one parameter piece live at a time.
+// Everything after the accumulator (reference-shifted log-sum-exp, slow path, merge) is gmm_score_mfma.hip's.
+#include <stdlib.h>
+
+#include "pcl_internal.h"
+
+namespace {
+
+#ifndef PCL_SPLIT_WG
+#define PCL_SPLIT_WG 256    // threads per workgroup = 64 x (waves sharing one LDS copy of the A tile)
+#endif
+#ifndef PCL_SPLIT_MINW
+#define PCL_SPLIT_MINW 2    // __launch_bounds__ waves per SIMD
+#endif
+constexpr int WG = PCL_SPLIT_WG;
+#ifndef PCL_SPLIT_NT
+#define PCL_SPLIT_NT 2      // frame column tiles (32 frames) per wave
+#endif
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, __bf16 &p1, __bf16 &p2, __bf16 &p3) {
+    p1 = (__bf16)x;
+    float r = x - (float)p1;
+    p2 = (__bf16)r;
+    r -= (float)p2;
+    p3 = (__bf16)r;
+}
+
+template <int D, int NT>
+__global__ __launch_bounds__(WG, PCL_SPLIT_MINW * 256 / WG > 0 ? PCL_SPLIT_MINW * 256 / WG : 1) void gmm_score_split_kernel(const float *__restrict__ frames, const uint4 *__restrict__ pm,
+                                                                const float *__restrict__ centers, int n_mtiles,
+                                                                const ScoreTile *__restrict__ tiles,
+                                                                const ScoreSeg *__restrict__ segs, double *__restrict__ out) {
+    constexpr int KS8 = (D + 8) / 8;       // K-steps of 16 (8 features per half-wave): D features + the constant slot
+    constexpr int CH = 3 * KS8;            // 1-KiB chunks (64 lanes x 16 B) per m-tile
+    constexpr int SC = D / 8, JC = D % 8;  // where the constant slot sits
+    const ScoreTile tile = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
+    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
+    const bool wave_active = tile.vstart + wave * NT * 32 < vend;   // a wave past the end still helps staging
+
+    // ---- B operand: this lane's frames, centred (squared on the low half-wave), split into three bf16 pieces
+    bf8v xb[NT][3][KS8];
+    long long oidx[NT];
+    bool valid[NT];
+    const float *cen = centers + (size_t)tile.state * D;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        int v = tile.vstart + (wave * NT + c) * 32 + col;
+        valid[c] = v < vend;
+        if (!valid[c]) v = tile.vstart;
+        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        }
+        const ScoreSeg sg = segs[lo];
+        const long long t = v - sg.vstart;
+        const float *fp = frames + (sg.frame0 + t) * D;
+#pragma unroll
+        for (int s = 0; s < KS8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * s + j;
+                float val = 0.f;
+                if (d < D) {
+                    const float xc = fp[d] - cen[d];
+                    val = half ? xc : xc * xc;
+                } else if (d == D) {
+                    val = half ? 0.f : 1.f;     // -ref (0 so far) | the constant's multiplier
+                }
+                __bf16 p1, p2, p3;
+                split3(val, p1, p2, p3);
+                xb[c][0][s][j] = p1;
+                xb[c][1][s][j] = p2;
+                xb[c][2][s][j] = p3;
+            }
+        oidx[c] = sg.out0 + t * (long long)sg.out_stride;
+    }
+
+    float sm[NT], ref[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        sm[c] = 0.f;
+        ref[c] = 0.f;
+    }
+
+    __shared__ __attribute__((aligned(16))) uint4 abuf[2][CH * 64];
+    const uint4 *pstate = pm + (size_t)tile.state * n_mtiles * (CH * 64);
+    auto dma = [&](int buf, int mt) {
+        const uint4 *src = pstate + (size_t)mt * (CH * 64);
+        for (int p = wave; p < CH; p += WG / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&abuf[buf][p * 64], 16, 0, 0);
+    };
+
+    auto process = [&](int mt) {
+        const uint4 *ab = abuf[mt & 1];
+        f16v acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        }
+        auto pass = [&](int pa, int pb) {
+#pragma unroll
+            for (int s = 0; s < KS8; ++s) {
+                const bf8v a = *reinterpret_cast<const bf8v *>(&ab[(pa * KS8 + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[c][pb][s], acc[c], 0, 0, 0);
+            }
+        };
+        pass(2, 0);
+        pass(1, 1);
+        pass(1, 0);
+        pass(0, 2);
+        pass(0, 1);
+        pass(0, 0);
+#ifdef PCL_DIAG_NOLSE
+#pragma unroll
+        for (int c = 0; c < NT; ++c) sm[c] += acc[c][0] + acc[c][15];   // diagnostic build: no log-sum-exp work (wrong results)
+        return;
+#endif
+        // reference-shifted log-sum-exp, see gmm_score_mfma.hip; "log zero" (zero-weight and padding mixtures) is the
+        // finite sentinel -3e38 here because an infinity would meet a zero piece of the other operand
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            f2v e[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) e[r] = f2v{__builtin_amdgcn_exp2f(acc[c][2 * r]), __builtin_amdgcn_exp2f(acc[c][2 * r + 1])};
+            const f2v t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
+            const f2v t = t0 + t1;
+            const float snew = sm[c] + (t.x + t.y);
+            if (mt == 0 || __any(!(snew < 3.0e38f))) {
+                float gm = acc[c][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
+                const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));   // max over the frame's 32 mixtures
+                float s = sm[c];
+                if ((mt == 0 || gp > 0.f) && gp > -1.0e37f) {
+                    s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] -= gp;
+                    ref[c] += gp;
+                    __bf16 p1, p2, p3;
+                    split3(-ref[c], p1, p2, p3);                                // exact: the pipe subtracts ref itself
+                    if (half) {
+                        xb[c][0][SC][JC] = p1;
+                        xb[c][1][SC][JC] = p2;
+                        xb[c][2][SC][JC] = p3;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
+                sm[c] = s;
+            } else {
+                sm[c] = snew;
+            }
+        }
+    };
+    dma(0, 0);
+    for (int mt = 0; mt < n_mtiles; ++mt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile mt have landed
+        __syncthreads();                                    // everyone's pieces have; buffer (mt+1)&1 is free
+        if (mt + 1 < n_mtiles) dma((mt + 1) & 1, mt + 1);
+        if (wave_active) process(mt);
+    }
+    constexpr double LN2 = 0.693147180559945309417232121458;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
+        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2 * ((double)ref[c] + ::log2(S)) : -INFINITY;
+    }
+}
+
+template <int D>
+void launch_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    hipLaunchKernelGGL((gmm_score_split_kernel<D, PCL_SPLIT_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
+                       reinterpret_cast<const uint4 *>(ctx->pm16), ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs, b->Bt);
+}
+
+}  // namespace
+
+int pcl_score_split_tile_frames() { return WG / 64 * PCL_SPLIT_NT * 32; }
+
+int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    if (n_tiles == 0) return PCL_OK;
+    pcl_timer_begin(ctx, "score");
+    switch (ctx->D) {
+        case 39: launch_t<39>(ctx, b, tiles, n_tiles); break;
+        case 26: launch_t<26>(ctx, b, tiles, n_tiles); break;
+        case 13: launch_t<13>(ctx, b, tiles, n_tiles); break;
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no split-bf16 scoring kernel for D=%d", ctx->D);
+    }
+    pcl_timer_end(ctx, "score");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}

@@ -2,7 +2,8 @@
 //
 //   derive: from the float64 master copy (mean, var, weight) build every layout the kernels read:
 //           the VALU scoring rows [s_d c_d ... k2] (f32 + f64), the per-state expansion centres and the
-//           MFMA layout [m-tile][KS4][64][4] of gmm_score_mfma.hip, and the f32 means.
+//           MFMA layout [m-tile][KS4][64][4] of gmm_score_mfma.hip, its split-bf16 twin [m-tile][3][KS8][64][8] of
+//           gmm_score_split.hip, and the f32 means.
 //   mstep:  Clustering.GMM.update_param (StatisticalModel/Clustering.py:682-693) for every state at once
 //           from the resident linear statistics:
 //               w = acc / alpha_acc          (= exp(acc - alpha_acc) of the log-domain reference)
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      int Mpad, int Mpad32, int D, int Dhost, int row, int flags,
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
-                                                     float *__restrict__ cond) {
+                                                     uint4 *__restrict__ pm16, float *__restrict__ cond) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
@@ -112,6 +113,41 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
         pt[e] = make_float4(v[0], v[1], v[2], v[3]);
     }
+    // split-bf16 layout [piece 3][KS8][64 lanes][8 bf16] of gmm_score_split.hip: the same f32 values, each written as
+    // the exact sum of three bf16 pieces; lane = half * 32 + mixture, element j = feature 8s + j
+    const int KS8 = (D + 8) / 8;
+    uint4 *pq = pm16 + ((size_t)j * nmt + mt) * (3 * KS8 * 64);
+    for (int e = tid; e < 3 * KS8 * 64; e += 256) {
+        const int p = e / (KS8 * 64), s = (e >> 6) % KS8, ln = e & 63, half = ln >> 5, cl = ln & 31;
+        const bool real_m = (m0 + cl) < M;
+        unsigned short h[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int dd = 8 * s + x;
+            float val = 0.f;
+            if (dd < D) {
+                if (real_m && dd < Dhost) {
+                    const double var = vr[cl * D + dd], dm = mu[cl * D + dd] - (double)cen[dd];
+                    val = half ? (float)(LOG2E * dm / var) : (float)(-LOG2E / (2.0 * var));
+                }
+            } else if (dd == D) {
+                val = half ? 1.f : (real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY);
+                if (!(val > -1.0e37f)) val = -3.0e38f;      // "log zero" stays finite: its pieces meet zeros of the other operand
+            }
+            // piece p of the round-to-nearest-even three-way split
+            float r = val;
+            unsigned short piece = 0;
+            for (int q = 0; q <= p; ++q) {
+                unsigned int u = __float_as_uint(r);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                piece = (unsigned short)(u >> 16);
+                r -= __uint_as_float((unsigned int)piece << 16);
+            }
+            if (val < -1.0e37f && p > 0) piece = 0;
+            h[x] = piece;
+        }
+        pq[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    }
 }
 
 // Clustering.GMM.update_param, one thread per (state, mixture, dim)
@@ -166,7 +202,7 @@ int pcl_launch_derive(pcl_ctx *ctx) {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
-                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, ctx->d_cond);
+                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16), ctx->d_cond);
     HIPCHK(ctx, hipGetLastError());
     // the per-state conditioning decides which kernel scores a state: bring it to the host (J floats)
     ctx->cond.resize(ctx->J);

@@ -69,7 +69,7 @@ int pcl_init(int device, pcl_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
     const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
-    ctx->score_variant = var ? atoi(var) : 3;
+    ctx->score_variant = var ? atoi(var) : 4;
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
     *out = ctx;
     return PCL_OK;
@@ -83,6 +83,7 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->var64);
     dev_free(ctx->w64);
     dev_free(ctx->pm32);
+    dev_free(ctx->pm16);
     dev_free(ctx->centers32);
     dev_free(ctx->d_cond);
     dev_free(ctx->stats);
@@ -190,6 +191,7 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->var64, nm));
     TRY(dev_alloc(ctx, &ctx->w64, nw));
     TRY(dev_alloc(ctx, &ctx->pm32, npm));
+    TRY(dev_alloc(ctx, &ctx->pm16, (size_t)J * (Mp32 / 32) * 3 * ((Dd + 8) / 8) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
@@ -534,8 +536,9 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
 
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
-    const bool mfma = precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D);
-    const int tf = mfma ? pcl_score_mfma_tile_frames() : pcl_score_tile_frames(ctx->D, precision);
+    const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D);
+    const int tf = mfma ? (ctx->score_variant == 4 ? pcl_score_split_tile_frames() : pcl_score_mfma_tile_frames())
+                        : pcl_score_tile_frames(ctx->D, precision);
     if (b->d_tiles && b->tile_frames == tf && b->tile_gen == ctx->model_gen) return PCL_OK;
     // MFMA mode: states whose centred expansion is ill conditioned go to the direct-form VALU kernel
     std::vector<size_t> good, bad;
@@ -570,8 +573,9 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     if (precision == PCL_F64) TRY(ensure_frames64(ctx));
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
-    if (precision == PCL_F32 && ctx->score_variant == 3 && pcl_score_mfma_supported(ctx->D)) {
-        TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
+    if (precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D)) {
+        if (ctx->score_variant == 4) TRY(pcl_launch_score_split(ctx, b, b->d_tiles, b->n_tiles));
+        else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
         TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
     } else {
         TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));

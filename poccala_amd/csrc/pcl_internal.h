@@ -64,8 +64,9 @@ struct pcl_ctx {
     double *params64 = nullptr;  // same layout, float64
     float *pm32 = nullptr;       // MFMA scoring layout: [J][Mpad32/32][KS4][64 lanes][4], see gmm_score_mfma.hip
     float *centers32 = nullptr;  // J * D per-state expansion centres c_j
+    unsigned short *pm16 = nullptr;   // split-bf16 scoring layout: [J][Mpad32/32][3 pieces][KS8][64 lanes][8], see gmm_score_split.hip
     int Mpad32 = 0;              // M rounded up to a multiple of 32
-    int score_variant = 0;       // 1 = VALU/LDS, 3 = f32 MFMA (default)
+    int score_variant = 0;       // 1 = VALU/LDS, 3 = f32-input MFMA, 4 = split-bf16 MFMA (default)
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
     // the magnitude of the terms that cancel in it.  States above cond_max are scored / accumulated by the
     // direct-form VALU kernels instead (f32 error of the expansion ~ 5e-7 * cond nats).
@@ -161,6 +162,8 @@ void pcl_accumulate_release(pcl_batch *b);
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
 int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
+int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
+int pcl_score_split_tile_frames();
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);
