@@ -65,10 +65,11 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
                                                           const real *__restrict__ params, int Mpad,
                                                           const ScoreTile *__restrict__ tiles,
                                                           const ScoreSeg *__restrict__ segs,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, const int *__restrict__ flags) {
     constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
     __shared__ __attribute__((aligned(16))) real lds[CH * ROW];
 
+    if (flags && !flags[blockIdx.x]) return;   // fix-up launch: only the tiles another kernel flagged
     const ScoreTile tile = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -198,7 +199,7 @@ __global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *
 template <int D, int R, int CH, typename real>
 void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const ScoreTile *tiles, int n_tiles) {
     hipLaunchKernelGGL((gmm_score_kernel<D, R, CH, real>), dim3(n_tiles), dim3(WG), 0, ctx->stream, frames, params,
-                       ctx->Mpad, tiles, b->d_segs, b->Bt);
+                       ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr);
 }
 
 // frames per lane for each (D, precision); the tile is WG * R frames.  x[R][D] must stay in VGPRs
@@ -222,6 +223,26 @@ int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b) {
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major) {
     dim3 grid(8, b->U);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, b->d_utt, src, dst, to_time_major);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+// direct-form rescoring of the tiles a matrix-pipe kernel flagged (same tile list: R * 256 frames per workgroup)
+int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags) {
+    if (n_tiles == 0) return PCL_OK;
+    const int tf = pcl_score_split16_tile_frames(), R = tf / WG;      // frames per lane so that a workgroup covers the same tile
+    if (tf % WG || (R != 1 && R != 2)) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: fix-up tile size mismatch");
+    pcl_timer_begin(ctx, "score_fixup");
+#define LAUNCHF(DD, RR) hipLaunchKernelGGL((gmm_score_kernel<DD, RR, PCL_CH32, float>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
+                                           ctx->params32, ctx->Mpad, tiles, b->d_segs, b->Bt, flags)
+#define CASEF(DD) case DD: if (R == 1) LAUNCHF(DD, 1); else LAUNCHF(DD, 2); break;
+    switch (ctx->D) {
+        CASEF(13) CASEF(26) CASEF(39)
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no fix-up scoring kernel for D=%d", ctx->D);
+    }
+#undef CASEF
+#undef LAUNCHF
+    pcl_timer_end(ctx, "score_fixup");
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

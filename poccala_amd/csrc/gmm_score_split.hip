@@ -32,7 +32,7 @@ namespace {
 #define PCL_SPLIT_WG 256    // threads per workgroup = 64 x (waves sharing one LDS copy of the A tile)
 #endif
 #ifndef PCL_SPLIT_MINW
-#define PCL_SPLIT_MINW 2    // __launch_bounds__ waves per SIMD
+#define PCL_SPLIT_MINW 2    // __launch_bounds__ waves per SIMD (bf16 x3 kernel: 195 VGPRs)
 #endif
 constexpr int WG = PCL_SPLIT_WG;
 #ifndef PCL_SPLIT_NT
@@ -201,6 +201,209 @@ __global__ __launch_bounds__(WG, PCL_SPLIT_MINW * 256 / WG > 0 ? PCL_SPLIT_MINW 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two-way f16 split: half the matrix work of the bf16 scheme.  f16 has 11 significand bits, so x = h1 + h2 carries 22
+// and a x = a1x1 + a1x2 + a2x1 + O(2^-22 |a x|): three f16 MFMAs per K-step.  f16's narrow exponent range is handled
+// by exact power-of-two scaling per (state, feature): A'' = coef 2^-e with max_m |A''| in [1, 2), B'' = feature 2^e
+// (model_derive.hip writes 2^e next to the layout); subnormal second pieces are honoured by the f16 MFMA
+// (tools/ubench_f16denorm.hip), so small features keep an ABSOLUTE error of 2^-25.  What does not fit f16 stays out
+// of it: the constant k'_m, the reference shift -ref_f and the finite "log zero" ride ONE extra bf16 MFMA per tile
+// (three pieces each, exact), and a frame whose scaled feature exceeds 6e4 (|x - c| beyond ~300 sigma of the tightest
+// mixture) raises its tile's flag: the direct-form kernel then rescores flagged tiles in the same call
+// (pcl_launch_score_fixup), so no input sees an overflowed result.
+#ifndef PCL_SPLIT16_NT
+#define PCL_SPLIT16_NT 2
+#endif
+#ifndef PCL_SPLIT16_MINW
+#define PCL_SPLIT16_MINW 3    // waves per SIMD (f16 x2 kernel: fits 168 VGPRs)
+#endif
+#ifndef PCL_SPLIT16_MTS
+#define PCL_SPLIT16_MTS 1     // m-tiles staged per workgroup barrier (2 and 4 measured no faster)
+#endif
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+
+template <int D, int NT>
+__global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_MINW * 256 / WG : 1) void gmm_score_split16_kernel(
+    const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
+    int n_mtiles, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
+    int *__restrict__ flags) {
+    constexpr int KS8 = (D + 7) / 8;       // K-steps of 16 over the 2D features (8 per half-wave)
+    constexpr int CH = 2 * KS8 + 1;        // 1-KiB chunks per m-tile: two f16 pieces + the bf16 constant chunk
+    constexpr float FMAXH = 6.0e4f;
+    const ScoreTile tile = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    if (tile.seg_lo >= tile.seg_hi) {       // padding tile of the XCD-aware order
+        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+        return;
+    }
+    __shared__ int s_ovf;
+    if (threadIdx.x == 0) s_ovf = 0;
+    __syncthreads();
+    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
+    const bool wave_active = tile.vstart + wave * NT * 32 < vend;
+
+    // ---- B operand: scaled features of this lane's frames in two f16 pieces, and the bf16 constant fragment
+    h8v xb[NT][2][KS8];
+    bf8v xc8[NT];
+    long long oidx[NT];
+    bool valid[NT];
+    const float *cen = centers + (size_t)tile.state * D;
+    const float *fs = fscale + ((size_t)tile.state * 2 + half) * (KS8 * 8);
+    bool ovf = false;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        int v = tile.vstart + (wave * NT + c) * 32 + col;
+        valid[c] = v < vend;
+        if (!valid[c]) v = tile.vstart;
+        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        }
+        const ScoreSeg sg = segs[lo];
+        const long long t = v - sg.vstart;
+        const float *fp = frames + (sg.frame0 + t) * D;
+#pragma unroll
+        for (int s = 0; s < KS8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * s + j;
+                float val = 0.f;
+                if (d < D) {
+                    const float xc = fp[d] - cen[d];
+                    val = (half ? xc : xc * xc) * fs[d];
+                    ovf |= __builtin_fabsf(val) > FMAXH;
+                    val = __builtin_fminf(__builtin_fmaxf(val, -FMAXH), FMAXH);
+                }
+                const _Float16 h1 = (_Float16)val;
+                xb[c][0][s][j] = h1;
+                xb[c][1][s][j] = (_Float16)(val - (float)h1);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xc8[c][j] = (__bf16)((half == 0 && j < 3) ? 1.f : 0.f);   // 1 1 1 -ref1 -ref2 -ref3 0 0
+        oidx[c] = sg.out0 + t * (long long)sg.out_stride;
+    }
+    if (__any(ovf) && lane == 0) s_ovf = 1;
+
+    float sm[NT], ref[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        sm[c] = 0.f;
+        ref[c] = 0.f;
+    }
+
+    // MTS m-tiles per LDS stage: one workgroup barrier per MTS x 32 mixtures
+    constexpr int MTS = PCL_SPLIT16_MTS;
+    __shared__ __attribute__((aligned(16))) uint4 abuf[2][MTS * CH * 64];
+    const uint4 *pstate = pm + (size_t)tile.state * n_mtiles * (CH * 64);
+    auto dma = [&](int buf, int stage) {
+        const uint4 *src = pstate + (size_t)stage * (MTS * CH * 64);
+        const int nch = min(MTS, n_mtiles - stage * MTS) * CH;
+        for (int p = wave; p < nch; p += WG / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&abuf[buf][p * 64], 16, 0, 0);
+    };
+
+    auto process = [&](int mt) {
+        const uint4 *ab = &abuf[(mt / MTS) & 1][(mt % MTS) * (CH * 64)];
+        f16v acc[NT];
+        {
+            const bf8v ac = *reinterpret_cast<const bf8v *>(&ab[(2 * KS8) * 64 + lane]);   // k'1 k'2 k'3 1 1 1 0 0
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                f16v z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac, xc8[c], z, 0, 0, 0);
+            }
+        }
+        auto pass = [&](int pa, int pb) {
+#pragma unroll
+            for (int s = 0; s < KS8; ++s) {
+                const h8v a = *reinterpret_cast<const h8v *>(&ab[(pa * KS8 + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[c][pb][s], acc[c], 0, 0, 0);
+            }
+        };
+#ifdef PCL_SPLIT_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        pass(1, 0);
+        pass(0, 1);
+        pass(0, 0);
+#ifdef PCL_SPLIT_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef PCL_DIAG_NOLSE
+#pragma unroll
+        for (int c = 0; c < NT; ++c) sm[c] += acc[c][0] + acc[c][15];
+        return;
+#endif
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            f2v e[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) e[r] = f2v{__builtin_amdgcn_exp2f(acc[c][2 * r]), __builtin_amdgcn_exp2f(acc[c][2 * r + 1])};
+            const f2v t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
+            const f2v t = t0 + t1;
+            const float snew = sm[c] + (t.x + t.y);
+            if (mt == 0 || __any(!(snew < 3.0e38f))) {
+                float gm = acc[c][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
+                const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));
+                float s = sm[c];
+                if ((mt == 0 || gp > 0.f) && gp > -1.0e37f) {
+                    s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] -= gp;
+                    ref[c] += gp;
+                    __bf16 p1, p2, p3;
+                    split3(-ref[c], p1, p2, p3);
+                    if (half == 0) {
+                        xc8[c][3] = p1;
+                        xc8[c][4] = p2;
+                        xc8[c][5] = p3;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
+                sm[c] = s;
+            } else {
+                sm[c] = snew;
+            }
+        }
+    };
+    const int n_stages = (n_mtiles + MTS - 1) / MTS;
+    dma(0, 0);
+    for (int st = 0; st < n_stages; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage st have landed
+        __syncthreads();                                    // everyone's have; the other buffer is free
+        if (st == 0 && threadIdx.x == 0) flags[blockIdx.x] = s_ovf;
+        if (st + 1 < n_stages) dma((st + 1) & 1, st + 1);
+        if (wave_active) {
+            const int mend = min(n_mtiles, (st + 1) * MTS);
+            for (int mt = st * MTS; mt < mend; ++mt) process(mt);
+        }
+    }
+    constexpr double LN2 = 0.693147180559945309417232121458;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
+        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2 * ((double)ref[c] + ::log2(S)) : -INFINITY;
+    }
+}
+
+template <int D>
+void launch16_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
+                       reinterpret_cast<const uint4 *>(ctx->pm16h), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs, b->Bt,
+                       b->d_tile_flags);
+}
+
 template <int D>
 void launch_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
     hipLaunchKernelGGL((gmm_score_split_kernel<D, PCL_SPLIT_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
@@ -210,6 +413,22 @@ void launch_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
 }  // namespace
 
 int pcl_score_split_tile_frames() { return WG / 64 * PCL_SPLIT_NT * 32; }
+
+int pcl_score_split16_tile_frames() { return WG / 64 * PCL_SPLIT16_NT * 32; }
+
+int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    if (n_tiles == 0) return PCL_OK;
+    pcl_timer_begin(ctx, "score");
+    switch (ctx->D) {
+        case 39: launch16_t<39>(ctx, b, tiles, n_tiles); break;
+        case 26: launch16_t<26>(ctx, b, tiles, n_tiles); break;
+        case 13: launch16_t<13>(ctx, b, tiles, n_tiles); break;
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no split-f16 scoring kernel for D=%d", ctx->D);
+    }
+    pcl_timer_end(ctx, "score");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
 
 int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
     if (n_tiles == 0) return PCL_OK;

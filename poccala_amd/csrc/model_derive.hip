@@ -27,6 +27,30 @@ __global__ void centers_kernel(const double *__restrict__ mean64, int M, int Mpa
     }
 }
 
+// one workgroup per state: exact power-of-two scale of every feature of the split-f16 layout (gmm_score_split.hip):
+// fscale[j][h][d] = 2^e with e = floor(log2 max_m |coef_m,h,d|), coef = -log2e/(2 var) (h = 0) or log2e (mu - c)/var
+// (h = 1), so that the scaled coefficients fill [1, 2) and the frame features carry the range
+__global__ void fscale_kernel(const double *__restrict__ mean64, const double *__restrict__ var64, const float *__restrict__ centers,
+                              int M, int Mpad, int D, int Dhost, int KS8, float *__restrict__ fscale) {
+    const int j = blockIdx.x;
+    for (int t = threadIdx.x; t < 2 * KS8 * 8; t += blockDim.x) {
+        const int h = t / (KS8 * 8), d = t % (KS8 * 8);
+        double mx = 0.0;
+        if (d < Dhost) {
+            const double c = (double)centers[(size_t)j * D + d];
+            for (int m = 0; m < M; ++m) {
+                const size_t o = ((size_t)j * Mpad + m) * D + d;
+                const double var = var64[o], coef = h ? LOG2E * (mean64[o] - c) / var : LOG2E / (2.0 * var);
+                mx = fmax(mx, fabs(coef));
+            }
+        }
+        int ex = 1;
+        if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)
+        ex = min(max(ex - 1, -60), 60);
+        fscale[((size_t)j * 2 + h) * (KS8 * 8) + d] = (float)ldexp(1.0, ex);
+    }
+}
+
 // one workgroup per (state, 32-mixture tile): the tile's mean/var rows are staged in LDS with coalesced
 // loads and every output layout is written with contiguous 8/16-byte stores
 __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
@@ -34,7 +58,8 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      int Mpad, int Mpad32, int D, int Dhost, int row, int flags,
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
-                                                     uint4 *__restrict__ pm16, float *__restrict__ cond) {
+                                                     uint4 *__restrict__ pm16, uint4 *__restrict__ pm16h,
+                                                     const float *__restrict__ fscale, float *__restrict__ cond) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
@@ -148,6 +173,51 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
         pq[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
     }
+    // split-f16 layout [piece 2][KS8f][64 lanes][8 f16] + one bf16 constant chunk [64 lanes][8]:
+    // coefficients scaled by 2^-e (fscale holds 2^e), lanes 0-31 of the constant chunk carry k'1 k'2 k'3 1 1 1 0 0
+    const int KS8f = (D + 7) / 8, CHf = 2 * KS8f + 1;
+    uint4 *ph = pm16h + ((size_t)j * nmt + mt) * (CHf * 64);
+    for (int e = tid; e < CHf * 64; e += 256) {
+        const int chunk = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
+        const bool real_m = (m0 + cl) < M;
+        unsigned short h[8];
+        if (chunk < 2 * KS8f) {
+            const int p = chunk / KS8f, s = chunk % KS8f;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int dd = 8 * s + x;
+                float val = 0.f;
+                if (dd < D && real_m && dd < Dhost) {
+                    const double var = vr[cl * D + dd], dm = mu[cl * D + dd] - (double)cen[dd];
+                    const double coef = half ? LOG2E * dm / var : -LOG2E / (2.0 * var);
+                    val = (float)(coef / (double)fscale[((size_t)j * 2 + half) * (KS8f * 8) + dd]);
+                }
+                const _Float16 h1 = (_Float16)val;
+                const _Float16 hp = p ? (_Float16)(val - (float)h1) : h1;
+                h[x] = __builtin_bit_cast(unsigned short, hp);
+            }
+        } else {
+            float kc = real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY;
+            const bool zero = !(kc > -1.0e37f);
+            if (zero) kc = -3.0e38f;
+            float r = kc;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                unsigned short piece = 0;
+                if (half == 0 && x < 3) {
+                    unsigned int u = __float_as_uint(r);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    piece = (unsigned short)(u >> 16);
+                    r -= __uint_as_float((unsigned int)piece << 16);
+                    if (zero && x > 0) piece = 0;
+                } else if (half == 0 && x < 6) {
+                    piece = 0x3f80;       // bf16 1.0
+                }
+                h[x] = piece;
+            }
+        }
+        ph[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    }
 }
 
 // Clustering.GMM.update_param, one thread per (state, mixture, dim)
@@ -198,11 +268,15 @@ int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64
 
 int pcl_launch_derive(pcl_ctx *ctx) {
     hipLaunchKernelGGL(centers_kernel, dim3(ctx->J), dim3(64), 0, ctx->stream, ctx->mean64, ctx->M, ctx->Mpad, ctx->D, ctx->centers32);
+    const int KS8f = (ctx->D + 7) / 8;
+    hipLaunchKernelGGL(fscale_kernel, dim3(ctx->J), dim3(128), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->centers32, ctx->M, ctx->Mpad,
+                       ctx->D, ctx->Dhost, KS8f, ctx->fscale);
     const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)ctx->D * sizeof(float);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
-                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16), ctx->d_cond);
+                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
+                       reinterpret_cast<uint4 *>(ctx->pm16h), ctx->fscale, ctx->d_cond);
     HIPCHK(ctx, hipGetLastError());
     // the per-state conditioning decides which kernel scores a state: bring it to the host (J floats)
     ctx->cond.resize(ctx->J);

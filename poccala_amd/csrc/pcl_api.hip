@@ -69,7 +69,7 @@ int pcl_init(int device, pcl_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
     const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
-    ctx->score_variant = var ? atoi(var) : 4;
+    ctx->score_variant = var ? atoi(var) : 5;
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
     *out = ctx;
     return PCL_OK;
@@ -84,6 +84,8 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->w64);
     dev_free(ctx->pm32);
     dev_free(ctx->pm16);
+    dev_free(ctx->pm16h);
+    dev_free(ctx->fscale);
     dev_free(ctx->centers32);
     dev_free(ctx->d_cond);
     dev_free(ctx->stats);
@@ -192,6 +194,8 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->w64, nw));
     TRY(dev_alloc(ctx, &ctx->pm32, npm));
     TRY(dev_alloc(ctx, &ctx->pm16, (size_t)J * (Mp32 / 32) * 3 * ((Dd + 8) / 8) * 64 * 8));
+    TRY(dev_alloc(ctx, &ctx->pm16h, (size_t)J * (Mp32 / 32) * (2 * ((Dd + 7) / 8) + 1) * 64 * 8));
+    TRY(dev_alloc(ctx, &ctx->fscale, (size_t)J * 2 * ((Dd + 7) / 8) * 8));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
@@ -325,7 +329,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
-    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->tmp); dev_free(b->nz_tmp);
+    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
     return PCL_OK;
 }
@@ -537,7 +541,7 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
     const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D);
-    const int tf = mfma ? (ctx->score_variant == 4 ? pcl_score_split_tile_frames() : pcl_score_mfma_tile_frames())
+    const int tf = mfma ? (ctx->score_variant == 5 ? pcl_score_split16_tile_frames() : ctx->score_variant == 4 ? pcl_score_split_tile_frames() : pcl_score_mfma_tile_frames())
                         : pcl_score_tile_frames(ctx->D, precision);
     if (b->d_tiles && b->tile_frames == tf && b->tile_gen == ctx->model_gen) return PCL_OK;
     // MFMA mode: states whose centred expansion is ill conditioned go to the direct-form VALU kernel
@@ -547,6 +551,8 @@ static int build_tiles(pcl_batch *b, int precision) {
     const std::vector<ScoreTile> tiles_v = bad.empty() ? std::vector<ScoreTile>() : make_tiles(b, bad, pcl_score_tile_frames(ctx->D, PCL_F32));
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
+    dev_free(b->d_tile_flags);
+    TRY(dev_alloc(ctx, &b->d_tile_flags, tiles.size()));
     b->n_tiles = (int)tiles.size();
     b->n_tiles_v = (int)tiles_v.size();
     b->tile_frames = tf;
@@ -574,7 +580,10 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
     if (precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D)) {
-        if (ctx->score_variant == 4) TRY(pcl_launch_score_split(ctx, b, b->d_tiles, b->n_tiles));
+        if (ctx->score_variant == 5) {
+            TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));
+            TRY(pcl_launch_score_fixup(ctx, b, b->d_tiles, b->n_tiles, b->d_tile_flags));   // tiles with out-of-range features
+        } else if (ctx->score_variant == 4) TRY(pcl_launch_score_split(ctx, b, b->d_tiles, b->n_tiles));
         else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
         TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
     } else {

@@ -65,8 +65,10 @@ struct pcl_ctx {
     float *pm32 = nullptr;       // MFMA scoring layout: [J][Mpad32/32][KS4][64 lanes][4], see gmm_score_mfma.hip
     float *centers32 = nullptr;  // J * D per-state expansion centres c_j
     unsigned short *pm16 = nullptr;   // split-bf16 scoring layout: [J][Mpad32/32][3 pieces][KS8][64 lanes][8], see gmm_score_split.hip
+    unsigned short *pm16h = nullptr;  // split-f16 scoring layout: [J][Mpad32/32][2 pieces x KS8f + 1 constant chunk][64 lanes][8]
+    float *fscale = nullptr;          // [J][2][KS8f*8] power-of-two feature scales of that layout
     int Mpad32 = 0;              // M rounded up to a multiple of 32
-    int score_variant = 0;       // 1 = VALU/LDS, 3 = f32-input MFMA, 4 = split-bf16 MFMA (default)
+    int score_variant = 0;       // 1 = VALU/LDS, 3 = f32-input MFMA, 4 = split-bf16 MFMA, 5 = split-f16 MFMA
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
     // the magnitude of the terms that cancel in it.  States above cond_max are scored / accumulated by the
     // direct-form VALU kernels instead (f32 error of the expansion ~ 5e-7 * cond nats).
@@ -121,6 +123,7 @@ struct pcl_batch {
     std::vector<int> work_states;
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
     std::vector<int> acc_ws, acc_lo, acc_hi; // accumulate's state order (well-conditioned first)
+    int *d_tile_flags = nullptr;             // split-f16 scoring: per tile, 1 = a scaled feature left the f16 range (rescored)
     ScoreTile *d_tiles_v = nullptr;          // MFMA mode only: tiles of ill-conditioned states for the VALU kernel
     int n_segs = 0, n_tiles = 0, n_tiles_v = 0, tile_frames = 0, tile_gen = -1;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
@@ -164,6 +167,9 @@ int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split_tile_frames();
+int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
+int pcl_score_split16_tile_frames();
+int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);

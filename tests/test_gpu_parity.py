@@ -683,3 +683,93 @@ def test_ill_conditioned_states_use_direct_form(eng):
         refj = po.gmm_point(xx, m2[j], v2[j], w2[j])
         np.testing.assert_allclose(Bm[0][r + 1], refj, rtol=5e-6, atol=F32_LOGLIK_ATOL)
     b.close()
+
+
+# ------------------------------------------------------------------ every f32 scoring kernel against the oracle
+# PCL_SCORE_VARIANT: 1 = direct form on the VALU, 3 = f32-input MFMA, 4 = three-way bf16 split, 5 = two-way f16 split
+# (the default).  The variant is read when the context is created, so each gets its own engine.
+@pytest.fixture(scope='module', params=[1, 3, 4, 5])
+def eng_variant(request):
+    import os
+    from poccala_amd import Engine
+    old = os.environ.get('PCL_SCORE_VARIANT')
+    os.environ['PCL_SCORE_VARIANT'] = str(request.param)
+    try:
+        e = Engine(0)
+    finally:
+        if old is None:
+            del os.environ['PCL_SCORE_VARIANT']
+        else:
+            os.environ['PCL_SCORE_VARIANT'] = old
+    yield e
+    e.close()
+
+
+def score_all_states(eng, mean, var, w, x):
+    from poccala_amd import PCL_F32
+    J = mean.shape[0]
+    T = x.shape[0]
+    eng.load_model(mean, var, w)
+    eng.load_frames(x)
+    b = eng.batch([J + 2], [T], [0])
+    b.set_states([np.concatenate([[-1], np.arange(J), [-2]]).astype(np.int32)])
+    b.score(PCL_F32)
+    got = b.get('B')[0][1:-1]
+    b.close()
+    with np.errstate(divide='ignore'):
+        ref = np.stack([po.gmm_point(x.astype(np.float64), mean[j], var[j], w[j]) for j in range(J)])
+    return got, ref
+
+
+@pytest.mark.parametrize('M,D', [(70, 39), (33, 26), (40, 13)])
+def test_score_variants_match_oracle(eng_variant, M, D):
+    rng = np.random.default_rng(5 + M)
+    J, T = 4, 300
+    mean = rng.standard_normal((J, M, D)) * 1.5
+    var = rng.uniform(0.3, 3.0, (J, M, D))
+    w = rng.dirichlet(np.ones(M), J)
+    w[1, 3] = 0.0                                         # log zero inside a tile
+    w[1] /= w[1].sum()
+    st, comp = rng.integers(0, J, T), rng.integers(0, M, T)
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((T, D))).astype(np.float32)
+    got, ref = score_all_states(eng_variant, mean, var, w, x)
+    np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)
+
+
+def test_score_variants_wide_dynamic_range(eng_variant):
+    """Variances from 1e-3 (the reference's floor) to 1e3 inside one state, a common offset, per-dimension scales six
+    decades apart: the power-of-two feature scaling of the f16 kernel and the centring of all of them."""
+    rng = np.random.default_rng(11)
+    J, M, D, T = 3, 64, 39, 256
+    dim_scale = 10.0 ** rng.uniform(-3, 3, D)             # feature d lives on the scale dim_scale[d]
+    sig = dim_scale[None, None, :] * 10.0 ** rng.uniform(-0.5, 0.5, (J, M, D))
+    var = sig ** 2
+    mean = 40.0 * dim_scale + sig * rng.standard_normal((J, M, D)) * 1.2
+    w = rng.dirichlet(np.ones(M), J)
+    st, comp = rng.integers(0, J, T), rng.integers(0, M, T)
+    x = (mean[st, comp] + sig[st, comp] * rng.standard_normal((T, D))).astype(np.float32)
+    got, ref = score_all_states(eng_variant, mean, var, w, x)
+    own = np.zeros_like(ref, dtype=bool)
+    own[st, np.arange(T)] = True
+    # float32 frames carry 40 sigma of offset: the input rounding alone moves ln b by ~1e-4 here
+    np.testing.assert_allclose(got[own], ref[own], rtol=5e-6, atol=2e-3)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-3)
+
+
+def test_score_variants_outlier_frames(eng_variant):
+    """Frames hundreds to millions of sigma away from every mixture: finite, hugely negative scores that still have
+    to match (the f16 kernel flags such tiles and the direct-form kernel rescores them in the same call)."""
+    rng = np.random.default_rng(13)
+    J, M, D, T = 3, 48, 39, 300
+    mean = rng.standard_normal((J, M, D))
+    var = rng.uniform(0.05, 2.0, (J, M, D))
+    w = rng.dirichlet(np.ones(M), J)
+    x = rng.standard_normal((T, D)).astype(np.float32)
+    x[5, 3] = 250.0                                       # ~1000 sigma
+    x[17] *= 400.0
+    x[100, :] = 1.0e4
+    x[101, 7] = -3.0e5
+    x[299, 38] = 3.0e6
+    got, ref = score_all_states(eng_variant, mean, var, w, x)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)

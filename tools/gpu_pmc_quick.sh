@@ -16,4 +16,4 @@ for f in glob.glob('pmc/**/*counter_collection.csv', recursive=True):
     for k, v in sorted(agg.items()):
         if 'score' in k[0]: print('%-52s %-26s per-dispatch=%.6g n=%d' % (k[0], k[1], v[0] / v[1], v[1]))
 P
-tail -1 trace.log pmc.log
+tail -n 1 trace.log pmc.log
