@@ -579,7 +579,10 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
     hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
                        b->acc_off, b->acc_list);
-    if (mfma && n_good > 0) {
+    if (mfma && n_good > 0 && ctx->score_variant >= 4) {
+        const int rc = pcl_launch_accumulate_split(ctx, b, n_good);     // bf16 matrix pipe (gmm_accumulate_split.hip)
+        if (rc != PCL_OK) return rc;
+    } else if (mfma && n_good > 0) {
         const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = n_good;
         const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
 #define LAUNCH_MFMA(DD)                                                                                                   \

@@ -167,6 +167,7 @@ int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split_tile_frames();
+int pcl_launch_accumulate_split(pcl_ctx *ctx, pcl_batch *b, int ns);
 int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split16_tile_frames();
 int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
