@@ -27,6 +27,12 @@ namespace {
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 constexpr int AW = 8;        // waves (32-mixture tiles) per workgroup
+#ifndef PCL_ACCS_P2_INTERLEAVE
+#define PCL_ACCS_P2_INTERLEAVE 1
+#endif
+#ifndef PCL_ACCS_P1_SPLIT
+#define PCL_ACCS_P1_SPLIT 0
+#endif
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {      // round to nearest even (finite inputs)
     unsigned int u = __float_as_uint(x);
@@ -137,35 +143,41 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
     // i), list entries of tile i+3 (ix3): a dependent pair of loads (entry -> frame row) under load takes longer than one
     // tile of MFMAs, and with one workgroup per CU nothing else covers it
     float xv1[2][2], xv2[2][2];
+    int vm1 = 0, vm2 = 0;
     int ix2[2] = {-1, -1}, ix3[2] = {-1, -1};
-    float cf1 = -3.0e38f, cf2 = -3.0e38f, cf3 = -3.0e38f;
+    double cf1 = -INFINITY, cf2 = -INFINITY, cf3 = -INFINITY;     // ln gamma - ln b, raw (scaled and clamped when stored)
     double lg1 = -INFINITY, lg2 = -INFINITY, lg3 = -INFINITY;
-    auto load_index = [&](long long f0, int (&ix)[2], float &cf, double &lg) {
+    auto load_index = [&](long long f0, int (&ix)[2], double &cf, double &lg) {
         const int nf = (f0 < end) ? (int)min(32LL, end - f0) : 0;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int f = 2 * item_fp + a;
             ix[a] = (item_on && f < nf) ? (int)list[f0 + f].frame : -1;
         }
-        cf = -3.0e38f;                                     // padding frame: g = exp2(-huge) = 0 (finite: its pieces meet zeros)
+        cf = -INFINITY;                                    // padding frame: g = 0
         lg = -INFINITY;
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
-            cf = __builtin_fmaxf((float)(a.coef * LOG2E), -3.0e38f);
+            cf = a.coef;
             lg = a.lg;
         }
     };
     const float cen0 = item_on ? cen[d0] : 0.f, cen1 = (item_on && pair_ok) ? cen[d0 + 1] : 0.f;
-    auto load_rows = [&](const int (&ix)[2], float (&x)[2][2]) {
+    // nothing here may consume a loaded value (no centring, no select on the data): the compiler would wait for the
+    // load on the spot and the whole gather latency would sit at the top of every tile (measured with in-kernel
+    // stamps: 2460 of 8200 cycles per tile).  Padding rows read frame 0 and are masked when they are stored.
+    auto load_rows = [&](const int (&ix)[2], float (&x)[2][2], int &vmask) {
+        vmask = 0;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const float *row = frames + (long long)ix[a] * D + d0;
-            x[a][0] = (ix[a] >= 0) ? row[0] - cen0 : 0.f;
-            x[a][1] = (ix[a] >= 0 && pair_ok) ? row[1] - cen1 : 0.f;
+            const float *row = frames + (long long)max(ix[a], 0) * D + d0;
+            x[a][0] = row[0];
+            x[a][1] = row[pair_ok ? 1 : 0];
+            vmask |= (ix[a] >= 0) << a;
         }
     };
     // one chunk = one side (x'^2 | x') of the block: 6 conversions, 12 four-byte LDS writes
-    auto store_chunk = [&](int buf, int side, const float (&xv)[2][2], bool force = false) {
+    auto store_chunk = [&](int buf, int side, const float (&xraw)[2][2], int vmask, bool force = false) {
 #ifdef PCL_ACCS_DIAG_NOSTORE
         if (!force) return;                               // diagnostic: only the prologue stages (both buffers), timing only
 #endif
@@ -177,7 +189,9 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
         unsigned int P[3][2];                              // [piece][frame]: dword = pieces of (d0, d0 + 1)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            float r0 = side ? xv[a][0] : xv[a][0] * xv[a][0], r1 = side ? xv[a][1] : xv[a][1] * xv[a][1];
+            const bool ok = (vmask >> a) & 1;
+            const float x0 = ok ? xraw[a][0] - cen0 : 0.f, x1 = (ok && pair_ok) ? xraw[a][1] - cen1 : 0.f;
+            float r0 = side ? x0 : x0 * x0, r1 = side ? x1 : x1 * x1;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const bf2v c = bf2v{(__bf16)r0, (__bf16)r1};                       // v_cvt_pk_bf16_f32, round to nearest even
@@ -214,14 +228,15 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
         }
         }
     };
-    auto store_cf = [&](int buf, float cfv, double lgv) {
+    auto store_cf = [&](int buf, double cfv, double lgv) {
         if (threadIdx.x < 32) {
             unsigned short *h1 = reinterpret_cast<unsigned short *>(&xe[buf][0]);
             const int f = threadIdx.x;
             if (slice == 0 && lgv > -INFINITY) galpha += exp(lgv);
             unsigned short c1, c2p, c3;
-            split3_bits(cfv, c1, c2p, c3);
-            if (cfv < -1.0e37f) c2p = c3 = 0;
+            const float cfl2 = __builtin_fmaxf((float)(cfv * LOG2E), -3.0e38f);   // finite: its pieces meet zeros of the other operand
+            split3_bits(cfl2, c1, c2p, c3);
+            if (cfl2 < -1.0e37f) c2p = c3 = 0;
             h1[((0 * KS8 + SC) * BS + 32 + f) * 8 + JC] = c1;               // slot d = D on the x' side carries cf
             h1[((1 * KS8 + SC) * BS + 32 + f) * 8 + JC] = c2p;
             h1[((2 * KS8 + SC) * BS + 32 + f) * 8 + JC] = c3;
@@ -229,27 +244,39 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
     };
     __syncthreads();
     load_index(beg, ix2, cf2, lg2);
-    load_rows(ix2, xv1);
-    store_chunk(0, 0, xv1, true);
-    store_chunk(0, 1, xv1, true);
+    load_rows(ix2, xv1, vm1);
+    store_chunk(0, 0, xv1, vm1, true);
+    store_chunk(0, 1, xv1, vm1, true);
     store_cf(0, cf2, lg2);
 #ifdef PCL_ACCS_DIAG_NOSTORE
-    store_chunk(1, 0, xv1, true);
-    store_chunk(1, 1, xv1, true);
+    store_chunk(1, 0, xv1, vm1, true);
+    store_chunk(1, 1, xv1, vm1, true);
 #endif
     load_index(beg + 32, ix2, cf1, lg1);
-    load_rows(ix2, xv1);                                 // tile 1
+    load_rows(ix2, xv1, vm1);                            // tile 1
     load_index(beg + 64, ix2, cf2, lg2);                 // tile 2
     __syncthreads();
     // one tile; the register sets alternate between calls (no moves: a move would wait for the loads just issued)
     //   xs/cfs/lgs: rows of tile i+1 to store      xl: rows of tile i+2 to load, from the entries ixs
     //   ixl/cfl/lgl: list entries of tile i+3 to load
-    auto tile_step = [&](long long f0, int buf, const float (&xs)[2][2], float cfs, double lgs, float (&xl)[2][2],
-                         const int (&ixs)[2], int (&ixl)[2], float &cfl, double &lgl) {
+#ifdef PCL_ACCS_STAMPS
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned int stamp_n = 0;
+#define STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += t_ - stamp_t; stamp_t = t_; }
+#else
+#define STAMP(k)
+#endif
+    auto tile_step = [&](long long f0, int buf, const float (&xs)[2][2], int vms, double cfs, double lgs, float (&xl)[2][2],
+                         int &vml, const int (&ixs)[2], int (&ixl)[2], double &cfl, double &lgl) {
         const bool more = f0 + 32 < end;
+#ifdef PCL_ACCS_STAMPS
+        unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+        ++stamp_n;
+#endif
         load_index(f0 + 96, ixl, cfl, lgl);              // tile i+3: list entries (issued first: vmcnt retires in order, and
-        load_rows(ixs, xl);                              // tile i+2's rows must not be waited for before the next step)
+        load_rows(ixs, xl, vml);                         // tile i+2's rows must not be waited for before the next step)
         __builtin_amdgcn_sched_barrier(0);               // keep the loads in front of the matrix work
+        STAMP(0)
         // The staging of tile i+1 is cut into its two sides and pinned between the MFMA groups of tile i: all 8 waves
         // run the same phase at the same time (workgroup barrier per tile), so anything left after the last MFMA is time
         // the matrix pipe idles.
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
         auto emit = [&](int upto) {
             __builtin_amdgcn_sched_barrier(0);
             for (; chunk < upto && chunk < 2; ++chunk)
-                if (more) store_chunk(buf ^ 1, chunk, xs);
+                if (more) store_chunk(buf ^ 1, chunk, xs, vms);
             __builtin_amdgcn_sched_barrier(0);
         };
         if (live) {
@@ -266,11 +293,21 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
             f16v d1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[r] = 0.f;
+#if PCL_ACCS_P1_SPLIT
+            f16v d1b;                                    // second chain: the small cross terms
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1b[r] = 0.f;
+#endif
             auto pass = [&](int px, int pp) {
 #pragma unroll
                 for (int s = 0; s < KS8; ++s) {
                     const bf8v a = __builtin_bit_cast(bf8v, x1[(px * KS8 + s) * BS + lane]);
+#if PCL_ACCS_P1_SPLIT
+                    if ((s & 1) == 0) d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[pp][s], d1, 0, 0, 0);
+                    else d1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[pp][s], d1b, 0, 0, 0);
+#else
                     d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[pp][s], d1, 0, 0, 0);
+#endif
                 }
             };
 #ifndef PCL_ACCS_DIAG_NOP1
@@ -282,6 +319,11 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
             pass(0, 1);
 #endif
             pass(0, 0);
+#if PCL_ACCS_P1_SPLIT
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] += d1b[r];
+#endif
+            STAMP(1)
             // posteriors gamma_t(j,m) (Clustering.py:660-661) in two bf16 pieces = the A fragments of product (2)
             bf8v g1[2], g2[2];
             {
@@ -300,7 +342,33 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
                 g2[0] = __builtin_bit_cast(bf8v, make_uint4(u2[0], u2[1], u2[2], u2[3]));
                 g2[1] = __builtin_bit_cast(bf8v, make_uint4(u2[4], u2[5], u2[6], u2[7]));
             }
+            STAMP(2)
             // (2) S[mixture][feature] += g^T . Xe
+#if PCL_ACCS_P2_INTERLEAVE
+            // the NCT column tiles are independent accumulators: issue them round robin so that a dependent MFMA is
+            // NCT instructions behind its producer (a single chain runs at half the pipe rate)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                bf8v bq[3][NCT];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) bq[p][ct] = __builtin_bit_cast(bf8v, x2[((p * NCT + ct) * 2 + sp) * BS + lane]);
+#ifndef PCL_ACCS_DIAG_NOP2
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[sp], bq[2][ct], S[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[sp], bq[1][ct], S[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[sp], bq[0][ct], S[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[sp], bq[1][ct], S[ct], 0, 0, 0);
+#endif
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[sp], bq[0][ct], S[ct], 0, 0, 0);
+                if (sp == 0) emit(2);
+            }
+#else
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -317,21 +385,33 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
                     S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[sp], b1, S[ct], 0, 0, 0);
                     if (ct == 0 && sp == 1) emit(2);
                 }
+#endif
         }
+        STAMP(3)
         emit(2);                                         // whatever is left (and everything on a wave without an m-tile)
         if (more) store_cf(buf ^ 1, cfs, lgs);           // nobody reads xe[buf^1] until the barrier below
+        STAMP(4)
+#ifndef PCL_ACCS_DIAG_NOBARRIER
         __syncthreads();
+#endif
+        STAMP(5)
     };
     // state before tile i: xv1 / cf1 = tile i+1, ix2 / cf2 = entries of tile i+2.  A step loads tile i+2's rows into the
     // other row set and tile i+3's entries into the other index set; only the two scalars per thread are moved.
     for (long long f0 = beg; f0 < end; f0 += 64) {
-        tile_step(f0, 0, xv1, cf1, lg1, xv2, ix2, ix3, cf3, lg3);
+        tile_step(f0, 0, xv1, vm1, cf1, lg1, xv2, vm2, ix2, ix3, cf3, lg3);
         cf1 = cf2; lg1 = lg2; cf2 = cf3; lg2 = lg3;
         if (f0 + 32 >= end) break;
-        tile_step(f0 + 32, 1, xv2, cf1, lg1, xv1, ix3, ix2, cf3, lg3);
+        tile_step(f0 + 32, 1, xv2, vm2, cf1, lg1, xv1, vm1, ix3, ix2, cf3, lg3);
         cf1 = cf2; lg1 = lg2; cf2 = cf3; lg2 = lg3;
     }
 
+#ifdef PCL_ACCS_STAMPS
+    if (blockIdx.x == 64 && lane == 0 && stamp_n)
+        printf("wave %d tiles %u: loads-issue %llu  P1(+chunk) %llu  exp/cvt %llu  P2(+chunk) %llu  tail stores %llu  barrier %llu  (memtime ticks per tile)\n",
+               wave, stamp_n, stamp_acc[0] / stamp_n, stamp_acc[1] / stamp_n, stamp_acc[2] / stamp_n, stamp_acc[3] / stamp_n,
+               stamp_acc[4] / stamp_n, stamp_acc[5] / stamp_n);
+#endif
     // ---- flush: lane = feature column, register = mixture row; cov = S2 - 2 d S1 + d^2 S0, mean = S1 + (c + bias) S0
     if (live) {
 #pragma unroll
