@@ -307,6 +307,12 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                                              (__attribute__((address_space(3))) void *)&abuf[buf][p * 64], 16, 0, 0);
     };
 
+#ifdef PCL_SPLIT_STAMPS
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_t = 0;
+#define SSTAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
+#else
+#define SSTAMP(k)
+#endif
     auto process = [&](int mt) {
         const uint4 *ab = &abuf[(mt / MTS) & 1][(mt % MTS) * (CH * 64)];
         f16v acc[NT];
@@ -334,6 +340,7 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
         pass(1, 0);
         pass(0, 1);
         pass(0, 0);
+        SSTAMP(1)
 #ifdef PCL_SPLIT_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -344,12 +351,25 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
 #endif
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
+#ifndef PCL_SPLIT_PKADD
+            float es[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) es[r] = __builtin_amdgcn_exp2f(acc[c][r]);
+            // plain v_add_f32 tree, pinned: under -O3 the compiler SLP-packs these into v_pk_add_f32, which costs far
+            // more than its issue slot beside MFMAs (in-kernel stamps: log-sum-exp phase 1830 -> 1230 cycles per m-tile)
+#pragma unroll
+            for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                for (int r = 0; r < w; ++r) asm volatile("v_add_f32 %0, %0, %1" : "+v"(es[r]) : "v"(es[r + w]));
+            const float snew = sm[c] + es[0];
+#else
             f2v e[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) e[r] = f2v{__builtin_amdgcn_exp2f(acc[c][2 * r]), __builtin_amdgcn_exp2f(acc[c][2 * r + 1])};
             const f2v t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
             const f2v t = t0 + t1;
             const float snew = sm[c] + (t.x + t.y);
+#endif
             if (mt == 0 || __any(!(snew < 3.0e38f))) {
                 float gm = acc[c][0];
 #pragma unroll
@@ -376,12 +396,18 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                 sm[c] = snew;
             }
         }
+        SSTAMP(2)
     };
     const int n_stages = (n_mtiles + MTS - 1) / MTS;
     dma(0, 0);
+#ifdef PCL_SPLIT_STAMPS
+    st_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int st = 0; st < n_stages; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage st have landed
+        SSTAMP(3)
         __syncthreads();                                    // everyone's have; the other buffer is free
+        SSTAMP(0)
         if (st == 0 && threadIdx.x == 0) flags[blockIdx.x] = s_ovf;
         if (st + 1 < n_stages) dma((st + 1) & 1, st + 1);
         if (wave_active) {
@@ -389,6 +415,11 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
             for (int mt = st * MTS; mt < mend; ++mt) process(mt);
         }
     }
+#ifdef PCL_SPLIT_STAMPS
+    if (blockIdx.x == 800 && lane == 0)
+        printf("wave %d: per m-tile: dma-wait %llu  barrier %llu  dma-issue+lds+mfma %llu  lse %llu (memtime ticks)\n", wave,
+               st_acc[3] / n_mtiles, st_acc[0] / n_mtiles, st_acc[1] / n_mtiles, st_acc[2] / n_mtiles);
+#endif
     constexpr double LN2 = 0.693147180559945309417232121458;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/v
 build() { # name flags
-  (cd poccala_amd/csrc && for f in pcl_api gmm_score gmm_score_mfma gmm_score_split hmm_dp gmm_accumulate model_derive mfcc pcl_comm; do
+  (cd poccala_amd/csrc && for f in pcl_api gmm_score gmm_score_mfma gmm_score_split hmm_dp gmm_accumulate gmm_accumulate_split model_derive mfcc pcl_comm; do
      if [ $f = gmm_score_split ] || [ $f = gmm_score ] || [ ! -f ../../gpurun_out/v/$f.o ]; then hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $2 -c $f.hip -o ../../gpurun_out/v/$f.o 2>/dev/null; fi; done
    hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_out/v/lib_$1.so ../../gpurun_out/v/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib)
 }
