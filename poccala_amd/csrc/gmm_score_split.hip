@@ -355,12 +355,14 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
             float es[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) es[r] = __builtin_amdgcn_exp2f(acc[c][r]);
-            // plain v_add_f32 tree, pinned: under -O3 the compiler SLP-packs these into v_pk_add_f32, which costs far
-            // more than its issue slot beside MFMAs (in-kernel stamps: log-sum-exp phase 1830 -> 1230 cycles per m-tile)
+            // plain v_add_f32 tree: under -O3 the compiler SLP-packs such adds into v_pk_add_f32, which costs far more than
+            // its issue slot beside MFMAs (in-kernel stamps: log-sum-exp phase 1830 -> 1230 cycles per m-tile), so this
+            // file is built with -fno-slp-vectorize (Makefile).  (Pinning the adds with inline asm instead returned wrong
+            // sums: the hazard recogniser does not cover a transcendental result consumed inside an asm block.)
 #pragma unroll
             for (int w = 8; w >= 1; w >>= 1)
 #pragma unroll
-                for (int r = 0; r < w; ++r) asm volatile("v_add_f32 %0, %0, %1" : "+v"(es[r]) : "v"(es[r + w]));
+                for (int r = 0; r < w; ++r) es[r] += es[r + w];
             const float snew = sm[c] + es[0];
 #else
             f2v e[8];
