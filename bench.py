@@ -44,6 +44,10 @@ def parse():
     p.add_argument('--workload', default='C4shard', help='poccala_amd.synth.CONFIGS key')
     p.add_argument('--utts', type=int, default=0, help='override utterances per GPU')
     p.add_argument('--precision', default='f32', choices=['f32', 'f64'])
+    p.add_argument('--batches', type=int, default=2,
+                   help='resident utterance batches (each of the full per-GPU size) that successive steps alternate between, as a '
+                        'data loader would: the forward-backward of step k runs on the library\'s second stream beside the '
+                        'scoring of step k+1; 1 = every step re-scores the same batch and the two phases serialise')
     p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
     p.add_argument('--traffic-bytes', type=float, default=None,
@@ -183,18 +187,30 @@ def main():
         cfg['U'] = args.utts
     t_setup = time.perf_counter()
     mean, var, w, trans = synth.make_model(cfg['units'], cfg['M'], cfg['D'], seed=1)
-    frames, lens, begin = synth.make_frames(cfg['U'], cfg['T'], cfg['D'], seed=1000 * rank)      # each rank its own shard
-    labels = synth.make_labels(cfg['U'], cfg['L'], cfg['units'], seed=2 + 7919 * rank)
+    nb = max(1, args.batches)
+    frames, lens_all, begin_all = synth.make_frames(cfg['U'] * nb, cfg['T'], cfg['D'], seed=1000 * rank)      # each rank its own shard
+    labels_all = synth.make_labels(cfg['U'] * nb, cfg['L'], cfg['units'], seed=2 + 7919 * rank)
     eng.load_model(mean, var, w)
     eng.load_frames(frames)
-    batch, n_states = make_sentence_batch(eng, labels, lens, begin, trans)
+    batches = []
+    for k in range(nb):
+        lo, hi = cfg['U'] * k, cfg['U'] * (k + 1)
+        bt, ns = make_sentence_batch(eng, labels_all[lo:hi], lens_all[lo:hi], begin_all[lo:hi], trans)
+        batches.append(bt)
+        if k == 0:
+            n_states = ns
+    lens, begin, labels = lens_all[:cfg['U']], begin_all[:cfg['U']], labels_all[:cfg['U']]      # batch 0: accounting and the CPU leg
     if use_dist:
         eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
     t_setup = time.perf_counter() - t_setup
 
+    step_no = [0]
+
     def step():
-        batch.score(P)
-        batch.forward_backward(fix_pi=False)
+        bt = batches[step_no[0] % nb]
+        step_no[0] += 1
+        bt.score(P)                                   # main stream
+        bt.forward_backward(fix_pi=False)             # second stream: runs beside the next step's scoring
 
     for _ in range(args.warmup):
         step()
@@ -281,6 +297,7 @@ def main():
         # untimed-region extras: Viterbi forced alignment and the full E-step (accumulate + RCCL all-reduce)
         eng.sync()
         barrier()
+        batch = batches[0]
         t1 = time.perf_counter()
         batch.viterbi()
         eng.sync()
@@ -305,7 +322,7 @@ def main():
         eng.sync()
         t_mstep = time.perf_counter() - t1
         t1 = time.perf_counter()
-        eng.load_frames(frames)
+        eng.load_frames(frames[:frames_per_rank])
         t_h2d = time.perf_counter() - t1
         t1 = time.perf_counter()
         batch.get('logp'); batch.get('gamma'); batch.get('ksai_nz')
@@ -333,6 +350,9 @@ def main():
                                    % (args.workload, cfg['U'], cfg['T'], cfg['D'], cfg['M'], cfg['units'], cfg['units'] * 3, cfg['L'],
                                       3 * cfg['L'] + 2, 3 * cfg['L']),
                        'utterances_total': cfg['U'] * world, 'frames_per_step_total': total_frames,
+                       'resident_batches': nb,
+                       'pipeline': ('forward-backward of step k on a second HIP stream beside the scoring of step k+1 (steps alternate '
+                                    'between %d resident batches)' % nb) if nb > 1 else 'score and forward-backward of a step serialise (one resident batch)',
                        'arithmetic': 'f32 Gaussian scoring (two-piece f16 split products on the matrix pipe, f32 accumulate), f64 dynamic programming' if P == PCL_F32 else 'f64',
                        'device': info['name'], 'cus': info['cus']},
             'roofline': roofline,
@@ -344,7 +364,8 @@ def main():
             out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value'],
                                    'vs_blas_gemm_formulation': value / cpu['gemm_value']}
         print(json.dumps(out))
-    batch.close()
+    for bt in batches:
+        bt.close()
     if use_dist:
         eng._lib.pcl_comm_destroy(eng._ctx)
     ctl.close()

@@ -61,7 +61,8 @@ int pcl_init(int device, pcl_ctx **out) {
     if (device < 0 || device >= n) PCL_FAIL(nullptr, PCL_ERR_INVALID, "pcl_init: device %d out of range [0,%d)", device, n);
     pcl_ctx *ctx = new pcl_ctx();
     ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess) {
         g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
         delete ctx;
         return PCL_ERR_HIP;
@@ -71,6 +72,7 @@ int pcl_init(int device, pcl_ctx **out) {
     const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
     ctx->score_variant = var ? atoi(var) : 5;
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
+    if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
     *out = ctx;
     return PCL_OK;
 }
@@ -98,6 +100,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipSetDevice(ctx->device);
     pcl_comm_destroy(ctx);
     hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->stream_dp);
     for (auto &kv : ctx->timers)
         for (auto &p : kv.second.ev) {
             hipEventDestroy(p.first);
@@ -107,6 +110,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     dev_free(ctx->frames32);
     dev_free(ctx->frames64);
     hipStreamDestroy(ctx->stream);
+    hipStreamDestroy(ctx->stream_dp);
     delete ctx;
     return PCL_OK;
 }
@@ -116,6 +120,18 @@ const char *pcl_last_error(pcl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_ini
 int pcl_sync(pcl_ctx *ctx) {
     if (!ctx) return PCL_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
+    return PCL_OK;
+}
+
+// The dynamic-programming kernels of a batch run on a second, higher-priority stream (one wave per utterance, no
+// matrix work: they fit beside another batch's scoring).  Anything else that touches the batch on the main stream
+// first orders the main stream behind them.
+static int batch_join(pcl_batch *b) {
+    if (b->dp_pending) {
+        HIPCHK(b->ctx, hipStreamWaitEvent(b->ctx->stream, b->ev_dp, 0));
+        b->dp_pending = false;
+    }
     return PCL_OK;
 }
 
@@ -132,6 +148,7 @@ int pcl_device_info(pcl_ctx *ctx, char *name, int cap, int *cus, size_t *hbm_byt
 int pcl_kernel_time(pcl_ctx *ctx, const char *which, float *total_ms, int *launches) {
     if (!ctx || !which) return PCL_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
     float tot = 0.f;
     int n = 0;
     auto it = ctx->timers.find(which);
@@ -322,6 +339,9 @@ int pcl_batch_destroy(pcl_batch *b) {
     if (!b) return PCL_OK;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
+    hipStreamSynchronize(b->ctx->stream_dp);
+    if (b->ev_dp) hipEventDestroy(b->ev_dp);
+    if (b->ev_main) hipEventDestroy(b->ev_main);
     pcl_accumulate_release(b);
     dev_free(b->d_utt); dev_free(b->Bt); dev_free(b->alpha); dev_free(b->beta); dev_free(b->lgam);
     dev_free(b->logpi); dev_free(b->pi_out); dev_free(b->gamma_out); dev_free(b->ksai);
@@ -337,6 +357,7 @@ int pcl_batch_destroy(pcl_batch *b) {
 int pcl_batch_set_transitions(pcl_batch *b, const double *logA, const double *logpi) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (!logA || !logpi) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_transitions: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // sparse structure: an entry is stored unless ln A == -inf
@@ -410,6 +431,7 @@ int pcl_batch_set_transitions(pcl_batch *b, const double *logA, const double *lo
 int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (!row_state) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: NULL argument");
     if (ctx->J == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_set_states: upload a model first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -478,6 +500,7 @@ static int ensure_tmp(pcl_batch *b) {
 int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (!B) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_emissions: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(ensure_tmp(b));
@@ -493,6 +516,7 @@ int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
 int pcl_batch_set_posteriors(pcl_batch *b, const double *lgamma) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (!lgamma) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_posteriors: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(ensure_tmp(b));
@@ -569,6 +593,7 @@ static int build_tiles(pcl_batch *b, int precision) {
 int pcl_batch_score(pcl_batch *b, int precision) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_score: precision %d", precision);
     if (ctx->J == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: no model uploaded");
     if (ctx->F == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: no frames uploaded");
@@ -611,7 +636,23 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
         TRY(dev_alloc(ctx, &b->qtrace, (size_t)b->U * PCL_MAX_PASS));
         TRY(dev_alloc(ctx, &b->npass, (size_t)b->U));
     }
-    TRY(pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold));
+    if (ctx->dp_async) {
+        // stream_dp waits for everything queued on the main stream so far (the scoring of this batch), runs the
+        // recursion, and leaves an event for whoever touches the batch next
+        if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
+        if (!b->ev_main) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(b->ev_main, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream_dp;                      // the launcher and its timer use ctx->stream
+        const int rc = pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold);
+        ctx->stream = main_stream;
+        if (rc != PCL_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(b->ev_dp, ctx->stream_dp));
+        b->dp_pending = true;
+    } else {
+        TRY(pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold));
+    }
     b->have_fb = true;
     b->have_post = true;
     return PCL_OK;
@@ -620,6 +661,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
 int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no transitions set");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no emissions (score or set_emissions first)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -636,6 +678,7 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
 int pcl_batch_get(pcl_batch *b, int what, void *host) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (!host) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_get: NULL host buffer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double *mat = nullptr;
@@ -693,6 +736,7 @@ int pcl_stats_zero(pcl_ctx *ctx) {
 int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
     if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate: precision %d", precision);
     if (!b->have_post) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: run pcl_batch_forward_backward (or set_posteriors) first");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no emissions");

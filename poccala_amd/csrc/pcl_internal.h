@@ -68,6 +68,8 @@ struct pcl_ctx {
     unsigned short *pm16h = nullptr;  // split-f16 scoring layout: [J][Mpad32/32][2 pieces x KS8f + 1 constant chunk][64 lanes][8]
     float *fscale = nullptr;          // [J][2][KS8f*8] power-of-two feature scales of that layout
     int Mpad32 = 0;              // M rounded up to a multiple of 32
+    hipStream_t stream_dp = nullptr;   // forward-backward runs here, beside the next batch's scoring on `stream`
+    bool dp_async = true;              // env PCL_DP_STREAM=0: everything on one stream
     int score_variant = 0;       // 1 = VALU/LDS, 3 = f32-input MFMA, 4 = split-bf16 MFMA, 5 = split-f16 MFMA
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
     // the magnitude of the terms that cancel in it.  States above cond_max are scored / accumulated by the
@@ -123,6 +125,8 @@ struct pcl_batch {
     std::vector<int> work_states;
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
     std::vector<int> acc_ws, acc_lo, acc_hi; // accumulate's state order (well-conditioned first)
+    hipEvent_t ev_main = nullptr, ev_dp = nullptr;   // main stream -> stream_dp hand-over, and back
+    bool dp_pending = false;                 // forward-backward queued on stream_dp and not yet joined
     int *d_tile_flags = nullptr;             // split-f16 scoring: per tile, 1 = a scaled feature left the f16 range (rescored)
     ScoreTile *d_tiles_v = nullptr;          // MFMA mode only: tiles of ill-conditioned states for the VALU kernel
     int n_segs = 0, n_tiles = 0, n_tiles_v = 0, tile_frames = 0, tile_gen = -1;
