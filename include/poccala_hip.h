@@ -13,12 +13,15 @@
  *     across the ABI.
  *   - The caller owns every host buffer (C-contiguous NumPy arrays).  The library
  *     owns all device memory (inside pcl_ctx / pcl_batch).
- *   - One pcl_ctx = one GPU = one HIP stream.  Calls on a ctx are serialised by the
- *     caller (one process or thread per GPU).  Uploads, downloads (pcl_batch_get,
+ *   - One pcl_ctx = one GPU.  Calls on a ctx are serialised by the caller (one process or
+ *     thread per GPU).  Internally a ctx owns two HIP streams: pcl_batch_forward_backward
+ *     runs on the second one, ordered after everything queued before it, so that it
+ *     overlaps the scoring of ANOTHER batch queued after it; any later call on the same
+ *     batch, pcl_sync and every download wait for it (env PCL_DP_STREAM=0: one stream).  Uploads, downloads (pcl_batch_get,
  *     pcl_*_download) and pcl_stats_allreduce are synchronous at return.  The compute
  *     calls -- pcl_batch_score / _forward_backward / _viterbi / _accumulate,
- *     pcl_stats_zero, pcl_mstep -- are ASYNCHRONOUS: they enqueue kernels on the ctx
- *     stream in call order and return; pcl_sync() or any download completes them.
+ *     pcl_stats_zero, pcl_mstep -- are ASYNCHRONOUS: they enqueue kernels in call order
+ *     and return; pcl_sync() or any download completes them.
  *   - Host-side matrices use the REFERENCE layout: (N,T) row-major emission /
  *     alpha / beta matrices, float64, log domain, -inf for impossible.
  *   - log A and log pi are passed ALREADY LOGGED by the caller (np.log), because
