@@ -773,3 +773,48 @@ def test_score_variants_outlier_frames(eng_variant):
     got, ref = score_all_states(eng_variant, mean, var, w, x)
     assert np.isfinite(got).all()
     np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)
+
+
+# ------------------------------------------------------------------ two batches pipelined over the two streams
+def test_two_batches_pipelined_match_single_stream():
+    """forward-backward runs on the library's second stream beside the scoring of another batch; interleaving two
+    batches (and re-scoring one while its recursion may still be in flight) must give exactly what one stream gives."""
+    import os
+    from poccala_amd import Engine, PCL_F32
+    from poccala_amd.engine import make_sentence_batch
+    mean, var, w, trans, frames, lens, begin, labels = small_problem(77, units=6, M=40, D=39, U=24, T=80, L=4)
+    h = 12
+
+    def run(dp):
+        old = os.environ.get('PCL_DP_STREAM')
+        os.environ['PCL_DP_STREAM'] = dp
+        try:
+            e = Engine(0)
+        finally:
+            if old is None:
+                del os.environ['PCL_DP_STREAM']
+            else:
+                os.environ['PCL_DP_STREAM'] = old
+        e.load_model(mean, var, w)
+        e.load_frames(frames)
+        a, _ = make_sentence_batch(e, labels[:h], lens[:h], begin[:h], trans)
+        b, _ = make_sentence_batch(e, labels[h:], lens[h:], begin[h:], trans)
+        for _ in range(3):                               # A's recursion beside B's scoring, then A again on top of its own
+            a.score(PCL_F32); a.forward_backward(fix_pi=False)
+            b.score(PCL_F32); b.forward_backward(fix_pi=False)
+        e.stats_zero()
+        a.accumulate(PCL_F32); b.accumulate(PCL_F32)
+        out = dict(la=a.get('logp'), lb=b.get('logp'), ga=a.get('lgamma'), gb=b.get('lgamma'), ka=a.get('ksai'), st=e.stats_download())
+        a.close(); b.close(); e.close()
+        return out
+
+    two, one = run('1'), run('0')
+    np.testing.assert_array_equal(two['la'], one['la'])
+    np.testing.assert_array_equal(two['lb'], one['lb'])
+    for u in range(h):
+        np.testing.assert_array_equal(two['ga'][u], one['ga'][u])
+        np.testing.assert_array_equal(two['ka'][u], one['ka'][u])
+    for u in range(len(lens) - h):
+        np.testing.assert_array_equal(two['gb'][u], one['gb'][u])
+    for key in two['st']:
+        np.testing.assert_array_equal(two['st'][key], one['st'][key])
