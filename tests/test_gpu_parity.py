@@ -818,3 +818,55 @@ def test_two_batches_pipelined_match_single_stream():
         np.testing.assert_array_equal(two['gb'][u], one['gb'][u])
     for key in two['st']:
         np.testing.assert_array_equal(two['st'][key], one['st'][key])
+
+
+# ------------------------------------------------------------------ the headline configuration at full size
+def test_c4_shard_full_size_properties(eng):
+    """configs[3] per-GPU shard = the bench workload: 1024 utterances x 300 frames, 39-dim, 2048-mix, 1000 units x 3
+    states.  Too big for the oracle as a whole, so: size-independent properties of the E-step on a sample of
+    utterances, conservation of the statistics over the whole shard, and a spot check of one utterance's 60 x 300 x 2048
+    Gaussians and its Baum-Welch pass against the oracle."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.engine import make_sentence_batch
+    c = synth.CONFIGS['C4shard']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
+    labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    cond, cmax = eng.model_conditioning()
+    assert (cond <= cmax).all()                               # the whole bench model runs on the matrix pipe
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    b.forward_backward(fix_pi=True)
+    lg, al, be, B, lp = (b.get(k) for k in ('lgamma', 'alpha', 'beta', 'B', 'logp'))
+    for u in range(0, c['U'], 97):
+        np.testing.assert_allclose(po.lse(lg[u], axis=0), 0.0, atol=1e-9)
+        lhs = po.lse(al[u][:, -1])
+        rhs = po.lse(np.log(1.0 / n[u]) + B[u][:, 0] + be[u][:, 0])
+        np.testing.assert_allclose(lhs, rhs, rtol=1e-10)
+        np.testing.assert_allclose(lhs, lp[u], rtol=1e-12)
+    b.viterbi()
+    assert np.all(b.get('point') <= lp + 1e-9)
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    st = eng.stats_download()
+    np.testing.assert_allclose(st['acc'].sum(axis=1), st['alpha_acc'], rtol=1e-4)
+    total_gamma = sum(np.exp(lg[u][1:-1]).sum() for u in range(c['U']))
+    np.testing.assert_allclose(st['alpha_acc'].sum(), total_gamma, rtol=1e-6)
+    # first moments: sum_m mean_acc[j,m,:] = sum_t gamma_t(j) (o_t + 100) for the states of one utterance's label is not
+    # separable per utterance, but over ALL states it is: sum_jm mean_acc = sum_t (sum_j gamma_t(j)) (o_t + 100)
+    occ = np.zeros(frames.shape[0])
+    for u in range(c['U']):
+        occ[begin[u]:begin[u] + lens[u]] = np.exp(lg[u][1:-1]).sum(axis=0)
+    ref_first = (occ[:, None] * (frames.astype(np.float64) + 100.0)).sum(axis=0)
+    np.testing.assert_allclose(st['mean_acc'].sum(axis=(0, 1)), ref_first, rtol=2e-5)
+    # spot check against the oracle
+    model = {unit: dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)])
+             for unit in set(labels[5])}
+    x = frames[begin[5]:begin[5] + lens[5]].astype(np.float64)
+    _, a, bref, pi = po.score_label(x, list(labels[5]), model)
+    fin_close(B[5], bref, rtol=0, atol=F32_LOGLIK_ATOL)
+    bw = po.baum_welch(a, pi, [bref], fix_code=1)
+    np.testing.assert_allclose(lp[5], bw['logp'][0], rtol=F32_RTOL)
+    b.close()
