@@ -26,7 +26,10 @@ namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
-constexpr int AW = 8;        // waves (32-mixture tiles) per workgroup
+#ifndef PCL_ACCS_AW
+#define PCL_ACCS_AW 8
+#endif
+constexpr int AW = PCL_ACCS_AW;   // waves (32-mixture tiles) per workgroup
 #ifndef PCL_ACCS_P2_INTERLEAVE
 #define PCL_ACCS_P2_INTERLEAVE 1
 #endif
@@ -54,7 +57,8 @@ __device__ __forceinline__ void split3_bits(float x, unsigned short &p1, unsigne
 constexpr int BS = 65;
 
 template <int D>
-__global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
+__global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(   // 2 waves per SIMD: one workgroup of 8 waves or two of 4
+   
     const float *__restrict__ frames, const uint4 *__restrict__ pm16, const float *__restrict__ centers,
     const double *__restrict__ means64, int M, int Mpad, int n_mtiles, int n_states, const int *__restrict__ work_states,
     const int *__restrict__ seg_lo, const int *__restrict__ seg_hi, const long long *__restrict__ off,
@@ -71,12 +75,9 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
     const int nslice = (n_mtiles + AW - 1) / AW;
     const int b = blockIdx.x;
     int w, slice;
-    if (nslice == 8) {
-        w = (b & 7) + 8 * (b >> 6);
-        slice = (b >> 3) & 7;
-    } else {
-        w = b / nslice;
-        slice = b - w * nslice;
+    {   // block b runs on XCD b % 8: states are dealt to the XCDs in groups of 8, all slices of a state on one XCD
+        w = (b & 7) + 8 * (b / (8 * nslice));
+        slice = (b >> 3) % nslice;
     }
     if (w >= n_states) return;
     const int j = work_states[w];
@@ -133,27 +134,42 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
     // block costs ~105 instructions instead of 4 x 62 with per-element splits and two-byte writes (which made
     // staging 40 % of the kernel: all 8 waves issue it, and instruction issue, not the matrix pipe, set the time).
     // (A variant with one thread per 16-byte fragment group needs gathers across 8 frame rows and measured slower.)
-    constexpr int NDP = (D + 1) / 2, NITEM = 16 * NDP;
-    static_assert(NITEM <= AW * 64, "one 2x2 block per thread");
-    const int item_dp = threadIdx.x % NDP, item_fp = threadIdx.x / NDP;      // lanes run along d: coalesced row reads
-    const bool item_on = (int)threadIdx.x < NITEM;
-    const int d0 = 2 * item_dp;
-    const bool pair_ok = d0 + 1 < D;                                       // D odd: the last block has one dimension
+    constexpr int NDP = (D + 1) / 2, NITEM = 16 * NDP, NPT = (NITEM + AW * 64 - 1) / (AW * 64);   // blocks per thread
+    int item_fp[NPT], d0[NPT];
+    bool item_on[NPT], pair_ok[NPT];
+    float cen0[NPT], cen1[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int item = threadIdx.x + k * AW * 64;
+        item_on[k] = item < NITEM;
+        item_fp[k] = item / NDP;                                               // lanes run along d: coalesced row reads
+        d0[k] = 2 * (item % NDP);
+        pair_ok[k] = d0[k] + 1 < D;                                            // D odd: the last block has one dimension
+        cen0[k] = item_on[k] ? cen[d0[k]] : 0.f;
+        cen1[k] = (item_on[k] && pair_ok[k]) ? cen[d0[k] + 1] : 0.f;
+    }
     // three stages in flight: rows of tile i+1 (xv1, stored during tile i), rows of tile i+2 (xv2, loading during tile
     // i), list entries of tile i+3 (ix3): a dependent pair of loads (entry -> frame row) under load takes longer than one
-    // tile of MFMAs, and with one workgroup per CU nothing else covers it
-    float xv1[2][2], xv2[2][2];
-    int vm1 = 0, vm2 = 0;
-    int ix2[2] = {-1, -1}, ix3[2] = {-1, -1};
+    // tile of MFMAs
+    float xv1[NPT][2][2], xv2[NPT][2][2];
+    int vm1[NPT], vm2[NPT];
+    int ix2[NPT][2], ix3[NPT][2];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        vm1[k] = vm2[k] = 0;
+        ix2[k][0] = ix2[k][1] = ix3[k][0] = ix3[k][1] = -1;
+    }
     double cf1 = -INFINITY, cf2 = -INFINITY, cf3 = -INFINITY;     // ln gamma - ln b, raw (scaled and clamped when stored)
     double lg1 = -INFINITY, lg2 = -INFINITY, lg3 = -INFINITY;
-    auto load_index = [&](long long f0, int (&ix)[2], double &cf, double &lg) {
+    auto load_index = [&](long long f0, int (&ix)[NPT][2], double &cf, double &lg) {
         const int nf = (f0 < end) ? (int)min(32LL, end - f0) : 0;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int f = 2 * item_fp + a;
-            ix[a] = (item_on && f < nf) ? (int)list[f0 + f].frame : -1;
-        }
+        for (int k = 0; k < NPT; ++k)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int f = 2 * item_fp[k] + a;
+                ix[k][a] = (item_on[k] && f < nf) ? (int)list[f0 + f].frame : -1;
+            }
         cf = -INFINITY;                                    // padding frame: g = 0
         lg = -INFINITY;
         if ((int)threadIdx.x < nf) {
@@ -162,27 +178,31 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
             lg = a.lg;
         }
     };
-    const float cen0 = item_on ? cen[d0] : 0.f, cen1 = (item_on && pair_ok) ? cen[d0 + 1] : 0.f;
     // nothing here may consume a loaded value (no centring, no select on the data): the compiler would wait for the
     // load on the spot and the whole gather latency would sit at the top of every tile (measured with in-kernel
     // stamps: 2460 of 8200 cycles per tile).  Padding rows read frame 0 and are masked when they are stored.
-    auto load_rows = [&](const int (&ix)[2], float (&x)[2][2], int &vmask) {
-        vmask = 0;
+    auto load_rows = [&](const int (&ix)[NPT][2], float (&x)[NPT][2][2], int (&vmask)[NPT]) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const float *row = frames + (long long)max(ix[a], 0) * D + d0;
-            x[a][0] = row[0];
-            x[a][1] = row[pair_ok ? 1 : 0];
-            vmask |= (ix[a] >= 0) << a;
+        for (int k = 0; k < NPT; ++k) {
+            vmask[k] = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float *row = frames + (long long)max(ix[k][a], 0) * D + d0[k];
+                x[k][a][0] = row[0];
+                x[k][a][1] = row[pair_ok[k] ? 1 : 0];
+                vmask[k] |= (ix[k][a] >= 0) << a;
+            }
         }
     };
-    // one chunk = one side (x'^2 | x') of the block: 6 conversions, 12 four-byte LDS writes
-    auto store_chunk = [&](int buf, int side, const float (&xraw)[2][2], int vmask, bool force = false) {
+    // one chunk = one side (x'^2 | x') of one block: 6 conversions, 12 four-byte LDS writes
+    auto store_chunk = [&](int buf, int chunk, const float (&xall)[NPT][2][2], const int (&vmall)[NPT], bool force = false) {
 #ifdef PCL_ACCS_DIAG_NOSTORE
         if (!force) return;                               // diagnostic: only the prologue stages (both buffers), timing only
 #endif
-        {
-        if (!item_on) return;
+        const int k = chunk >> 1, side = chunk & 1;
+        if (!item_on[k]) return;
+        const float (&xraw)[2][2] = xall[k];
+        const int vmask = vmall[k];
         unsigned int *w1 = reinterpret_cast<unsigned int *>(&xe[buf][0]);
         unsigned int *w2 = w1 + (size_t)L1 * 4;
         typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const bool ok = (vmask >> a) & 1;
-            const float x0 = ok ? xraw[a][0] - cen0 : 0.f, x1 = (ok && pair_ok) ? xraw[a][1] - cen1 : 0.f;
+            const float x0 = ok ? xraw[a][0] - cen0[k] : 0.f, x1 = (ok && pair_ok[k]) ? xraw[a][1] - cen1[k] : 0.f;
             float r0 = side ? x0 : x0 * x0, r1 = side ? x1 : x1 * x1;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -201,23 +221,23 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
                 r1 -= __uint_as_float(u & 0xffff0000u);
             }
         }
-        const int s = d0 >> 3, jd = d0 & 7;
+        const int s = d0[k] >> 3, jd = d0[k] & 7;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int f = 2 * item_fp + a;
+            const int f = 2 * item_fp[k] + a;
             const int o = ((0 * KS8 + s) * BS + side * 32 + f) * 4 + (jd >> 1);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                if (pair_ok) w1[o + p * (KS8 * BS * 4)] = P[p][a];
+                if (pair_ok[k]) w1[o + p * (KS8 * BS * 4)] = P[p][a];
                 else reinterpret_cast<unsigned short *>(w1)[2 * (o + p * (KS8 * BS * 4))] = (unsigned short)P[p][a];   // slot d = D is not ours
             }
         }
         // feature-major: dword = the same piece of frames (2 fp, 2 fp + 1) for one column
-        const int f0 = 2 * item_fp, sp = f0 >> 4, fq = f0 & 15, hh = (fq >> 2) & 1, jj = ((fq >> 3) << 2) | (fq & 3);
+        const int f0 = 2 * item_fp[k], sp = f0 >> 4, fq = f0 & 15, hh = (fq >> 2) & 1, jj = ((fq >> 3) << 2) | (fq & 3);
 #pragma unroll
         for (int bdim = 0; bdim < 2; ++bdim) {
-            if (bdim == 1 && !pair_ok) break;
-            const int c2 = 2 * (d0 + bdim) + side, ct = c2 >> 5, c = c2 & 31;
+            if (bdim == 1 && !pair_ok[k]) break;
+            const int c2 = 2 * (d0[k] + bdim) + side, ct = c2 >> 5, c = c2 & 31;
             const int o = (((0 * NCT + ct) * 2 + sp) * BS + hh * 32 + c) * 4 + (jj >> 1);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -225,7 +245,6 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
                                             : __builtin_amdgcn_perm(P[p][1], P[p][0], 0x05040100u);     // lo halves
                 w2[o + p * (NCT * 2 * BS * 4)] = q;
             }
-        }
         }
     };
     auto store_cf = [&](int buf, double cfv, double lgv) {
@@ -245,12 +264,12 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
     __syncthreads();
     load_index(beg, ix2, cf2, lg2);
     load_rows(ix2, xv1, vm1);
-    store_chunk(0, 0, xv1, vm1, true);
-    store_chunk(0, 1, xv1, vm1, true);
+#pragma unroll
+    for (int ch = 0; ch < 2 * NPT; ++ch) store_chunk(0, ch, xv1, vm1, true);
     store_cf(0, cf2, lg2);
 #ifdef PCL_ACCS_DIAG_NOSTORE
-    store_chunk(1, 0, xv1, vm1, true);
-    store_chunk(1, 1, xv1, vm1, true);
+#pragma unroll
+    for (int ch = 0; ch < 2 * NPT; ++ch) store_chunk(1, ch, xv1, vm1, true);
 #endif
     load_index(beg + 32, ix2, cf1, lg1);
     load_rows(ix2, xv1, vm1);                            // tile 1
@@ -266,8 +285,9 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
 #else
 #define STAMP(k)
 #endif
-    auto tile_step = [&](long long f0, int buf, const float (&xs)[2][2], int vms, double cfs, double lgs, float (&xl)[2][2],
-                         int &vml, const int (&ixs)[2], int (&ixl)[2], double &cfl, double &lgl) {
+    auto tile_step = [&](long long f0, int buf, const float (&xs)[NPT][2][2], const int (&vms)[NPT], double cfs, double lgs,
+                         float (&xl)[NPT][2][2], int (&vml)[NPT], const int (&ixs)[NPT][2], int (&ixl)[NPT][2], double &cfl,
+                         double &lgl) {
         const bool more = f0 + 32 < end;
 #ifdef PCL_ACCS_STAMPS
         unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
         int chunk = 0;
         auto emit = [&](int upto) {
             __builtin_amdgcn_sched_barrier(0);
-            for (; chunk < upto && chunk < 2; ++chunk)
+            for (; chunk < upto * NPT && chunk < 2 * NPT; ++chunk)
                 if (more) store_chunk(buf ^ 1, chunk, xs, vms);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -448,7 +468,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(
 int pcl_launch_accumulate_split(pcl_ctx *ctx, pcl_batch *b, int ns) {
     if (ns == 0) return PCL_OK;
     const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW;
-    const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
+    const int nblocks = ((ns + 7) / 8) * 8 * nslice;
 #define LAUNCH_SPLIT(DD)                                                                                                  \
     hipLaunchKernelGGL((gmm_accumulate_split_kernel<DD>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32,   \
                        reinterpret_cast<const uint4 *>(ctx->pm16), ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, \
