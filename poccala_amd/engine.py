@@ -143,8 +143,23 @@ class Engine(object):
         return buf.tobytes()
 
     def comm_init(self, rank, nranks, unique_id):
+        """ncclCommInitRank.  RCCL prints a version banner with C stdio on stdout; a caller that owes its parent
+        exactly one line of stdout (bench.py) would see it arrive AFTER its own output when libc flushes at exit, so
+        file descriptor 1 points at stderr while the communicator is created."""
+        import ctypes, os, sys
         buf = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
-        self._check(self._lib.pcl_comm_init(self._ctx, int(rank), int(nranks), ptr(buf)))
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        libc.fflush(None)
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = self._lib.pcl_comm_init(self._ctx, int(rank), int(nranks), ptr(buf))
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        self._check(rc)
 
     def stats_allreduce(self):
         self._check(self._lib.pcl_stats_allreduce(self._ctx))
