@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
                                                      uint4 *__restrict__ pm16, uint4 *__restrict__ pm16h,
-                                                     const float *__restrict__ fscale, float *__restrict__ cond) {
+                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
@@ -93,29 +93,35 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         kqs[tid] = LOG2E * kq;
         // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats order
         // like their bit patterns, so an integer atomicMax works)
-        if (m < M) atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
+        if (m < M && (what & PCL_LAYOUT_COND)) atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
     }
     __syncthreads();
     // VALU scoring rows [s_d c_d ... k2 pad] and the f32 means (only mixtures inside the Mpad grid)
+    const bool w32 = what & PCL_LAYOUT_P32, wr64 = what & PCL_LAYOUT_P64;
+    if (w32 || wr64)
     for (int e = tid; e < 32 * D; e += 256) {
         const int ml = e / D, d = e - ml * D, m = m0 + ml;
         if (m >= Mpad) continue;
         const bool ok = m < M && d < Dhost;
         const double s = ok ? sqrt(LOG2E / (2.0 * vr[e])) : 0.0, c = ok ? -mu[e] * s : 0.0;
         const size_t o = ((size_t)j * Mpad + m) * row + 2 * d;
-        *reinterpret_cast<double2 *>(params64 + o) = make_double2(s, c);
-        *reinterpret_cast<float2 *>(params32 + o) = make_float2((float)s, (float)c);
-        mean32[((size_t)j * Mpad + m) * D + d] = ok ? (float)mu[e] : 0.f;
+        if (wr64) *reinterpret_cast<double2 *>(params64 + o) = make_double2(s, c);
+        if (w32) {
+            *reinterpret_cast<float2 *>(params32 + o) = make_float2((float)s, (float)c);
+            mean32[((size_t)j * Mpad + m) * D + d] = ok ? (float)mu[e] : 0.f;
+        }
     }
+    if (w32 || wr64)
     for (int e = tid; e < 32 * (row - 2 * D); e += 256) {
         const int ml = e / (row - 2 * D), k = 2 * D + e % (row - 2 * D), m = m0 + ml;
         if (m >= Mpad) continue;
         const double v = (k == 2 * D) ? k2s[ml] : 0.0;
-        params64[((size_t)j * Mpad + m) * row + k] = v;
-        params32[((size_t)j * Mpad + m) * row + k] = (float)v;
+        if (wr64) params64[((size_t)j * Mpad + m) * row + k] = v;
+        if (w32) params32[((size_t)j * Mpad + m) * row + k] = (float)v;
     }
     // MFMA layout [KS4][64 lanes][4]: lane = half * 32 + mixture, element = k-step 4q + e
     float4 *pt = reinterpret_cast<float4 *>(pm32) + ((size_t)j * nmt + mt) * (KS4 * 64);
+    if (what & PCL_LAYOUT_PM32)
     for (int e = tid; e < KS4 * 64; e += 256) {
         const int q = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
         const bool real_m = (m0 + cl) < M;
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     // the exact sum of three bf16 pieces; lane = half * 32 + mixture, element j = feature 8s + j
     const int KS8 = (D + 8) / 8;
     uint4 *pq = pm16 + ((size_t)j * nmt + mt) * (3 * KS8 * 64);
+    if (what & PCL_LAYOUT_PM16)
     for (int e = tid; e < 3 * KS8 * 64; e += 256) {
         const int p = e / (KS8 * 64), s = (e >> 6) % KS8, ln = e & 63, half = ln >> 5, cl = ln & 31;
         const bool real_m = (m0 + cl) < M;
@@ -177,6 +184,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     // coefficients scaled by 2^-e (fscale holds 2^e), lanes 0-31 of the constant chunk carry k'1 k'2 k'3 1 1 1 0 0
     const int KS8f = (D + 7) / 8, CHf = 2 * KS8f + 1;
     uint4 *ph = pm16h + ((size_t)j * nmt + mt) * (CHf * 64);
+    if (what & PCL_LAYOUT_PM16H)
     for (int e = tid; e < CHf * 64; e += 256) {
         const int chunk = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
         const bool real_m = (m0 + cl) < M;
@@ -266,23 +274,50 @@ int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64
     return PCL_OK;
 }
 
+// layouts every launch of the active scoring variant reads; the others (f64 parity mode) are derived on first use
+static int eager_layouts(const pcl_ctx *ctx) {
+    int what = PCL_LAYOUT_P32 | PCL_LAYOUT_COND;              // direct-form f32 kernels: fix-up, ill-conditioned states, variant 1
+    if (ctx->score_variant == 3) what |= PCL_LAYOUT_PM32;
+    if (ctx->score_variant >= 4) what |= PCL_LAYOUT_PM16;     // variant 4 scoring and the split accumulate kernel
+    if (ctx->score_variant == 5) what |= PCL_LAYOUT_PM16H;
+    return what;
+}
+
+static int launch_derive_kernel(pcl_ctx *ctx, int what) {
+    const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)ctx->D * sizeof(float);
+    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
+                       ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
+                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
+                       reinterpret_cast<uint4 *>(ctx->pm16h), ctx->fscale, ctx->d_cond, what);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
 int pcl_launch_derive(pcl_ctx *ctx) {
     hipLaunchKernelGGL(centers_kernel, dim3(ctx->J), dim3(64), 0, ctx->stream, ctx->mean64, ctx->M, ctx->Mpad, ctx->D, ctx->centers32);
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(fscale_kernel, dim3(ctx->J), dim3(128), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->centers32, ctx->M, ctx->Mpad,
                        ctx->D, ctx->Dhost, KS8f, ctx->fscale);
-    const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)ctx->D * sizeof(float);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
-                       ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
-                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
-                       reinterpret_cast<uint4 *>(ctx->pm16h), ctx->fscale, ctx->d_cond);
-    HIPCHK(ctx, hipGetLastError());
+    const int what = eager_layouts(ctx);
+    const int rc = launch_derive_kernel(ctx, what);
+    if (rc != PCL_OK) return rc;
+    ctx->layouts_valid = what;
     // the per-state conditioning decides which kernel scores a state: bring it to the host (J floats)
     ctx->cond.resize(ctx->J);
     HIPCHK(ctx, hipMemcpyAsync(ctx->cond.data(), ctx->d_cond, (size_t)ctx->J * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ++ctx->model_gen;
+    return PCL_OK;
+}
+
+// derive whatever of `need` the current model does not have yet (same master copy, same centres: no new generation)
+int pcl_ensure_layouts(pcl_ctx *ctx, int need) {
+    const int missing = need & ~ctx->layouts_valid;
+    if (!missing) return PCL_OK;
+    const int rc = launch_derive_kernel(ctx, missing);
+    if (rc != PCL_OK) return rc;
+    ctx->layouts_valid |= missing;
     return PCL_OK;
 }
 

@@ -601,7 +601,10 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     if (ctx->FDhost != ctx->Dhost)  // DataDimensionError, Clustering.py:749-751
         PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (precision == PCL_F64) TRY(ensure_frames64(ctx));
+    if (precision == PCL_F64) {
+        TRY(ensure_frames64(ctx));
+        TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P64));
+    }
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
     if (precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D)) {
@@ -742,7 +745,10 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no emissions");
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (precision == PCL_F64) TRY(ensure_frames64(ctx));
+    if (precision == PCL_F64) {
+        TRY(ensure_frames64(ctx));
+        TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P64));
+    }
     return pcl_launch_accumulate(ctx, b, precision);
 }
 
