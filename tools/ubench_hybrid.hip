@@ -6,6 +6,10 @@
 #include <stdio.h>
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+#ifndef MFMA_BF16
+#define MFMA_BF16 0
+#endif
 
 template <int VMODE>   // 0: v_fma_f32, 1: v_pk_fma_f32, 2: v_fma_f32 with one exp per 39 fma
 __global__ __launch_bounds__(512) void k(float *out, unsigned long long *cyc, float a, float b, int iters_m, int iters_v) {
@@ -15,10 +19,19 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *cyc, fl
     if (wave < 4) {
         f16v acc = {0};
         float av = a + threadIdx.x * 1e-6f, bv = b;
+#if MFMA_BF16
+        bf8v a8, b8;
+        for (int j = 0; j < 8; ++j) { a8[j] = (__bf16)(av + j); b8[j] = (__bf16)(bv * (j + 1)); }
+        for (int it = 0; it < iters_m; ++it) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);   // 16 x 32 cyc = the same 512 cyc
+        }
+#else
         for (int it = 0; it < iters_m; ++it) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
+#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += acc[i];
     } else {
@@ -70,7 +83,7 @@ void run(const char *name, int iters_m, int iters_v, float *out, unsigned long l
     (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     double cm = 0, cv = 0;
     for (int b = 0; b < nb; ++b) for (int w = 0; w < 8; ++w) (w < 4 ? cm : cv) += (double)h[b * 8 + w] / (nb * 4);
-    const double fm = (double)nb * 4 * iters_m * 8 * (2.0 * 32 * 32 * 2);
+    const double fm = (double)nb * 4 * iters_m * (MFMA_BF16 ? 16 * (2.0 * 32 * 32 * 16) : 8 * (2.0 * 32 * 32 * 2));
     const double fv = (double)nb * 4 * iters_v * (VMODE == 1 ? 16 * 128 * 2.0 : 32 * 64 * 2.0);
     printf("%-34s %8.3f ms  MFMA %6.1f TF  VALU %6.1f TF  sum %6.1f | memtime ticks/wave: mfma %.0f valu %.0f\n", name, ms,
            fm / (ms * 1e-3) / 1e12, fv / (ms * 1e-3) / 1e12, (fm + fv) / (ms * 1e-3) / 1e12, cm, cv);
