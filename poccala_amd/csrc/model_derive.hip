@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
     double *mu = sh, *vr = sh + 32 * D, *k2s = vr + 32 * D, *kqs = k2s + 32;
     float *cen = reinterpret_cast<float *>(kqs + 32);
+    float *fa = cen + D, *fb = fa + 32 * D;       // the f32 coefficients of the expansion: a = -log2e/(2 var), b = log2e (mu - c)/var
     const int tid = threadIdx.x;
     for (int e = tid; e < 32 * D; e += 256) {
         const int m = m0 + e / D;
@@ -74,26 +75,45 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     }
     for (int d = tid; d < D; d += 256) cen[d] = centers[(size_t)j * D + d];
     __syncthreads();
-    if (tid < 32) {
-        const int m = m0 + tid;
+    {
+        // 8 lanes per mixture: per-dimension terms, then a 3-step shuffle reduction
+        const int ml = tid >> 3, sub = tid & 7, m = m0 + ml;
+        const bool real_m = m < M;
         double sumvar = 0.0, sumlog = 0.0, kq = 0.0;
-        for (int d = 0; d < Dhost; ++d) {
-            const double v = vr[tid * D + d], dm = mu[tid * D + d] - (double)cen[d];
-            sumvar += v;
-            sumlog += log(v);
-            kq += dm * dm / (2.0 * v);
+        for (int dd = sub; dd < D; dd += 8) {
+            float a = 0.f, b = 0.f;
+            if (dd < Dhost) {
+                const double v = vr[ml * D + dd], dm = mu[ml * D + dd] - (double)cen[dd];
+                sumvar += v;
+                if (flags & PCL_MODEL_LOGDET) sumlog += log(v);
+                kq += dm * dm / (2.0 * v);
+                if (real_m) {
+                    a = (float)(-LOG2E / (2.0 * v));
+                    b = (float)(LOG2E * dm / v);
+                }
+            }
+            fa[ml * D + dd] = a;
+            fb[ml * D + dd] = b;
         }
-        double k2 = -INFINITY;
-        if (m < M) {
-            // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var); textbook log-determinant only on request
-            const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
-            k2 = LOG2E * (log(w64[(size_t)j * Mpad + m]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            sumvar += __shfl_xor(sumvar, o, 64);
+            sumlog += __shfl_xor(sumlog, o, 64);
+            kq += __shfl_xor(kq, o, 64);
         }
-        k2s[tid] = k2;
-        kqs[tid] = LOG2E * kq;
-        // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats order
-        // like their bit patterns, so an integer atomicMax works)
-        if (m < M && (what & PCL_LAYOUT_COND)) atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
+        if (sub == 0) {
+            double k2 = -INFINITY;
+            if (real_m) {
+                // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var); textbook log-determinant only on request
+                const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
+                k2 = LOG2E * (log(w64[(size_t)j * Mpad + m]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
+            }
+            k2s[ml] = k2;
+            kqs[ml] = LOG2E * kq;
+            // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats
+            // order like their bit patterns, so an integer atomicMax works)
+            if (real_m && (what & PCL_LAYOUT_COND)) atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
+        }
     }
     __syncthreads();
     // VALU scoring rows [s_d c_d ... k2 pad] and the f32 means (only mixtures inside the Mpad grid)
@@ -131,10 +151,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             const int s = 4 * q + x;
             float val = 0.f;
             if (s < D) {
-                if (real_m && s < Dhost) {
-                    const double var = vr[cl * D + s], dm = mu[cl * D + s] - (double)cen[s];
-                    val = half ? (float)(LOG2E * dm / var) : (float)(-LOG2E / (2.0 * var));
-                }
+                val = half ? fb[cl * D + s] : fa[cl * D + s];
             } else if (s == D) {
                 // the constant pair: k' on the low half-wave, 1 in the spare slot (multiplied by 0 in plain
                 // scoring, by -ref / cf in the kernels that use the slot)
@@ -149,36 +166,35 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     const int KS8 = (D + 8) / 8;
     uint4 *pq = pm16 + ((size_t)j * nmt + mt) * (3 * KS8 * 64);
     if (what & PCL_LAYOUT_PM16)
-    for (int e = tid; e < 3 * KS8 * 64; e += 256) {
-        const int p = e / (KS8 * 64), s = (e >> 6) % KS8, ln = e & 63, half = ln >> 5, cl = ln & 31;
+    for (int e = tid; e < KS8 * 64; e += 256) {           // one thread per (k-step, lane): all three pieces of its 8 values
+        const int s = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
         const bool real_m = (m0 + cl) < M;
-        unsigned short h[8];
+        unsigned short h[3][8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const int dd = 8 * s + x;
             float val = 0.f;
             if (dd < D) {
-                if (real_m && dd < Dhost) {
-                    const double var = vr[cl * D + dd], dm = mu[cl * D + dd] - (double)cen[dd];
-                    val = half ? (float)(LOG2E * dm / var) : (float)(-LOG2E / (2.0 * var));
-                }
+                val = half ? fb[cl * D + dd] : fa[cl * D + dd];
             } else if (dd == D) {
                 val = half ? 1.f : (real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY);
                 if (!(val > -1.0e37f)) val = -3.0e38f;      // "log zero" stays finite: its pieces meet zeros of the other operand
             }
-            // piece p of the round-to-nearest-even three-way split
+            // round-to-nearest-even three-way split
             float r = val;
-            unsigned short piece = 0;
-            for (int q = 0; q <= p; ++q) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
                 unsigned int u = __float_as_uint(r);
                 u += 0x7fffu + ((u >> 16) & 1u);
-                piece = (unsigned short)(u >> 16);
-                r -= __uint_as_float((unsigned int)piece << 16);
+                h[p][x] = (unsigned short)(u >> 16);
+                r -= __uint_as_float((unsigned int)h[p][x] << 16);
             }
-            if (val < -1.0e37f && p > 0) piece = 0;
-            h[x] = piece;
+            if (val < -1.0e37f) h[1][x] = h[2][x] = 0;
         }
-        pq[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            pq[(p * KS8 + s) * 64 + ln] = make_uint4(h[p][0] | ((unsigned)h[p][1] << 16), h[p][2] | ((unsigned)h[p][3] << 16),
+                                                     h[p][4] | ((unsigned)h[p][5] << 16), h[p][6] | ((unsigned)h[p][7] << 16));
     }
     // split-f16 layout [piece 2][KS8f][64 lanes][8 f16] + one bf16 constant chunk [64 lanes][8]:
     // coefficients scaled by 2^-e (fscale holds 2^e), lanes 0-31 of the constant chunk carry k'1 k'2 k'3 1 1 1 0 0
@@ -195,11 +211,8 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             for (int x = 0; x < 8; ++x) {
                 const int dd = 8 * s + x;
                 float val = 0.f;
-                if (dd < D && real_m && dd < Dhost) {
-                    const double var = vr[cl * D + dd], dm = mu[cl * D + dd] - (double)cen[dd];
-                    const double coef = half ? LOG2E * dm / var : -LOG2E / (2.0 * var);
-                    val = (float)(coef / (double)fscale[((size_t)j * 2 + half) * (KS8f * 8) + dd]);
-                }
+                if (dd < D)      // power-of-two scaling commutes with the f32 rounding of the coefficient
+                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) / fscale[((size_t)j * 2 + half) * (KS8f * 8) + dd];
                 const _Float16 h1 = (_Float16)val;
                 const _Float16 hp = p ? (_Float16)(val - (float)h1) : h1;
                 h[x] = __builtin_bit_cast(unsigned short, hp);
@@ -284,7 +297,7 @@ static int eager_layouts(const pcl_ctx *ctx) {
 }
 
 static int launch_derive_kernel(pcl_ctx *ctx, int what) {
-    const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)ctx->D * sizeof(float);
+    const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)(ctx->D + 2 * 32 * ctx->D) * sizeof(float);
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
