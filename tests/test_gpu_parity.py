@@ -900,3 +900,54 @@ def test_score_fuzz_default_variant(eng, seed):
     fin = np.isfinite(ref)
     # the float32 input rounding of offset data is part of both sides' inputs; the tolerance covers the f32 evaluation
     np.testing.assert_allclose(got[fin], ref[fin], rtol=5e-6, atol=2e-3 if np.abs(offset / scale).max() > 5 else F32_LOGLIK_ATOL)
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_estep_fuzz_default_variant(eng, seed):
+    """E-step statistics of random small problems (peaked posteriors: frames sampled from the label's states, so
+    many (frame, mixture) posteriors are tiny and some mixtures are almost never responsible) against the oracle."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.engine import make_sentence_batch
+    rng = np.random.default_rng(500 + seed)
+    D = int(rng.choice([13, 26, 39]))
+    units, M, U, L, PER = int(rng.integers(2, 6)), int(rng.integers(2, 70)), int(rng.integers(2, 7)), int(rng.integers(1, 4)), int(rng.integers(2, 6))
+    mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
+    mean = mean * 2.0                                            # well separated mixtures: peaked mixture posteriors
+    labels = [list(rng.integers(0, units, L)) for _ in range(U)]
+    TU = L * (S - 2) * PER
+    lens = np.full(U, TU, dtype=np.int64)
+    begin = np.arange(U, dtype=np.int64) * TU
+    st = np.concatenate([np.repeat([unit * (S - 2) + k for unit in lab for k in range(S - 2)], PER) for lab in labels])
+    comp = rng.integers(0, M, len(st))
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((len(st), D))).astype(np.float32)
+    eng.load_model(mean, var, w)
+    eng.load_frames(x)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    b.forward_backward(fix_pi=False)
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    stt = eng.stats_download()
+    model = oracle_model(mean, var, w, trans)
+    J = mean.shape[0]
+    refs = dict(acc=np.zeros((J, M)), alpha_acc=np.zeros(J), mean_acc=np.zeros((J, M, D)), cov_acc=np.zeros((J, M, D)))
+    lp = b.get('logp')
+    for u, lab in enumerate(labels):
+        xx = x[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        bw, accs, _ = po.estep_utterance(xx, list(lab), model)
+        np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=F32_RTOL)
+        for pos, unit in enumerate(lab):
+            for k in range(S - 2):
+                jj = unit * (S - 2) + k
+                a = accs[pos].gmm[k]
+                for key in refs:
+                    refs[key][jj] += np.exp(a[key])
+    for key in refs:
+        scale = np.abs(refs[key]).max()
+        np.testing.assert_allclose(stt[key], refs[key], rtol=2 * F32_RTOL, atol=scale * 1e-6, err_msg=key)
+    # mixtures with a meaningful occupancy: their re-estimated means must agree to 1e-4 of a standard deviation scale
+    occ = refs['acc'] > 1e-3
+    mu_ref = refs['mean_acc'][occ] / refs['acc'][occ][:, None] - 100.0
+    mu_got = stt['mean_acc'][occ] / stt['acc'][occ][:, None] - 100.0
+    np.testing.assert_allclose(mu_got, mu_ref, rtol=0, atol=2e-4)
+    b.close()
