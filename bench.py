@@ -263,6 +263,7 @@ def main():
             'executed_mfma_tflops.  On random operands the chip holds ~1.84 GHz under this kernel (2.4 GHz spec), '
             'matrix pipe 60 % busy (profiles/)'),
     }
+    KERNELS[6] = ('gmm_score_split16x_kernel<39>', BF16_MFMA_PEAK_TFLOPS / 3, KERNELS[5][2] + ' (16x16x32 MFMA shape, constants in f16 on one K axis of 256)')
     score_kernel_name, score_peak, score_note = KERNELS.get(score_variant, KERNELS[1])
     pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
     flop_per_launch = pairs * cfg['M'] * (3 * cfg['D'] + 4)
@@ -285,7 +286,7 @@ def main():
                     kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
-                    executed_mfma_tflops=(pairs * cfg['M'] * {4: 960, 5: 512}[score_variant] / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant in (4, 5) else None,
+                    executed_mfma_tflops=(pairs * cfg['M'] * {4: 960, 5: 512, 6: 512}[score_variant] / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant in (4, 5, 6) else None,
                     frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
                     note=score_note,
                     hbm_algorithmic_bytes_per_launch=alg_bytes,

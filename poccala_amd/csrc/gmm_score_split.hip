@@ -349,6 +349,7 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
         for (int c = 0; c < NT; ++c) sm[c] += acc[c][0] + acc[c][15];
         return;
 #endif
+#ifndef PCL_SPLIT16_ONE_CHECK      // one wave-uniform slow-path test for both column tiles measured no faster (17.27 vs 17.20 ms)
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
 #ifndef PCL_SPLIT_PKADD
@@ -398,6 +399,53 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                 sm[c] = snew;
             }
         }
+#else
+        // fast path for both column tiles first, ONE wave-uniform test for the slow path
+        float snew[NT];
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            float es[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) es[r] = __builtin_amdgcn_exp2f(acc[c][r]);
+            // plain v_add_f32 tree: this file is built with -fno-slp-vectorize (Makefile), see the note further up
+#pragma unroll
+            for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                for (int r = 0; r < w; ++r) es[r] += es[r + w];
+            snew[c] = sm[c] + es[0];
+            bad |= !(snew[c] < 3.0e38f);
+        }
+        if (mt != 0 && !__any(bad)) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) sm[c] = snew[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                float gm = acc[c][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
+                const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));
+                float s = sm[c];
+                if ((mt == 0 || gp > 0.f) && gp > -1.0e37f) {
+                    s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] -= gp;
+                    ref[c] += gp;
+                    __bf16 p1, p2, p3;
+                    split3(-ref[c], p1, p2, p3);
+                    if (half == 0) {
+                        xc8[c][3] = p1;
+                        xc8[c][4] = p2;
+                        xc8[c][5] = p3;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
+                sm[c] = s;
+            }
+        }
+#endif
         SSTAMP(2)
     };
     const int n_stages = (n_mtiles + MTS - 1) / MTS;
@@ -430,6 +478,214 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same two-way f16 split on v_mfma_f32_16x16x32_f16 (variant 6).  Under this kernel the chip is power limited
+// (1.7-1.8 GHz, matrix pipe ~65 % busy), and on random operands the 16x16x32 shape delivers ~1.14 x the FLOP/s of
+// 32x32x16 at equal cycles (tools/ubench_shape.hip: 1520 vs 1330 TFLOP/s with this kernel's LDS re-reads and
+// exponentials; 1965 vs 1900 on all-zero operands: it is the clock, not the cycles).  To keep the cycles equal the three
+// passes and the constants share ONE K axis, [a2 x1 | a1 x2 | a1 x1 | constants | 0] = 3 x 80 + 8 -> 256 for D = 39
+// (eight K-steps of 32 per 16 x 16 tile, 64 MFMAs of 16 cycles per 32 mixtures x 64 frames: the 1024 cycles of the
+// 32x32x16 kernel), which means the constants ride in f16 as well: k'_m, -ref_f in three f16 pieces each (33 bits), log
+// zero = -6e4, and a state whose real k' exceeds 5e4 (model_derive.hip) or a frame whose reference drops below -5e4
+// (flag + fix-up) leaves this kernel like an out-of-range feature does.
+// Lane l = 16 g + r: A fragment = mixture r, K block 4 s + g; B fragment = frame r, same block; accumulator register
+// q = mixture 4 g + q of frame r: a lane owns 8 of a frame's 32 mixtures per m-tile, the four lane groups are merged
+// at the end (and in the slow path that raises ref).
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(WG, 2) void gmm_score_split16x_kernel(
+    const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
+    int n_mtiles, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
+    int *__restrict__ flags) {
+    constexpr int SEG8 = (2 * D + 7) / 8;              // 8-element blocks per pass segment
+    constexpr int CT = 3 * SEG8;                       // the constants block
+    constexpr int NKS = (CT + 1 + 3) / 4;              // K-steps of 32
+    constexpr int SCT = CT / 4, GCT = CT % 4;          // K-step and lane group that hold the constants block
+    constexpr int KS8f = (D + 7) / 8;                  // fscale row stride / 8
+    constexpr int NC = 4;                              // frame sub-tiles (16 frames) per wave
+    constexpr int XS = D + 1;                          // LDS row stride of the staged frames
+    constexpr float FMAXH = 6.0e4f;
+    static_assert(WG == 256, "4 waves x 64 frames");
+    const ScoreTile tile = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
+    if (tile.seg_lo >= tile.seg_hi) {                  // padding tile of the XCD-aware order
+        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+        return;
+    }
+    __shared__ int s_ovf;
+    __shared__ float xs[4][64 * XS];                   // centred frames of each wave
+    __shared__ long long oidx_s[4][64];
+    __shared__ float cen_s[D], fs_s[2][D];
+    __shared__ __attribute__((aligned(16))) uint4 abuf[2][2 * NKS * 64];
+    if (threadIdx.x == 0) s_ovf = 0;
+    for (int d = threadIdx.x; d < D; d += WG) {
+        cen_s[d] = centers[(size_t)tile.state * D + d];
+        fs_s[0][d] = fscale[((size_t)tile.state * 2 + 0) * (KS8f * 8) + d];
+        fs_s[1][d] = fscale[((size_t)tile.state * 2 + 1) * (KS8f * 8) + d];
+    }
+    __syncthreads();
+    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
+    const bool wave_active = tile.vstart + wave * 64 < vend;
+    {   // lane = frame: locate it, stage its centred row
+        int v = tile.vstart + wave * 64 + lane;
+        const bool ok = v < vend;
+        if (!ok) v = tile.vstart;
+        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        }
+        const ScoreSeg sg = segs[lo];
+        const long long t = v - sg.vstart;
+        const float *fp = frames + (sg.frame0 + t) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xs[wave][lane * XS + d] = fp[d] - cen_s[d];
+        oidx_s[wave][lane] = ok ? sg.out0 + t * (long long)sg.out_stride : -1;
+    }
+    __syncthreads();
+
+    // ---- B operand: block 4 s + g of the long K axis for frame c * 16 + col, f16
+    h8v xb[NC][NKS];
+    bool ovf = false;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const int t = 4 * s + g;
+        const int seg = t / SEG8, tt = t - seg * SEG8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = 8 * tt + j;
+            const bool feat = t < CT && i < 2 * D;
+            const int side = (i >= D), dd = feat ? i - side * D : 0;
+            const float fsv = fs_s[side][dd];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float xc = xs[wave][(c * 16 + col) * XS + dd];
+                float val = (side ? xc : xc * xc) * fsv;
+                ovf |= feat && (__builtin_fabsf(val) > FMAXH);
+                val = __builtin_fminf(__builtin_fmaxf(val, -FMAXH), FMAXH);
+                const _Float16 h1 = (_Float16)val;
+                _Float16 piece = (seg == 1) ? (_Float16)(val - (float)h1) : h1;      // x1 | x2 | x1
+                if (!feat) piece = (t == CT && j < 3) ? (_Float16)1.f : (_Float16)0.f;   // constants block: 1 1 1 -r1 -r2 -r3 0 0
+                xb[c][s][j] = piece;
+            }
+        }
+    }
+    if (__any(ovf) && lane == 0) s_ovf = 1;
+
+    float sm[NC], ref[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        sm[c] = 0.f;
+        ref[c] = 0.f;
+    }
+    bool ref_ovf = false;
+
+    const uint4 *pstate = pm + (size_t)tile.state * n_mtiles * (2 * NKS * 64);
+    auto dma = [&](int buf, int mt) {
+        const uint4 *src = pstate + (size_t)mt * (2 * NKS * 64);
+        for (int p = wave; p < 2 * NKS; p += WG / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&abuf[buf][p * 64], 16, 0, 0);
+    };
+    auto process = [&](int mt) {
+        const uint4 *ab = abuf[mt & 1];
+        f4v acc[2][NC];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[m][c] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const h8v a = *reinterpret_cast<const h8v *>(&ab[(m * NKS + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[c][s], acc[m][c], 0, 0, 0);
+            }
+#ifdef PCL_DIAG_NOLSE
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sm[c] += acc[0][c][0] + acc[1][c][3];
+        return;
+#endif
+        // fast path for all four frame sub-tiles first, ONE wave-uniform test for the slow path
+        float snew[NC];
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float es[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) es[r] = __builtin_amdgcn_exp2f(acc[r >> 2][c][r & 3]);
+#pragma unroll
+            for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+                for (int r = 0; r < w; ++r) es[r] += es[r + w];
+            snew[c] = sm[c] + es[0];
+            bad |= !(snew[c] < 3.0e38f);
+        }
+        if (mt != 0 && !__any(bad)) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sm[c] = snew[c];
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float gm = acc[0][c][0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) gm = __builtin_fmaxf(gm, acc[r >> 2][c][r & 3]);
+            gm = __builtin_fmaxf(gm, __shfl_xor(gm, 16, 64));
+            const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));      // max over the frame's 32 mixtures
+            float s = sm[c];
+            // everything below -5e4: log zero, or a frame the f16 constants cannot follow -> the direct form decides
+            if (mt == 0 && !(gp > -5.0e4f)) ref_ovf = true;
+            if ((mt == 0 || gp > 0.f) && gp > -5.0e4f) {
+                s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r >> 2][c][r & 3] -= gp;
+                ref[c] += gp;
+                const float nr = __builtin_fminf(__builtin_fmaxf(-ref[c], -FMAXH), FMAXH);
+                ref_ovf |= __builtin_fabsf(ref[c]) > 5.0e4f;
+                const _Float16 r1 = (_Float16)nr;
+                const _Float16 r2 = (_Float16)(nr - (float)r1);
+                const _Float16 r3 = (_Float16)(nr - (float)r1 - (float)r2);
+                if (g == GCT) {
+                    xb[c][SCT][3] = r1;
+                    xb[c][SCT][4] = r2;
+                    xb[c][SCT][5] = r3;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += __builtin_amdgcn_exp2f(acc[r >> 2][c][r & 3]);
+            sm[c] = s;
+        }
+    };
+    dma(0, 0);
+    for (int mt = 0; mt < n_mtiles; ++mt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile mt have landed
+        __syncthreads();                                    // everyone's have; the other buffer is free
+        if (mt + 1 < n_mtiles) dma((mt + 1) & 1, mt + 1);
+        if (wave_active) process(mt);
+    }
+    if (__any(ref_ovf) && lane == 0) s_ovf = 1;
+    constexpr double LN2 = 0.693147180559945309417232121458;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float t = sm[c] + __shfl_xor(sm[c], 16, 64);
+        const double S = (double)t + (double)__shfl_xor(t, 32, 64);
+        const long long o = oidx_s[wave][c * 16 + col];
+        if (o >= 0 && g == 0) out[o] = (S > 0) ? LN2 * ((double)ref[c] + ::log2(S)) : -INFINITY;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = s_ovf;
+}
+
+template <int D>
+void launch16x_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    hipLaunchKernelGGL((gmm_score_split16x_kernel<D>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
+                       reinterpret_cast<const uint4 *>(ctx->pm16x), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs, b->Bt,
+                       b->d_tile_flags);
+}
+
 template <int D>
 void launch16_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
     hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
@@ -457,6 +713,20 @@ int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles,
         case 26: launch16_t<26>(ctx, b, tiles, n_tiles); break;
         case 13: launch16_t<13>(ctx, b, tiles, n_tiles); break;
         default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no split-f16 scoring kernel for D=%d", ctx->D);
+    }
+    pcl_timer_end(ctx, "score");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_score_split16x(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    if (n_tiles == 0) return PCL_OK;
+    pcl_timer_begin(ctx, "score");
+    switch (ctx->D) {
+        case 39: launch16x_t<39>(ctx, b, tiles, n_tiles); break;
+        case 26: launch16x_t<26>(ctx, b, tiles, n_tiles); break;
+        case 13: launch16x_t<13>(ctx, b, tiles, n_tiles); break;
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no 16x16x32 split-f16 scoring kernel for D=%d", ctx->D);
     }
     pcl_timer_end(ctx, "score");
     HIPCHK(ctx, hipGetLastError());

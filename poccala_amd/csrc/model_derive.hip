@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
                                                      uint4 *__restrict__ pm16, uint4 *__restrict__ pm16h,
-                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what) {
+                                                     uint4 *__restrict__ pm16x, const float *__restrict__ fscale,
+                                                     float *__restrict__ cond, int what) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
@@ -112,7 +113,13 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             kqs[ml] = LOG2E * kq;
             // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats
             // order like their bit patterns, so an integer atomicMax works)
-            if (real_m && (what & PCL_LAYOUT_COND)) atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
+            if (real_m && (what & PCL_LAYOUT_COND)) {
+                atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
+                // the 16x16x32 kernel keeps the constant in f16 pieces: a real k' beyond their range sends the state to
+                // the direct-form kernels as well
+                if ((what & PCL_LAYOUT_PM16X) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
+                    atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint(1.0e30f));
+            }
         }
     }
     __syncthreads();
@@ -239,6 +246,48 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
         ph[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
     }
+    // 16x16x32 layout of gmm_score_split.hip (variant 6): one long K axis = [a2 | a1 | a1 | constants | 0], each segment
+    // SEG = 2D rounded up to 8; [mixture sub-tile 2][K-step][64 lanes][8 f16], lane = 16 g + row: row = mixture, block
+    // t = 4 s + g of 8 consecutive K positions.  Constants block: k'1 k'2 k'3 1 1 1 0 0 (f16 pieces; log zero = -6e4).
+    if (what & PCL_LAYOUT_PM16X) {
+        const int SEG8 = (2 * D + 7) / 8, NKS = (3 * SEG8 + 1 + 3) / 4;
+        uint4 *px = pm16x + ((size_t)j * nmt + mt) * (2 * NKS * 64);
+        for (int e = tid; e < 2 * NKS * 64; e += 256) {
+            const int msub = e / (NKS * 64), s = (e >> 6) % NKS, ln = e & 63, g = ln >> 4, cl = msub * 16 + (ln & 15);
+            const bool real_m = (m0 + cl) < M;
+            const int t = 4 * s + g;
+            unsigned short h[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) h[x] = 0;
+            if (t < 3 * SEG8) {
+                const int seg = t / SEG8, tt = t - seg * SEG8;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int i = 8 * tt + x;
+                    if (i < 2 * D) {
+                        const int side = i >= D, dd = i - side * D;
+                        const float val = (side ? fb[cl * D + dd] : fa[cl * D + dd]) / fscale[((size_t)j * 2 + side) * (KS8f * 8) + dd];
+                        const _Float16 h1 = (_Float16)val;
+                        const _Float16 hp = (seg == 0) ? (_Float16)(val - (float)h1) : h1;       // a2 | a1 | a1
+                        h[x] = __builtin_bit_cast(unsigned short, hp);
+                    }
+                }
+            } else if (t == 3 * SEG8) {
+                float kc = real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY;
+                const bool zero = !(kc > -5.0e4f);
+                if (zero) kc = -6.0e4f;
+                float r = kc;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) {
+                    const _Float16 hp = (_Float16)r;
+                    r -= (float)hp;
+                    h[x] = (zero && x > 0) ? 0 : __builtin_bit_cast(unsigned short, hp);
+                }
+                h[3] = h[4] = h[5] = 0x3c00;      // f16 1.0
+            }
+            px[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+        }
+    }
 }
 
 // Clustering.GMM.update_param, one thread per (state, mixture, dim)
@@ -293,6 +342,7 @@ static int eager_layouts(const pcl_ctx *ctx) {
     if (ctx->score_variant == 3) what |= PCL_LAYOUT_PM32;
     if (ctx->score_variant >= 4) what |= PCL_LAYOUT_PM16;     // variant 4 scoring and the split accumulate kernel
     if (ctx->score_variant == 5) what |= PCL_LAYOUT_PM16H;
+    if (ctx->score_variant == 6) what |= PCL_LAYOUT_PM16X;
     return what;
 }
 
@@ -301,7 +351,7 @@ static int launch_derive_kernel(pcl_ctx *ctx, int what) {
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
-                       reinterpret_cast<uint4 *>(ctx->pm16h), ctx->fscale, ctx->d_cond, what);
+                       reinterpret_cast<uint4 *>(ctx->pm16h), reinterpret_cast<uint4 *>(ctx->pm16x), ctx->fscale, ctx->d_cond, what);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

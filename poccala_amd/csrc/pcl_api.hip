@@ -87,6 +87,7 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->pm32);
     dev_free(ctx->pm16);
     dev_free(ctx->pm16h);
+    dev_free(ctx->pm16x);
     dev_free(ctx->fscale);
     dev_free(ctx->centers32);
     dev_free(ctx->d_cond);
@@ -212,6 +213,7 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->pm32, npm));
     TRY(dev_alloc(ctx, &ctx->pm16, (size_t)J * (Mp32 / 32) * 3 * ((Dd + 8) / 8) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->pm16h, (size_t)J * (Mp32 / 32) * (2 * ((Dd + 7) / 8) + 1) * 64 * 8));
+    TRY(dev_alloc(ctx, &ctx->pm16x, (size_t)J * (Mp32 / 32) * 2 * ((3 * ((2 * Dd + 7) / 8) + 1 + 3) / 4) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->fscale, (size_t)J * 2 * ((Dd + 7) / 8) * 8));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));
@@ -565,7 +567,7 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
     const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D);
-    const int tf = mfma ? (ctx->score_variant == 5 ? pcl_score_split16_tile_frames() : ctx->score_variant == 4 ? pcl_score_split_tile_frames() : pcl_score_mfma_tile_frames())
+    const int tf = mfma ? (ctx->score_variant >= 5 ? pcl_score_split16_tile_frames() : ctx->score_variant == 4 ? pcl_score_split_tile_frames() : pcl_score_mfma_tile_frames())
                         : pcl_score_tile_frames(ctx->D, precision);
     if (b->d_tiles && b->tile_frames == tf && b->tile_gen == ctx->model_gen) return PCL_OK;
     // MFMA mode: states whose centred expansion is ill conditioned go to the direct-form VALU kernel
@@ -608,8 +610,9 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
     if (precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D)) {
-        if (ctx->score_variant == 5) {
-            TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));
+        if (ctx->score_variant >= 5) {
+            if (ctx->score_variant == 6) TRY(pcl_launch_score_split16x(ctx, b, b->d_tiles, b->n_tiles));
+            else TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));
             TRY(pcl_launch_score_fixup(ctx, b, b->d_tiles, b->n_tiles, b->d_tile_flags));   // tiles with out-of-range features
         } else if (ctx->score_variant == 4) TRY(pcl_launch_score_split(ctx, b, b->d_tiles, b->n_tiles));
         else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));

@@ -1,0 +1,15 @@
+# A/B builds of the scoring kernel measured with the pipelined bench (two resident batches, forward-backward beside scoring)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/v
+build() { # name flags
+  (cd poccala_amd/csrc && for f in pcl_api gmm_score gmm_score_mfma gmm_score_split hmm_dp gmm_accumulate gmm_accumulate_split model_derive mfcc pcl_comm; do
+     if [ $f = gmm_score_split ] || [ $f = gmm_score ] || [ ! -f ../../gpurun_out/v/$f.o ]; then hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $( [ $f = gmm_score_split ] && echo -fno-slp-vectorize ) $2 -c $f.hip -o ../../gpurun_out/v/$f.o 2>/dev/null; fi; done
+   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_out/v/lib_$1.so ../../gpurun_out/v/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib)
+}
+run() { POCCALA_HIP_LIB=$GRAFT_REPO_ROOT/gpurun_out/v/lib_$1.so timeout 300 python bench.py --steps 10 --warmup 2 --cpu-baseline 0 --extra 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('$1:', round(d['value']/1e6,2), 'M frames/s', round(d['ms_per_step'],2), 'ms/step; score', round(r['kernel_avg_ms'],2), ' fb', round(r['fb_kernel_avg_ms'],2))" >> gpurun_out/bench_ab.log; }
+rm -f gpurun_out/bench_ab.log gpurun_out/v/*
+for v in "$@"; do name=$(echo "$v" | tr -d ' =-' | tr -c 'A-Za-z0-9\n' '_'); build "x$name" "$v"; run "x$name"; done
+cat gpurun_out/bench_ab.log
