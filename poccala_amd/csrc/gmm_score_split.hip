@@ -77,10 +77,18 @@ __global__ __launch_bounds__(WG, PCL_SPLIT_MINW * 256 / WG > 0 ? PCL_SPLIT_MINW 
         int v = tile.vstart + (wave * NT + c) * 32 + col;
         valid[c] = v < vend;
         if (!valid[c]) v = tile.vstart;
-        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        // last segment with vstart <= v: almost always seg0 or its successor (two dependent loads instead of the
+        // ~log2(#segments) of a full search, at the start of every tile), the search only for what is left
+        int lo = tile.seg0, hi = tile.seg_hi - 1;
+        if (lo < hi && segs[lo + 1].vstart <= v) {
+            ++lo;
+            if (lo < hi && segs[lo + 1].vstart <= v) {
+                ++lo;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+                }
+            }
         }
         const ScoreSeg sg = segs[lo];
         const long long t = v - sg.vstart;
@@ -258,10 +266,18 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
         int v = tile.vstart + (wave * NT + c) * 32 + col;
         valid[c] = v < vend;
         if (!valid[c]) v = tile.vstart;
-        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        // last segment with vstart <= v: almost always seg0 or its successor (two dependent loads instead of the
+        // ~log2(#segments) of a full search, at the start of every tile), the search only for what is left
+        int lo = tile.seg0, hi = tile.seg_hi - 1;
+        if (lo < hi && segs[lo + 1].vstart <= v) {
+            ++lo;
+            if (lo < hi && segs[lo + 1].vstart <= v) {
+                ++lo;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+                }
+            }
         }
         const ScoreSeg sg = segs[lo];
         const long long t = v - sg.vstart;
@@ -531,10 +547,18 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_split16x_kernel(
         int v = tile.vstart + wave * 64 + lane;
         const bool ok = v < vend;
         if (!ok) v = tile.vstart;
-        int lo = tile.seg_lo, hi = tile.seg_hi - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        // last segment with vstart <= v: almost always seg0 or its successor (two dependent loads instead of the
+        // ~log2(#segments) of a full search, at the start of every tile), the search only for what is left
+        int lo = tile.seg0, hi = tile.seg_hi - 1;
+        if (lo < hi && segs[lo + 1].vstart <= v) {
+            ++lo;
+            if (lo < hi && segs[lo + 1].vstart <= v) {
+                ++lo;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+                }
+            }
         }
         const ScoreSeg sg = segs[lo];
         const long long t = v - sg.vstart;

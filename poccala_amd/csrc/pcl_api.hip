@@ -552,7 +552,11 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
         int g = 0;
         for (int x = 1; x < NXCD; ++x)
             if (load[x] < load[g]) g = x;          // least-loaded XCD queue
-        for (long long v = 0; v < tot; v += tf) queue[g].push_back(ScoreTile{b->work_states[k], lo, hi, (int)v});
+        int s0 = lo;
+        for (long long v = 0; v < tot; v += tf) {
+            while (s0 + 1 < hi && b->segs[s0 + 1].vstart <= v) ++s0;
+            queue[g].push_back(ScoreTile{b->work_states[k], lo, hi, (int)v, s0});
+        }
         load[g] += (tot + tf - 1) / tf;
     }
     size_t depth = 0;
@@ -560,7 +564,7 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
     std::vector<ScoreTile> tiles;
     tiles.reserve(depth * NXCD);
     for (size_t q = 0; q < depth; ++q)
-        for (int x = 0; x < NXCD; ++x) tiles.push_back(q < queue[x].size() ? queue[x][q] : ScoreTile{0, 0, 0, 0});
+        for (int x = 0; x < NXCD; ++x) tiles.push_back(q < queue[x].size() ? queue[x][q] : ScoreTile{0, 0, 0, 0, 0});
     return tiles;
 }
 

@@ -27,6 +27,7 @@ struct ScoreTile {
     int state;
     int seg_lo, seg_hi;  // the state's segments are segs[seg_lo, seg_hi)
     int vstart;
+    int seg0;            // the segment that contains vstart: a frame of the tile is almost always in seg0 or seg0 + 1
 };
 // One sentence HMM (time-major device matrices: element (t, n) at b_off + t*N + n).
 struct UttDesc {
