@@ -303,6 +303,13 @@ def main():
         batch.viterbi()
         eng.sync()
         t_vit = time.perf_counter() - t1
+        # what follows alignment in training scheme 1 (next row f2): per-frame unit and GMM-state assignment
+        ids = [np.repeat(np.asarray(lab, dtype=np.int32), 3) for lab in labels]
+        row_unit = [np.concatenate([[i[0]], i, [i[-1]]]).astype(np.int32) for i in ids]
+        t1 = time.perf_counter()
+        batch.regroup(row_unit, 3)
+        t_regroup = time.perf_counter() - t1
+        rg_ms, _ = eng.kernel_time('regroup')
         eng.stats_zero()
         eng.sync()
         barrier()
@@ -329,6 +336,7 @@ def main():
         batch.get('logp'); batch.get('gamma'); batch.get('ksai_nz')
         t_d2h = time.perf_counter() - t1
         extra = dict(viterbi_frames_per_s_per_gpu=frames_per_rank / t_vit, viterbi_kernel_ms=vit_ms,
+                     regroup_kernel_ms=rg_ms, regroup_call_ms=t_regroup * 1e3,
                      estep_frames_per_s=total_frames / t_estep, estep_ms=t_estep * 1e3, accumulate_ms=acc_ms, allreduce_ms=ar_ms,
                      mstep_ms=t_mstep * 1e3, frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
                      pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),

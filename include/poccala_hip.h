@@ -143,6 +143,14 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold);
 /* A14: LHMM.viterbi (LHMM.py:546-609), end_state_back = 0|1 (quirk Q9). Bit-exact in f64. */
 int pcl_batch_viterbi(pcl_batch *b, int end_state_back);
 
+/* Next row f2: what follows forced alignment in training scheme 1, per frame, on the device.  row_unit: ragged (N_u,)
+ * int32, the unit each HMM row belongs to (the `states` dictionary of AcousticModel.embedded, AcousticModel.py:968-976,
+ * as integers).  Outputs, ragged (T_u,) int32: frame_unit[t] = unit of the Viterbi path at t (the name sequence of
+ * AcousticModel.viterbi, :1016-1027) and frame_k[t] = which of the unit's gmm_num GMM states the frame is given to when
+ * every run of equal unit (AcousticModel.discriminate, :937-955) is cut into gmm_num slices the way __eq_segment mode 'g'
+ * (:614-625) and __get_gmmdata (:629-644) do.  Needs pcl_batch_viterbi first.  Synchronous. */
+int pcl_batch_regroup(pcl_batch *b, const int32_t *row_unit, int gmm_num, int32_t *frame_unit, int32_t *frame_k);
+
 /* Copy a result to a caller buffer (layouts in pcl_get_what). */
 int pcl_batch_get(pcl_batch *b, int what, void *host);
 

@@ -467,3 +467,48 @@ def align_utterance(x, label, model, s=5):
     point, path = viterbi(a, pi, b)
     names = np.array([states[int(k)] for k in path])
     return point, path, names
+
+
+# --------------------------------------------------------------------------
+# next row f2: what follows forced alignment in training scheme 1
+#   AcousticModel.__eq_segment   AcousticModel.py:587-627   (private; pinned through its mangled name, golden G12)
+#   AcousticModel.__get_gmmdata  AcousticModel.py:629-644
+# --------------------------------------------------------------------------
+def eq_segment_e(data, label):
+    """mode 'e' (:606-613): an utterance cut into len(label) equal chunks of len(data) // len(label) frames, in label
+    order; the remainder frames at the end belong to nobody.  Returns [(unit, block)]."""
+    chunk = len(data) // len(label)
+    return [(u, data[i * chunk:(i + 1) * chunk]) for i, u in enumerate(label)]
+
+
+def eq_segment_g(data, n):
+    """mode 'g' (:614-625): one block cut into n slices, the first n-1 of len(data) // n frames, the last takes the
+    rest (so a block shorter than n gives n-1 empty slices and everything in the last)."""
+    chunk = len(data) // n
+    out = [data[k * chunk:(k + 1) * chunk] for k in range(n - 1)]
+    out.append(data[(n - 1) * chunk:])
+    return out
+
+
+def get_gmmdata(blocks, gmm_num):
+    """(:629-644) the k-th slices of all blocks of a unit, concatenated in block order: the data of GMM state k."""
+    parts = [eq_segment_g(b, gmm_num) for b in blocks]
+    return [np.concatenate([p[k] for p in parts], axis=0) for k in range(gmm_num)]
+
+
+def regroup_frame_states(unit_seq, gmm_num):
+    """Per-frame form of discriminate (:937-955) + __get_gmmdata for one aligned utterance: unit_seq[t] = unit of frame
+    t (AcousticModel.viterbi's name sequence).  Returns k[t] = which of the unit's gmm_num GMM states frame t is given
+    to.  Runs are maximal blocks of equal unit (the same unit twice in a row is ONE run, as np.where/np.diff see it)."""
+    unit_seq = np.asarray(unit_seq)
+    t_n = len(unit_seq)
+    k = np.zeros(t_n, dtype=np.int64)
+    start = 0
+    for t in range(1, t_n + 1):
+        if t == t_n or unit_seq[t] != unit_seq[start]:
+            n = t - start
+            chunk = n // gmm_num
+            pos = np.arange(n)
+            k[start:t] = gmm_num - 1 if chunk == 0 else np.minimum(pos // chunk, gmm_num - 1)
+            start = t
+    return k

@@ -225,6 +225,61 @@ class AcousticModel(DataInitialization):
                     out.setdefault(unit, []).append(data[loc])
         return out, dropped
 
+    def eq_segment(self, data, arg=None, mode='e', save=None):
+        """AcousticModel.__eq_segment (AcousticModel.py:587-627).  mode 'e': the utterance is cut into len(arg) equal
+        chunks, one per label unit, handed to `save(unit, block)` (the reference's __save_data pickles them); the
+        remainder frames are dropped.  mode 'g': one block cut into `arg` slices, the last takes the remainder."""
+        if mode == 'e':
+            chunk = len(data) // len(arg)
+            for i, u in enumerate(arg):
+                if save is not None:
+                    save(u, data[i * chunk:(i + 1) * chunk])
+            return None
+        if mode == 'g':
+            chunk = len(data) // arg
+            out = [data[k * chunk:(k + 1) * chunk] for k in range(arg - 1)]
+            out.append(data[(arg - 1) * chunk:])
+            return out
+        raise ValueError('eq_segment: mode must be \'e\' or \'g\'')   # the reference raises ClassError here
+
+    def get_gmmdata(self, data):
+        """AcousticModel.__get_gmmdata (AcousticModel.py:629-644): the data of each of the unit's S-2 GMM states."""
+        gmm_num = self.__state_num - 2
+        parts = [self.eq_segment(block, gmm_num, mode='g') for block in data]
+        return [np.concatenate([p_[k] for p_ in parts], axis=0) for k in range(gmm_num)]
+
+    def regroup_batch(self, labels, data_list, unit_hmms, precision=PCL_F64, engine=None):
+        """Forced alignment -> the re-estimation data of every GMM state, for many utterances, on the device: Viterbi
+        (`align_batch`'s kernels), then `pcl_batch_regroup` instead of discriminate + __save_data + __get_gmmdata
+        (AcousticModel.py:758-764, 629-644).  Returns ({unit: [S-2 arrays (n_k, D)]}, dropped): for each unit the frames
+        of its GMM states, in utterance then time order; an utterance whose path misses a label unit is dropped
+        (:754-757)."""
+        engine = engine or default_engine()
+        b, n, units, idx = self._sentence_batch(labels, data_list, unit_hmms, engine)
+        b.score(precision)
+        b.viterbi()
+        s = self.__state_num
+        row_unit = []
+        for lab in labels:
+            ids = np.repeat([idx[u] for u in lab], s - 2)
+            row_unit.append(np.concatenate([[ids[0]], ids, [ids[-1]]]).astype(np.int32))     # entry / exit rows: first / last unit
+        fu, fk = b.regroup(row_unit, s - 2)
+        b.close()
+        names = {i: u for u, i in idx.items()}
+        out, dropped = {}, []
+        for u, lab in enumerate(labels):
+            if len(np.unique(fu[u])) < len(set(lab)):
+                dropped.append(u)
+                continue
+            data = np.asarray(data_list[u])
+            for i in np.unique(fu[u]):
+                slot = out.setdefault(names[i], [[] for _ in range(s - 2)])
+                for k in range(s - 2):
+                    slot[k].append(data[(fu[u] == i) & (fk[u] == k)])
+        d = np.asarray(data_list[0]).shape[1]
+        return ({unit: [np.concatenate(parts, axis=0) if parts else np.zeros((0, d)) for parts in slots]
+                 for unit, slots in out.items()}, dropped)
+
     def save_batch_acc(self, stats, hmm_acc, unit_hmms):
         """Write the result of `estep_batch` as reference-format accumulator files (log domain, float64,
         SURVEY T3): <unit>/HMM/{ksai-acc,gamma-acc}/..., <unit>/GMM_k/{acc,alpha-acc,mean-acc,covariance-acc}/...

@@ -468,6 +468,70 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     return PCL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// next row f2: what follows forced alignment in training scheme 1 (the loop at AcousticModel.py:758-764 and
+// __get_gmmdata, :629-644), per frame: unit[t] = the unit whose HMM the Viterbi path is in at t; runs = maximal
+// blocks of equal unit (AcousticModel.discriminate, :937-955: the same unit twice in a row is ONE run); a run of n
+// frames is cut into gmm_num slices, the first gmm_num-1 of n / gmm_num frames, the last takes the rest
+// (__eq_segment mode 'g', :614-625); k[t] = the slice of frame t.  One wave per utterance: run starts by a forward
+// max-scan over boundary flags, run ends by a backward min-scan, both through LDS.
+__global__ void hmm_regroup_kernel(const UttDesc *__restrict__ utts, const int32_t *__restrict__ path,
+                                   const int32_t *__restrict__ row_unit, int gmm_num, int32_t *__restrict__ frame_unit,
+                                   int32_t *__restrict__ frame_k) {
+    extern __shared__ int rg[];                       // [Tmax] units, [Tmax] run starts
+    const UttDesc d = utts[blockIdx.x];
+    const int T = d.T, lane = threadIdx.x;
+    int *un = rg, *st = rg + T;
+    for (int t = lane; t < T; t += 64) un[t] = row_unit[d.vec_off + path[d.path_off + t]];
+    __syncthreads();
+    // forward: start of the run of t
+    int carry = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        int v = -1;
+        if (t < T && (t == 0 || un[t] != un[t - 1])) v = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int w = __shfl_up(v, o, 64);
+            if (lane >= o) v = max(v, w);
+        }
+        v = max(v, carry);
+        if (t < T) st[t] = v;
+        carry = __shfl(v, 63, 64);
+    }
+    __syncthreads();
+    // backward: end (exclusive) of the run of t, then the slice
+    int carry_e = T;
+    for (int t0 = (T - 1) / 64 * 64; t0 >= 0; t0 -= 64) {
+        const int t = t0 + lane;
+        int e = 0x7fffffff;
+        if (t < T && (t == T - 1 || un[t + 1] != un[t])) e = t + 1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int w = __shfl_down(e, o, 64);
+            if (lane + o < 64) e = min(e, w);
+        }
+        e = min(e, carry_e);
+        if (t < T) {
+            const int n = e - st[t], chunk = n / gmm_num, pos = t - st[t];
+            frame_unit[d.path_off + t] = un[t];
+            frame_k[d.path_off + t] = (chunk == 0) ? gmm_num - 1 : min(pos / chunk, gmm_num - 1);
+        }
+        carry_e = __shfl(e, 0, 64);
+    }
+}
+
+int pcl_launch_regroup(pcl_ctx *ctx, pcl_batch *b, const int32_t *d_row_unit, int gmm_num, int32_t *d_frame_unit, int32_t *d_frame_k) {
+    const size_t shm = (size_t)2 * b->Tmax * sizeof(int);
+    if (shm > 64 * 1024) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_regroup: utterances of %d frames exceed the 8192-frame limit", b->Tmax);
+    pcl_timer_begin(ctx, "regroup");
+    hipLaunchKernelGGL(hmm_regroup_kernel, dim3(b->U), dim3(64), shm, ctx->stream, b->d_utt, b->path, d_row_unit, gmm_num, d_frame_unit,
+                       d_frame_k);
+    pcl_timer_end(ctx, "regroup");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
 int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back) {
     const int NP = (b->Nmax + 63) / 64 * 64;
     if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);

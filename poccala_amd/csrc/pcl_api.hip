@@ -685,6 +685,27 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
     return PCL_OK;
 }
 
+int pcl_batch_regroup(pcl_batch *b, const int32_t *row_unit, int gmm_num, int32_t *frame_unit, int32_t *frame_k) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    TRY(batch_join(b));
+    if (!row_unit || !frame_unit || !frame_k || gmm_num < 1) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_regroup: bad arguments");
+    if (!b->have_vit) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_regroup: run pcl_batch_viterbi first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t *d_ru = nullptr, *d_fu = nullptr, *d_fk = nullptr;
+    int rc = dev_alloc(ctx, &d_ru, (size_t)b->sumN);
+    if (rc == PCL_OK) rc = dev_alloc(ctx, &d_fu, (size_t)b->sumT);
+    if (rc == PCL_OK) rc = dev_alloc(ctx, &d_fk, (size_t)b->sumT);
+    if (rc == PCL_OK && hipMemcpyAsync(d_ru, row_unit, (size_t)b->sumN * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PCL_ERR_HIP;
+    if (rc == PCL_OK) rc = pcl_launch_regroup(ctx, b, d_ru, gmm_num, d_fu, d_fk);
+    if (rc == PCL_OK && hipMemcpyAsync(frame_unit, d_fu, (size_t)b->sumT * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_ERR_HIP;
+    if (rc == PCL_OK && hipMemcpyAsync(frame_k, d_fk, (size_t)b->sumT * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_ERR_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == PCL_OK) rc = PCL_ERR_HIP;
+    dev_free(d_ru); dev_free(d_fu); dev_free(d_fk);
+    if (rc == PCL_ERR_HIP) PCL_FAIL(ctx, PCL_ERR_HIP, "pcl_batch_regroup: HIP error");
+    return rc;
+}
+
 int pcl_batch_get(pcl_batch *b, int what, void *host) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;

@@ -166,6 +166,7 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile 
 int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b);
 int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold);
 int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back);
+int pcl_launch_regroup(pcl_ctx *ctx, pcl_batch *b, const int32_t *d_row_unit, int gmm_num, int32_t *d_frame_unit, int32_t *d_frame_k);
 int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst);
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
 void pcl_accumulate_release(pcl_batch *b);

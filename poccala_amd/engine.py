@@ -254,6 +254,17 @@ class Batch(object):
         self._check(self._lib.pcl_batch_accumulate(self._b, int(precision)))
 
     # ------------------------------------------------------------------ outputs
+    def regroup(self, row_unit, gmm_num):
+        """Per-frame regrouping after viterbi() (AcousticModel.py:758-764 + __get_gmmdata :629-644): row_unit[u] = (N_u,)
+        unit id of every HMM row.  Returns (frame_unit, frame_k): per utterance (T_u,) int32 arrays, the unit the path
+        is in and the GMM state (slice of the unit's run) each frame is given to."""
+        ru = self._ragged(row_unit, lambda u: (self.N[u],), dtype=np.int32)
+        fu = np.empty(int(self._t_off[-1]), dtype=np.int32)
+        fk = np.empty(int(self._t_off[-1]), dtype=np.int32)
+        self._check(self._lib.pcl_batch_regroup(self._b, ptr(ru), int(gmm_num), ptr(fu), ptr(fk)))
+        cut = lambda flat: [flat[self._t_off[u]:self._t_off[u + 1]] for u in range(self.U)]
+        return cut(fu), cut(fk)
+
     def get(self, what):
         """List of per-utterance arrays (or a (U,...) array for per-utterance scalars)."""
         code = GET[what]

@@ -231,3 +231,82 @@ def test_lhmm_with_several_utterances(golden, tag):
     np.testing.assert_allclose(h.pi, g['pi_' + tag], rtol=1e-9, atol=1e-300)
     fin_close(unit.ksai_acc, g['ksai_acc_' + tag], rtol=1e-10)
     fin_close(unit.gamma_acc, g['gamma_acc_' + tag], rtol=1e-10)
+
+
+def test_regroup_kernel_matches_oracle_and_golden(golden):
+    """pcl_batch_regroup (next row f2) against the oracle's per-frame form, which golden G12 pins to the reference's own
+    discriminate / __eq_segment / __get_gmmdata: random left-right paths are forced through the Viterbi kernel by a
+    one-hot emission matrix, incl. runs shorter than the number of GMM states, a unit repeated back to back, T = 1."""
+    from poccala_amd import Engine
+    from oracle import poccala_oracle as po
+    rng = np.random.default_rng(21)
+    eng = Engine(0)
+    U, e = 9, S - 2
+    n_list, t_list, a_list, pi_list, b_list, row_units, want_rows = [], [], [], [], [], [], []
+    for u in range(U):
+        L = int(rng.integers(1, 6))
+        lab = list(rng.integers(0, 4, L))
+        if u == 1:
+            lab = [2, 2, 1]                               # the same unit twice in a row: ONE run
+        N = e * len(lab) + 2
+        T = 1 if u == 0 else int(rng.integers(N, 4 * N))
+        # a monotone row sequence over the emitting rows, every row visited at least once when T allows it
+        rows = np.sort(np.concatenate([np.arange(1, N - 1), rng.integers(1, N - 1, max(T - (N - 2), 0))]))[:T]
+        if T < N - 2:
+            rows = np.arange(1, 1 + T)
+        A = np.full((N, N), -np.inf)
+        for i in range(N - 1):
+            A[i, i] = np.log(0.5)
+            A[i, i + 1] = np.log(0.5)
+        pi = np.full(N, -np.inf)
+        pi[rows[0]] = 0.0
+        B = np.full((N, T), -50.0)
+        B[rows, np.arange(T)] = 0.0                       # the path is forced
+        ids = np.repeat(lab, e)
+        n_list.append(N); t_list.append(T); a_list.append(A); pi_list.append(pi); b_list.append(B)
+        row_units.append(np.concatenate([[ids[0]], ids, [ids[-1]]]).astype(np.int32))
+        want_rows.append(rows)
+    b = eng.batch(n_list, t_list)                        # emissions are given: no frames behind this batch
+    b.set_transitions(a_list, pi_list)
+    b.set_emissions(b_list)
+    b.viterbi()
+    paths = b.get('path')
+    fu, fk = b.regroup(row_units, e)
+    for u in range(U):
+        np.testing.assert_array_equal(paths[u], want_rows[u])
+        unit_seq = row_units[u][paths[u]]
+        np.testing.assert_array_equal(fu[u], unit_seq)
+        np.testing.assert_array_equal(fk[u], po.regroup_frame_states(unit_seq, e))
+    b.close()
+    eng.close()
+
+
+def test_regroup_batch_equals_discriminate_and_get_gmmdata(golden, tmp_path):
+    """The drop-in's device path (Viterbi + pcl_batch_regroup) returns, per unit, exactly the GMM-state data the
+    reference's flow builds on the host: discriminate -> blocks -> __get_gmmdata."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd import PCL_F64
+    g = golden('G6_small_fix0')
+    label, hmm_list = build_units(g)
+    am = AcousticModel(RecLog(), 'XIF_tone', state_num=S, mix_level=4, dct_num=13, delta_1=False, delta_2=False,
+                       parameters_path=str(tmp_path))
+    unit_hmms = {u: hmm_list[label.index(u)] for u in set(label)}
+    data = [g['x'], g['x'][::-1].copy()]
+    labels = [label, label]
+    got, dropped = am.regroup_batch(labels, data, unit_hmms, precision=PCL_F64)
+    segs, dropped2 = am.segment_batch(labels, data, unit_hmms, precision=PCL_F64)
+    assert dropped == dropped2
+    for u in segs:
+        want = am.get_gmmdata(segs[u])
+        for k in range(S - 2):
+            np.testing.assert_array_equal(got[u][k], want[k])
+    # the two small helpers against the golden made by the reference's private methods
+    G12 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'G12_regroup.npz'))
+    for n in G12['g_lens']:
+        sl = am.eq_segment(G12['g_data_%d' % n], S - 2, mode='g')
+        assert [len(x) for x in sl] == list(G12['g_sizes_%d' % n])
+    saved = []
+    am.eq_segment(G12['e_data'], list(G12['e_label']), mode='e', save=lambda unit, blk: saved.append((unit, blk)))
+    assert [u for u, _ in saved] == list(G12['e_units'])
+    for i, (_, blk) in enumerate(saved):
+        np.testing.assert_array_equal(blk, G12['e_block_%d' % i])
