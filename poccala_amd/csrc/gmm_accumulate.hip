@@ -95,7 +95,7 @@ __global__ void acc_fill_kernel(const ScoreSeg *__restrict__ segs, int n_segs, c
             ActiveFrame a;
             a.frame = sg.frame0 + t;
             a.coef = lg - lb;
-            a.lg = lg;
+            a.lg = exp(lg);
             list[pos + rank] = a;
         }
         pos += __popcll(mask);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cf[threadIdx.x] = (real)(a.coef * LOG2E);
-            if (blockIdx.x == 0) galpha += exp(a.lg);
+            if (blockIdx.x == 0) galpha += a.lg;
         }
         __syncthreads();
         for (int f = 0; f < nf; ++f) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
     float xv[NE];
     long long fidx[NE];                                      // frame rows of the tile after next (one more stage ahead)
     float cfv = -INFINITY, cfn = -INFINITY;
-    double lgv = -INFINITY, lgn = -INFINITY;
+    double lgv = 0.0, lgn = 0.0;
     auto stage_index = [&](long long f0) {                   // level 1 of the gather: list entries
         const int nf = (f0 < end) ? (int)min(32LL, end - f0) : 0;
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
             fidx[k] = (e < 32 * D && f < nf) ? list[f0 + f].frame : -1;
         }
         cfn = -INFINITY;                                     // padding frame: g = exp2(-inf) = 0
-        lgn = -INFINITY;
+        lgn = 0.0;
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cfn = (float)(a.coef * LOG2E);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
         }
         if (threadIdx.x < 32) {
             const int f = threadIdx.x;
-            if (slice == 0 && lgv > -INFINITY) galpha += exp(lgv);
+            if (slice == 0) galpha += lgv;
             x[f * XSTR + 2 * D] = 1.f;
             x[f * XSTR + 2 * D + 1] = cfv;
             for (int k = 2 * D + 2; k < XSTR; ++k) x[f * XSTR + k] = 0.f;

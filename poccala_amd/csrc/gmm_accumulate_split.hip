@@ -160,7 +160,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(   // 
         ix2[k][0] = ix2[k][1] = ix3[k][0] = ix3[k][1] = -1;
     }
     double cf1 = -INFINITY, cf2 = -INFINITY, cf3 = -INFINITY;     // ln gamma - ln b, raw (scaled and clamped when stored)
-    double lg1 = -INFINITY, lg2 = -INFINITY, lg3 = -INFINITY;
+    double lg1 = 0.0, lg2 = 0.0, lg3 = 0.0;
     auto load_index = [&](long long f0, int (&ix)[NPT][2], double &cf, double &lg) {
         const int nf = (f0 < end) ? (int)min(32LL, end - f0) : 0;
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(   // 
                 ix[k][a] = (item_on[k] && f < nf) ? (int)list[f0 + f].frame : -1;
             }
         cf = -INFINITY;                                    // padding frame: g = 0
-        lg = -INFINITY;
+        lg = 0.0;
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cf = a.coef;
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(   // 
             const bool ok = (vmask >> a) & 1;
             const float x0 = ok ? xraw[a][0] - cen0[k] : 0.f, x1 = (ok && pair_ok[k]) ? xraw[a][1] - cen1[k] : 0.f;
             float r0 = side ? x0 : x0 * x0, r1 = side ? x1 : x1 * x1;
+#ifndef PCL_ACCS_TRUNC_SPLIT       // the truncating variant below measured the same (47.9 vs 48.0 ms)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const bf2v c = bf2v{(__bf16)r0, (__bf16)r1};                       // v_cvt_pk_bf16_f32, round to nearest even
@@ -220,6 +221,19 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(   // 
                 r0 -= __uint_as_float(u << 16);
                 r1 -= __uint_as_float(u & 0xffff0000u);
             }
+#else
+            // truncating split: a piece is the top 16 bits of what is left (8 significand bits each, 24 in all: still an
+            // exact decomposition); one v_perm packs the (d, d + 1) pair, and there is no conversion to undo
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned int u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
+                P[p][a] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);              // (hi16 of r0) | (hi16 of r1) << 16
+                if (p < 2) {
+                    r0 -= __uint_as_float(u0 & 0xffff0000u);
+                    r1 -= __uint_as_float(u1 & 0xffff0000u);
+                }
+            }
+#endif
         }
         const int s = d0[k] >> 3, jd = d0[k] & 7;
 #pragma unroll
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_split_kernel(   // 
         if (threadIdx.x < 32) {
             unsigned short *h1 = reinterpret_cast<unsigned short *>(&xe[buf][0]);
             const int f = threadIdx.x;
-            if (slice == 0 && lgv > -INFINITY) galpha += exp(lgv);
+            if (slice == 0) galpha += lgv;                    // gamma_t(j) itself (the list holds exp(ln gamma))
             unsigned short c1, c2p, c3;
             const float cfl2 = __builtin_fmaxf((float)(cfv * LOG2E), -3.0e38f);   // finite: its pieces meet zeros of the other operand
             split3_bits(cfl2, c1, c2p, c3);

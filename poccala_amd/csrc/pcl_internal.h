@@ -45,7 +45,7 @@ struct UttDesc {
 struct ActiveFrame {
     long long frame;  // row of the frame matrix
     double coef;      // ln gamma_t(j) - ln b_j(o_t)
-    double lg;        // ln gamma_t(j)
+    double lg;        // gamma_t(j) = exp(ln gamma_t(j)), taken once when the list is built (alpha_acc sums it)
 };
 
 // ---------------------------------------------------------------- host-side objects
