@@ -212,6 +212,12 @@ def main():
         bt.score(P)                                   # main stream
         bt.forward_backward(fix_pi=False)             # second stream: runs beside the next step's scoring
 
+    # setup, not a step: every resident batch once, so that lazy allocations (tile lists, alpha/beta/xi buffers) never land
+    # in a timed step whatever --warmup is
+    for bt in batches:
+        bt.score(P)
+        bt.forward_backward(fix_pi=False)
+    eng.sync()
     for _ in range(args.warmup):
         step()
     eng.sync()
