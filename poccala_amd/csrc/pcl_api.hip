@@ -617,7 +617,9 @@ int pcl_batch_score(pcl_batch *b, int precision) {
         if (ctx->score_variant >= 5) {
             if (ctx->score_variant == 6) TRY(pcl_launch_score_split16x(ctx, b, b->d_tiles, b->n_tiles));
             else TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));
+#ifndef PCL_DIAG_NOFIXUP
             TRY(pcl_launch_score_fixup(ctx, b, b->d_tiles, b->n_tiles, b->d_tile_flags));   // tiles with out-of-range features
+#endif
         } else if (ctx->score_variant == 4) TRY(pcl_launch_score_split(ctx, b, b->d_tiles, b->n_tiles));
         else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
         TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
