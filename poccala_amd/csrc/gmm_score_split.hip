@@ -230,13 +230,20 @@ __global__ __launch_bounds__(WG, PCL_SPLIT_MINW * 256 / WG > 0 ? PCL_SPLIT_MINW 
 #endif
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
-template <int D, int NT>
+template <int D, int NT, bool FOLD>
 __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_MINW * 256 / WG : 1) void gmm_score_split16_kernel(
     const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
     int n_mtiles, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
-    int *__restrict__ flags) {
+    int *__restrict__ flags, const double *__restrict__ kzero) {
+    // FOLD (variant 7): no constant MFMA.  The spare slot d = D of each side carries the constants in f16:
+    //   a1: [k1 | 0]   a2: [k2 | 1]   x1: [1 | -ref']   x2: [0 | 0]   ->  a2 x1 + a1 x2 + a1 x1 = k1 + k2 - ref'
+    // with k1 + k2 = k'_m - K0_j (K0_j = max_m k'_m, added back in f64 at the end, so the 22 bits go to a small number)
+    // and ref' the f16-rounded reference (any nearby value serves).  Log zero is -6e4; a frame whose reference leaves
+    // the f16 range is flagged for the direct-form fix-up like an out-of-range feature.
+    static_assert(!FOLD || D % 8 != 0, "the folded constants need a spare slot");
     constexpr int KS8 = (D + 7) / 8;       // K-steps of 16 over the 2D features (8 per half-wave)
-    constexpr int CH = 2 * KS8 + 1;        // 1-KiB chunks per m-tile: two f16 pieces + the bf16 constant chunk
+    constexpr int CH = FOLD ? 2 * KS8 : 2 * KS8 + 1;   // 1-KiB chunks per m-tile: two f16 pieces (+ the bf16 constant chunk)
+    constexpr int SC = D / 8, JC = D % 8;  // the spare slot
     constexpr float FMAXH = 6.0e4f;
     const ScoreTile tile = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                     ovf |= __builtin_fabsf(val) > FMAXH;
                     val = __builtin_fminf(__builtin_fmaxf(val, -FMAXH), FMAXH);
                 }
+                if (FOLD && d == D) val = half ? 0.f : 1.f;      // x1: [1 | -ref' (0 so far)]
                 const _Float16 h1 = (_Float16)val;
                 xb[c][0][s][j] = h1;
                 xb[c][1][s][j] = (_Float16)(val - (float)h1);
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
         sm[c] = 0.f;
         ref[c] = 0.f;
     }
+    bool ref_ovf = false;
 
     // MTS m-tiles per LDS stage: one workgroup barrier per MTS x 32 mixtures
     constexpr int MTS = PCL_SPLIT16_MTS;
@@ -332,7 +341,12 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
     auto process = [&](int mt) {
         const uint4 *ab = &abuf[(mt / MTS) & 1][(mt % MTS) * (CH * 64)];
         f16v acc[NT];
-        {
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        } else {
             const bf8v ac = *reinterpret_cast<const bf8v *>(&ab[(2 * KS8) * 64 + lane]);   // k'1 k'2 k'3 1 1 1 0 0
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
@@ -395,7 +409,20 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                 for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
                 const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));
                 float s = sm[c];
-                if ((mt == 0 || gp > 0.f) && gp > -1.0e37f) {
+                if constexpr (FOLD) {
+                    if (mt == 0 && !(gp > -5.0e4f)) ref_ovf = true;      // log zero everywhere, or out of the f16 constants' reach
+                    if ((mt == 0 || gp > 0.f) && gp > -5.0e4f) {
+                        // the reference the pipe subtracts is the f16-rounded one: shift by what it actually moves
+                        const _Float16 r1 = (_Float16)__builtin_fminf(__builtin_fmaxf(-(ref[c] + gp), -FMAXH), FMAXH);
+                        const float nref = -(float)r1, dl = nref - ref[c];
+                        ref_ovf |= __builtin_fabsf(nref) > 5.0e4f;
+                        s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-dl);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[c][r] -= dl;
+                        ref[c] = nref;
+                        if (half) xb[c][0][SC][JC] = r1;
+                    }
+                } else if ((mt == 0 || gp > 0.f) && gp > -1.0e37f) {
                     s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[c][r] -= gp;
@@ -487,10 +514,16 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                st_acc[3] / n_mtiles, st_acc[0] / n_mtiles, st_acc[1] / n_mtiles, st_acc[2] / n_mtiles);
 #endif
     constexpr double LN2 = 0.693147180559945309417232121458;
+    const double k0 = FOLD ? kzero[tile.state] : 0.0;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
-        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2 * ((double)ref[c] + ::log2(S)) : -INFINITY;
+        if (valid[c] && half == 0) out[oidx[c]] = (S > 0) ? LN2 * ((double)ref[c] + k0 + ::log2(S)) : -INFINITY;
+    }
+    if constexpr (FOLD) {
+        if (__any(ref_ovf) && lane == 0) s_ovf = 1;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_ovf) flags[blockIdx.x] = 1;     // (the flag of the features was stored after the first barrier)
     }
 }
 
@@ -712,9 +745,14 @@ void launch16x_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles
 
 template <int D>
 void launch16_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
-    hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
-                       reinterpret_cast<const uint4 *>(ctx->pm16h), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs, b->Bt,
-                       b->d_tile_flags);
+    if (ctx->score_variant == 7)
+        hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
+                           reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs,
+                           b->Bt, b->d_tile_flags, ctx->kzero);
+    else
+        hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT, false>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
+                           reinterpret_cast<const uint4 *>(ctx->pm16h), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs,
+                           b->Bt, b->d_tile_flags, (const double *)nullptr);
 }
 
 template <int D>

@@ -51,6 +51,21 @@ __global__ void fscale_kernel(const double *__restrict__ mean64, const double *_
     }
 }
 
+// K0_j = max_m k'_m (log2 units) of the centred expansion, for the folded-constant layout (gmm_score_split.hip variant 7
+// keeps k'_m - K0_j in two f16 pieces and adds K0_j back in f64).  A first, write-free pass of derive_kernel
+// (PCL_LAYOUT_KZERO) takes the maximum with an integer atomicMax on order-preserving float bits; this turns them back.
+__device__ __forceinline__ int ordered_bits(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__global__ void kzero_finish_kernel(const int *__restrict__ bits, int J, double *__restrict__ kzero) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    const int i = bits[j];
+    const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
+    kzero[j] = (i == (int)0x80000000 || !(f > -3.0e38f)) ? 0.0 : (double)f;      // no real mixture at all: anything
+}
+
 // one workgroup per (state, 32-mixture tile): the tile's mean/var rows are staged in LDS with coalesced
 // loads and every output layout is written with contiguous 8/16-byte stores
 __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
@@ -59,8 +74,9 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
                                                      uint4 *__restrict__ pm16, uint4 *__restrict__ pm16h,
-                                                     uint4 *__restrict__ pm16x, const float *__restrict__ fscale,
-                                                     float *__restrict__ cond, int what) {
+                                                     uint4 *__restrict__ pm16x, uint4 *__restrict__ pm16f,
+                                                     const double *__restrict__ kzero, int *__restrict__ kz_bits,
+                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
@@ -111,18 +127,20 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             }
             k2s[ml] = k2;
             kqs[ml] = LOG2E * kq;
+            if ((what & PCL_LAYOUT_KZERO) && real_m && k2 > -INFINITY) atomicMax(kz_bits + j, ordered_bits((float)(k2 - LOG2E * kq)));
             // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats
             // order like their bit patterns, so an integer atomicMax works)
             if (real_m && (what & PCL_LAYOUT_COND)) {
                 atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
                 // the 16x16x32 kernel keeps the constant in f16 pieces: a real k' beyond their range sends the state to
                 // the direct-form kernels as well
-                if ((what & PCL_LAYOUT_PM16X) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
+                if ((what & (PCL_LAYOUT_PM16X | PCL_LAYOUT_PM16F)) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
                     atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint(1.0e30f));
             }
         }
     }
     __syncthreads();
+    if (what == PCL_LAYOUT_KZERO) return;
     // VALU scoring rows [s_d c_d ... k2 pad] and the f32 means (only mixtures inside the Mpad grid)
     const bool w32 = what & PCL_LAYOUT_P32, wr64 = what & PCL_LAYOUT_P64;
     if (w32 || wr64)
@@ -246,6 +264,41 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
         ph[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
     }
+    // folded-constant f16 layout (variant 7): [piece 2][KS8f][64 lanes][8 f16] as above, and in the spare slot d = D:
+    // a1: [k1 | 0], a2: [k2 | 1] with k1 + k2 = k'_m - K0_j in f16 pieces (log zero = -6e4)
+    if (what & PCL_LAYOUT_PM16F) {
+        uint4 *pf = pm16f + ((size_t)j * nmt + mt) * (2 * KS8f * 64);
+        const double k0 = kzero[j];
+        for (int e = tid; e < 2 * KS8f * 64; e += 256) {
+            const int p = (e >> 6) / KS8f, s = (e >> 6) % KS8f, ln = e & 63, half = ln >> 5, cl = ln & 31;
+            const bool real_m = (m0 + cl) < M;
+            unsigned short h[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int dd = 8 * s + x;
+                float val = 0.f;
+                bool is_const = false;
+                if (dd < D) {
+                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) / fscale[((size_t)j * 2 + half) * (KS8f * 8) + dd];
+                } else if (dd == D) {
+                    is_const = true;
+                    if (half == 0) {
+                        const double kp = real_m ? k2s[cl] - kqs[cl] - k0 : -INFINITY;
+                        val = (kp > -5.0e4) ? (float)kp : -6.0e4f;
+                    } else {
+                        val = 1.f;
+                    }
+                }
+                const _Float16 h1 = (_Float16)val;
+                _Float16 hp;
+                if (!is_const) hp = p ? (_Float16)(val - (float)h1) : h1;
+                else if (half == 0) hp = p ? ((val <= -6.0e4f) ? (_Float16)0.f : (_Float16)(val - (float)h1)) : h1;    // k1 | k2
+                else hp = p ? (_Float16)1.f : (_Float16)0.f;                                                       // a1: 0, a2: 1
+                h[x] = __builtin_bit_cast(unsigned short, hp);
+            }
+            pf[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+        }
+    }
     // 16x16x32 layout of gmm_score_split.hip (variant 6): one long K axis = [a2 | a1 | a1 | constants | 0], each segment
     // SEG = 2D rounded up to 8; [mixture sub-tile 2][K-step][64 lanes][8 f16], lane = 16 g + row: row = mixture, block
     // t = 4 s + g of 8 consecutive K positions.  Constants block: k'1 k'2 k'3 1 1 1 0 0 (f16 pieces; log zero = -6e4).
@@ -343,6 +396,7 @@ static int eager_layouts(const pcl_ctx *ctx) {
     if (ctx->score_variant >= 4) what |= PCL_LAYOUT_PM16;     // variant 4 scoring and the split accumulate kernel
     if (ctx->score_variant == 5) what |= PCL_LAYOUT_PM16H;
     if (ctx->score_variant == 6) what |= PCL_LAYOUT_PM16X;
+    if (ctx->score_variant == 7) what |= PCL_LAYOUT_PM16F;
     return what;
 }
 
@@ -351,7 +405,8 @@ static int launch_derive_kernel(pcl_ctx *ctx, int what) {
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
-                       reinterpret_cast<uint4 *>(ctx->pm16h), reinterpret_cast<uint4 *>(ctx->pm16x), ctx->fscale, ctx->d_cond, what);
+                       reinterpret_cast<uint4 *>(ctx->pm16h), reinterpret_cast<uint4 *>(ctx->pm16x), reinterpret_cast<uint4 *>(ctx->pm16f),
+                       ctx->kzero, ctx->kz_bits, ctx->fscale, ctx->d_cond, what);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }
@@ -363,6 +418,12 @@ int pcl_launch_derive(pcl_ctx *ctx) {
                        ctx->D, ctx->Dhost, KS8f, ctx->fscale);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     const int what = eager_layouts(ctx);
+    if (what & PCL_LAYOUT_PM16F) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->kz_bits, 0x80, (size_t)ctx->J * sizeof(int), ctx->stream));      // 0x80808080: below every real value
+        const int rk = launch_derive_kernel(ctx, PCL_LAYOUT_KZERO);
+        if (rk != PCL_OK) return rk;
+        hipLaunchKernelGGL(kzero_finish_kernel, dim3((ctx->J + 255) / 256), dim3(256), 0, ctx->stream, ctx->kz_bits, ctx->J, ctx->kzero);
+    }
     const int rc = launch_derive_kernel(ctx, what);
     if (rc != PCL_OK) return rc;
     ctx->layouts_valid = what;

@@ -70,7 +70,7 @@ int pcl_init(int device, pcl_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
     const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
-    ctx->score_variant = var ? atoi(var) : 5;
+    ctx->score_variant = var ? atoi(var) : 7;
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
     *out = ctx;
@@ -88,6 +88,9 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->pm16);
     dev_free(ctx->pm16h);
     dev_free(ctx->pm16x);
+    dev_free(ctx->pm16f);
+    dev_free(ctx->kzero);
+    dev_free(ctx->kz_bits);
     dev_free(ctx->fscale);
     dev_free(ctx->centers32);
     dev_free(ctx->d_cond);
@@ -214,6 +217,9 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->pm16, (size_t)J * (Mp32 / 32) * 3 * ((Dd + 8) / 8) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->pm16h, (size_t)J * (Mp32 / 32) * (2 * ((Dd + 7) / 8) + 1) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->pm16x, (size_t)J * (Mp32 / 32) * 2 * ((3 * ((2 * Dd + 7) / 8) + 1 + 3) / 4) * 64 * 8));
+    TRY(dev_alloc(ctx, &ctx->pm16f, (size_t)J * (Mp32 / 32) * 2 * ((Dd + 7) / 8) * 64 * 8));
+    TRY(dev_alloc(ctx, &ctx->kzero, (size_t)J));
+    TRY(dev_alloc(ctx, &ctx->kz_bits, (size_t)J));
     TRY(dev_alloc(ctx, &ctx->fscale, (size_t)J * 2 * ((Dd + 7) / 8) * 8));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));

@@ -36,10 +36,10 @@ pairs, M, D = 18432000, 2048, 39
 flop = pairs * M * (3 * D + 4)
 fetch, write = val['FETCH_SIZE'] * 1024, val['WRITE_SIZE'] * 1024
 cyc = val['GRBM_GUI_ACTIVE'] / 8
-out += ['', '## derived (gmm_score_split16_kernel<39,2>, 18,432,000 (frame,state) pairs x 2048 mixtures per launch)',
+out += ['', '## derived (gmm_score_split16_kernel<39,2,true>, 18,432,000 (frame,state) pairs x 2048 mixtures per launch)',
         'kernel %.2f ms/launch (rocprofv3 trace pass) -> %.1f TFLOP/s algorithmic (%.4f TFLOP/launch) = %.3f of 838.9 (f16 MFMA peak / 3 split products), %.2f x the f32-input MFMA peak 157.3'
         % (ms, flop / ms / 1e9, flop / 1e12, flop / ms / 1e9 / 838.9, flop / ms / 1e9 / 157.3),
-        'executed MFMA work: 16 x v_mfma_f32_32x32x16 per 1024 Gaussians = %.0f TFLOP/s of f16/bf16 MFMA flops' % (pairs * M * 512 / ms / 1e9),
+        'executed MFMA work: 15 x v_mfma_f32_32x32x16 per 1024 Gaussians = %.0f TFLOP/s of f16/bf16 MFMA flops' % (pairs * M * 480 / ms / 1e9),
         'GRBM_GUI_ACTIVE %.4g (sum of 8 XCDs) -> %.3g cycles -> clock held %.2f GHz over %.2f ms; SQ_VALU_MFMA_BUSY_CYCLES %.4g / 1024 SIMDs = %.3g cycles -> matrix pipe %.0f %% busy'
         % (val['GRBM_GUI_ACTIVE'], cyc, cyc / ms / 1e6, ms, val['SQ_VALU_MFMA_BUSY_CYCLES'], val['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024, 100 * val['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc),
         'FETCH_SIZE %.4g KiB/launch = %.2f GB; WRITE_SIZE %.4g KiB = %.2f GB' % (val['FETCH_SIZE'], fetch / 1e9, val['WRITE_SIZE'], write / 1e9),
