@@ -1,4 +1,11 @@
-// gmm_score_split.hip -- GMM scoring with f32-accurate products on the bf16 matrix pipe (gfx950).
+// gmm_score_split.hip -- GMM scoring with f32-accurate products on the bf16 / f16 matrix pipe (gfx950).
+//
+// Three kernels, one idea (split every f32 operand into exact low-precision pieces, keep the cross products that matter):
+//   gmm_score_split_kernel      three bf16 pieces, six products                        PCL_SCORE_VARIANT=4
+//   gmm_score_split16_kernel    two f16 pieces, three products; FOLD = false: constants on one extra bf16 MFMA (5),
+//                               FOLD = true: constants in the spare K slot of the f16 passes (7, the default)
+//   gmm_score_split16x_kernel   the two-piece f16 scheme on 16x16x32 MFMAs, one K axis     (6)
+// The text below introduces the scheme on the bf16 kernel; each of the others starts with what it changes.
 //
 // Same reference rows as gmm_score.hip (A1/A4/A6: util.py:20-31, Clustering.py:740-767, LHMM.py:163-187) and the
 // same contraction as gmm_score_mfma.hip:
