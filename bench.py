@@ -13,14 +13,19 @@ belongs to the accumulate stage, measured separately under "extra").
 
 Inputs (frames, model, batch descriptors) are resident in HBM before the timed region.  Timing:
 barrier + device sync on both sides of exactly K steps, MAX over ranks; rank 0 prints ONE JSON line.
-Multi-GPU: one process per GPU (launched by torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from
-the env).  The barrier / max / RCCL-id broadcast go over a small TCP control plane
-(poccala_amd.distributed.Control) so that the GPU processes never import torch, whose wheel bundles a second
-HIP runtime; the GPU work goes through libpoccala_hip.so and RCCL.
+Multi-GPU: one process per GPU.  Launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the
+env), or by itself: `python bench.py --gpus N` with no launcher env spawns N rank processes (subprocess, before
+anything touches HIP; the parent never does), waits for them and exits non-zero if any of them failed.  The barrier /
+max / RCCL-id broadcast go over a small authenticated TCP control plane (poccala_amd.distributed.Control) so that the
+GPU processes never import torch, whose wheel bundles a second HIP runtime; the GPU work goes through
+libpoccala_hip.so and RCCL.
 """
 import argparse
 import json
 import os
+import secrets
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,9 +56,45 @@ def parse():
     p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
     p.add_argument('--traffic-bytes', type=float, default=None,
-                   help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass; default: the figure '
-                        'committed in profiles/r01_bench_summary.txt (FETCH_SIZE + WRITE_SIZE passes, tools/gpu_profile.sh)')
+                   help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md '
+                        'prescribes (2 x FETCH_SIZE for the wide streaming reads + WRITE_SIZE); default: the figure committed in '
+                        'profiles/ (tools/gpu_profile.sh)')
+    p.add_argument('--payload', default='f64', choices=['f64', 'f32'], help='wire format of the E-step exchange measured under "extra"')
     return p.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` without a launcher: spawn the N ranks ourselves.
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """The parent never imports poccala_amd (no HIP call here): it starts one child per rank with the launcher env
+    torch.distributed.run would give it, passes the children's stdout through (rank 0 prints the JSON line), and
+    returns non-zero if any child failed (the others are then terminated by PID)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    token = secrets.token_hex(16)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), POCCALA_CTRL_TOKEN=token)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p_ in list(pending):
+            code = p_.poll()
+            if code is None:
+                continue
+            pending.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:          # a failed rank would leave the others waiting at a barrier
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 # ------------------------------------------------------------------------------------------------
@@ -157,31 +198,53 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
                                 'of scoring + one faithful forward/backward lattice per core, scaled to frames/s over %d cores' % (len(jobs_v[0][1]), cores))
 
 
+# per scoring kernel: name, the peak its arithmetic is priced against, and what that peak means
+KERNELS = {
+    0: ('gmm_score_kernel<39,2,32,double>', FP32_VECTOR_PEAK_TFLOPS / 2, 'f64 parity mode on the VALU (78.6 TFLOP/s f64 vector peak)'),
+    1: ('gmm_score_kernel<39,3,64,float>', FP32_VECTOR_PEAK_TFLOPS, 'f32 VALU kernel (PCL_SCORE_VARIANT=1); peak = 157.3 TFLOP/s f32 vector'),
+    3: ('gmm_score_mfma_kernel<39,2>', FP32_VECTOR_PEAK_TFLOPS,
+        'quadratic form on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3); peak = 157.3 TFLOP/s '
+        'dense f32 MFMA (= f32 vector peak)'),
+    4: ('gmm_score_split_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 6,
+        'quadratic form of the diagonal Gaussians as an f32-ACCURATE contraction on the bf16 matrix pipe: every f32 operand '
+        'is the exact sum of three bf16 pieces and six of the nine cross products are kept (dropped terms < 2^-24 relative; '
+        'measured error vs float64 at or below the exact f32 FMA chain, same parity tolerances), f32 accumulate, '
+        'log-sum-exp on the VALU.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; peak = '
+        '2516.6 TFLOP/s dense bf16 MFMA / 6 products per f32-accurate product = 419.4 (the f32-input MFMA peak is 157.3); '
+        'the kernel executes 6 x 2(2D+2) = 960 bf16 MFMA flops per Gaussian: see executed_mfma_tflops'),
+    5: ('gmm_score_split16_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 3,
+        'quadratic form of the diagonal Gaussians as an f32-class contraction on the f16 matrix pipe: every f32 operand is '
+        'scaled by an exact power of two per (state, feature) and written as the sum of two f16 pieces (22 significand '
+        'bits), three of the four cross products are kept, f32 accumulate; the constant, the log-sum-exp reference and '
+        'log-zero ride one exact three-piece bf16 MFMA per tile; tiles whose scaled features leave the f16 range are '
+        'rescored by the direct-form kernel in the same call.  Measured |d ln b| vs float64 2.5e-5 at |ln b| ~ 85 (f32 FMA '
+        'chain 1.0e-5), same parity tolerances.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; '
+        'peak = 2516.6 TFLOP/s dense f16 MFMA / 3 products per f32-class product = 838.9 (f32-input MFMA peak: 157.3); '
+        'the kernel executes 16 MFMAs of 32x32x16 per 1024 Gaussians = 512 MFMA flops per Gaussian: see '
+        'executed_mfma_tflops.  On random operands the chip holds ~1.84 GHz under this kernel (2.4 GHz spec), '
+        'matrix pipe 60 % busy (profiles/)'),
+}
+KERNELS[7] = ('gmm_score_split16_kernel<39,2,true>', BF16_MFMA_PEAK_TFLOPS / 3,
+              KERNELS[5][2].replace('the constant, the log-sum-exp reference and log-zero ride one exact three-piece bf16 MFMA per tile',
+                                    'the constant (relative to a per-state K0 added back in f64), the log-sum-exp reference and log-zero ride '
+                                    'in the spare K slot of the f16 passes')
+              .replace('16 MFMAs of 32x32x16 per 1024 Gaussians = 512 MFMA flops', '15 MFMAs of 32x32x16 per 1024 Gaussians = 480 MFMA flops')
+              .replace('2.5e-5', '1.5e-5'))
+KERNELS[6] = ('gmm_score_split16x_kernel<39>', BF16_MFMA_PEAK_TFLOPS / 3, KERNELS[5][2] + ' (16x16x32 MFMA shape, constants in f16 on one K axis of 256)')
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
-    from poccala_amd import Engine, PCL_F32, PCL_F64, synth
-    from poccala_amd.engine import make_sentence_batch
-    eng = Engine(int(os.environ.get('POCCALA_DEVICE', local)))   # override only for single-GPU rehearsals of the N > 1 path
-    # control plane: a few tiny host-side exchanges over TCP (poccala_amd.distributed.Control), no torch in
-    # the GPU processes; the statistics themselves travel over RCCL inside the library.
-    from poccala_amd.distributed import Control
-    use_dist = (world > 1 or bool(os.environ.get('POCCALA_FORCE_DIST'))) and not os.environ.get('POCCALA_NO_RCCL')
-    # FORCE_DIST: exercise RCCL at world 1; NO_RCCL: rehearse the N > 1 control flow with all ranks on one GPU
-    ctl = Control(rank, world)
-
-    def barrier():
-        ctl.barrier()
-
-    P = PCL_F32 if args.precision == 'f32' else PCL_F64
+    from poccala_amd import synth
+    P_name = args.precision
     cfg = dict(synth.CONFIGS[args.workload])
     if args.utts:
         cfg['U'] = args.utts
@@ -190,18 +253,47 @@ def main():
     nb = max(1, args.batches)
     frames, lens_all, begin_all = synth.make_frames(cfg['U'] * nb, cfg['T'], cfg['D'], seed=1000 * rank)      # each rank its own shard
     labels_all = synth.make_labels(cfg['U'] * nb, cfg['L'], cfg['units'], seed=2 + 7919 * rank)
+    lens, begin, labels = lens_all[:cfg['U']], begin_all[:cfg['U']], labels_all[:cfg['U']]      # batch 0: accounting and the CPU leg
+
+    # CPU baseline leg first: its worker pool is forked BEFORE this process initialises HIP
+    cpu = None
+    if args.cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels)
+
+    from poccala_amd import Engine, PCL_F32, PCL_F64
+    from poccala_amd.engine import device_count
+    P = PCL_F32 if P_name == 'f32' else PCL_F64
+    ndev = device_count()
+    dev = int(os.environ.get('POCCALA_DEVICE', local))
+    shared = False
+    if dev >= ndev and ndev > 0 and os.environ.get('POCCALA_SHARE_DEVICE'):
+        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: several ranks per device, and the host
+        # transport in place of RCCL (which refuses two ranks on one device)
+        dev, shared = dev % ndev, True
+    elif dev >= ndev:
+        sys.exit('bench.py: rank %d needs HIP device %d but %d are visible (POCCALA_SHARE_DEVICE=1 rehearses several ranks per device)' % (rank, dev, ndev))
+    eng = Engine(dev)
+    eng.enable_timing(True)
+    # control plane: a few tiny host-side exchanges over TCP (poccala_amd.distributed.Control), no torch in
+    # the GPU processes; the statistics themselves travel over RCCL inside the library.
+    from poccala_amd.distributed import Control
+    ctl = Control(rank, world)
+    barrier = ctl.barrier
+
     eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
     eng.load_frames(frames)
     batches = []
     for k in range(nb):
         lo, hi = cfg['U'] * k, cfg['U'] * (k + 1)
-        bt, ns = make_sentence_batch(eng, labels_all[lo:hi], lens_all[lo:hi], begin_all[lo:hi], trans)
-        batches.append(bt)
-        if k == 0:
-            n_states = ns
-    lens, begin, labels = lens_all[:cfg['U']], begin_all[:cfg['U']], labels_all[:cfg['U']]      # batch 0: accounting and the CPU leg
-    if use_dist:
-        eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
+        batches.append(eng.label_batch(labels_all[lo:hi], lens_all[lo:hi], begin_all[lo:hi]))     # AcousticModel.embedded, in the library
+    n_states = batches[0].N
+    if world > 1 or os.environ.get('POCCALA_FORCE_DIST'):          # FORCE_DIST: exercise RCCL at world 1
+        if shared or os.environ.get('POCCALA_NO_RCCL'):
+            eng.comm_init_host(rank, world, ctl.allgather_bytes)
+        else:
+            eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
+    comm = eng.comm_info()
     t_setup = time.perf_counter() - t_setup
 
     step_no = [0]
@@ -243,120 +335,37 @@ def main():
     score_variant = int(os.environ.get('PCL_SCORE_VARIANT', '7'))
     if P == PCL_F64:
         score_variant = 0
-    # per scoring kernel: name, the peak its arithmetic is priced against, and what that peak means
-    KERNELS = {
-        0: ('gmm_score_kernel<39,2,32,double>', FP32_VECTOR_PEAK_TFLOPS / 2, 'f64 parity mode on the VALU (78.6 TFLOP/s f64 vector peak)'),
-        1: ('gmm_score_kernel<39,3,64,float>', FP32_VECTOR_PEAK_TFLOPS, 'f32 VALU kernel (PCL_SCORE_VARIANT=1); peak = 157.3 TFLOP/s f32 vector'),
-        3: ('gmm_score_mfma_kernel<39,2>', FP32_VECTOR_PEAK_TFLOPS,
-            'quadratic form on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3); peak = 157.3 TFLOP/s '
-            'dense f32 MFMA (= f32 vector peak)'),
-        4: ('gmm_score_split_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 6,
-            'quadratic form of the diagonal Gaussians as an f32-ACCURATE contraction on the bf16 matrix pipe: every f32 operand '
-            'is the exact sum of three bf16 pieces and six of the nine cross products are kept (dropped terms < 2^-24 relative; '
-            'measured error vs float64 at or below the exact f32 FMA chain, same parity tolerances), f32 accumulate, '
-            'log-sum-exp on the VALU.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; peak = '
-            '2516.6 TFLOP/s dense bf16 MFMA / 6 products per f32-accurate product = 419.4 (the f32-input MFMA peak is 157.3); '
-            'the kernel executes 6 x 2(2D+2) = 960 bf16 MFMA flops per Gaussian: see executed_mfma_tflops'),
-        5: ('gmm_score_split16_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 3,
-            'quadratic form of the diagonal Gaussians as an f32-class contraction on the f16 matrix pipe: every f32 operand is '
-            'scaled by an exact power of two per (state, feature) and written as the sum of two f16 pieces (22 significand '
-            'bits), three of the four cross products are kept, f32 accumulate; the constant, the log-sum-exp reference and '
-            'log-zero ride one exact three-piece bf16 MFMA per tile; tiles whose scaled features leave the f16 range are '
-            'rescored by the direct-form kernel in the same call.  Measured |d ln b| vs float64 2.5e-5 at |ln b| ~ 85 (f32 FMA '
-            'chain 1.0e-5), same parity tolerances.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; '
-            'peak = 2516.6 TFLOP/s dense f16 MFMA / 3 products per f32-class product = 838.9 (f32-input MFMA peak: 157.3); '
-            'the kernel executes 16 MFMAs of 32x32x16 per 1024 Gaussians = 512 MFMA flops per Gaussian: see '
-            'executed_mfma_tflops.  On random operands the chip holds ~1.84 GHz under this kernel (2.4 GHz spec), '
-            'matrix pipe 60 % busy (profiles/)'),
-    }
-    KERNELS[7] = ('gmm_score_split16_kernel<39,2,true>', BF16_MFMA_PEAK_TFLOPS / 3,
-                  KERNELS[5][2].replace('the constant, the log-sum-exp reference and log-zero ride one exact three-piece bf16 MFMA per tile',
-                                        'the constant (relative to a per-state K0 added back in f64), the log-sum-exp reference and log-zero ride '
-                                        'in the spare K slot of the f16 passes')
-                  .replace('16 MFMAs of 32x32x16 per 1024 Gaussians = 512 MFMA flops', '15 MFMAs of 32x32x16 per 1024 Gaussians = 480 MFMA flops')
-                  .replace('2.5e-5', '1.5e-5'))
-    KERNELS[6] = ('gmm_score_split16x_kernel<39>', BF16_MFMA_PEAK_TFLOPS / 3, KERNELS[5][2] + ' (16x16x32 MFMA shape, constants in f16 on one K axis of 256)')
     score_kernel_name, score_peak, score_note = KERNELS.get(score_variant, KERNELS[1])
     pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
     flop_per_launch = pairs * cfg['M'] * (3 * cfg['D'] + 4)
     score_avg_ms = score_ms / max(score_n, 1)
     achieved = flop_per_launch / (score_avg_ms * 1e-3) / 1e12 if score_n else None
-    # algorithmic HBM bytes per scoring launch: frames read once per scored state row (4D) is an upper
-    # bound served from L2; the honest algorithmic figure is frames once + parameters once + B written once
+    # algorithmic HBM bytes per scoring launch: frames once + parameters of the states with work once + B written once
     alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + pairs * 8
-    traffic = args.traffic_bytes
+    traffic, traffic_raw = args.traffic_bytes, None
     if traffic is None and args.workload == 'C4shard' and not args.utts and P == PCL_F32 and score_variant == 7:
-        try:   # PMC counters cannot be read from inside the run: use the committed separate-pass measurement
-            for line in open(os.path.join(ROOT, 'profiles', 'r01_bench_summary.txt')):
-                if line.startswith('traffic_bytes for bench.py'):
-                    traffic = float(line.split(':')[1])
-        except OSError:
-            pass
+        traffic, traffic_raw = committed_traffic()
     roofline = dict(bound='mfma', achieved=achieved, peak=score_peak, unit='TFLOP/s',
                     frac=(achieved / score_peak) if achieved else None,
-                    traffic=traffic, traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_bench_summary.txt), per launch',
+                    traffic=traffic,
+                    traffic_source='separate rocprofv3 --pmc passes of this command (FETCH_SIZE; WRITE_SIZE), per launch of the scoring kernel, '
+                                   'corrected as MI355X_MICROARCH.md prescribes for gfx950: 2 x FETCH_SIZE (the parameter stream is 16-B-per-lane '
+                                   'global_load_lds, tallied at half its bytes) + WRITE_SIZE; raw counters in traffic_raw; summary in profiles/',
+                    traffic_raw=traffic_raw,
                     kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
-                    executed_mfma_tflops=(pairs * cfg['M'] * {4: 960, 5: 512, 6: 512, 7: 480}[score_variant] / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant in (4, 5, 6, 7) else None,
+                    executed_mfma_tflops=(pairs * cfg['M'] * {4: 960, 7: 480}[score_variant] / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant in (4, 7) else None,
                     frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
-                    note=score_note,
+                    note=score_note + '  SURVEY 8(d) priced this path against the 157.3 TFLOP/s FP32 vector roof; the contraction now runs on the '
+                                      'f16 matrix pipe, so that roof no longer applies (frac_of_f32_mfma_peak > 1) and peak is the f16 dense MFMA peak / 3.',
                     hbm_algorithmic_bytes_per_launch=alg_bytes,
                     hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_n else None,
                     fb_kernel_avg_ms=fb_ms / max(fb_n, 1))
 
     extra = None
     if args.extra:
-        # untimed-region extras: Viterbi forced alignment and the full E-step (accumulate + RCCL all-reduce)
-        eng.sync()
-        barrier()
-        batch = batches[0]
-        t1 = time.perf_counter()
-        batch.viterbi()
-        eng.sync()
-        t_vit = time.perf_counter() - t1
-        # what follows alignment in training scheme 1 (next row f2): per-frame unit and GMM-state assignment
-        ids = [np.repeat(np.asarray(lab, dtype=np.int32), 3) for lab in labels]
-        row_unit = [np.concatenate([[i[0]], i, [i[-1]]]).astype(np.int32) for i in ids]
-        t1 = time.perf_counter()
-        batch.regroup(row_unit, 3)
-        t_regroup = time.perf_counter() - t1
-        rg_ms, _ = eng.kernel_time('regroup')
-        eng.stats_zero()
-        eng.sync()
-        barrier()
-        t1 = time.perf_counter()
-        batch.score(P)
-        batch.forward_backward(fix_pi=False)
-        batch.accumulate(P)
-        eng.stats_allreduce()
-        eng.sync()
-        barrier()
-        t_estep = time.perf_counter() - t1
-        acc_ms, acc_n = eng.kernel_time('accumulate')
-        ar_ms, ar_n = eng.kernel_time('allreduce')
-        vit_ms, _ = eng.kernel_time('viterbi')
-        # M-step on the device (A15) and the PCIe legs the timed region excludes
-        t1 = time.perf_counter()
-        eng.mstep(1e-3)
-        eng.sync()
-        t_mstep = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        eng.load_frames(frames[:frames_per_rank])
-        t_h2d = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        batch.get('logp'); batch.get('gamma'); batch.get('ksai_nz')
-        t_d2h = time.perf_counter() - t1
-        extra = dict(viterbi_frames_per_s_per_gpu=frames_per_rank / t_vit, viterbi_kernel_ms=vit_ms,
-                     regroup_kernel_ms=rg_ms, regroup_call_ms=t_regroup * 1e3,
-                     estep_frames_per_s=total_frames / t_estep, estep_ms=t_estep * 1e3, accumulate_ms=acc_ms, allreduce_ms=ar_ms,
-                     mstep_ms=t_mstep * 1e3, frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
-                     pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),
-                     setup_s=t_setup)
-
-    cpu = None
-    if args.cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels)
+        extra = extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans)
 
     if rank == 0:
         info = eng.device_info()
@@ -374,23 +383,119 @@ def main():
                        'resident_batches': nb,
                        'pipeline': ('forward-backward of step k on a second HIP stream beside the scoring of step k+1 (steps alternate '
                                     'between %d resident batches)' % nb) if nb > 1 else 'score and forward-backward of a step serialise (one resident batch)',
-                       'arithmetic': 'f32 Gaussian scoring (two-piece f16 split products on the matrix pipe, f32 accumulate), f64 dynamic programming' if P == PCL_F32 else 'f64',
+                       'arithmetic': ('f32-CLASS Gaussian scoring: every operand as two f16 pieces (22 significand bits), three f16 MFMA products per '
+                                      'f32 product, f32 accumulate (measured |d ln b| vs float64 1.5e-5 at |ln b| ~ 85; the exact f32 chain gives '
+                                      '1.0e-5); f64 dynamic programming.  The strict-f32 kernel (v_mfma_f32_32x32x2_f32) is timed under extra.strict_f32'
+                                      ) if P == PCL_F32 else 'f64',
+                       'transport': comm['transport'], 'rccl_nranks': comm['rccl_nranks'],
                        'device': info['name'], 'cus': info['cus']},
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
         if extra:
             out['extra'] = extra
+            if extra.get('roofline_estep'):
+                out['roofline_estep'] = extra.pop('roofline_estep')
         if cpu:
             out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value'],
                                    'vs_blas_gemm_formulation': value / cpu['gemm_value']}
         print(json.dumps(out))
+        sys.stdout.flush()
+    barrier()
     for bt in batches:
         bt.close()
-    if use_dist:
-        eng._lib.pcl_comm_destroy(eng._ctx)
+    eng._lib.pcl_comm_destroy(eng._ctx)
     ctl.close()
     eng.close()
+
+
+def committed_traffic():
+    """HBM bytes per scoring launch from the committed PMC passes of this command (counters cannot be read from inside the
+    run): (corrected bytes, {'FETCH_SIZE_bytes', 'WRITE_SIZE_bytes', 'file'}) or (None, None)."""
+    for name in ('r02_bench_summary.txt', 'r01_bench_summary.txt'):
+        try:
+            fetch = write = None
+            for line in open(os.path.join(ROOT, 'profiles', name)):
+                if 'gmm_score_split16_kernel' in line and 'FETCH_SIZE' in line:
+                    fetch = float(line.split('per-dispatch=')[1]) * 1024.0            # rocprofv3 reports KiB
+                if 'gmm_score_split16_kernel' in line and 'WRITE_SIZE' in line:
+                    write = float(line.split('per-dispatch=')[1]) * 1024.0
+            if fetch is not None and write is not None:
+                return 2.0 * fetch + write, dict(FETCH_SIZE_bytes=fetch, WRITE_SIZE_bytes=write, file='profiles/' + name)
+        except (OSError, ValueError, IndexError):
+            pass
+    return None, None
+
+
+def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans):
+    """Untimed-region measurements: forced alignment, the full E-step with the statistics exchange and both M-steps, PCIe legs."""
+    from poccala_amd import PCL_F32, PCL_F64
+    barrier = ctl.barrier
+    world = ctl.world
+    eng.sync()
+    barrier()
+    batch = batches[0]
+    t1 = time.perf_counter()
+    batch.viterbi()
+    eng.sync()
+    t_vit = time.perf_counter() - t1
+    # what follows alignment in training scheme 1 (next row f2): per-frame unit and GMM-state assignment
+    ids = [np.repeat(np.asarray(lab, dtype=np.int32), 3) for lab in labels]
+    row_unit = [np.concatenate([[i[0]], i, [i[-1]]]).astype(np.int32) for i in ids]
+    t1 = time.perf_counter()
+    batch.regroup(row_unit, 3)
+    t_regroup = time.perf_counter() - t1
+    rg_ms, _ = eng.kernel_time('regroup')
+    vit_ms, _ = eng.kernel_time('viterbi')
+    # PCIe legs the timed region excludes (the whole resident frame matrix, per batch)
+    t1 = time.perf_counter()
+    eng.load_frames(frames)
+    t_h2d = (time.perf_counter() - t1) / len(batches)
+    # full E-step: score -> forward-backward -> GMM statistics + per-unit transition accumulators -> exchange
+    # (reduce-scatter by state range -> M-step on the owned states -> all-gather of the model) -> transition M-step
+    payload = PCL_F32 if args.payload == 'f32' else PCL_F64
+    for k in ('accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive', 'score', 'fb'):
+        eng.kernel_time(k)
+    eng.stats_zero()
+    eng.sync()
+    barrier()
+    t1 = time.perf_counter()
+    batch.score(P)
+    batch.forward_backward(fix_pi=False)
+    batch.accumulate(P)
+    batch.accumulate_hmm()
+    eng.sync()
+    t_local = time.perf_counter() - t1
+    eng.em_exchange(1e-3, payload, True)
+    eng.sync()
+    t_rank = time.perf_counter() - t1
+    barrier()
+    t_estep = time.perf_counter() - t1
+    kt = {k: eng.kernel_time(k)[0] for k in ('accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive', 'score', 'fb')}
+    per_rank = ctl.allgather(dict(rank=ctl.rank, estep_local_ms=t_local * 1e3, estep_ms=t_rank * 1e3, exchange_ms=(t_rank - t_local) * 1e3,
+                                  reduce_scatter_ms=kt['reduce_scatter'], mstep_owned_ms=kt['mstep_owned'], all_gather_ms=kt['all_gather'],
+                                  derive_ms=kt['derive'], accumulate_ms=kt['accumulate'], hmm_acc_ms=kt['hmm_acc']))
+    t1 = time.perf_counter()
+    batch.get('logp'); batch.get('gamma'); eng.hmm_acc_download()
+    t_d2h = time.perf_counter() - t1
+    # E-step accounting (SURVEY 8d): accumulate = recompute + two weighted moments = M (7D + 8) flop per (frame, state) pair
+    acc_ms = kt['accumulate']
+    acc_flop = pairs * cfg['M'] * (7 * cfg['D'] + 8)
+    extra = dict(viterbi_frames_per_s_per_gpu=frames_per_rank / t_vit, viterbi_kernel_ms=vit_ms,
+                 regroup_kernel_ms=rg_ms, regroup_call_ms=t_regroup * 1e3,
+                 estep_frames_per_s=total_frames / t_estep, estep_ms=t_estep * 1e3, accumulate_ms=acc_ms, hmm_acc_ms=kt['hmm_acc'],
+                 exchange=dict(payload=args.payload, per_rank=per_rank,
+                               what='reduce-scatter of the GMM statistics by state range -> GMM.update_param on the owned J/N states -> '
+                                    'all-gather of (mean, var, weight) -> layouts re-derived; per-unit transition accumulators merged by max + sum '
+                                    'all-reduces, transition M-step on every rank; one rank: the M-step alone'),
+                 frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
+                 pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),
+                 setup_s=t_setup,
+                 roofline_estep=dict(kernel='gmm_accumulate_split_kernel<39>', ms=acc_ms, bound='mfma',
+                                     flop_per_launch=acc_flop, algorithmic_tflops=acc_flop / (acc_ms * 1e-3) / 1e12 if acc_ms else None,
+                                     note='bench features are random N(0,1): flat posteriors, ~78 % of the (frame, state) pairs survive the exact '
+                                          'underflow compaction; aligned speech is peaked (see estep_peaked)'))
+    return extra
 
 
 if __name__ == '__main__':

@@ -91,6 +91,11 @@ int pcl_device_info(pcl_ctx *ctx, char *name, int cap, int *cus, size_t *hbm_byt
  * stream around every launch: which = "score" | "fb" | "viterbi" | "accumulate" | "allreduce".
  * Returns the summed milliseconds and the number of launches, then resets the group. */
 int pcl_kernel_time(pcl_ctx *ctx, const char *which, float *total_ms, int *launches);
+/* The events behind pcl_kernel_time are recorded only while timing is on (default off, or env PCL_TIMERS=1): a
+ * training run that never queries them pays nothing and keeps nothing.  Turning it off drops pending events. */
+int pcl_timing_enable(pcl_ctx *ctx, int on);
+/* HIP devices visible to this process (0 without a GPU); does not create a context. */
+int pcl_device_count(int *n);
 
 /* ------------------------------------------------------------------ model
  * Replaces Clustering.GMM parameter state (T2: mean (M,D), covariance (M,D,D) of which only the
@@ -151,6 +156,38 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back);
  * (:614-625) and __get_gmmdata (:629-644) do.  Needs pcl_batch_viterbi first.  Synchronous. */
 int pcl_batch_regroup(pcl_batch *b, const int32_t *row_unit, int gmm_num, int32_t *frame_unit, int32_t *frame_k);
 
+/* ----------------------------------------------------------------- unit inventory and label-built batches
+ * The reference builds, PER UTTERANCE, one LHMM per label unit (AcousticModel.init_unit / init_parameter,
+ * AcousticModel.py:164-240: transmat (S,S), S-2 GMM states between an entry and an exit VirtualState) and glues them
+ * into a sentence HMM (AcousticModel.embedded, :957-1014).  Here the inventory is uploaded once:
+ *   trans      [n_units][S][S]  unit transition matrices (LHMM.transmat), linear
+ *   log_trans  the same through np.log on the caller's side (bit-exact Viterbi is defined on those values; NULL:
+ *              this library's libm log is used)
+ * Unit i owns the GMM states i*(S-2) .. i*(S-2)+S-3 of the uploaded model (pcl_model_upload with J = n_units*(S-2)). */
+int pcl_units_upload(pcl_ctx *ctx, int n_units, int S, const double *trans, const double *log_trans);
+int pcl_units_download(pcl_ctx *ctx, double *trans /* [n_units][S][S], after pcl_mstep_transitions */);
+
+/* A7 for U utterances at once: labels = concatenated unit ids, label_len[u] of them per utterance.  Builds what
+ * AcousticModel.embedded builds -- N_u = (S-2) L_u + 2 states, the banded transition structure (embedded_transmat
+ * :979-989), the row -> GMM state map (embedded_prob :990-1001), uniform pi (embedded_pi :1003-1006; logpi[u] =
+ * np.log(1/N_u) from the caller, NULL: libm) -- and keeps the label structure with the batch for pcl_batch_accumulate_hmm.
+ * Equivalent to pcl_batch_create + pcl_batch_set_transitions + pcl_batch_set_states on host-built matrices. */
+int pcl_batch_create_labels(pcl_ctx *ctx, int U, const int32_t *label_len, const int32_t *labels, const int32_t *T,
+                            const int64_t *frame_begin, const double *logpi, pcl_batch **out);
+/* Rebuild the batch's transitions from the CURRENT unit inventory (after pcl_mstep_transitions / pcl_em_exchange). */
+int pcl_batch_refresh_transitions(pcl_batch *b);
+
+/* A12, HMM half: LHMM.update_acc (LHMM.py:473-500) + LHMM.add_acc (:149-161) for every utterance x label position of
+ * the batch: the (S-2,S) block of un-normalised ln xi and the (S-2,) slice of ln gamma (quirk Q5) of each position are
+ * log-sum-exp'ed into context-resident per-unit accumulators ksai_acc [n_units][S-2][S], gamma_acc [n_units][S-2]
+ * (log domain, initial -inf, LHMM.py:84-85).  pcl_stats_zero resets them too.  Needs pcl_batch_forward_backward. */
+int pcl_batch_accumulate_hmm(pcl_batch *b);
+int pcl_hmm_acc_zero(pcl_ctx *ctx);
+int pcl_hmm_acc_download(pcl_ctx *ctx, double *ksai_acc, double *gamma_acc);
+/* A15, transition half: LHMM.update_param (LHMM.py:519-520): transmat[1:-1,:] = exp(ksai_acc - gamma_acc[:,None]) for
+ * every unit that occurred; a unit that never occurred keeps its matrix (the reference would write NaN). */
+int pcl_mstep_transitions(pcl_ctx *ctx);
+
 /* Copy a result to a caller buffer (layouts in pcl_get_what). */
 int pcl_batch_get(pcl_batch *b, int what, void *host);
 
@@ -200,7 +237,23 @@ int pcl_mfcc(pcl_ctx *ctx, int U, const double *signal, const int64_t *sig_off, 
  * id_bytes is a 128-byte ncclUniqueId made by rank 0 and distributed by the caller. */
 int pcl_comm_unique_id(void *id_bytes128);
 int pcl_comm_init(pcl_ctx *ctx, int rank, int nranks, const void *id_bytes128);
+/* Rehearsal transport for several ranks on ONE device (RCCL refuses that: "Duplicate GPU detected"): every collective
+ * becomes an all-gather of host bytes through `fn` (returns 0 on success; recv_all = nranks * bytes, in rank order).
+ * Same orchestration code as the RCCL path; refuses exchanges beyond 256 MiB.  Not a production path. */
+typedef int (*pcl_allgather_fn)(void *user, const void *send, size_t bytes, void *recv_all);
+int pcl_comm_init_host(pcl_ctx *ctx, int rank, int nranks, pcl_allgather_fn fn, void *user);
+/* transport: 0 none, 1 RCCL, 2 host rehearsal; rccl_nranks = ncclCommCount (0 unless transport 1).  NULLs are skipped. */
+int pcl_comm_info(pcl_ctx *ctx, int *rank, int *nranks, int *transport, int *rccl_nranks);
+/* Sum all-reduce of all GMM statistics (f64) + log-sum-exp merge of the per-unit HMM accumulators: afterwards every
+ * rank holds the global statistics (then pcl_mstep on every rank).  Kept for parity checks; the E-step uses: */
 int pcl_stats_allreduce(pcl_ctx *ctx);
+/* The E-step exchange + M-step: reduce-scatter of the GMM statistics by state range -> GMM.update_param
+ * (Clustering.py:682-693) on the owned J/nranks states -> all-gather of (mean, var, weight) -> every layout re-derived;
+ * the per-unit HMM accumulators are merged by max + sum all-reduces and, if update_transitions, LHMM.update_param's
+ * transition update (LHMM.py:519-520) follows.  payload: PCL_F64, or PCL_F32 = half the bytes on the wire (sums and
+ * parameters rounded to f32 in flight; every rank continues from the same rounded model).  With one rank and no
+ * communicator this is pcl_mstep (+ pcl_mstep_transitions).  Synchronous at return. */
+int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_transitions);
 int pcl_comm_destroy(pcl_ctx *ctx);
 
 #ifdef __cplusplus

@@ -13,12 +13,10 @@ import numpy as np
 
 from ..Exceptions import NullLog
 from .._lib import PCL_F32, PCL_F64
-from ..engine import make_sentence_batch
 from ..runtime import default_engine
 from ..StatisticalModel.Clustering import Clustering
 from ..StatisticalModel.DataInitialization import DataInitialization
 from ..StatisticalModel.LHMM import LHMM
-from ..StatisticalModel.util import matrix_log_sum_exp
 
 
 class AcousticModel(DataInitialization):
@@ -150,12 +148,13 @@ class AcousticModel(DataInitialization):
     def _sentence_batch(self, labels, data_list, unit_hmms, engine):
         units, idx, (mean, var, w), trans = self._model_arrays(unit_hmms)
         engine.load_model(mean, var, w)
+        engine.load_units(np.stack(trans))
         lens = np.array([len(d) for d in data_list], dtype=np.int32)
         begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
         engine.load_frames(np.concatenate([np.asarray(d) for d in data_list], axis=0))
-        unit_ids = [np.array([idx[u] for u in lab]) for lab in labels]
-        b, n = make_sentence_batch(engine, unit_ids, lens, begin, trans, self.__state_num)
-        return b, n, units, idx
+        unit_ids = [np.array([idx[u] for u in lab], dtype=np.int32) for lab in labels]
+        b = engine.label_batch(unit_ids, lens, begin)        # AcousticModel.embedded for every utterance, in the library
+        return b, b.N, units, idx
 
     def align_batch(self, labels, data_list, unit_hmms, precision=PCL_F64, engine=None):
         """Forced alignment of many utterances at once (call stack C, AcousticModel.py:723-768):
@@ -175,34 +174,27 @@ class AcousticModel(DataInitialization):
 
     def estep_batch(self, labels, data_list, unit_hmms, fix_code=0, precision=PCL_F32, engine=None):
         """E-step of many utterances at once (call stack B, AcousticModel.py:884-916).  Returns
-        (stats, hmm_acc): `stats` = linear-domain GMM statistics per state (engine.stats_download,
+        (stats, hmm_acc, logp): `stats` = linear-domain GMM statistics per state (engine.stats_download,
         states ordered unit-major over sorted(unit_hmms)); `hmm_acc[unit]` = (ksai_acc (S-2,S),
-        gamma_acc (S-2,)) log-domain, merged over every occurrence as LHMM.add_acc does."""
+        gamma_acc (S-2,)) log-domain, merged over every occurrence as LHMM.add_acc does (LHMM.py:149-161,
+        473-500).  Everything per utterance x label position runs in the library: the sentence HMMs are built
+        from the labels there (pcl_batch_create_labels) and the per-unit merge is a kernel
+        (pcl_batch_accumulate_hmm); nothing here loops over utterances."""
         engine = engine or default_engine()
-        s = self.__state_num
-        e = s - 2
         b, n, units, idx = self._sentence_batch(labels, data_list, unit_hmms, engine)
         b.score(precision)
         b.forward_backward(fix_pi=bool(fix_code & 1))
+        engine.stats_zero()                       # GMM statistics and the per-unit HMM accumulators
         stats = None
         if not fix_code & 2:
-            engine.stats_zero()
             b.accumulate(precision)
             stats = engine.stats_download()
         hmm_acc = {}
         if not fix_code & 4:
-            nz, ga = b.get('ksai_nz'), b.get('gamma')          # only the stored transitions cross PCIe
-            parts = {u: ([], []) for u in units}
-            for uu, lab in enumerate(labels):
-                dense = np.full((n[uu], n[uu]), -np.inf)
-                dense[b.nz_index[uu]] = nz[uu]
-                kv, gv = dense[1:-1, :], ga[uu][1:-1]
-                for pos, unit in enumerate(lab):
-                    parts[unit][0].append(kv[pos * e:(pos + 1) * e, pos * e:pos * e + s])
-                    parts[unit][1].append(gv[pos * e:(pos + 1) * e].reshape(1, -1))
-            for unit, (kl, gl) in parts.items():
-                if kl:
-                    hmm_acc[unit] = (matrix_log_sum_exp(kl, axis_x=e), matrix_log_sum_exp(gl, axis_x=1).reshape(-1))
+            b.accumulate_hmm()
+            ks, ga = engine.hmm_acc_download()
+            seen = np.bincount(b.labels, minlength=len(units)) > 0
+            hmm_acc = {unit: (ks[i], ga[i]) for i, unit in enumerate(units) if seen[i]}
         logp = b.get('logp')
         b.close()
         return stats, hmm_acc, logp
@@ -289,6 +281,10 @@ class AcousticModel(DataInitialization):
         for ui, unit in enumerate(units):
             hmm = unit_hmms[unit]
             touched = False
+            # the files hold THIS batch's accumulators only (the reference writes one set per utterance from fresh unit
+            # objects, AcousticModel.py:897-913): start from ln 0, or a second call would save batch 1 + batch 2 and the
+            # merge (init_acc) would count batch 1 twice
+            hmm.reset_acc()
             if unit in hmm_acc:
                 hmm.add_acc(hmm_acc[unit][0], hmm_acc[unit][1])
                 touched = True
@@ -296,12 +292,12 @@ class AcousticModel(DataInitialization):
                 with np.errstate(divide='ignore'):
                     for k in range(e):
                         j = ui * e + k
-                        if stats['alpha_acc'][j] > 0:
-                            g = hmm.profunction[1 + k]
-                            g.acc = np.log(stats['acc'][j])
-                            g.alpha_acc = float(np.log(stats['alpha_acc'][j]))
-                            g.mean_acc = np.log(stats['mean_acc'][j])
-                            g.covariance_acc = list(np.log(stats['cov_acc'][j]))
-                            touched = True
+                        g = hmm.profunction[1 + k]
+                        g.acc = np.log(stats['acc'][j])                 # ln 0 = -inf for a state no frame reached
+                        g.alpha_acc = float(np.log(stats['alpha_acc'][j]))
+                        g.mean_acc = np.log(stats['mean_acc'][j])
+                        g.covariance_acc = list(np.log(stats['cov_acc'][j]))
+                        touched = touched or stats['alpha_acc'][j] > 0
             if touched:
                 self.save_acc(unit, hmm)
+                hmm.reset_acc()

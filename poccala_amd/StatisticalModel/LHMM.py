@@ -103,6 +103,11 @@ class LHMM(DataInitialization):
         self.__gamma_acc = matrix_log_sum_exp([self.__gamma_acc.reshape(1, -1), gamma_value.reshape(1, -1)],
                                               axis_x=1).reshape(-1)
 
+    def reset_acc(self):
+        """Accumulators back to ln 0 (their state after __init__, LHMM.py:84-85)."""
+        self.__ksai_acc = np.full((self.__statesnum - 2, self.__statesnum), -np.inf)
+        self.__gamma_acc = np.full((self.__statesnum - 2,), -np.inf)
+
     # ------------------------------------------------------------------ A6 cal_observation_pro (LHMM.py:163-187)
     def cal_observation_pro(self, data, data_t, normalize=False, standard=False, precision=PCL_F64):
         if standard:

@@ -46,6 +46,19 @@ PROTOTYPES = {
     'pcl_model_conditioning': (_i, [_vp, _vp, _vp]),
     'pcl_batch_regroup': (_i, [_vp, _vp, _i, _vp, _vp]),
     'pcl_mfcc': (_i, [_vp, _i, _vp, _vp, _i, _d, _d, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_int64]),
+    'pcl_timing_enable': (_i, [_vp, _i]),
+    'pcl_device_count': (_i, [C.POINTER(_i)]),
+    'pcl_units_upload': (_i, [_vp, _i, _i, _vp, _vp]),
+    'pcl_units_download': (_i, [_vp, _vp]),
+    'pcl_batch_create_labels': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    'pcl_batch_refresh_transitions': (_i, [_vp]),
+    'pcl_batch_accumulate_hmm': (_i, [_vp]),
+    'pcl_hmm_acc_zero': (_i, [_vp]),
+    'pcl_hmm_acc_download': (_i, [_vp, _vp, _vp]),
+    'pcl_mstep_transitions': (_i, [_vp]),
+    'pcl_comm_init_host': (_i, [_vp, _i, _i, _vp, _vp]),
+    'pcl_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'pcl_em_exchange': (_i, [_vp, _d, _i, _i]),
     'pcl_comm_unique_id': (_i, [_vp]),
     'pcl_comm_init': (_i, [_vp, _i, _i, _vp]),
     'pcl_stats_allreduce': (_i, [_vp]),
@@ -60,6 +73,8 @@ class PoccalaHipError(RuntimeError):
         super().__init__('libpoccala_hip: %s (status %d)' % (msg, code))
         self.code = code
 
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)   # pcl_allgather_fn
 
 _lib = None
 

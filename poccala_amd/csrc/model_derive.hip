@@ -346,19 +346,27 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
 // Clustering.GMM.update_param, one thread per (state, mixture, dim)
 __global__ void mstep_kernel(const double *__restrict__ st_acc, const double *__restrict__ st_alpha,
                              const double *__restrict__ st_mean, const double *__restrict__ st_cov, int J, int M, int Mpad,
-                             int D, int Dhost, double bias, double floor_var, double *__restrict__ mean64,
-                             double *__restrict__ var64, double *__restrict__ w64) {
+                             int D, int Dhost, double bias, double floor_var, int j_lo, int j_hi,
+                             double *__restrict__ mean64, double *__restrict__ var64, double *__restrict__ w64) {
     const long long total = (long long)J * Mpad * D;
     for (long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
         const int d = (int)(gid % D);
         const long long jm = gid / D;
         const int m = (int)(jm % Mpad), j = (int)(jm / Mpad);
         if (m >= M || d >= Dhost) continue;
-        const double a = st_acc[jm];
-        if (d == 0) w64[jm] = a / st_alpha[j];                   // Clustering.py:685
+        if (j < j_lo || j >= j_hi) continue;                     // multi-GPU: a rank re-estimates the states it owns
+        const double a = st_acc[jm], al = st_alpha[j];
+        // A state no frame reached (alpha_acc = 0) keeps its model; a mixture of a seen state whose occupancy is exactly
+        // 0 -- every gamma_t(j,m) flushed to zero in the f32 accumulate, or pruned at 2^-150 -- gets weight 0 (= acc /
+        // alpha_acc) and keeps its mean and variance: 0/0 would make it NaN, one NaN mixture turns the state's whole
+        // log-sum-exp NaN and an all-reduce spreads it to every rank.  (The reference's log-domain accumulators stay
+        // finite for such a mixture and give it a vanishing weight, Clustering.py:685.)
+        if (!(al > 0.0)) continue;
+        if (d == 0) w64[jm] = a / al;                            // Clustering.py:685
+        if (!(a > 0.0)) continue;
         mean64[gid] = st_mean[gid] / a - bias;                   // :686
         double c = st_cov[gid] / a;                              // :688
-        if (c < floor_var) c = floor_var;                        // :689-692
+        if (!(c >= floor_var)) c = floor_var;                    // :689-692 (also catches a NaN from upstream)
         var64[gid] = c;
     }
 }
@@ -445,11 +453,19 @@ int pcl_ensure_layouts(pcl_ctx *ctx, int need) {
     return PCL_OK;
 }
 
+// GMM.update_param for the states [j_lo, j_hi) only (the master copy; the caller re-derives the layouts)
+int pcl_launch_mstep_range(pcl_ctx *ctx, double floor_var, int j_lo, int j_hi) {
+    hipLaunchKernelGGL(mstep_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_acc, ctx->st_alpha, ctx->st_mean,
+                       ctx->st_cov, ctx->J, ctx->M, ctx->Mpad, ctx->D, ctx->Dhost, 100.0, floor_var, j_lo, j_hi, ctx->mean64,
+                       ctx->var64, ctx->w64);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var) {
     pcl_timer_begin(ctx, "mstep");
-    hipLaunchKernelGGL(mstep_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_acc, ctx->st_alpha, ctx->st_mean,
-                       ctx->st_cov, ctx->J, ctx->M, ctx->Mpad, ctx->D, ctx->Dhost, 100.0, floor_var, ctx->mean64, ctx->var64, ctx->w64);
-    int r = pcl_launch_derive(ctx);
+    int r = pcl_launch_mstep_range(ctx, floor_var, 0, ctx->J);
+    if (r == PCL_OK) r = pcl_launch_derive(ctx);
     pcl_timer_end(ctx, "mstep");
     HIPCHK(ctx, hipGetLastError());
     return r;

@@ -18,35 +18,30 @@ void pcl_set_error(pcl_ctx *ctx, const char *msg) {
 }
 
 // ---------------------------------------------------------------- timers (HIP events on ctx->stream)
+// Opt-in (pcl_timing_enable / env PCL_TIMERS=1): a training run that never asks for kernel times must not pay two
+// hipEventCreate per launch nor keep the events alive until the context dies.
 void pcl_timer_begin(pcl_ctx *ctx, const char *which) {
+    if (!ctx->timing) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
     hipEventRecord(a, ctx->stream);
     ctx->timers[which].ev.push_back({a, b});
 }
 void pcl_timer_end(pcl_ctx *ctx, const char *which) {
+    if (!ctx->timing) return;
     auto &t = ctx->timers[which];
     if (!t.ev.empty()) hipEventRecord(t.ev.back().second, ctx->stream);
 }
 
-template <typename T>
-static int dev_alloc(pcl_ctx *ctx, T **p, size_t n) {
-    *p = nullptr;
-    if (n == 0) n = 1;
-    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
-    if (e != hipSuccess) PCL_FAIL(ctx, PCL_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
-    return PCL_OK;
+static void drop_timers(pcl_ctx *ctx) {
+    for (auto &kv : ctx->timers) {
+        for (auto &p : kv.second.ev) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        kv.second.ev.clear();
+    }
 }
-template <typename T>
-static void dev_free(T *&p) {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-}
-#define TRY(x)                    \
-    do {                          \
-        int _r = (x);             \
-        if (_r != PCL_OK) return _r; \
-    } while (0)
 
 extern "C" {
 
@@ -73,6 +68,7 @@ int pcl_init(int device, pcl_ctx **out) {
     ctx->score_variant = var ? atoi(var) : 7;
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
+    if (const char *tm = getenv("PCL_TIMERS")) ctx->timing = atoi(tm) != 0;
     *out = ctx;
     return PCL_OK;
 }
@@ -105,12 +101,9 @@ int pcl_destroy(pcl_ctx *ctx) {
     pcl_comm_destroy(ctx);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream_dp);
-    for (auto &kv : ctx->timers)
-        for (auto &p : kv.second.ev) {
-            hipEventDestroy(p.first);
-            hipEventDestroy(p.second);
-        }
+    drop_timers(ctx);
     free_model(ctx);
+    pcl_units_release(ctx);
     dev_free(ctx->frames32);
     dev_free(ctx->frames64);
     hipStreamDestroy(ctx->stream);
@@ -146,6 +139,15 @@ int pcl_device_info(pcl_ctx *ctx, char *name, int cap, int *cus, size_t *hbm_byt
     if (name && cap > 0) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return PCL_OK;
+}
+
+int pcl_timing_enable(pcl_ctx *ctx, int on) {
+    if (!ctx) return PCL_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
+    if (!on) drop_timers(ctx);
+    ctx->timing = on != 0;
     return PCL_OK;
 }
 
@@ -307,6 +309,7 @@ int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, co
         d.b_off = bo;
         d.mat_off = mo;
         d.frame0 = frame_begin ? frame_begin[u] : -1;
+        if (frame_begin) b->max_frame_end = std::max(b->max_frame_end, (long long)frame_begin[u] + T[u]);
         d.T = T[u];
         d.N = N[u];
         d.vec_off = (int)vo;
@@ -351,6 +354,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
     pcl_accumulate_release(b);
+    pcl_batch_units_release(b);
     dev_free(b->d_utt); dev_free(b->Bt); dev_free(b->alpha); dev_free(b->beta); dev_free(b->lgam);
     dev_free(b->logpi); dev_free(b->pi_out); dev_free(b->gamma_out); dev_free(b->ksai);
     dev_free(b->logp); dev_free(b->qtrace); dev_free(b->point); dev_free(b->npass); dev_free(b->path);
@@ -359,6 +363,41 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
     dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
+    return PCL_OK;
+}
+
+// Upload the sparse transition structure of every utterance (CSR successors / CSC predecessors, both with ascending
+// indices; entries with ln A = -inf are not stored) and ln pi.  row_ptr / col_ptr: sumN + U entries (N_u + 1 per
+// utterance, local offsets); the UttDesc nnz_off fields must already be set.
+int pcl_batch_upload_sparse(pcl_batch *b, const std::vector<int> &row_ptr, const std::vector<int> &col_idx,
+                            const std::vector<double> &csr_val, const std::vector<int> &col_ptr,
+                            const std::vector<int> &row_idx, const std::vector<double> &csc_val, const double *logpi) {
+    pcl_ctx *ctx = b->ctx;
+    b->nnz = (long long)col_idx.size();
+    dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
+    dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
+    dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->nz_tmp);
+    const size_t nz = (size_t)b->nnz, np = row_ptr.size();
+    TRY(dev_alloc(ctx, &b->row_ptr, np));
+    TRY(dev_alloc(ctx, &b->col_ptr, np));
+    TRY(dev_alloc(ctx, &b->col_idx, nz));
+    TRY(dev_alloc(ctx, &b->row_idx, nz));
+    TRY(dev_alloc(ctx, &b->csr_val, nz));
+    TRY(dev_alloc(ctx, &b->csc_val, nz));
+    TRY(dev_alloc(ctx, &b->xi_m, nz));
+    TRY(dev_alloc(ctx, &b->xi_s, nz));
+    HIPCHK(ctx, hipMemcpy(b->row_ptr, row_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->col_ptr, col_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
+    if (nz) {
+        HIPCHK(ctx, hipMemcpy(b->col_idx, col_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(b->row_idx, row_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(b->csr_val, csr_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(b->csc_val, csc_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(ctx, hipMemcpy(b->logpi, logpi, (size_t)b->sumN * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    b->have_trans = true;
+    b->have_fb = b->have_vit = false;
     return PCL_OK;
 }
 
@@ -408,44 +447,24 @@ int pcl_batch_set_transitions(pcl_batch *b, const double *logA, const double *lo
         col_ptr[d.ptr_off + N] = cc;
         if (col_idx.size() > 0x7fffffffULL) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_transitions: too many transitions");
     }
-    b->nnz = (long long)col_idx.size();
-    dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
-    dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
-    dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->nz_tmp);
-    const size_t nz = (size_t)b->nnz, np = row_ptr.size();
-    TRY(dev_alloc(ctx, &b->row_ptr, np));
-    TRY(dev_alloc(ctx, &b->col_ptr, np));
-    TRY(dev_alloc(ctx, &b->col_idx, nz));
-    TRY(dev_alloc(ctx, &b->row_idx, nz));
-    TRY(dev_alloc(ctx, &b->csr_val, nz));
-    TRY(dev_alloc(ctx, &b->csc_val, nz));
-    TRY(dev_alloc(ctx, &b->xi_m, nz));
-    TRY(dev_alloc(ctx, &b->xi_s, nz));
-    HIPCHK(ctx, hipMemcpy(b->row_ptr, row_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(b->col_ptr, col_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
-    if (nz) {
-        HIPCHK(ctx, hipMemcpy(b->col_idx, col_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(b->row_idx, row_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(b->csr_val, csr_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(b->csc_val, csc_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIPCHK(ctx, hipMemcpy(b->logpi, logpi, (size_t)b->sumN * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
-    b->have_trans = true;
-    b->have_fb = b->have_vit = false;
-    return PCL_OK;
+    return pcl_batch_upload_sparse(b, row_ptr, col_idx, csr_val, col_ptr, row_idx, csc_val, logpi);
 }
 
 int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state) {
     if (!b) return PCL_ERR_INVALID;
-    pcl_ctx *ctx = b->ctx;
     TRY(batch_join(b));
-    if (!row_state) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: NULL argument");
+    if (!row_state) PCL_FAIL(b->ctx, PCL_ERR_INVALID, "pcl_batch_set_states: NULL argument");
+    return pcl_batch_set_states_impl(b, row_state);
+}
+
+int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
+    pcl_ctx *ctx = b->ctx;
     if (ctx->J == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_set_states: upload a model first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     b->row_state.assign(row_state, row_state + b->sumN);
     // count segments per state
     std::vector<int> count(ctx->J, 0);
+    int max_state = -1;
     for (int u = 0; u < b->U; ++u) {
         const UttDesc &d = b->utt[u];
         for (int n = 0; n < d.N; ++n) {
@@ -454,6 +473,7 @@ int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state) {
             if (st >= 0) {
                 if (d.frame0 < 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_set_states: batch was created without frame_begin");
                 ++count[st];
+                max_state = std::max(max_state, st);
             }
         }
     }
@@ -497,6 +517,22 @@ int pcl_batch_set_states(pcl_batch *b, const int32_t *row_state) {
     HIPCHK(ctx, hipMemcpy(b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
     b->have_states = true;
+    b->max_state = max_state;
+    b->model_J = ctx->J;
+    return PCL_OK;
+}
+
+// A batch outlives pcl_frames_upload / pcl_model_upload calls (the drop-in classes re-upload on the shared engine all
+// the time): its frame rows and state ids were checked against the buffers of THEN.  Re-check against the buffers of
+// NOW before any kernel indexes them.
+static int batch_revalidate(pcl_batch *b, const char *who) {
+    pcl_ctx *ctx = b->ctx;
+    if (b->max_frame_end > ctx->F)
+        PCL_FAIL(ctx, PCL_ERR_STATE, "%s: the batch refers to frame rows up to %lld but the frame matrix now has %lld rows (re-uploaded after the batch was created)",
+                 who, b->max_frame_end, (long long)ctx->F);
+    if (b->have_states && (b->max_state >= ctx->J || b->model_J != ctx->J))
+        PCL_FAIL(ctx, PCL_ERR_STATE, "%s: the batch was laid out for a model of %d states (largest id used %d) but the model now has %d (re-uploaded after pcl_batch_set_states)",
+                 who, b->model_J, b->max_state, ctx->J);
     return PCL_OK;
 }
 
@@ -612,6 +648,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_score: pcl_batch_set_states was not called");
     if (ctx->FDhost != ctx->Dhost)  // DataDimensionError, Clustering.py:749-751
         PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
+    TRY(batch_revalidate(b, "pcl_batch_score"));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (precision == PCL_F64) {
         TRY(ensure_frames64(ctx));
@@ -769,6 +806,7 @@ int pcl_stats_zero(pcl_ctx *ctx) {
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_zero: no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->stats, 0, ctx->stats_len * sizeof(double), ctx->stream));
+    if (ctx->hmm_ksai) return pcl_hmm_acc_zero(ctx);      // the per-unit transition accumulators restart at ln 0 (LHMM.py:84-85)
     return PCL_OK;
 }
 
@@ -780,6 +818,9 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b->have_post) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: run pcl_batch_forward_backward (or set_posteriors) first");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no emissions");
     if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
+    if (ctx->F == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no frames uploaded");
+    if (ctx->FDhost != ctx->Dhost) PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
+    TRY(batch_revalidate(b, "pcl_batch_accumulate"));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (precision == PCL_F64) {
         TRY(ensure_frames64(ctx));

@@ -1,15 +1,253 @@
-// pcl_comm.hip -- the one collective of the path: sum of the E-step statistics over the GPUs of a
-// node with RCCL over xGMI.  Replaces the reference's file-based accumulator merge
-// (StatisticalModel/LHMM.py:256-290, StatisticalModel/Clustering.py:314-367): there every worker
-// np.save()s log-domain accumulators and a reducer log-sum-exps the files; here the statistics are
-// linear-domain float64 sums resident in HBM, so the merge is a single ncclSum all-reduce.
+// pcl_comm.hip -- the one exchange of the path: the E-step statistics of the GPUs of a node, over RCCL / xGMI.
+//
+// Replaces the reference's file-based accumulator merge and the per-unit M-step that follows it
+// (StatisticalModel/LHMM.py:256-290, StatisticalModel/Clustering.py:314-367; AcousticModel.multi_embedded_training_2,
+// AcousticModel/AcousticModel.py:918-935): there every worker np.save()s log-domain accumulators, a reducer
+// log-sum-exps the files unit by unit and re-estimates that unit.  Here:
+//
+//   pcl_em_exchange   reduce-scatter of the GMM statistics by STATE RANGE (rank r owns states [r J/n, (r+1) J/n))
+//                     -> GMM.update_param on the owned states only -> all-gather of the new (mean, var, weight)
+//                     -> every rank re-derives its scoring layouts.
+//                     Same bytes on the wire as an all-reduce, but the M-step is 1/n of the work per GPU and what
+//                     comes back is the next iteration's model.  xGMI is point to point: each rank receives n-1 shards
+//                     of J/n states concurrently over its n-1 links.  payload PCL_F64 (parity) or PCL_F32 (half the
+//                     bytes: sums and parameters rounded to f32 on the wire, f64 on both sides of it).
+//   pcl_stats_allreduce   the plain sum all-reduce of everything (every rank then holds the global statistics).
+// The per-unit transition accumulators are un-normalised LOG values (quirk Q5): their merge is a log-sum-exp =
+// max all-reduce, exp(x - max), sum all-reduce, log (tiny: units x 18 doubles), done by both entry points.
+//
+// Transport: RCCL (pcl_comm_init).  pcl_comm_init_host is a rehearsal transport for several ranks on ONE device --
+// RCCL refuses that ("Duplicate GPU detected") -- where every collective goes through a caller-supplied all-gather
+// of host bytes; it runs the same orchestration code and is limited to small problems.
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "pcl_internal.h"
 
+namespace {
+
+constexpr size_t HOST_TRANSPORT_MAX_BYTES = 256u << 20;
+
+__global__ void to_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+__global__ void to_f64_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+
+// mean_acc = sum g (o + bias) sits near (100 + mu) acc: rounded to f32 as it is, the bias would turn a 6e-8 relative
+// rounding into 6e-6 absolute on the re-estimated mean.  On the wire travels  sum g (o - c_j) = mean_acc - (bias + c_j) acc
+// (c_j = the state's expansion centre), which is of the size of the features' spread; the owner adds the term back in f64.
+__global__ void mean_to_f32_kernel(const double *__restrict__ st_mean, const double *__restrict__ st_acc, const float *__restrict__ centers,
+                                   int Mpad, int D, double bias, float *__restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t jm = i / D;
+        const int d = (int)(i - jm * D);
+        const size_t j = jm / Mpad;
+        dst[i] = (float)(st_mean[i] - (bias + (double)centers[j * D + d]) * st_acc[jm]);
+    }
+}
+__global__ void mean_from_f32_kernel(const float *__restrict__ src, const double *__restrict__ st_acc, const float *__restrict__ centers,
+                                     int Mpad, int D, double bias, double *__restrict__ st_mean, size_t lo, size_t cnt) {
+    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < cnt; k += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = lo + k, jm = i / D;
+        const int d = (int)(i - jm * D);
+        const size_t j = jm / Mpad;
+        st_mean[i] = (double)src[i] + (bias + (double)centers[j * D + d]) * st_acc[jm];
+    }
+}
+
+struct Part {            // one array that is partitioned by state: `per_state` elements per state
+    double *base;
+    size_t per_state;
+};
+
+int nccl_fail(pcl_ctx *ctx, const char *what, ncclResult_t r) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, ncclGetErrorString(r));
+    pcl_set_error(ctx, buf);
+    return PCL_ERR_COMM;
+}
+
+// ---- host-callback transport: all-gather of every rank's bytes, reduced / sliced here
+int host_gather(pcl_ctx *ctx, const void *dev, size_t bytes, std::vector<char> &all) {
+    if (bytes * (size_t)ctx->nranks > HOST_TRANSPORT_MAX_BYTES)
+        PCL_FAIL(ctx, PCL_ERR_INVALID, "host rehearsal transport: %zu bytes x %d ranks is beyond its %zu-byte limit (use RCCL: one GPU per rank)",
+                 bytes, ctx->nranks, HOST_TRANSPORT_MAX_BYTES);
+    std::vector<char> mine(bytes);
+    HIPCHK(ctx, hipMemcpyAsync(mine.data(), dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    all.resize(bytes * (size_t)ctx->nranks);
+    if (ctx->host_allgather(ctx->host_user, mine.data(), bytes, all.data()) != 0) PCL_FAIL(ctx, PCL_ERR_COMM, "host rehearsal transport: the all-gather callback failed");
+    return PCL_OK;
+}
+
+template <typename T>
+int host_allreduce(pcl_ctx *ctx, T *dev, size_t n, bool is_max) {
+    std::vector<char> all;
+    TRY(host_gather(ctx, dev, n * sizeof(T), all));
+    std::vector<T> out(n);
+    const T *a = reinterpret_cast<const T *>(all.data());
+    for (size_t i = 0; i < n; ++i) {
+        T v = a[i];
+        for (int r = 1; r < ctx->nranks; ++r) {
+            const T w = a[(size_t)r * n + i];
+            v = is_max ? (w > v ? w : v) : v + w;          // ranks in order: the same sum on every rank
+        }
+        out[i] = v;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dev, out.data(), n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+// sum all-reduce / max all-reduce of a device array, on whichever transport is up
+template <typename T>
+int allreduce(pcl_ctx *ctx, T *dev, size_t n, bool is_max) {
+    if (ctx->transport == 2) return host_allreduce(ctx, dev, n, is_max);
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    ncclResult_t r = ncclAllReduce(dev, dev, n, dt, is_max ? ncclMax : ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return nccl_fail(ctx, "ncclAllReduce", r);
+    return PCL_OK;
+}
+
+// state range of a rank: balanced, contiguous; equal sizes when nranks divides J (then native reduce-scatter / all-gather)
+inline int range_lo(int J, int nranks, int r) { return (int)((long long)J * r / nranks); }
+
+// In-place reduce-scatter by state range of every array of `parts`: afterwards rank r holds the global sums of ITS states
+// (the rest of the array is stale partial data).
+template <typename T>
+int reduce_scatter_parts(pcl_ctx *ctx, T *const *bases, const size_t *per_state, int nparts, int J) {
+    const int n = ctx->nranks, me = ctx->rank;
+    if (ctx->transport == 2) {
+        for (int p = 0; p < nparts; ++p) {
+            const size_t tot = per_state[p] * (size_t)J;
+            std::vector<char> all;
+            TRY(host_gather(ctx, bases[p], tot * sizeof(T), all));
+            const T *a = reinterpret_cast<const T *>(all.data());
+            const size_t lo = per_state[p] * (size_t)range_lo(J, n, me), hi = per_state[p] * (size_t)range_lo(J, n, me + 1);
+            std::vector<T> out(hi - lo);
+            for (size_t i = lo; i < hi; ++i) {
+                T v = a[i];
+                for (int r = 1; r < n; ++r) v += a[(size_t)r * tot + i];
+                out[i - lo] = v;
+            }
+            if (hi > lo) HIPCHK(ctx, hipMemcpyAsync(bases[p] + lo, out.data(), (hi - lo) * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return PCL_OK;
+    }
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    ncclResult_t r = ncclGroupStart();
+    if (r != ncclSuccess) return nccl_fail(ctx, "ncclGroupStart", r);
+    for (int p = 0; p < nparts && r == ncclSuccess; ++p) {
+        if (J % n == 0) {
+            const size_t cnt = per_state[p] * (size_t)(J / n);
+            r = ncclReduceScatter(bases[p], bases[p] + cnt * me, cnt, dt, ncclSum, comm, ctx->stream);
+        } else {
+            for (int root = 0; root < n && r == ncclSuccess; ++root) {      // uneven ranges: one rooted reduce per owner
+                const size_t lo = per_state[p] * (size_t)range_lo(J, n, root), hi = per_state[p] * (size_t)range_lo(J, n, root + 1);
+                if (hi > lo) r = ncclReduce(bases[p] + lo, bases[p] + lo, hi - lo, dt, ncclSum, root, comm, ctx->stream);
+            }
+        }
+    }
+    const ncclResult_t re = ncclGroupEnd();
+    if (r != ncclSuccess) return nccl_fail(ctx, "ncclReduceScatter", r);
+    if (re != ncclSuccess) return nccl_fail(ctx, "ncclGroupEnd", re);
+    return PCL_OK;
+}
+
+// In-place all-gather by state range: every rank contributes its own states and ends with all of them.
+template <typename T>
+int all_gather_parts(pcl_ctx *ctx, T *const *bases, const size_t *per_state, int nparts, int J) {
+    const int n = ctx->nranks, me = ctx->rank;
+    if (ctx->transport == 2) {
+        for (int p = 0; p < nparts; ++p) {
+            const size_t tot = per_state[p] * (size_t)J;
+            std::vector<char> all;
+            TRY(host_gather(ctx, bases[p], tot * sizeof(T), all));
+            const T *a = reinterpret_cast<const T *>(all.data());
+            std::vector<T> out(tot);
+            for (int r = 0; r < n; ++r) {
+                const size_t lo = per_state[p] * (size_t)range_lo(J, n, r), hi = per_state[p] * (size_t)range_lo(J, n, r + 1);
+                if (hi > lo) memcpy(out.data() + lo, a + (size_t)r * tot + lo, (hi - lo) * sizeof(T));
+            }
+            HIPCHK(ctx, hipMemcpyAsync(bases[p], out.data(), tot * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        (void)me;
+        return PCL_OK;
+    }
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    ncclResult_t r = ncclGroupStart();
+    if (r != ncclSuccess) return nccl_fail(ctx, "ncclGroupStart", r);
+    for (int p = 0; p < nparts && r == ncclSuccess; ++p) {
+        if (J % n == 0) {
+            const size_t cnt = per_state[p] * (size_t)(J / n);
+            r = ncclAllGather(bases[p] + cnt * me, bases[p], cnt, dt, comm, ctx->stream);
+        } else {
+            for (int root = 0; root < n && r == ncclSuccess; ++root) {
+                const size_t lo = per_state[p] * (size_t)range_lo(J, n, root), hi = per_state[p] * (size_t)range_lo(J, n, root + 1);
+                if (hi > lo) r = ncclBroadcast(bases[p] + lo, bases[p] + lo, hi - lo, dt, root, comm, ctx->stream);
+            }
+        }
+    }
+    const ncclResult_t re = ncclGroupEnd();
+    if (r != ncclSuccess) return nccl_fail(ctx, "ncclAllGather", r);
+    if (re != ncclSuccess) return nccl_fail(ctx, "ncclGroupEnd", re);
+    return PCL_OK;
+}
+
+// log-sum-exp merge of the per-unit transition accumulators over the ranks (LHMM.py:272-290 does it over files)
+int merge_hmm_acc(pcl_ctx *ctx) {
+    if (!ctx->hmm_ksai || ctx->nranks == 1) return PCL_OK;
+    const size_t n = (size_t)ctx->n_units * (ctx->S - 2) * (ctx->S + 1);
+    double *top = nullptr;
+    TRY(dev_alloc(ctx, &top, n));
+    int rc = pcl_launch_hmm_acc_merge_prepare(ctx, top);
+    if (rc == PCL_OK) rc = allreduce(ctx, top, n, true);
+    if (rc == PCL_OK) rc = pcl_launch_hmm_acc_merge_scale(ctx, top);
+    if (rc == PCL_OK) rc = allreduce(ctx, ctx->hmm_ksai, n, false);
+    if (rc == PCL_OK) rc = pcl_launch_hmm_acc_merge_finish(ctx, top);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == PCL_OK) rc = PCL_ERR_HIP;
+    dev_free(top);
+    return rc;
+}
+
+int ensure_payload32(pcl_ctx *ctx, size_t n) {
+    if (ctx->payload32_len >= n) return PCL_OK;
+    if (ctx->payload32) (void)hipFree(ctx->payload32);
+    ctx->payload32 = nullptr;
+    ctx->payload32_len = 0;
+    float *p = nullptr;
+    TRY(dev_alloc(ctx, &p, n));
+    ctx->payload32 = p;
+    ctx->payload32_len = n;
+    return PCL_OK;
+}
+
+}  // namespace
+
+void pcl_comm_release(pcl_ctx *ctx) {
+    if (ctx->payload32) (void)hipFree(ctx->payload32);
+    ctx->payload32 = nullptr;
+    ctx->payload32_len = 0;
+}
+
 extern "C" {
+
+int pcl_device_count(int *n) {
+    if (!n) return PCL_ERR_INVALID;
+    int c = 0;
+    const hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+    return PCL_OK;
+}
 
 int pcl_comm_unique_id(void *id_bytes128) {
     if (!id_bytes128) return PCL_ERR_INVALID;
@@ -34,19 +272,132 @@ int pcl_comm_init(pcl_ctx *ctx, int rank, int nranks, const void *id_bytes128) {
     ctx->comm = (void *)comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    ctx->transport = 1;
+    return PCL_OK;
+}
+
+int pcl_comm_init_host(pcl_ctx *ctx, int rank, int nranks, pcl_allgather_fn fn, void *user) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!fn || nranks < 1 || rank < 0 || rank >= nranks) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_comm_init_host: rank %d of %d", rank, nranks);
+    pcl_comm_destroy(ctx);
+    ctx->host_allgather = fn;
+    ctx->host_user = user;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    ctx->transport = 2;
+    return PCL_OK;
+}
+
+int pcl_comm_info(pcl_ctx *ctx, int *rank, int *nranks, int *transport, int *rccl_nranks) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (rank) *rank = ctx->rank;
+    if (nranks) *nranks = ctx->nranks;
+    if (transport) *transport = ctx->transport;
+    if (rccl_nranks) {
+        *rccl_nranks = 0;
+        if (ctx->transport == 1) {
+            int c = 0;
+            ncclResult_t r = ncclCommCount((ncclComm_t)ctx->comm, &c);
+            if (r != ncclSuccess) PCL_FAIL(ctx, PCL_ERR_COMM, "ncclCommCount: %s", ncclGetErrorString(r));
+            *rccl_nranks = c;
+        }
+    }
     return PCL_OK;
 }
 
 int pcl_stats_allreduce(pcl_ctx *ctx) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_allreduce: no model uploaded");
-    if (ctx->nranks == 1 && !ctx->comm) return PCL_OK;   // single GPU: nothing to merge
-    if (!ctx->comm) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_allreduce: pcl_comm_init was not called");
+    if (ctx->transport == 0) {
+        if (ctx->nranks == 1) return PCL_OK;   // single GPU: nothing to merge
+        PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_allreduce: pcl_comm_init was not called");
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pcl_timer_begin(ctx, "allreduce");
-    ncclResult_t r = ncclAllReduce(ctx->stats, ctx->stats, ctx->stats_len, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+    int rc = allreduce(ctx, ctx->stats, ctx->stats_len, false);
     pcl_timer_end(ctx, "allreduce");
-    if (r != ncclSuccess) PCL_FAIL(ctx, PCL_ERR_COMM, "ncclAllReduce: %s", ncclGetErrorString(r));
+    if (rc != PCL_OK) return rc;
+    TRY(merge_hmm_acc(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_transitions) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: no model uploaded");
+    if (payload != PCL_F64 && payload != PCL_F32) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_em_exchange: payload %d", payload);
+    if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: pcl_comm_init was not called");
+    if (update_transitions && !ctx->hmm_ksai) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: update_transitions without pcl_units_upload");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int J = ctx->J, n = ctx->nranks, me = ctx->rank;
+    const size_t mp = (size_t)ctx->Mpad, mpd = mp * ctx->D;
+    const bool solo = ctx->transport == 0;                       // one GPU: the M-step alone
+    const int j_lo = solo ? 0 : range_lo(J, n, me), j_hi = solo ? J : range_lo(J, n, me + 1);
+    int rc = PCL_OK;
+    if (!solo) {
+        pcl_timer_begin(ctx, "reduce_scatter");
+        if (payload == PCL_F64) {
+            double *bases[4] = {ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov};
+            const size_t per[4] = {mp, 1, mpd, mpd};
+            rc = reduce_scatter_parts<double>(ctx, bases, per, 4, J);
+        } else {
+            TRY(ensure_payload32(ctx, ctx->stats_len));
+            float *f = (float *)ctx->payload32;
+            hipLaunchKernelGGL(to_f32_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->stats, f, ctx->stats_len);
+            float *bases[4] = {f, f + (size_t)J * mp, f + (size_t)J * mp + J, f + (size_t)J * mp + J + (size_t)J * mpd};
+            hipLaunchKernelGGL(mean_to_f32_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_mean, ctx->st_acc, ctx->centers32, ctx->Mpad,
+                               ctx->D, 100.0, bases[2], (size_t)J * mpd);
+            const size_t per[4] = {mp, 1, mpd, mpd};
+            rc = reduce_scatter_parts<float>(ctx, bases, per, 4, J);
+            double *dst[4] = {ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov};
+            for (int p = 0; p < 4 && rc == PCL_OK; ++p) {      // the owned slices back to f64, where the M-step reads them
+                const size_t lo = per[p] * (size_t)j_lo, cnt = per[p] * (size_t)(j_hi - j_lo);
+                if (!cnt) continue;
+                if (p == 2) hipLaunchKernelGGL(mean_from_f32_kernel, dim3(1024), dim3(256), 0, ctx->stream, bases[2], ctx->st_acc, ctx->centers32,
+                                               ctx->Mpad, ctx->D, 100.0, ctx->st_mean, lo, cnt);      // after p == 0 put the summed acc back
+                else hipLaunchKernelGGL(to_f64_kernel, dim3(1024), dim3(256), 0, ctx->stream, bases[p] + lo, dst[p] + lo, cnt);
+            }
+        }
+        pcl_timer_end(ctx, "reduce_scatter");
+        if (rc != PCL_OK) return rc;
+    }
+    // GMM.update_param (Clustering.py:682-693) for the owned states
+    pcl_timer_begin(ctx, "mstep_owned");
+    rc = pcl_launch_mstep_range(ctx, c_covariance, j_lo, j_hi);
+    pcl_timer_end(ctx, "mstep_owned");
+    if (rc != PCL_OK) return rc;
+    if (!solo) {
+        pcl_timer_begin(ctx, "all_gather");
+        if (payload == PCL_F64) {
+            double *bases[3] = {ctx->mean64, ctx->var64, ctx->w64};
+            const size_t per[3] = {mpd, mpd, mp};
+            rc = all_gather_parts<double>(ctx, bases, per, 3, J);
+        } else {
+            const size_t tot = (size_t)J * (2 * mpd + mp);
+            TRY(ensure_payload32(ctx, tot));
+            float *f = (float *)ctx->payload32;
+            float *bases[3] = {f, f + (size_t)J * mpd, f + 2 * (size_t)J * mpd};
+            const size_t per[3] = {mpd, mpd, mp};
+            double *src[3] = {ctx->mean64, ctx->var64, ctx->w64};
+            for (int p = 0; p < 3; ++p) {
+                const size_t lo = per[p] * (size_t)j_lo, cnt = per[p] * (size_t)(j_hi - j_lo);
+                if (cnt) hipLaunchKernelGGL(to_f32_kernel, dim3(1024), dim3(256), 0, ctx->stream, src[p] + lo, bases[p] + lo, cnt);
+            }
+            rc = all_gather_parts<float>(ctx, bases, per, 3, J);
+            // every rank, the owner included, continues from the f32-rounded parameters: one model on all GPUs
+            for (int p = 0; p < 3 && rc == PCL_OK; ++p)
+                hipLaunchKernelGGL(to_f64_kernel, dim3(4096), dim3(256), 0, ctx->stream, bases[p], src[p], per[p] * (size_t)J);
+        }
+        pcl_timer_end(ctx, "all_gather");
+        if (rc != PCL_OK) return rc;
+        TRY(merge_hmm_acc(ctx));
+    }
+    if (update_transitions) TRY(pcl_launch_trans_mstep(ctx));     // tiny, identical on every rank after the merge
+    pcl_timer_begin(ctx, "derive");
+    rc = pcl_launch_derive(ctx);                                   // every scoring layout, from the gathered master copy
+    pcl_timer_end(ctx, "derive");
+    if (rc != PCL_OK) return rc;
+    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PCL_OK;
 }
@@ -57,8 +408,12 @@ int pcl_comm_destroy(pcl_ctx *ctx) {
         ncclCommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
     }
+    ctx->host_allgather = nullptr;
+    ctx->host_user = nullptr;
+    ctx->transport = 0;
     ctx->rank = 0;
     ctx->nranks = 1;
+    pcl_comm_release(ctx);
     return PCL_OK;
 }
 

@@ -96,16 +96,30 @@ struct pcl_ctx {
     double *stats = nullptr;  // one allocation: [acc J*Mpad | alpha J | mean J*Mpad*D | cov J*Mpad*D]
     size_t stats_len = 0;
     double *st_acc = nullptr, *st_alpha = nullptr, *st_mean = nullptr, *st_cov = nullptr;
-    // RCCL
+    // unit inventory (hmm_units.hip): n_units HMMs of S states, unit i owns GMM states i*(S-2) .. i*(S-2)+S-3
+    int n_units = 0, S = 0;
+    std::vector<double> unit_trans, unit_logtrans;   // host copies [n_units][S][S]: transmat and np.log(transmat)
+    double *d_unit_trans = nullptr;                  // device copy of unit_trans (the transition M-step writes it)
+    double *hmm_ksai = nullptr, *hmm_gamma = nullptr;   // per-unit accumulators, LOG domain: [n_units][S-2][S], [n_units][S-2]
+    // multi-GPU (pcl_comm.hip): RCCL communicator, or the host-callback rehearsal transport
     void *comm = nullptr;
     int rank = 0, nranks = 1;
+    int transport = 0;                               // 0 none, 1 RCCL, 2 host callback (several ranks on ONE device)
+    pcl_allgather_fn host_allgather = nullptr;
+    void *host_user = nullptr;
+    void *payload32 = nullptr;                       // f32 staging of the statistics / parameters (payload = PCL_F32)
+    size_t payload32_len = 0;
     std::map<std::string, KernelTimer> timers;
+    bool timing = false;         // pcl_timing_enable / env PCL_TIMERS: record HIP events around every launch
 };
 
 struct pcl_batch {
     pcl_ctx *ctx = nullptr;
     int U = 0, Nmax = 0, Tmax = 0;
     long long sumNT = 0, sumN = 0, sumT = 0, sumNN = 0;
+    long long max_frame_end = 0;   // max over utterances of frame_begin + T: re-validated against the CURRENT frame matrix
+    int model_J = 0;               // J of the model the state lists were built for
+    int max_state = -1;            // largest GMM state id any row refers to: re-validated against the CURRENT model
     std::vector<UttDesc> utt;  // host copy
     std::vector<int32_t> row_state;
     bool have_trans = false, have_states = false, have_B = false, have_fb = false, have_vit = false, have_post = false;
@@ -144,6 +158,12 @@ struct pcl_batch {
     ActiveFrame *acc_list = nullptr;
     int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
     size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
+    // label-built batches (pcl_batch_create_labels): the labels, and per unit the list of its occurrences
+    bool from_labels = false;
+    std::vector<int32_t> label_len, labels;
+    std::vector<double> logpi_u;             // ln pi of every state of utterance u (uniform 1/N, AcousticModel.py:1003-1006)
+    int n_occ = 0;
+    int *occ_ptr = nullptr, *occ_utt = nullptr, *occ_row0 = nullptr;   // unit -> [occ_ptr[u], occ_ptr[u+1]) -> (utterance, first emitting row)
 };
 
 // ---------------------------------------------------------------- error helpers
@@ -161,6 +181,33 @@ struct pcl_batch {
     } while (0)
 
 void pcl_set_error(pcl_ctx *ctx, const char *msg);
+
+template <typename T>
+static inline int dev_alloc(pcl_ctx *ctx, T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) PCL_FAIL(ctx, PCL_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    return PCL_OK;
+}
+template <typename T>
+static inline void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+#define TRY(x)                    \
+    do {                          \
+        int _r = (x);             \
+        if (_r != PCL_OK) return _r; \
+    } while (0)
+
+// shared by pcl_api.hip and hmm_units.hip (C linkage, internal)
+extern "C" {
+int pcl_batch_upload_sparse(pcl_batch *b, const std::vector<int> &row_ptr, const std::vector<int> &col_idx,
+                            const std::vector<double> &csr_val, const std::vector<int> &col_ptr,
+                            const std::vector<int> &row_idx, const std::vector<double> &csc_val, const double *logpi);
+int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state);
+}
 void pcl_timer_begin(pcl_ctx *ctx, const char *which);
 void pcl_timer_end(pcl_ctx *ctx, const char *which);
 
@@ -191,4 +238,12 @@ enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_P
 inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) { return !ctx->cond.empty() && ctx->cond[j] > ctx->cond_max; }
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
+int pcl_launch_mstep_range(pcl_ctx *ctx, double floor_var, int j_lo, int j_hi);
+int pcl_launch_hmm_acc_merge_prepare(pcl_ctx *ctx, double *top);          // top[i] = acc[i] (copy for the max all-reduce)
+int pcl_launch_hmm_acc_merge_scale(pcl_ctx *ctx, const double *top);      // acc[i] = exp(acc[i] - top[i]) (0 where top = -inf)
+int pcl_launch_hmm_acc_merge_finish(pcl_ctx *ctx, const double *top);     // acc[i] = top[i] + ln(acc[i])
+int pcl_launch_trans_mstep(pcl_ctx *ctx);
+void pcl_units_release(pcl_ctx *ctx);
+void pcl_batch_units_release(pcl_batch *b);
+void pcl_comm_release(pcl_ctx *ctx);
 int pcl_launch_pack(pcl_ctx *ctx, const double *src, int inner, double *dst);

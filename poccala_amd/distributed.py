@@ -51,47 +51,117 @@ def allreduce_sum_host(arr, dist):
 
 # ---------------------------------------------------------------------------------------------------
 # Control plane without torch: a star over TCP (rank 0 = hub) for the few tiny host-side exchanges a
-# GPU rank needs (barrier, max of a float, broadcast of the 128-byte RCCL id, log-domain merge of the
-# per-unit HMM accumulators).  GPU processes therefore never import torch: torch's wheel bundles its
-# own libamdhip64 / librccl (same sonames as /opt/rocm's) and two HIP runtimes in one process crash
-# at exit.  Rendezvous: MASTER_ADDR and MASTER_PORT + 1 + k from the torch.distributed.run env
-# (MASTER_PORT itself belongs to the launcher's store).
+# GPU rank needs (barrier, max of a float, broadcast of the 128-byte RCCL id, per-rank timings).  GPU
+# processes therefore never import torch: torch's wheel bundles its own libamdhip64 / librccl (same
+# sonames as /opt/rocm's) and two HIP runtimes in one process crash at exit.  Rendezvous: MASTER_ADDR
+# and MASTER_PORT + 1 + k from the launcher's env (MASTER_PORT itself belongs to the launcher's store).
+#
+# Wire format: fixed binary frames, never pickle -- a frame is  magic(4) kind(1) length(8)  + payload,
+# kind in {none, bytes, float64/int64/int32 ndarray (dtype code, ndim, shape, raw data), float, JSON
+# text}; nothing received is ever executed or unpickled.  Every connection is authenticated both ways
+# with HMAC-SHA256 over a fresh challenge, keyed by a token the launcher hands to all ranks
+# (POCCALA_CTRL_TOKEN; bench.py's self-spawn makes a random one per job); rank ids are range-checked
+# and duplicates refused.  The hub binds MASTER_ADDR only (127.0.0.1 on one node).
 # ---------------------------------------------------------------------------------------------------
+import hashlib
+import hmac
+import json
 import os
-import pickle
 import socket
 import struct
 import time
 
-_MAGIC = b'PCLCTRL1'
+_MAGIC = b'PCL2'
+_K_NONE, _K_BYTES, _K_ARRAY, _K_FLOAT, _K_JSON = 0, 1, 2, 3, 4
+_DTYPES = {0: np.dtype('<f8'), 1: np.dtype('<i8'), 2: np.dtype('<i4')}
+_DCODE = {v: k for k, v in _DTYPES.items()}
+_MAX_FRAME = 1 << 30
+
+
+def _token():
+    t = os.environ.get('POCCALA_CTRL_TOKEN')
+    if t is None:   # a foreign launcher (torch.distributed.run): the job's run id is all the ranks share
+        t = 'run:%s:%s' % (os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('MASTER_PORT', ''))
+    return t.encode()
+
+
+def _exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError('control plane: peer closed')
+        buf += chunk
+    return bytes(buf)
+
+
+def _encode(obj):
+    if obj is None:
+        return _K_NONE, b''
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        return _K_BYTES, bytes(obj)
+    if isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        if a.dtype not in _DCODE:
+            a = a.astype(np.float64)
+        return _K_ARRAY, struct.pack('<BB', _DCODE[a.dtype], a.ndim) + struct.pack('<%dq' % a.ndim, *a.shape) + a.tobytes()
+    if isinstance(obj, (float, np.floating)):
+        return _K_FLOAT, struct.pack('<d', float(obj))
+    return _K_JSON, json.dumps(obj).encode()            # small dict / list / int / str control data
+
+
+def _decode(kind, data):
+    if kind == _K_NONE:
+        return None
+    if kind == _K_BYTES:
+        return data
+    if kind == _K_ARRAY:
+        code, ndim = struct.unpack_from('<BB', data, 0)
+        if code not in _DTYPES or ndim > 8:
+            raise ValueError('control plane: bad array header')
+        shape = struct.unpack_from('<%dq' % ndim, data, 2)
+        dt = _DTYPES[code]
+        off = 2 + 8 * ndim
+        if any(d < 0 for d in shape) or int(np.prod(shape, dtype=np.int64)) * dt.itemsize != len(data) - off:
+            raise ValueError('control plane: array size mismatch')
+        return np.frombuffer(data, dtype=dt, offset=off).reshape(shape).copy()
+    if kind == _K_FLOAT:
+        return struct.unpack('<d', data)[0]
+    if kind == _K_JSON:
+        return json.loads(data.decode())
+    raise ValueError('control plane: unknown frame kind %d' % kind)
 
 
 def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
-    sock.sendall(struct.pack('!Q', len(data)) + data)
+    kind, data = _encode(obj)
+    sock.sendall(_MAGIC + struct.pack('<BQ', kind, len(data)) + data)
 
 
 def _recv(sock):
-    def exact(n):
-        buf = b''
-        while len(buf) < n:
-            chunk = sock.recv(n - len(buf))
-            if not chunk:
-                raise ConnectionError('control plane: peer closed')
-            buf += chunk
-        return buf
-    (n,) = struct.unpack('!Q', exact(8))
-    return pickle.loads(exact(n))
+    hdr = _exact(sock, 13)
+    if hdr[:4] != _MAGIC:
+        raise ValueError('control plane: bad magic')
+    kind, n = struct.unpack('<BQ', hdr[4:])
+    if n > _MAX_FRAME:
+        raise ValueError('control plane: frame too large')
+    return _decode(kind, _exact(sock, n))
+
+
+def _mac(token, *parts):
+    return hmac.new(token, b'|'.join(parts), hashlib.sha256).digest()
 
 
 class Control(object):
-    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=300.0):
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=300.0, token=None):
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else rank
         self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else world
         self.peers = []
         self.hub = None
         if self.world == 1:
             return
+        if not 0 <= self.rank < self.world:
+            raise ValueError('control plane: rank %d outside [0,%d)' % (self.rank, self.world))
+        token = _token() if token is None else token
         addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
         base = int(port if port is not None else int(os.environ.get('MASTER_PORT', '29500')) + 1)
         if self.rank == 0:
@@ -112,29 +182,49 @@ class Control(object):
             slots = [None] * self.world
             while sum(s is not None for s in slots[1:]) < self.world - 1:
                 c, _ = srv.accept()
-                c.settimeout(timeout)
-                hello = _recv(c)
-                if not (isinstance(hello, tuple) and hello[0] == _MAGIC):
-                    c.close()
-                    continue
-                slots[hello[1]] = c
-                _send(c, _MAGIC)
+                try:
+                    c.settimeout(10.0)
+                    # challenge -> (rank, HMAC(challenge | rank | client nonce)) -> HMAC(client nonce | 'hub')
+                    challenge = os.urandom(16)
+                    c.sendall(_MAGIC + challenge)
+                    reply = _exact(c, 4 + 4 + 16 + 32)
+                    if reply[:4] != _MAGIC:
+                        raise ValueError('bad magic')
+                    (r,) = struct.unpack('<I', reply[4:8])
+                    nonce, mac = reply[8:24], reply[24:56]
+                    if not hmac.compare_digest(mac, _mac(token, challenge, struct.pack('<I', r), nonce)):
+                        raise ValueError('authentication failed')
+                    if not 0 < r < self.world or slots[r] is not None:
+                        raise ValueError('rank %d out of range or already connected' % r)
+                    c.sendall(_mac(token, nonce, b'hub'))
+                    c.settimeout(timeout)
+                    slots[r] = c
+                except (OSError, ValueError, ConnectionError, struct.error):
+                    c.close()                    # a stranger, a wrong token or a duplicate: drop it, keep listening
             srv.close()
             self.peers = slots
         else:
             deadline = time.time() + timeout
             while self.hub is None:
                 for k in range(32):
+                    s = None
                     try:
                         s = socket.create_connection((addr, base + k), timeout=2.0)
                         s.settimeout(5.0)                   # a foreign service on this port must not stall us
-                        _send(s, (_MAGIC, self.rank))
-                        if _recv(s) == _MAGIC:
-                            s.settimeout(timeout)
-                            self.hub = s
-                            break
-                        s.close()
-                    except (OSError, ConnectionError, pickle.UnpicklingError, struct.error, EOFError, ValueError):
+                        hello = _exact(s, 20)
+                        if hello[:4] != _MAGIC:
+                            raise ValueError('not the hub')
+                        nonce = os.urandom(16)
+                        rb = struct.pack('<I', self.rank)
+                        s.sendall(_MAGIC + rb + nonce + _mac(token, hello[4:], rb, nonce))
+                        if not hmac.compare_digest(_exact(s, 32), _mac(token, nonce, b'hub')):
+                            raise ValueError('the hub failed to authenticate')
+                        s.settimeout(timeout)
+                        self.hub = s
+                        break
+                    except (OSError, ConnectionError, struct.error, ValueError):
+                        if s is not None:
+                            s.close()
                         continue
                 if self.hub is None:
                     if time.time() > deadline:
@@ -142,16 +232,22 @@ class Control(object):
                     time.sleep(0.2)
 
     def allgather(self, obj):
-        """List of every rank's object, in rank order, on every rank."""
+        """List of every rank's object, in rank order, on every rank.  Objects: None, bytes, float, float64 / int
+        ndarrays, or JSON-serialisable control data."""
         if self.world == 1:
             return [obj]
         if self.rank == 0:
             items = [obj] + [_recv(self.peers[r]) for r in range(1, self.world)]
             for r in range(1, self.world):
-                _send(self.peers[r], items)
+                for it in items:
+                    _send(self.peers[r], it)
             return items
         _send(self.hub, obj)
-        return _recv(self.hub)
+        return [_recv(self.hub) for _ in range(self.world)]
+
+    def allgather_bytes(self, data):
+        """Every rank's byte string in rank order (the transport of Engine.comm_init_host)."""
+        return [bytes(x) for x in self.allgather(bytes(data))]
 
     def barrier(self):
         self.allgather(None)

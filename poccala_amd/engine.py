@@ -18,6 +18,13 @@ from . import _lib
 from ._lib import GET, PCL_F32, PCL_F64, PCL_MAX_PASS, PCL_ROW_ENTRY, PCL_ROW_EXIT, PoccalaHipError, as_c, ptr
 
 
+def device_count():
+    """HIP devices visible to this process (0 without a GPU)."""
+    n = C.c_int(0)
+    _lib.load().pcl_device_count(C.byref(n))
+    return n.value
+
+
 class Engine(object):
     """One GPU: `Engine(device)`.  Raises if libpoccala_hip.so is missing or no GPU is present."""
 
@@ -31,6 +38,7 @@ class Engine(object):
             raise PoccalaHipError(rc, (msg or b'pcl_init failed').decode())
         self.device = int(device)
         self.J = self.M = self.D = 0
+        self.n_units = self.S = 0
         self.F = 0
         self._batches = []   # weak refs to live batches: destroyed before the context
 
@@ -65,8 +73,12 @@ class Engine(object):
         self._check(self._lib.pcl_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
         return dict(name=name.value.decode(), cus=cus.value, hbm_bytes=mem.value)
 
+    def enable_timing(self, on=True):
+        """Record HIP events around every kernel launch for `kernel_time` (off by default: a training run pays nothing)."""
+        self._check(self._lib.pcl_timing_enable(self._ctx, 1 if on else 0))
+
     def kernel_time(self, which):
-        """(total_ms, launches) of a kernel group since the last query (HIP events on the ctx stream)."""
+        """(total_ms, launches) of a kernel group since the last query (HIP events on the ctx stream; `enable_timing` first)."""
         ms = C.c_float()
         n = C.c_int()
         self._check(self._lib.pcl_kernel_time(self._ctx, which.encode(), C.byref(ms), C.byref(n)))
@@ -100,6 +112,43 @@ class Engine(object):
 
     def batch(self, N, T, frame_begin=None):
         return Batch(self, N, T, frame_begin)
+
+    # ------------------------------------------------------------------ unit inventory, label-built batches
+    def load_units(self, unit_trans):
+        """unit_trans: (n_units, S, S) transition matrices (LHMM.transmat of every unit HMM, AcousticModel.py:174-181).
+        Unit i owns GMM states i*(S-2) .. of the loaded model.  ln A is taken here with np.log, the values the
+        reference's forward / Viterbi use (LHMM.py:340,571)."""
+        t = as_c(unit_trans, np.float64)
+        if t.ndim != 3 or t.shape[1] != t.shape[2]:
+            raise ValueError('unit_trans must be (n_units, S, S)')
+        with np.errstate(divide='ignore'):
+            lt = np.ascontiguousarray(np.log(t))
+        self._check(self._lib.pcl_units_upload(self._ctx, t.shape[0], t.shape[1], ptr(t), ptr(lt)))
+        self.n_units, self.S = int(t.shape[0]), int(t.shape[1])
+
+    def units_download(self):
+        t = np.empty((self.n_units, self.S, self.S))
+        self._check(self._lib.pcl_units_download(self._ctx, ptr(t)))
+        return t
+
+    def label_batch(self, unit_ids, T, frame_begin):
+        """Sentence HMMs of a list of labels (AcousticModel.embedded for every utterance at once, in the library)."""
+        return Batch(self, None, T, frame_begin, unit_ids=unit_ids)
+
+    def hmm_acc_zero(self):
+        self._check(self._lib.pcl_hmm_acc_zero(self._ctx))
+
+    def hmm_acc_download(self):
+        """(ksai_acc (n_units, S-2, S), gamma_acc (n_units, S-2)): log domain, -inf where nothing was added
+        (LHMM.ksai_acc / LHMM.gamma_acc of every unit, merged over all label positions of all batches)."""
+        ks = np.empty((self.n_units, self.S - 2, self.S))
+        ga = np.empty((self.n_units, self.S - 2))
+        self._check(self._lib.pcl_hmm_acc_download(self._ctx, ptr(ks), ptr(ga)))
+        return ks, ga
+
+    def mstep_transitions(self):
+        """LHMM.update_param's transition update for every unit that occurred (LHMM.py:519-520)."""
+        self._check(self._lib.pcl_mstep_transitions(self._ctx))
 
     # ------------------------------------------------------------------ E-step statistics
     def stats_zero(self):
@@ -161,26 +210,65 @@ class Engine(object):
             os.close(saved)
         self._check(rc)
 
+    def comm_init_host(self, rank, nranks, allgather_bytes):
+        """Rehearsal transport for several ranks on ONE device (RCCL refuses duplicate devices): `allgather_bytes(b)`
+        returns every rank's bytes in rank order (poccala_amd.distributed.Control.allgather_bytes)."""
+        def cb(user, send, nbytes, recv_all):
+            try:
+                parts = allgather_bytes(C.string_at(send, nbytes))
+                if len(parts) != nranks or any(len(x) != nbytes for x in parts):
+                    return 1
+                C.memmove(recv_all, b''.join(parts), nbytes * nranks)
+                return 0
+            except Exception:          # never let an exception cross the C boundary
+                return 2
+        self._host_cb = _lib.ALLGATHER_FN(cb)       # keep the thunk alive as long as the context
+        self._check(self._lib.pcl_comm_init_host(self._ctx, int(rank), int(nranks), self._host_cb, None))
+
+    def comm_info(self):
+        r, n, t, c = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.pcl_comm_info(self._ctx, C.byref(r), C.byref(n), C.byref(t), C.byref(c)))
+        return dict(rank=r.value, nranks=n.value, transport={0: 'none', 1: 'rccl', 2: 'host-rehearsal'}[t.value], rccl_nranks=c.value)
+
     def stats_allreduce(self):
         self._check(self._lib.pcl_stats_allreduce(self._ctx))
+
+    def em_exchange(self, c_covariance=1e-3, payload=PCL_F64, update_transitions=False):
+        """reduce-scatter of the statistics by state range -> M-step on the owned states -> all-gather of the model
+        (+ merge of the per-unit HMM accumulators, + the transition update on request).  One rank: the M-step."""
+        self._check(self._lib.pcl_em_exchange(self._ctx, float(c_covariance), int(payload), 1 if update_transitions else 0))
 
 
 class Batch(object):
     """U sentence HMMs.  N[u] states, T[u] frames; matrices cross the boundary in the reference's
     (N,T) float64 layout, one array per utterance."""
 
-    def __init__(self, engine, N, T, frame_begin=None):
+    def __init__(self, engine, N, T, frame_begin=None, unit_ids=None):
         self.eng = engine
         self._lib = engine._lib
-        self.N = as_c(N, np.int32).reshape(-1)
         self.T = as_c(T, np.int32).reshape(-1)
-        if self.N.shape != self.T.shape or self.N.size == 0:
-            raise ValueError('N and T must be equal-length, non-empty')
-        self.U = int(self.N.size)
-        fb = None if frame_begin is None else as_c(frame_begin, np.int64).reshape(-1)
         self._b = C.c_void_p()
-        engine._check(self._lib.pcl_batch_create(engine._ctx, self.U, ptr(self.N), ptr(self.T), ptr(fb),
-                                                 C.byref(self._b)))
+        if unit_ids is not None:
+            # label-built: N_u = (S-2) L_u + 2 (AcousticModel.py:966); structure built by pcl_batch_create_labels
+            lens = np.array([len(l) for l in unit_ids], dtype=np.int32)
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in unit_ids]), dtype=np.int32)
+            self.N = ((engine.S - 2) * lens + 2).astype(np.int32)
+            if self.N.shape != self.T.shape or self.N.size == 0 or frame_begin is None:
+                raise ValueError('labels, T and frame_begin must be equal-length, non-empty')
+            self.U = int(self.N.size)
+            fb = as_c(frame_begin, np.int64).reshape(-1)
+            logpi = np.ascontiguousarray(np.log(1.0 / self.N.astype(np.float64)))     # np.log(np.ones(N) / N), AcousticModel.py:1005
+            self.label_len, self.labels = lens, flat
+            engine._check(self._lib.pcl_batch_create_labels(engine._ctx, self.U, ptr(lens), ptr(flat), ptr(self.T), ptr(fb),
+                                                            ptr(logpi), C.byref(self._b)))
+        else:
+            self.N = as_c(N, np.int32).reshape(-1)
+            if self.N.shape != self.T.shape or self.N.size == 0:
+                raise ValueError('N and T must be equal-length, non-empty')
+            self.U = int(self.N.size)
+            fb = None if frame_begin is None else as_c(frame_begin, np.int64).reshape(-1)
+            engine._check(self._lib.pcl_batch_create(engine._ctx, self.U, ptr(self.N), ptr(self.T), ptr(fb),
+                                                     C.byref(self._b)))
         engine._batches.append(weakref.ref(self))
         n64, t64 = self.N.astype(np.int64), self.T.astype(np.int64)
         self._nt_off = np.concatenate([[0], np.cumsum(n64 * t64)])
@@ -252,6 +340,14 @@ class Batch(object):
 
     def accumulate(self, precision=PCL_F32):
         self._check(self._lib.pcl_batch_accumulate(self._b, int(precision)))
+
+    def accumulate_hmm(self):
+        """Per-unit ksai_acc / gamma_acc of every label position (LHMM.update_acc + add_acc); label-built batches only."""
+        self._check(self._lib.pcl_batch_accumulate_hmm(self._b))
+
+    def refresh_transitions(self):
+        """Take the engine's CURRENT unit transitions (after mstep_transitions / em_exchange); label-built batches only."""
+        self._check(self._lib.pcl_batch_refresh_transitions(self._b))
 
     # ------------------------------------------------------------------ outputs
     def regroup(self, row_unit, gmm_num):

@@ -1,0 +1,489 @@
+"""GPU tests of the round-2 C-ABI additions: the unit inventory and label-built batches (A7 in the library), the
+per-unit transition accumulators and their M-step (A12 / A15 on the device), the guarded GMM M-step, batch
+re-validation, opt-in timers, and the E-step exchange (reduce-scatter -> owner M-step -> all-gather) rehearsed with
+two GPU processes on one device."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import poccala_oracle as po
+
+pytestmark = pytest.mark.gpu
+S = 5
+E = S - 2
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from poccala_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def fin_close(got, ref, rtol, atol=0.0):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=rtol, atol=atol)
+
+
+def problem(seed, units=4, M=8, D=13, U=7, T=50, L=3, ragged=True, dense_trans=False):
+    from poccala_amd import synth
+    mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
+    if dense_trans:   # unit matrices with every allowed entry of rows 1..S-2 non-zero (skips, back loops)
+        rng = np.random.default_rng(seed + 9)
+        trans = []
+        for _ in range(units):
+            a = np.zeros((S, S))
+            a[0, 1:3] = [0.8, 0.2]
+            a[1:-1, :] = rng.dirichlet(np.ones(S), size=E)
+            a[1:-1, 0] = 0.0                      # nothing returns to the entry column of the own unit ...
+            a[1:-1] /= a[1:-1].sum(axis=1, keepdims=True)
+            trans.append(a)
+    frames, lens, begin = synth.make_frames(U, T, D, seed=seed + 1, ragged=ragged)
+    labels = synth.make_labels(U, L, units, seed=seed + 2)
+    return mean, var, w, trans, frames, lens, begin, labels
+
+
+def oracle_model(mean, var, w, trans):
+    return {u: dict(trans=trans[u], gmms=[(mean[u * E + k], var[u * E + k], w[u * E + k]) for k in range(E)])
+            for u in range(len(trans))}
+
+
+# ------------------------------------------------------------------ A7 in the library
+@pytest.mark.parametrize('dense', [False, True])
+def test_label_batch_equals_host_built_batch(eng, dense):
+    """pcl_batch_create_labels builds what AcousticModel.embedded builds (AcousticModel.py:957-1014): the same
+    emissions, forward-backward results and Viterbi paths, bit for bit, as a batch fed host-built (N,N) matrices."""
+    from poccala_amd import PCL_F64
+    from poccala_amd.engine import make_sentence_batch
+    mean, var, w, trans, frames, lens, begin, labels = problem(41, dense_trans=dense)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    ref, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    lab = eng.label_batch(labels, lens, begin)
+    assert np.array_equal(lab.N, n)
+    for b in (ref, lab):
+        b.score(PCL_F64)
+        b.forward_backward()
+        b.viterbi()
+    for what in ('B', 'alpha', 'beta', 'lgamma', 'ksai', 'gamma', 'pi', 'path'):
+        for x, y in zip(ref.get(what), lab.get(what)):
+            assert np.array_equal(x, y), what
+    for what in ('logp', 'point', 'npass'):
+        assert np.array_equal(ref.get(what), lab.get(what)), what
+    # and against the oracle's own construction of the sentence HMM
+    model = oracle_model(mean, var, w, trans)
+    x = frames[begin[2]:begin[2] + lens[2]].astype(np.float64)
+    _, a, bref, pi = po.score_label(x, list(labels[2]), model)
+    bw = po.baum_welch(a, pi, [bref])
+    np.testing.assert_allclose(lab.get('logp')[2], bw['logp'][0], rtol=1e-10)
+    ref.close()
+    lab.close()
+
+
+# ------------------------------------------------------------------ A12 on the device
+@pytest.mark.parametrize('dense', [False, True])
+def test_hmm_accumulators_match_oracle(eng, dense):
+    """pcl_batch_accumulate_hmm = LHMM.update_acc + add_acc over every utterance x label position (LHMM.py:473-500,
+    149-161), merged per unit, against the oracle's per-position accumulators log-added per unit; two batches
+    accumulate into the same context-resident accumulators."""
+    from poccala_amd import PCL_F64
+    mean, var, w, trans, frames, lens, begin, labels = problem(77, units=5, U=11, L=4, dense_trans=dense)
+    model = oracle_model(mean, var, w, trans)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    eng.stats_zero()
+    halves = [np.arange(0, 6), np.arange(6, 11)]
+    for idx in halves:
+        b = eng.label_batch([labels[u] for u in idx], lens[idx], begin[idx])
+        b.score(PCL_F64)
+        b.forward_backward()
+        b.accumulate_hmm()
+        b.close()
+    ks, ga = eng.hmm_acc_download()
+    rk = np.full((5, E, S), -np.inf)
+    rg = np.full((5, E), -np.inf)
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, accs, _ = po.estep_utterance(x, list(lab), model)
+        for pos, unit in enumerate(lab):
+            rk[unit] = np.logaddexp(rk[unit], accs[pos].ksai_acc)
+            rg[unit] = np.logaddexp(rg[unit], accs[pos].gamma_acc)
+    fin_close(ks, rk, rtol=1e-10)
+    fin_close(ga, rg, rtol=1e-10)
+    # transition M-step (LHMM.py:519-520) for the units that occurred; the others keep their matrix
+    eng.mstep_transitions()
+    got = eng.units_download()
+    for unit in range(5):
+        if np.isfinite(rg[unit]).all():
+            np.testing.assert_allclose(got[unit], po.hmm_update_param(trans[unit], rk[unit], rg[unit]), rtol=1e-9, atol=1e-300)
+        else:
+            assert np.array_equal(got[unit], trans[unit])
+    eng.stats_zero()
+    ks, ga = eng.hmm_acc_download()
+    assert np.isneginf(ks).all() and np.isneginf(ga).all()
+
+
+@pytest.mark.parametrize('case', ['G6_small_fix0', 'G6_small_fix1', 'G8_floor', 'G6_n62_fix0'])
+def test_hmm_accumulators_golden(eng, golden, case):
+    """The reference's own per-position ksai_acc / gamma_acc (golden G6 / G8, written by the reference's
+    update_acc), merged per unit, through the C-ABI at 1e-10; and the reference's new transition matrices."""
+    from poccala_amd import PCL_F64
+    g = golden(case)
+    names = [str(u) for u in g['unit_names']]
+    label = [names.index(str(u)) for u in g['label']]
+    x = g['x']
+    mean = np.stack([g['mean_%d_%d' % (u, k)] for u in range(len(names)) for k in range(E)])
+    var = np.stack([g['var_%d_%d' % (u, k)] for u in range(len(names)) for k in range(E)])
+    w = np.stack([g['w_%d_%d' % (u, k)] for u in range(len(names)) for k in range(E)])
+    trans = np.stack([g['trans_%d' % u] for u in range(len(names))])
+    eng.load_model(mean, var, w)
+    eng.load_frames(x)
+    eng.load_units(trans)
+    b = eng.label_batch([label], [len(x)], [0])
+    b.score(PCL_F64)
+    fix = int(g['fix_code'])
+    b.forward_backward(fix_pi=bool(fix & 1))
+    fin_close(b.get('B')[0], g['emb_B'], rtol=1e-12)
+    np.testing.assert_allclose(b.get('logp')[0], float(g['bw_logp']), rtol=1e-10)
+    eng.stats_zero()
+    b.accumulate_hmm()
+    ks, ga = eng.hmm_acc_download()
+    b.close()
+    for unit in set(label):
+        pos = [p for p, u in enumerate(label) if u == unit]
+        rk = np.full((E, S), -np.inf)
+        rg = np.full(E, -np.inf)
+        for p in pos:
+            rk = np.logaddexp(rk, g['ksai_acc_%d' % p])
+            rg = np.logaddexp(rg, g['gamma_acc_%d' % p])
+        fin_close(ks[unit], rk, rtol=1e-10)
+        fin_close(ga[unit], rg, rtol=1e-10)
+    if not fix & 4 and len(set(label)) == len(label):       # every unit once: the reference's update_param output applies as is
+        eng.mstep_transitions()
+        got = eng.units_download()
+        for p, unit in enumerate(label):
+            np.testing.assert_allclose(got[unit], g['new_trans_%d' % p], rtol=1e-9, atol=1e-300)
+
+
+def test_em_loop_stays_on_device(eng):
+    """E-step -> em_exchange (one rank: GMM + transition M-step) -> refresh_transitions -> second E-step, against the
+    oracle doing the same with merged accumulators and update_param."""
+    from poccala_amd import PCL_F64
+    mean, var, w, trans, frames, lens, begin, labels = problem(123, units=3, M=4, U=14, T=70, L=3)
+    model = oracle_model(mean, var, w, trans)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F64)
+    b.forward_backward()
+    eng.stats_zero()
+    b.accumulate(PCL_F64)
+    b.accumulate_hmm()
+    eng.em_exchange(c_covariance=1e-3, update_transitions=True)
+    nm, nv, nw = eng.model_download()
+    nt = eng.units_download()
+    J, M, D = mean.shape
+    merged = [dict(acc=np.full(M, -np.inf), alpha_acc=-np.inf, mean_acc=np.full((M, D), -np.inf), cov_acc=np.full((M, D), -np.inf)) for _ in range(J)]
+    rk = np.full((3, E, S), -np.inf)
+    rg = np.full((3, E), -np.inf)
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, accs, _ = po.estep_utterance(x, list(lab), model)
+        for pos, unit in enumerate(lab):
+            rk[unit] = np.logaddexp(rk[unit], accs[pos].ksai_acc)
+            rg[unit] = np.logaddexp(rg[unit], accs[pos].gamma_acc)
+            for k in range(E):
+                mj, a = merged[unit * E + k], accs[pos].gmm[k]
+                for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+                    mj[key] = np.logaddexp(mj[key], a[key])
+    new_model = {}
+    for unit in range(3):
+        gm = []
+        for k in range(E):
+            rw, rm, rv = po.gmm_update_param(merged[unit * E + k], c_covariance=1e-3)
+            np.testing.assert_allclose(nw[unit * E + k], rw, rtol=1e-8)
+            np.testing.assert_allclose(nm[unit * E + k], rm, rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(nv[unit * E + k], rv, rtol=1e-7)
+            gm.append((rm, rv, rw))
+        rt = po.hmm_update_param(trans[unit], rk[unit], rg[unit])
+        np.testing.assert_allclose(nt[unit], rt, rtol=1e-9, atol=1e-300)
+        new_model[unit] = dict(trans=rt, gmms=gm)
+    # second E-step with the re-estimated model, transitions refreshed in the live batch
+    b.refresh_transitions()
+    b.score(PCL_F64)
+    b.forward_backward()
+    lp = b.get('logp')
+    for u in (0, 5, 13):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, a, bref, pi = po.score_label(x, list(labels[u]), new_model)
+        np.testing.assert_allclose(lp[u], po.baum_welch(a, pi, [bref])['logp'][0], rtol=1e-7)
+    b.close()
+
+
+# ------------------------------------------------------------------ ADVICE r1
+def test_mstep_unseen_state_and_zero_occupancy_mixture(eng):
+    """A state no utterance contains keeps its parameters; a mixture of a seen state whose occupancy is exactly zero in
+    the f32 statistics gets weight 0 and keeps its mean / variance; nothing becomes NaN, the layouts are re-derived
+    and the next E-step is finite.  (The reference would produce NaN for the unseen state and a vanishing weight for
+    the far mixture, Clustering.py:685-692.)"""
+    from poccala_amd import PCL_F32
+    mean, var, w, trans, frames, lens, begin, labels = problem(9, units=3, M=6, D=13, U=6, T=60, L=2)
+    labels = [np.array([0, 1]) for _ in labels]                 # unit 2 (states 6..8) is never seen
+    mean = mean.copy()
+    var = var.copy()
+    mean[0, 5] += 400.0                                         # a mixture of a seen state 400 sigma away: gamma flushes to 0
+    var[0, 5] = 0.5
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F32)
+    b.forward_backward()
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    b.accumulate_hmm()
+    st = eng.stats_download()
+    assert st['acc'][0, 5] == 0.0 and (st['alpha_acc'][6:] == 0).all()
+    eng.em_exchange(c_covariance=1e-3, update_transitions=True)
+    nm, nv, nw = eng.model_download()
+    nt = eng.units_download()
+    assert np.isfinite(nm).all() and np.isfinite(nv).all() and np.isfinite(nw).all() and np.isfinite(nt).all()
+    assert np.array_equal(nm[6:], mean[6:]) and np.array_equal(nv[6:], var[6:]) and np.array_equal(nw[6:], w[6:])
+    assert np.array_equal(nt[2], trans[2])
+    assert nw[0, 5] == 0.0 and np.array_equal(nm[0, 5], mean[0, 5]) and np.array_equal(nv[0, 5], var[0, 5])
+    np.testing.assert_allclose(nw[:6].sum(axis=1), 1.0, rtol=1e-5)
+    # the seen mixtures follow the oracle (f32 tolerance)
+    model = oracle_model(mean, var, w, trans)
+    J, M, D = mean.shape
+    mj = dict(acc=np.full(M, -np.inf), alpha_acc=-np.inf, mean_acc=np.full((M, D), -np.inf), cov_acc=np.full((M, D), -np.inf))
+    for u, lab in enumerate(labels):
+        x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        _, accs, _ = po.estep_utterance(x, list(lab), model)
+        a = accs[0].gmm[1]                                      # unit 0, state 1
+        for key in mj:
+            mj[key] = np.logaddexp(mj[key], a[key])
+    rw, rm, rv = po.gmm_update_param(mj, c_covariance=1e-3)
+    np.testing.assert_allclose(nw[1], rw, rtol=2e-4)
+    np.testing.assert_allclose(nm[1], rm, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(nv[1], rv, rtol=2e-3)
+    b.refresh_transitions()
+    b.score(PCL_F32)
+    b.forward_backward()
+    assert np.isfinite(b.get('logp')).all()
+    b.close()
+
+
+def test_batch_is_revalidated_after_reuploads(eng):
+    """A live batch whose frame rows or state ids no longer exist in the re-uploaded buffers fails with PCL_ERR_STATE
+    instead of indexing out of bounds."""
+    from poccala_amd import PCL_F32, PoccalaHipError
+    mean, var, w, trans, frames, lens, begin, labels = problem(5)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F32)
+    b.forward_backward()
+    eng.load_frames(frames[:int(lens[0])])                      # shorter frame matrix
+    with pytest.raises(PoccalaHipError) as ei:
+        b.score(PCL_F32)
+    assert ei.value.code == -3
+    with pytest.raises(PoccalaHipError):
+        b.accumulate(PCL_F32)
+    eng.load_frames(frames)
+    b.score(PCL_F32)                                            # valid again
+    eng.load_model(mean[:6], var[:6], w[:6])                    # fewer states than the batch refers to
+    with pytest.raises(PoccalaHipError) as ei:
+        b.score(PCL_F32)
+    assert ei.value.code == -3
+    b.close()
+
+
+def test_timers_are_opt_in(eng):
+    from poccala_amd import PCL_F32
+    mean, var, w, trans, frames, lens, begin, labels = problem(6)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    eng.enable_timing(False)
+    b.score(PCL_F32)
+    assert eng.kernel_time('score') == (0.0, 0)
+    eng.enable_timing(True)
+    b.score(PCL_F32)
+    b.score(PCL_F32)
+    ms, n = eng.kernel_time('score')
+    assert n == 2 and ms > 0
+    eng.enable_timing(False)
+    b.close()
+
+
+def test_save_batch_acc_twice_merges_to_the_sum(tmp_path):
+    """two batches saved one after the other must merge (init_acc) to batch 1 + batch 2, for the HMM
+    accumulators as for the GMM ones."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd.Exceptions import NullLog
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    from poccala_amd.StatisticalModel.LHMM import LHMM
+    from poccala_amd import PCL_F64
+    mean, var, w, trans, frames, lens, begin, labels = problem(15, units=2, M=3, D=5, U=6, T=40, L=2)
+    names = ['a', 'b']
+
+    def units():
+        out = {}
+        for ui, u in enumerate(names):
+            gm = [Clustering.GMM(NullLog(), dimension=5, mix_level=3, alpha=w[ui * E + k].copy(), mean=mean[ui * E + k].copy(),
+                                 covariance=np.array([np.diag(v) for v in var[ui * E + k]]), gmm_id=k) for k in range(E)]
+            prof = [AcousticModel.VirtualState(1.)] + gm + [AcousticModel.VirtualState(0.)]
+            out[u] = LHMM({i: u for i in range(S)}, S, NullLog(), transmat=trans[ui].copy(), profunc=prof)
+        return out
+    am = AcousticModel(NullLog(), 'T', state_num=S, dct_num=5, delta_1=False, delta_2=False, parameters_path=str(tmp_path))
+    hm = units()
+    data = [frames[begin[u]:begin[u] + lens[u]].astype(np.float64) for u in range(6)]
+    lab = [[names[i] for i in l] for l in labels]
+    parts = []
+    for idx in (range(0, 3), range(3, 6)):
+        st, ha, _ = am.estep_batch([lab[u] for u in idx], [data[u] for u in idx], hm, precision=PCL_F64)
+        parts.append((st, ha))
+        am.save_batch_acc(st, ha, hm)
+    st_all, ha_all, _ = am.estep_batch(lab, data, hm, precision=PCL_F64)
+    fresh = units()
+    for u in names:
+        fresh[u].init_acc(am.unit_path(u))
+        if u in ha_all:
+            fin_close(fresh[u].ksai_acc, ha_all[u][0], rtol=1e-10)
+            fin_close(fresh[u].gamma_acc, ha_all[u][1], rtol=1e-10)
+        for k in range(E):
+            g = fresh[u].profunction[1 + k]
+            g.init_acc(am.unit_path(u))
+            j = names.index(u) * E + k
+            with np.errstate(divide='ignore'):
+                fin_close(g.acc, np.log(st_all['acc'][j]), rtol=1e-9, atol=1e-9)
+                fin_close(np.float64(g.alpha_acc), np.log(st_all['alpha_acc'][j]), rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------ the E-step exchange, two GPU processes on one device
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _exchange_worker(rank, world, port, payload, uneven, q):
+    try:
+        from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+        from poccala_amd.distributed import Control, shard_range
+        units = 5 if uneven else 4                      # J = 15 states over 2 ranks: 7 + 8 (the rooted-reduce path)
+        mean, var, w, trans = synth.make_model(units, 6, 13, seed=71)
+        frames, lens, begin = synth.make_frames(10, 60, 13, seed=72, ragged=True)
+        labels = synth.make_labels(10, 3, units, seed=73)
+        eng = Engine(0)
+        ctl = Control(rank, world, addr='127.0.0.1', port=port, token=b't')
+        if world > 1:
+            eng.comm_init_host(rank, world, ctl.allgather_bytes)
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        lo, hi = shard_range(10, rank, world)
+        f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
+        eng.load_frames(frames[f0:f1])
+        b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi] - f0)
+        b.score(PCL_F64)
+        b.forward_backward()
+        eng.stats_zero()
+        b.accumulate(PCL_F64)
+        b.accumulate_hmm()
+        eng.em_exchange(1e-3, PCL_F32 if payload == 'f32' else PCL_F64, True)
+        info = eng.comm_info()
+        m, v, ww = eng.model_download()
+        t = eng.units_download()
+        b.refresh_transitions()
+        b.score(PCL_F64)
+        b.forward_backward()
+        lp = b.get('logp')
+        b.close()
+        ctl.barrier()
+        ctl.close()
+        eng.close()
+        q.put((rank, info, m, v, ww, t, lp))
+    except Exception as e:      # noqa
+        import traceback
+        q.put((rank, 'error', traceback.format_exc()))
+
+
+@pytest.mark.parametrize('payload,uneven', [('f64', False), ('f64', True), ('f32', False)])
+def test_em_exchange_world2_on_one_device_equals_single_rank(payload, uneven):
+    """two GPU processes (both on device 0, host rehearsal transport in place of RCCL, which
+    refuses duplicate devices) shard the utterances, reduce-scatter the statistics by state range, re-estimate the
+    states they own and all-gather the model: every rank must end with the model a single rank computes from all
+    utterances (f64 payload: 1e-12; f32 payload: the f32 rounding of it), and with the same next-iteration
+    log-likelihoods for its utterances."""
+    ctx = mp.get_context('spawn')
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, payload, uneven, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        for g in got:
+            assert g[1] != 'error', g[2]
+        res[world] = sorted(got, key=lambda g: g[0])
+    single = res[1][0]
+    assert single[1]['transport'] == 'none'
+    tol = dict(rtol=1e-12, atol=0) if payload == "f64" else dict(rtol=1e-6, atol=1e-6)
+    for g in res[2]:
+        assert g[1]['transport'] == 'host-rehearsal' and g[1]['nranks'] == 2
+        for k in (2, 3, 4):
+            np.testing.assert_allclose(g[k], single[k], **tol)
+        np.testing.assert_allclose(g[5], single[5], rtol=1e-12, atol=1e-300)
+    for k in (2, 3, 4, 5):                                       # one model on every GPU
+        assert np.array_equal(res[2][0][k], res[2][1][k])
+    lp2 = np.concatenate([g[6] for g in res[2]])
+    np.testing.assert_allclose(lp2, single[6], rtol=1e-10 if payload == 'f64' else 1e-6)
+
+
+def test_rccl_world1_em_exchange_and_allreduce(eng):
+    """RCCL itself (ncclCommInitRank, reduce-scatter, all-gather, all-reduce) at the one world size a one-GPU box
+    allows: the exchange must leave what pcl_mstep leaves."""
+    from poccala_amd import PCL_F64
+    mean, var, w, trans, frames, lens, begin, labels = problem(88)
+    res = []
+    for use_rccl in (False, True):
+        eng.load_model(mean, var, w)
+        eng.load_frames(frames)
+        eng.load_units(np.stack(trans))
+        if use_rccl:
+            eng.comm_init(0, 1, eng.comm_unique_id())
+            info = eng.comm_info()
+            assert info['transport'] == 'rccl' and info['rccl_nranks'] == 1
+        b = eng.label_batch(labels, lens, begin)
+        b.score(PCL_F64)
+        b.forward_backward()
+        eng.stats_zero()
+        b.accumulate(PCL_F64)
+        b.accumulate_hmm()
+        if use_rccl:
+            eng.stats_allreduce()
+        eng.em_exchange(1e-3, PCL_F64, True)
+        res.append(eng.model_download() + (eng.units_download(),))
+        b.close()
+        if use_rccl:
+            eng._lib.pcl_comm_destroy(eng._ctx)
+    for a, b_ in zip(*res):
+        assert np.array_equal(a, b_)

@@ -113,3 +113,55 @@ def test_tcp_control_plane_world2():
     assert np.isneginf(lse[0, 0])
     np.testing.assert_allclose(lse[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-14)
     np.testing.assert_allclose(sm, 3.0)
+
+
+def _auth_worker(kind, port, q):
+    from poccala_amd.distributed import Control
+    if kind == 'hub':
+        ctl = Control(0, 2, addr='127.0.0.1', port=port, token=b'job-secret', timeout=60)
+        got = ctl.allgather(np.arange(3, dtype=np.float64))
+        ctl.close()
+        q.put(('hub', [g.tolist() for g in got]))
+    elif kind == 'good':
+        import time
+        time.sleep(1.5)                       # let the impostors try first
+        ctl = Control(1, 2, addr='127.0.0.1', port=port, token=b'job-secret', timeout=60)
+        ctl.allgather(np.arange(3, dtype=np.float64) + 10)
+        ctl.close()
+    else:                                     # wrong token, or a rank id outside the job
+        try:
+            Control(1 if kind == 'bad-token' else 7, 2 if kind == 'bad-token' else 8, addr='127.0.0.1', port=port,
+                    token=b'wrong' if kind == 'bad-token' else b'job-secret', timeout=3)
+            q.put((kind, 'connected'))
+        except (RuntimeError, ValueError):
+            q.put((kind, 'refused'))
+
+
+def test_control_plane_refuses_wrong_token_and_bad_rank():
+    """the hub must authenticate its peers, range-check rank ids and never unpickle what it receives."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    kinds = ['hub', 'bad-token', 'bad-rank', 'good']
+    procs = [ctx.Process(target=_auth_worker, args=(k, port, q)) for k in kinds]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=60) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res['bad-token'] == 'refused' and res['bad-rank'] == 'refused'
+    assert res['hub'] == [[0.0, 1.0, 2.0], [10.0, 11.0, 12.0]]
+
+
+def test_control_plane_frames_are_not_pickle():
+    import poccala_amd.distributed as d
+    src = open(d.__file__).read()
+    assert 'import pickle' not in src and 'pickle.loads' not in src
+    for obj in (None, b'\x00' * 128, 2.5, np.array([[1.0, -np.inf]]), np.arange(4, dtype=np.int32), {'a': [1, 2]}):
+        kind, data = d._encode(obj)
+        back = d._decode(kind, data)
+        if isinstance(obj, np.ndarray):
+            assert back.dtype == obj.dtype and np.array_equal(back, obj)
+        else:
+            assert back == obj

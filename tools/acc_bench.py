@@ -9,7 +9,7 @@ U, M, units, D, T, L = 1024, 2048, 1000, 39, 300, 20
 mean, var, w, trans = synth.make_model(units, M, D)
 frames, lens, begin = synth.make_frames(U, T, D)
 labels = synth.make_labels(U, L, units)
-eng = Engine(0)
+eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w); eng.load_frames(frames)
 b, n = make_sentence_batch(eng, labels, lens, begin, trans)
 b.score(PCL_F32); b.forward_backward(fix_pi=False)

@@ -10,7 +10,7 @@ c = synth.CONFIGS['C5shard']
 U = int(sys.argv[1]) if len(sys.argv) > 1 else c['U']
 mean, var, w, _ = synth.make_model(c['units'], c['M'], c['D'])
 frames, lens, begin = synth.make_frames(U, c['T'], c['D'])
-eng = Engine(0)
+eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w); eng.load_frames(frames)
 J = c['units'] * 3
 b = eng.batch([J + 2] * U, lens, begin)

@@ -22,7 +22,7 @@ for u, lab in enumerate(labels):
     mix = rng.integers(0, c['M'], size=T)
     frames[u * T:(u + 1) * T] = mean[states, mix] + np.sqrt(var[states, mix]) * rng.standard_normal((T, D))
 lens = np.full(U, T, dtype=np.int32); begin = np.arange(U, dtype=np.int64) * T
-eng = Engine(0)
+eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w)
 for name, fr in (('model-sampled features', frames), ('random features (bench)', synth.make_frames(U, T, D)[0])):
     eng.load_frames(fr)

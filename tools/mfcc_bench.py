@@ -9,7 +9,7 @@ U = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rng = np.random.default_rng(0)
 n = 400 + 299 * 200
 sigs = [np.round(2000 * rng.standard_normal(n)) for _ in range(U)]
-eng = Engine(0)
+eng = Engine(0); eng.enable_timing(True)
 out = mfcc_batch(sigs, 16000, d1=True, d2=True, engine=eng); eng.kernel_time('mfcc')
 t0 = time.perf_counter()
 out = mfcc_batch(sigs, 16000, d1=True, d2=True, engine=eng)

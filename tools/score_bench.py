@@ -16,7 +16,7 @@ frames, lens, begin = synth.make_frames(U, T, D)
 labels = synth.make_labels(U, L, units)
 if os.environ.get('ZERO'):      # power experiment: trivial operands (all-zero frames, identical unit-variance mixtures)
     frames[:] = 0; mean[:] = 0; var[:] = 1
-eng = Engine(0)
+eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w)
 eng.load_frames(frames)
 b, n = make_sentence_batch(eng, labels, lens, begin, trans)
