@@ -242,6 +242,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     args.gpus = world
+    if os.environ.get('POCCALA_HANG_DUMP'):       # diagnostics: where is every thread after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['POCCALA_HANG_DUMP']), repeat=True, file=sys.stderr)
 
     from poccala_amd import synth
     P_name = args.precision
