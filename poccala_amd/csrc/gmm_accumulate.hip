@@ -24,6 +24,10 @@
 //      in chunks and read back as broadcasts.  Per (frame, mixture, dim): y = x s + c; q += y^2
 //      (2 FMA), then z = g y; S1 += z; S2 += z y (3 ops).  Centred, scaled moments avoid the
 //      cancellation of raw moments: (o - mu) = y / s, (o - mu)^2 = y^2 / s^2.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "pcl_internal.h"
 
 namespace {
@@ -121,7 +125,11 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     const real *__restrict__ frames, const real *__restrict__ params, const real *__restrict__ means, int Mpad,
     const int *__restrict__ work_states, const int *__restrict__ seg_lo, const int *__restrict__ seg_hi,
     const long long *__restrict__ off, const ActiveFrame *__restrict__ list, double bias, double *__restrict__ st_acc,
-    double *__restrict__ st_alpha, double *__restrict__ st_mean, double *__restrict__ st_cov) {
+    double *__restrict__ st_alpha, double *__restrict__ st_mean, double *__restrict__ st_cov,
+    const int *__restrict__ tile_off, const unsigned int *__restrict__ tile_mask, const int *__restrict__ state_flag) {
+    // tile_mask != NULL (fix-up of the f16 producer / consumer path, gmm_accumulate_f16.hip): only the frames whose bit is set
+    // in their 32-frame tile's mask are accumulated -- the ones that path took out because a scaled feature left the f16
+    // range -- and alpha_acc is left alone (the consumer summed gamma_t(j) of every frame).
     constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
     constexpr int XS = (D + 3) / 4 * 4;
     __shared__ __attribute__((aligned(16))) real xs[FC * XS];
@@ -129,6 +137,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     __shared__ double red[WG / 64];
 
     const int w = blockIdx.y;
+    if (state_flag && !state_flag[w]) return;                            // fix-up mode: nothing of this state was left out
     const int j = work_states[w];
     const long long beg = off[seg_lo[w]], end = off[seg_hi[w]];
     if (beg == end) return;
@@ -157,6 +166,11 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
 
     for (long long f0 = beg; f0 < end; f0 += FC) {
         const int nf = (int)min((long long)FC, end - f0);
+        unsigned int fmask = 0xffffffffu;
+        if (tile_mask) {
+            fmask = tile_mask[tile_off[w] + (int)((f0 - beg) / FC)];
+            if (fmask == 0u) continue;                                   // (uniform over the workgroup)
+        }
         __syncthreads();
         // stage the chunk: FC x D features (rows gathered by index) and the per-frame coefficient
         for (int e = threadIdx.x; e < nf * D; e += WG) {
@@ -165,8 +179,8 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
         }
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
-            cf[threadIdx.x] = (real)(a.coef * LOG2E);
-            if (blockIdx.x == 0) galpha += a.lg;
+            cf[threadIdx.x] = ((fmask >> threadIdx.x) & 1u) ? (real)(a.coef * LOG2E) : (real)-INFINITY;
+            if (blockIdx.x == 0 && !tile_mask) galpha += a.lg;
         }
         __syncthreads();
         for (int f = 0; f < nf; ++f) {
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
             }
         }
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && !tile_mask) {
         // deterministic block sum of the per-thread partial posteriors
         double v = galpha;
 #pragma unroll
@@ -493,13 +507,30 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
 }
 
 template <int D, typename real, int MINW>
-void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const real *means, int first, int count) {
+void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const real *means, int first, int count,
+                  const int *tile_off = nullptr, const unsigned int *tile_mask = nullptr, const int *state_flag = nullptr) {
     if (count == 0) return;
     dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)count);
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
                        ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
-                       ctx->st_alpha, ctx->st_mean, ctx->st_cov);
+                       ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag);
 }
+
+// f32, states [first, first + count) of the accumulate order (optionally only the frames a tile mask marks)
+void launch_acc_f32(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int *tile_off = nullptr, const unsigned int *tile_mask = nullptr,
+                    const int *state_flag = nullptr) {
+    switch (ctx->D) {
+#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count, tile_off, tile_mask, state_flag); break;
+        CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)
+#undef CASE32
+#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count, tile_off, tile_mask, state_flag); break;
+        CASE32W(48) CASE32W(64)
+#undef CASE32W
+        default: break;
+    }
+}
+
+bool device_dim_supported(int D) { return D == 13 || D == 26 || D == 39 || D == 8 || D == 16 || D == 24 || D == 32 || D == 40 || D == 48 || D == 64; }
 
 }  // namespace
 
@@ -510,6 +541,19 @@ void pcl_accumulate_release(pcl_batch *b) {
     if (b->d_work_states) (void)hipFree(b->d_work_states);
     if (b->d_seg_lo) (void)hipFree(b->d_seg_lo);
     if (b->d_seg_hi) (void)hipFree(b->d_seg_hi);
+    for (int k = 0; k < 2; ++k) {
+        if (b->acc16_images[k]) (void)hipFree(b->acc16_images[k]);
+        if (b->acc16_tile_off[k]) (void)hipFree(b->acc16_tile_off[k]);
+        if (b->acc16_tile_mask[k]) (void)hipFree(b->acc16_tile_mask[k]);
+        if (b->acc16_state_flag[k]) (void)hipFree(b->acc16_state_flag[k]);
+        if (b->acc16_ev_prod[k]) (void)hipEventDestroy(b->acc16_ev_prod[k]);
+        if (b->acc16_ev_cons[k]) (void)hipEventDestroy(b->acc16_ev_cons[k]);
+        b->acc16_images[k] = nullptr; b->acc16_tile_off[k] = nullptr; b->acc16_tile_mask[k] = nullptr; b->acc16_state_flag[k] = nullptr;
+        b->acc16_ev_prod[k] = b->acc16_ev_cons[k] = nullptr;
+    }
+    if (b->acc16_ev_start) (void)hipEventDestroy(b->acc16_ev_start);
+    b->acc16_ev_start = nullptr;
+    b->acc16_cap_tiles = b->acc16_cap_states = 0;
     b->acc_cnt = nullptr; b->acc_off = nullptr; b->acc_list = nullptr;
     b->d_work_states = b->d_seg_lo = b->d_seg_hi = nullptr;
     b->acc_cap_list = b->acc_cap_segs = b->acc_cap_states = 0;
@@ -579,7 +623,92 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
     hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
                        b->acc_off, b->acc_list);
-    if (mfma && n_good > 0 && ctx->score_variant >= 4) {
+    static const bool acc_bf16 = getenv("PCL_ACC_BF16") && atoi(getenv("PCL_ACC_BF16")) != 0;      // A/B: the round-1 kernel
+    if (mfma && n_good > 0 && ctx->score_variant == 7 && !acc_bf16) {
+        // producer / consumer on the f16 + bf16 matrix pipes (gmm_accumulate_f16.hip), in groups of states whose tile
+        // images fit the image buffer (worst case: every frame of the state survives)
+        static const size_t budget = (size_t)(getenv("PCL_ACC_IMAGE_MB") ? atol(getenv("PCL_ACC_IMAGE_MB")) : 2048) << 20;   // per buffer set, two sets
+        const size_t ib = pcl_acc16_image_bytes(D);
+        // group by the ACTUAL tile counts: the scan result comes back (n_segs + 1 offsets, one short copy behind the scan
+        // kernel) -- on peaked posteriors a tenth of the frames survive, and sizing the groups for the worst case made
+        // eight half-empty launches, each with its parameter prologue and statistics flush, out of one
+        std::vector<long long> off_h((size_t)b->n_segs + 1);
+        HIPCHK(ctx, hipMemcpyAsync(off_h.data(), b->acc_off, off_h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int> wtiles(n_good);
+        size_t worst = 0, biggest = 0;
+        for (int k = 0; k < n_good; ++k) {
+            wtiles[k] = (int)((off_h[b->acc_hi[k]] - off_h[b->acc_lo[k]] + 31) / 32);
+            worst += wtiles[k];
+            biggest = std::max(biggest, (size_t)wtiles[k]);
+        }
+        const size_t by_budget = std::max<size_t>(budget / ib, 1);
+        size_t cap_tiles = std::max(biggest, std::min(worst, by_budget));
+        if (b->acc16_cap_tiles >= cap_tiles) cap_tiles = b->acc16_cap_tiles;                 // never shrink: the counts move from call to call
+        else cap_tiles = std::max(cap_tiles, std::min(cap_tiles + cap_tiles / 4, std::max(by_budget, biggest)));   // grow with headroom
+        if (b->acc16_cap_tiles < cap_tiles) {
+            for (int k = 0; k < 2; ++k) {
+                if (b->acc16_images[k]) (void)hipFree(b->acc16_images[k]);
+                if (b->acc16_tile_mask[k]) (void)hipFree(b->acc16_tile_mask[k]);
+                b->acc16_images[k] = nullptr; b->acc16_tile_mask[k] = nullptr;
+                HIPCHK(ctx, hipMalloc(&b->acc16_images[k], cap_tiles * ib));
+                HIPCHK(ctx, hipMalloc((void **)&b->acc16_tile_mask[k], cap_tiles * sizeof(unsigned int)));
+            }
+            b->acc16_cap_tiles = cap_tiles;
+        }
+        if (b->acc16_cap_states < (size_t)n_good + 1) {
+            for (int k = 0; k < 2; ++k) {
+                if (b->acc16_tile_off[k]) (void)hipFree(b->acc16_tile_off[k]);
+                if (b->acc16_state_flag[k]) (void)hipFree(b->acc16_state_flag[k]);
+                b->acc16_tile_off[k] = b->acc16_state_flag[k] = nullptr;
+                HIPCHK(ctx, hipMalloc((void **)&b->acc16_tile_off[k], ((size_t)n_good + 1) * sizeof(int)));
+                HIPCHK(ctx, hipMalloc((void **)&b->acc16_state_flag[k], ((size_t)n_good + 1) * sizeof(int)));
+            }
+            b->acc16_cap_states = (size_t)n_good + 1;
+        }
+        if (!b->acc16_ev_start) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&b->acc16_ev_start, hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(ctx, hipEventCreateWithFlags(&b->acc16_ev_prod[k], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&b->acc16_ev_cons[k], hipEventDisableTiming));
+            }
+        }
+        // groups of states: (first, count, worst-case tiles)
+        std::vector<int> gfirst, gcount, gtiles;
+        for (int first = 0; first < n_good;) {
+            size_t t = 0;
+            int last = first;
+            while (last < n_good && t + wtiles[last] <= cap_tiles) t += wtiles[last++];
+            gfirst.push_back(first); gcount.push_back(last - first); gtiles.push_back((int)t);
+            first = last;
+        }
+        // the producer of group g + 1 runs on the auxiliary stream beside the consumer of group g (it is HBM-write
+        // bound, the consumer matrix-pipe bound, and a consumer workgroup leaves registers for one small wave per SIMD)
+        static const bool overlap = !(getenv("PCL_ACC_OVERLAP") && atoi(getenv("PCL_ACC_OVERLAP")) == 0);
+        hipStream_t ps = overlap ? ctx->stream_aux : ctx->stream;
+        HIPCHK(ctx, hipEventRecord(b->acc16_ev_start, ctx->stream));            // the active-frame lists are complete
+        if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ps, b->acc16_ev_start, 0));
+        const int G = (int)gfirst.size();
+        auto produce = [&](int g) -> int {
+            const int buf = g & 1;
+            if (overlap && g >= 2) HIPCHK(ctx, hipStreamWaitEvent(ps, b->acc16_ev_cons[buf], 0));      // the buffer set is free again
+            const int rc = pcl_launch_acc16_produce(ctx, b, gfirst[g], gcount[g], gtiles[g], buf, ps);
+            if (rc != PCL_OK) return rc;
+            if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_prod[buf], ps));
+            return PCL_OK;
+        };
+        if (G > 0) { const int rc = produce(0); if (rc != PCL_OK) return rc; }
+        for (int g = 0; g < G; ++g) {
+            const int buf = g & 1;
+            if (overlap && g + 1 < G) { const int rc = produce(g + 1); if (rc != PCL_OK) return rc; }
+            if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->acc16_ev_prod[buf], 0));
+            int rc = pcl_launch_acc16_consume(ctx, b, gfirst[g], gcount[g], buf, ctx->stream);
+            if (rc != PCL_OK) return rc;
+            launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
+            if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));
+            if (!overlap && g + 1 < G) { rc = produce(g + 1); if (rc != PCL_OK) return rc; }
+        }
+    } else if (mfma && n_good > 0 && ctx->score_variant >= 4) {
         const int rc = pcl_launch_accumulate_split(ctx, b, n_good);     // bf16 matrix pipe (gmm_accumulate_split.hip)
         if (rc != PCL_OK) return rc;
     } else if (mfma && n_good > 0) {
@@ -594,15 +723,8 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     }
     if (precision == PCL_F32) {
         const int first = mfma ? n_good : 0, count = mfma ? n_bad : (int)ns;
-        switch (D) {
-#define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count); break;
-            CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)
-#undef CASE32
-#define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count); break;
-            CASE32W(48) CASE32W(64)
-#undef CASE32W
-            default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 accumulate kernel for padded D=%d", D);
-        }
+        if (device_dim_supported(D)) launch_acc_f32(ctx, b, first, count);
+        else PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 accumulate kernel for padded D=%d", D);
     } else {
         switch (D) {
 #define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, ctx->frames64, ctx->params64, ctx->mean64, 0, (int)ns); break;

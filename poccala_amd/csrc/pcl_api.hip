@@ -57,7 +57,8 @@ int pcl_init(int device, pcl_ctx **out) {
     pcl_ctx *ctx = new pcl_ctx();
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess) {
+        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess ||
+        (e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess) {
         g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
         delete ctx;
         return PCL_ERR_HIP;
@@ -101,6 +102,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     pcl_comm_destroy(ctx);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream_dp);
+    hipStreamSynchronize(ctx->stream_aux);
     drop_timers(ctx);
     free_model(ctx);
     pcl_units_release(ctx);
@@ -108,6 +110,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     dev_free(ctx->frames64);
     hipStreamDestroy(ctx->stream);
     hipStreamDestroy(ctx->stream_dp);
+    hipStreamDestroy(ctx->stream_aux);
     delete ctx;
     return PCL_OK;
 }
@@ -118,6 +121,7 @@ int pcl_sync(pcl_ctx *ctx) {
     if (!ctx) return PCL_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_aux));
     return PCL_OK;
 }
 
@@ -351,6 +355,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     hipStreamSynchronize(b->ctx->stream_dp);
+    hipStreamSynchronize(b->ctx->stream_aux);
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
     pcl_accumulate_release(b);

@@ -75,6 +75,7 @@ struct pcl_ctx {
     int Mpad32 = 0;              // M rounded up to a multiple of 32
     int layouts_valid = 0;             // PCL_LAYOUT_* derived for the current model (the f64 rows are derived on first use)
     hipStream_t stream_dp = nullptr;   // forward-backward runs here, beside the next batch's scoring on `stream`
+    hipStream_t stream_aux = nullptr;  // the accumulate pass's tile-image producer runs here, beside its consumer on `stream`
     bool dp_async = true;              // env PCL_DP_STREAM=0: everything on one stream
     int score_variant = 0;       // 1 = VALU/LDS, 3 = f32-input MFMA, 4 = split-bf16 MFMA, 5 = split-f16 MFMA (32x32x16), 6 = split-f16 MFMA (16x16x32), 7 = split-f16 with the constants folded into the spare K slots
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
@@ -158,6 +159,13 @@ struct pcl_batch {
     ActiveFrame *acc_list = nullptr;
     int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
     size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
+    // producer / consumer accumulate (gmm_accumulate_f16.hip): tile images in LDS order, per-state tile offsets, outlier masks
+    // two sets: the producer of state group g + 1 runs on the auxiliary stream beside the consumer of group g
+    void *acc16_images[2] = {nullptr, nullptr};
+    int *acc16_tile_off[2] = {nullptr, nullptr}, *acc16_state_flag[2] = {nullptr, nullptr};
+    unsigned int *acc16_tile_mask[2] = {nullptr, nullptr};
+    hipEvent_t acc16_ev_prod[2] = {nullptr, nullptr}, acc16_ev_cons[2] = {nullptr, nullptr}, acc16_ev_start = nullptr;
+    size_t acc16_cap_tiles = 0, acc16_cap_states = 0;
     // label-built batches (pcl_batch_create_labels): the labels, and per unit the list of its occurrences
     bool from_labels = false;
     std::vector<int32_t> label_len, labels;
@@ -226,6 +234,9 @@ int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, in
 int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split_tile_frames();
 int pcl_launch_accumulate_split(pcl_ctx *ctx, pcl_batch *b, int ns);
+int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int max_tiles, int buf, hipStream_t stream);
+int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, hipStream_t stream);
+size_t pcl_acc16_image_bytes(int D);
 int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_launch_score_split16x(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split16_tile_frames();

@@ -487,3 +487,44 @@ def test_rccl_world1_em_exchange_and_allreduce(eng):
             eng._lib.pcl_comm_destroy(eng._ctx)
     for a, b_ in zip(*res):
         assert np.array_equal(a, b_)
+
+
+def test_accumulate_outlier_frames_take_the_direct_form_fixup(eng):
+    """Frames whose scaled features leave the f16 range (here: thousands of sigma from a tight mixture) are taken out of the
+    producer / consumer accumulate path and added by the direct-form kernel: the statistics must match the oracle's
+    GMM.update_acc (Clustering.py:653-680) for the whole block, outliers included, and equal the all-VALU path."""
+    import os
+    from poccala_amd import PCL_F32
+    rng = np.random.default_rng(404)
+    M, D, T = 40, 39, 100
+    mean = rng.standard_normal((2, M, D))
+    var = rng.uniform(0.5, 2.0, (2, M, D))
+    var[0, :4] = 1e-2                                            # tight mixtures: the feature scales of state 0 are large
+    w = rng.dirichlet(np.ones(M), size=2)
+    x = rng.standard_normal((T, D))
+    x[7] += 3.0e3                                                # ~3e4 sigma of the tight mixtures: scaled x'^2 overflows f16
+    x[55, 3] -= 4.0e3
+    x = x.astype(np.float32)
+    eng.load_model(mean, var, w)
+    eng.load_frames(x)
+    b = eng.batch([4], [T], [0])
+    b.set_states([np.array([-1, 0, 1, -2], dtype=np.int32)])
+    b.score(PCL_F32)
+    lb = b.get('B')[0]
+    lg = np.log(rng.dirichlet(np.ones(2), size=T).T)             # posteriors of the two emitting rows
+    ninf = np.full(T, -np.inf)
+    b.set_posteriors([np.stack([ninf, lg[0], lg[1], ninf])])
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    st = eng.stats_download()
+    b.close()
+    xx = x.astype(np.float64)
+    for j in range(2):
+        acc = dict(acc=np.full(M, -np.inf), alpha_acc=-np.inf, mean_acc=np.full((M, D), -np.inf), cov_acc=np.full((M, D), -np.inf))
+        bj = po.gmm_point(xx, mean[j], var[j], w[j])
+        po.gmm_update_acc(acc, lg[j], bj, xx, mean[j], var[j], w[j])
+        for key, got in (('acc', st['acc'][j]), ('mean_acc', st['mean_acc'][j]), ('cov_acc', st['cov_acc'][j])):
+            ref = np.exp(acc[key])
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-6 * ref.max(), err_msg='%s state %d' % (key, j))
+        np.testing.assert_allclose(st['alpha_acc'][j], np.exp(acc['alpha_acc']), rtol=1e-6)
+    np.testing.assert_allclose(lb[1], po.gmm_point(xx, mean[0], var[0], w[0]), rtol=1e-5, atol=2e-4 * 1e3)
