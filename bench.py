@@ -268,11 +268,11 @@ def main():
     P = PCL_F32 if P_name == 'f32' else PCL_F64
     ndev = device_count()
     dev = int(os.environ.get('POCCALA_DEVICE', local))
-    shared = False
-    if dev >= ndev and ndev > 0 and os.environ.get('POCCALA_SHARE_DEVICE'):
-        # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: several ranks per device, and the host
-        # transport in place of RCCL (which refuses two ranks on one device)
-        dev, shared = dev % ndev, True
+    # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (POCCALA_SHARE_DEVICE=1): several ranks per device, and
+    # on EVERY rank the host transport in place of RCCL (which refuses two ranks on one device)
+    shared = bool(os.environ.get('POCCALA_SHARE_DEVICE')) and 0 < ndev < world
+    if shared:
+        dev = dev % ndev
     elif dev >= ndev:
         sys.exit('bench.py: rank %d needs HIP device %d but %d are visible (POCCALA_SHARE_DEVICE=1 rehearses several ranks per device)' % (rank, dev, ndev))
     eng = Engine(dev)

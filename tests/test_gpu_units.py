@@ -502,8 +502,11 @@ def test_accumulate_outlier_frames_take_the_direct_form_fixup(eng):
     var[0, :4] = 1e-2                                            # tight mixtures: the feature scales of state 0 are large
     w = rng.dirichlet(np.ones(M), size=2)
     x = rng.standard_normal((T, D))
-    x[7] += 3.0e3                                                # ~3e4 sigma of the tight mixtures: scaled x'^2 overflows f16
-    x[55, 3] -= 4.0e3
+    # one feature 40 units out: 400 sigma of the tight mixtures, whose power-of-two scale (64) takes x'^2 = 1600 past the
+    # f16 range (6e4) -- the frame leaves the matrix-pipe path -- while the exponent itself (~1e3) is still something f32
+    # resolves to ~1e-4: further out NO f32 evaluation of ln gamma_t(j,m) = ln N - ln b keeps 1e-4 (both terms ~x^2)
+    x[7, 0] += 40.0
+    x[55, 3] += 45.0
     x = x.astype(np.float32)
     eng.load_model(mean, var, w)
     eng.load_frames(x)
@@ -525,6 +528,6 @@ def test_accumulate_outlier_frames_take_the_direct_form_fixup(eng):
         po.gmm_update_acc(acc, lg[j], bj, xx, mean[j], var[j], w[j])
         for key, got in (('acc', st['acc'][j]), ('mean_acc', st['mean_acc'][j]), ('cov_acc', st['cov_acc'][j])):
             ref = np.exp(acc[key])
-            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-6 * ref.max(), err_msg='%s state %d' % (key, j))
+            np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-6 * ref.max(), err_msg='%s state %d' % (key, j))
         np.testing.assert_allclose(st['alpha_acc'][j], np.exp(acc['alpha_acc']), rtol=1e-6)
-    np.testing.assert_allclose(lb[1], po.gmm_point(xx, mean[0], var[0], w[0]), rtol=1e-5, atol=2e-4 * 1e3)
+    np.testing.assert_allclose(lb[1], po.gmm_point(xx, mean[0], var[0], w[0]), rtol=1e-5, atol=2e-4)
