@@ -188,6 +188,28 @@ int pcl_hmm_acc_download(pcl_ctx *ctx, double *ksai_acc, double *gamma_acc);
  * every unit that occurred; a unit that never occurred keeps its matrix (the reference would write NaN). */
 int pcl_mstep_transitions(pcl_ctx *ctx);
 
+/* ----------------------------------------------------------------- decoder (next row f3: the decode half of config 5)
+ * The pronunciation tree Lexicon.PronunciationLexicon builds (Lexicon/PronunciationLexicon.py:45-94), flattened: node i
+ * spells node_nunits[i] (1 or 2) units node_units[2 i ..] of the uploaded inventory (a reading split at the comma:
+ * initial + final, or a lone final: Token.__init__, Decoder.py:225), its children are child_idx[child_ptr[i] ..
+ * child_ptr[i+1]) in the tree's insertion order, node_word[i] != 0 where words end, roots = the first-character nodes.
+ * Needs pcl_units_upload first; a new pcl_units_upload drops the tree. */
+int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, const int32_t *node_nunits, const int32_t *child_ptr,
+                       const int32_t *child_idx, const int32_t *node_word, int n_roots, const int32_t *roots);
+/* A16: frame-synchronous token passing (Decoder.py:91-167, Token.viterbi :250-288) for every utterance of an ALL-STATE
+ * batch (rows entry, GMM state 0 .. J-1, exit; emissions from pcl_batch_score).  beam 0.85 and min_distinct 8 are the
+ * reference's pruning rule (:34,:159-167), candidate its `transfer` width (:175); max_tokens bounds the live tokens of one
+ * utterance (hand-overs beyond it are dropped and flagged); logpi_* = np.log(1/N) for N = S+0 / 2(S-2)+2 states from the
+ * caller.  The reference code is dead: the gaps D1-D5 filled here are listed in
+ * oracle/decoder_oracle.py, the restatement this entry point is tested against bit for bit.  PARITY UNPINNED. */
+int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate, int max_tokens, double logpi_one_unit,
+                     double logpi_two_units);
+/* Results (NULL pointers are skipped): n_final (U,) tokens returned per utterance; node / score / hist (U, candidate), best
+ * first; the word history: hist_n (U,) entries, hist_prev / hist_node (U, Tmax): entry h = (previous entry or -1, node whose
+ * word ended); n_tokens (U, Tmax): live tokens after every frame; overflow (U,): 1 if max_tokens was hit. */
+int pcl_batch_decode_get(pcl_batch *b, int32_t *n_final, int32_t *node, double *score, int32_t *hist, int32_t *hist_n,
+                         int32_t *hist_prev, int32_t *hist_node, int32_t *n_tokens, int32_t *overflow);
+
 /* Copy a result to a caller buffer (layouts in pcl_get_what). */
 int pcl_batch_get(pcl_batch *b, int what, void *host);
 

@@ -56,6 +56,9 @@ PROTOTYPES = {
     'pcl_hmm_acc_zero': (_i, [_vp]),
     'pcl_hmm_acc_download': (_i, [_vp, _vp, _vp]),
     'pcl_mstep_transitions': (_i, [_vp]),
+    'pcl_lexicon_upload': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'pcl_batch_decode': (_i, [_vp, _d, _i, _i, _i, _d, _d]),
+    'pcl_batch_decode_get': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcl_comm_init_host': (_i, [_vp, _i, _i, _vp, _vp]),
     'pcl_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'pcl_em_exchange': (_i, [_vp, _d, _i, _i]),

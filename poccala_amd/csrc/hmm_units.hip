@@ -99,6 +99,7 @@ __global__ void trans_mstep_kernel(const double *__restrict__ acc_ksai, const do
 }  // namespace
 
 void pcl_units_release(pcl_ctx *ctx) {
+    pcl_lexicon_release(ctx);                        // the tree names units of this inventory: upload it again after new units
     dev_free(ctx->d_unit_trans);
     dev_free(ctx->hmm_ksai);
     ctx->hmm_gamma = nullptr;                        // inside the hmm_ksai allocation

@@ -360,6 +360,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     if (b->ev_main) hipEventDestroy(b->ev_main);
     pcl_accumulate_release(b);
     pcl_batch_units_release(b);
+    pcl_batch_decode_release(b);
     dev_free(b->d_utt); dev_free(b->Bt); dev_free(b->alpha); dev_free(b->beta); dev_free(b->lgam);
     dev_free(b->logpi); dev_free(b->pi_out); dev_free(b->gamma_out); dev_free(b->ksai);
     dev_free(b->logp); dev_free(b->qtrace); dev_free(b->point); dev_free(b->npass); dev_free(b->path);

@@ -102,6 +102,10 @@ struct pcl_ctx {
     std::vector<double> unit_trans, unit_logtrans;   // host copies [n_units][S][S]: transmat and np.log(transmat)
     double *d_unit_trans = nullptr;                  // device copy of unit_trans (the transition M-step writes it)
     double *hmm_ksai = nullptr, *hmm_gamma = nullptr;   // per-unit accumulators, LOG domain: [n_units][S-2][S], [n_units][S-2]
+    // pronunciation tree for the decoder (hmm_decode.hip)
+    int *lex_units = nullptr, *lex_nunits = nullptr, *lex_child_ptr = nullptr, *lex_child_idx = nullptr, *lex_word = nullptr, *lex_roots = nullptr;
+    double *d_unit_logtrans = nullptr;
+    int lex_nodes = 0, lex_nroots = 0, lex_units_gen = 0;
     // multi-GPU (pcl_comm.hip): RCCL communicator, or the host-callback rehearsal transport
     void *comm = nullptr;
     int rank = 0, nranks = 1;
@@ -166,6 +170,12 @@ struct pcl_batch {
     unsigned int *acc16_tile_mask[2] = {nullptr, nullptr};
     hipEvent_t acc16_ev_prod[2] = {nullptr, nullptr}, acc16_ev_cons[2] = {nullptr, nullptr}, acc16_ev_start = nullptr;
     size_t acc16_cap_tiles = 0, acc16_cap_states = 0;
+    // decoder state (hmm_decode.hip): token buffers, node -> token map, scratch, results
+    char *dec_tok = nullptr;
+    int *dec_slot = nullptr, *dec_work = nullptr, *dec_int = nullptr;
+    double *dec_score = nullptr;
+    int dec_cap = 0, dec_cand = 0, dec_nodes = 0;
+    bool have_dec = false;
     // label-built batches (pcl_batch_create_labels): the labels, and per unit the list of its occurrences
     bool from_labels = false;
     std::vector<int32_t> label_len, labels;
@@ -257,4 +267,6 @@ int pcl_launch_trans_mstep(pcl_ctx *ctx);
 void pcl_units_release(pcl_ctx *ctx);
 void pcl_batch_units_release(pcl_batch *b);
 void pcl_comm_release(pcl_ctx *ctx);
+void pcl_lexicon_release(pcl_ctx *ctx);
+void pcl_batch_decode_release(pcl_batch *b);
 int pcl_launch_pack(pcl_ctx *ctx, const double *src, int inner, double *dst);

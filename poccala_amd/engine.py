@@ -135,6 +135,26 @@ class Engine(object):
         """Sentence HMMs of a list of labels (AcousticModel.embedded for every utterance at once, in the library)."""
         return Batch(self, None, T, frame_begin, unit_ids=unit_ids)
 
+    def load_lexicon(self, tree):
+        """The flat pronunciation tree of Lexicon.PronunciationLexicon.compile (units = ids of the loaded inventory)."""
+        nu = as_c(tree['node_units'], np.int32)
+        nn = as_c(tree['node_nunits'], np.int32)
+        cp = as_c(tree['child_ptr'], np.int32)
+        ci = as_c(tree['child_idx'], np.int32) if len(tree['child_idx']) else np.zeros(1, dtype=np.int32)
+        nw = as_c(tree['node_word'], np.int32)
+        ro = as_c(tree['roots'], np.int32)
+        self._check(self._lib.pcl_lexicon_upload(self._ctx, len(nn), ptr(nu), ptr(nn), ptr(cp), ptr(ci), ptr(nw), len(ro), ptr(ro)))
+        self.n_nodes = len(nn)
+
+    def all_state_batch(self, T, frame_begin):
+        """Batch whose emission rows are [entry, every GMM state 0..J-1, exit]: what the decoder reads (BASELINE config 5:
+        no label, every state of the inventory is scored for every frame)."""
+        T = as_c(T, np.int32).reshape(-1)
+        b = Batch(self, np.full(len(T), self.J + 2, dtype=np.int32), T, frame_begin)
+        rows = np.concatenate([[PCL_ROW_ENTRY], np.arange(self.J), [PCL_ROW_EXIT]]).astype(np.int32)
+        b.set_states([rows] * len(T))
+        return b
+
     def hmm_acc_zero(self):
         self._check(self._lib.pcl_hmm_acc_zero(self._ctx))
 
@@ -344,6 +364,25 @@ class Batch(object):
     def accumulate_hmm(self):
         """Per-unit ksai_acc / gamma_acc of every label position (LHMM.update_acc + add_acc); label-built batches only."""
         self._check(self._lib.pcl_batch_accumulate_hmm(self._b))
+
+    def decode(self, beam=0.85, min_distinct=8, candidate=5, max_tokens=4096):
+        """Token passing over the loaded pronunciation tree (Decoder.py:91-167, 250-288) for every utterance of an all-state
+        batch.  Returns a list (one dict per utterance): final = [(node, score, hist)] best first, history = [(prev, node)],
+        n_tokens (T,) live tokens after every frame, overflow."""
+        e = self.eng.S - 2
+        lp = np.log(np.array([1.0 / (e + 2), 1.0 / (2 * e + 2)]))               # np.log(np.ones(N) / N), AcousticModel.py:1005
+        self._check(self._lib.pcl_batch_decode(self._b, float(beam), int(min_distinct), int(candidate), int(max_tokens), float(lp[0]), float(lp[1])))
+        U, c, tm = self.U, int(candidate), int(self.T.max())
+        nf = np.empty(U, np.int32); node = np.empty((U, c), np.int32); score = np.empty((U, c)); hist = np.empty((U, c), np.int32)
+        hn = np.empty(U, np.int32); hp = np.empty((U, tm), np.int32); hnode = np.empty((U, tm), np.int32)
+        nt = np.empty((U, tm), np.int32); ov = np.empty(U, np.int32)
+        self._check(self._lib.pcl_batch_decode_get(self._b, ptr(nf), ptr(node), ptr(score), ptr(hist), ptr(hn), ptr(hp), ptr(hnode), ptr(nt), ptr(ov)))
+        out = []
+        for u in range(U):
+            out.append(dict(final=[(int(node[u, k]), float(score[u, k]), int(hist[u, k])) for k in range(nf[u])],
+                            history=[(int(hp[u, k]), int(hnode[u, k])) for k in range(hn[u])],
+                            n_tokens=nt[u, :self.T[u]].copy(), overflow=bool(ov[u])))
+        return out
 
     def refresh_transitions(self):
         """Take the engine's CURRENT unit transitions (after mstep_transitions / em_exchange); label-built batches only."""

@@ -1,0 +1,140 @@
+"""The token-passing decoder (BASELINE config 5's decode half) on the GPU against its CPU restatement
+(oracle/decoder_oracle.py; PARITY UNPINNED against the reference, whose Decoder.py cannot run): bit-exact scores, nodes,
+histories and token counts given identical emissions, plus the properties the recursion guarantees."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import decoder_oracle as do
+from oracle import poccala_oracle as po
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+S, E = 5, 3
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from poccala_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def lex(tmp_path_factory):
+    from poccala_amd.Lexicon import PinYin, PronunciationLexicon
+    g = json.load(open(os.path.join(HERE, 'golden', 'G13_lexicon.json')))
+    path = str(tmp_path_factory.mktemp('lex') / 'Mandarin.dat')
+    with open(path, 'w') as f:
+        for k, v in g['table'].items():
+            f.write('%s\t%s\n' % (k, v))
+    py = PinYin(path)
+    lx = PronunciationLexicon()
+    lx.generate_lexicon(words=g['words'], pinyin=py)
+    units = sorted({u for w in g['words'] for r in py.word2pinyin(w) for x in r for u in x.split(',')})
+    return lx, units, lx.compile({u: i for i, u in enumerate(units)})
+
+
+def model_for(units, M, D, seed, dense=False):
+    from poccala_amd import synth
+    mean, var, w, trans = synth.make_model(len(units), M, D, seed=seed)
+    if dense:
+        rng = np.random.default_rng(seed + 1)
+        trans = []
+        for _ in units:
+            a = np.zeros((S, S))
+            a[0, 1:3] = [0.7, 0.3]
+            a[1:-1, 1:] = rng.dirichlet(np.ones(S - 1), size=E)
+            trans.append(a)
+    return mean, var, w, np.stack(trans)
+
+
+@pytest.mark.parametrize('dense,beam,cap', [(False, 0.85, 4096), (True, 0.85, 4096), (False, 1.0, 4096), (False, 0.5, 4096), (False, 0.85, 230)])
+def test_decode_matches_cpu_restatement_bit_for_bit(eng, lex, dense, beam, cap):
+    from poccala_amd import PCL_F64, synth
+    lx, units, tree = lex
+    mean, var, w, trans = model_for(units, 3, 13, 11, dense)
+    frames, lens, begin = synth.make_frames(4, 90, 13, seed=12, ragged=True)
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F64)
+    B = b.get('B')
+    got = b.decode(beam=beam, candidate=6, max_tokens=cap)
+    b.close()
+    for u in range(4):
+        b_all = B[u][1:-1]                                       # (J, T): the same emissions the device decoded from
+        trace = []
+        fin, hist = do.decode(tree, list(trans), b_all, beam=beam, candidate=6, max_tokens=cap, trace=trace)
+        g = got[u]
+        assert np.array_equal(g['n_tokens'], np.array(trace)), (u, g['n_tokens'][:12], trace[:12])
+        assert g['history'] == [(int(p), int(n)) for p, n in hist]
+        assert [(n, h) for n, _, h in g['final']] == [(n, h) for n, _, h in fin]
+        assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]          # bit-exact float64
+        assert g['overflow'] == (cap < 4096 and max(trace) >= cap)
+    # the words come out through the history chain
+    words = do.words_of(fin[0], hist, tree)
+    assert all(isinstance(wl, list) and wl for wl in words)
+
+
+def test_decode_properties(eng, lex):
+    """Token scores are sums of per-frame maxima of max-recursions, so no token can beat the per-frame bound
+    sum_t max_j ln b_j(o_t) + ln(1/5) (every step adds at most the best emission plus a log-probability <= 0, the first at
+    most ln pi); with pruning off every token alive at the end is at least as good as under the beam; and a one-frame
+    utterance returns the first-step scores of the first characters."""
+    from poccala_amd import PCL_F64, synth
+    lx, units, tree = lex
+    mean, var, w, trans = model_for(units, 2, 13, 21)
+    frames, lens, begin = synth.make_frames(3, 60, 13, seed=22, ragged=True)
+    lens[2] = 1
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F64)
+    B = b.get('B')
+    pruned = b.decode(beam=0.85, candidate=5)
+    free = b.decode(beam=1.0, candidate=5)
+    b.close()
+    for u in range(2):
+        bound = B[u][1:-1].max(axis=0)
+        assert free[u]['final'][0][1] <= np.cumsum(bound).sum() + 1e-9          # score = sum over frames of the running maximum
+        assert free[u]['final'][0][1] >= pruned[u]['final'][0][1]
+        assert (free[u]['n_tokens'] >= pruned[u]['n_tokens']).all()
+    # T = 1: nothing but the first step of every first-character node
+    col = B[2][1:-1][:, 0]
+    best = max(np.log(1.0 / (E * n + 2)) + max(0.0, max(col[int(uu) * E + k] for uu in row[:n] for k in range(E)))
+               for row, n, r in ((tree['node_units'][r], tree['node_nunits'][r], r) for r in tree['roots']))
+    np.testing.assert_allclose(free[2]['final'][0][1], best, rtol=1e-12)
+    assert free[2]['n_tokens'].tolist() == [len(tree['roots'])]
+
+
+def test_decode_batch_dropin_and_errors(eng, lex):
+    from poccala_amd import Decoder, PCL_F32, PoccalaHipError, synth
+    lx, units, tree0 = lex
+    mean, var, w, trans = model_for(units, 2, 13, 31)
+    tree = Decoder.load_inventory(eng, units, mean, var, w, trans, lx)
+    assert tree['names'] == tree0['names']
+    frames, lens, begin = synth.make_frames(2, 50, 13, seed=32)
+    out = Decoder.decode_batch([frames[:50], frames[50:]], tree, engine=eng, precision=PCL_F32)
+    assert len(out) == 2 and all(np.isfinite(s) for _, s, _ in out)
+    # a label-built (not all-state) batch is refused
+    eng.load_frames(frames)
+    b = eng.label_batch([[0, 1]], [50], [0])
+    b.score(PCL_F32)
+    with pytest.raises(PoccalaHipError):
+        b.decode()
+    b.close()
+    # a new unit inventory drops the tree
+    eng.load_units(trans)
+    b = eng.all_state_batch([50], [0])
+    b.score(PCL_F32)
+    with pytest.raises(PoccalaHipError):
+        b.decode()
+    b.close()
