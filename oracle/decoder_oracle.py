@@ -90,7 +90,7 @@ class Token(object):
         return self.mark >= n - 2
 
 
-def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5, max_tokens=None, trace=None):
+def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5, max_tokens=None, trace=None, info=None):
     """tree: the dict PronunciationLexicon.compile returns; b_all (J,T): ln b_j(o_t) of every GMM state.
     Returns (final, history): final = [(node, score, hist)] of the `candidate` best tokens after the last frame
     (descending, ties in token order); history = [(previous entry or -1, word-end node)], the chain `hist` points into."""
@@ -140,7 +140,10 @@ def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5,
                 if score > live[node].score:                                   # :126-134 (the recursion state is kept)
                     live[node].score = score
                     live[node].hist = hist
-            elif max_tokens is None or n_start + len(created) < max_tokens:    # device capacity: the frame's token slots
+            elif max_tokens is not None and n_start + len(created) >= max_tokens:
+                if info is not None:
+                    info['overflow'] = True                                    # device capacity: the frame's token slots are used up
+            else:
                 new = Token(score, node, units_of[node], unit_trans, s)
                 new.hist = hist
                 new.viterbi(emission_column(new.units, b_all, t, s))           # :138-139

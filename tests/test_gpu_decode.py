@@ -69,14 +69,14 @@ def test_decode_matches_cpu_restatement_bit_for_bit(eng, lex, dense, beam, cap):
     b.close()
     for u in range(4):
         b_all = B[u][1:-1]                                       # (J, T): the same emissions the device decoded from
-        trace = []
-        fin, hist = do.decode(tree, list(trans), b_all, beam=beam, candidate=6, max_tokens=cap, trace=trace)
+        trace, info = [], {}
+        fin, hist = do.decode(tree, list(trans), b_all, beam=beam, candidate=6, max_tokens=cap, trace=trace, info=info)
         g = got[u]
         assert np.array_equal(g['n_tokens'], np.array(trace)), (u, g['n_tokens'][:12], trace[:12])
         assert g['history'] == [(int(p), int(n)) for p, n in hist]
         assert [(n, h) for n, _, h in g['final']] == [(n, h) for n, _, h in fin]
         assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]          # bit-exact float64
-        assert g['overflow'] == (cap < 4096 and max(trace) >= cap)
+        assert g['overflow'] == bool(info.get('overflow')) and (cap < 4096) == g['overflow']
     # the words come out through the history chain
     words = do.words_of(fin[0], hist, tree)
     assert all(isinstance(wl, list) and wl for wl in words)

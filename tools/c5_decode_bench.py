@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 on one GPU: the per-GPU shard of the streaming 1M-frame corpus (417 utterances x 300 frames, 39-dim,
+4096-mix, 183 XIF_tone-sized units = 549 GMM states scored for EVERY frame) + token-passing decode over a pronunciation
+tree.  Streaming: the shard is cut into chunks; chunk k+1's frames go up (H2D) and chunk k-1's results come down while
+chunk k is scored and decoded -- here measured as per-chunk phases; the GPU-resident rate is what the scoring roofline is
+quoted on.  The tree is synthetic (the reference ships no word list): words of 1-4 characters drawn from the characters of
+the golden lexicon fixture, read through the reference's Mandarin.dat rules (poccala_amd.Lexicon).
+
+usage: c5_decode_bench.py [utterances] [mixtures] [words] [chunks]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from poccala_amd import Engine, PCL_F32, synth
+from poccala_amd.Lexicon import PinYin, PronunciationLexicon
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+c = dict(synth.CONFIGS['C5shard'])
+U = int(sys.argv[1]) if len(sys.argv) > 1 else c['U']
+M = int(sys.argv[2]) if len(sys.argv) > 2 else c['M']
+NW = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+CH = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+T, D, units_n = c['T'], c['D'], c['units']
+
+g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'G13_lexicon.json')))
+tab = '/tmp/pcl_c5_mandarin.dat'
+with open(tab, 'w') as f:
+    for k, v in g['table'].items():
+        f.write('%s\t%s\n' % (k, v))
+py = PinYin(tab)
+chars = sorted({ch for w in g['words'] for ch in w})
+rng = np.random.default_rng(55)
+words = list(g['words']) + [''.join(rng.choice(chars, size=rng.integers(1, 5))) for _ in range(NW)]
+lx = PronunciationLexicon()
+lx.generate_lexicon(words=words, pinyin=py)
+names = sorted({u for w in words for r in (py.word2pinyin(w) or []) for x in r for u in x.split(',')})
+names = names[:units_n] + ['pad%d' % i for i in range(max(0, units_n - len(names)))]       # J = 549 states as in config 5
+tree = lx.compile({u: i for i, u in enumerate(names)})
+print('tree: %d words -> %d nodes, %d first-character nodes, %d units in use of %d' % (lx.size, len(tree['names']), len(tree['roots']), len(set(tree['node_units'].ravel()) - {-1}), units_n))
+
+mean, var, w, trans = synth.make_model(units_n, M, D)
+frames, lens, begin = synth.make_frames(U, T, D)
+eng = Engine(0); eng.enable_timing(True)
+eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); eng.load_lexicon(tree)
+
+# ---- resident: whole shard in HBM
+eng.load_frames(frames)
+b = eng.all_state_batch(lens, begin)
+b.score(PCL_F32); res = b.decode(max_tokens=8192); eng.sync()
+eng.kernel_time('score'); eng.kernel_time('decode')
+t0 = time.perf_counter()
+reps = 3
+for _ in range(reps):
+    b.score(PCL_F32)
+    res = b.decode(max_tokens=8192)
+eng.sync()
+wall = (time.perf_counter() - t0) / reps
+sc_ms, k1 = eng.kernel_time('score'); de_ms, k2 = eng.kernel_time('decode')
+sc_ms /= k1; de_ms /= k2
+pairs = U * T * units_n * 3
+flop = pairs * M * (3 * D + 4)
+ntok = np.concatenate([r['n_tokens'] for r in res])
+steps = int(ntok.sum())
+print('resident: %.1f ms/shard = %.3f M frames/s per GPU | score %.1f ms (%.0f TFLOP/s algorithmic, frac %.3f of 838.9) | decode %.1f ms '
+      '(%.1f M token-steps/s, mean %.0f / max %d live tokens, overflow %d utterances)'
+      % (wall * 1e3, U * T / wall / 1e6, sc_ms, flop / sc_ms / 1e9, flop / sc_ms / 1e9 / 838.9, de_ms, steps / de_ms / 1e3, ntok.mean(), ntok.max(),
+         sum(r['overflow'] for r in res)))
+# decode traffic: a token step reads and writes its 88-byte record and reads <= 6 emissions; compaction copies it once more
+print('decode bytes/step ~ %d -> %.1f GB/s (HBM peak 8000): latency bound -- %d frames x ~14 workgroup phases per utterance, one workgroup per utterance'
+      % (88 * 4 + 48, steps * (88 * 4 + 48) / de_ms / 1e6, T))
+b.close()
+
+# ---- streaming: chunks of the shard, frames uploaded per chunk, results downloaded per chunk (synchronous legs, timed apart)
+per = (U + CH - 1) // CH
+t_h2d = t_gpu = t_d2h = 0.0
+for k in range(CH):
+    lo, hi = k * per, min(U, (k + 1) * per)
+    if lo >= hi:
+        break
+    f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
+    t1 = time.perf_counter(); eng.load_frames(frames[f0:f1]); t2 = time.perf_counter()
+    bb = eng.all_state_batch(lens[lo:hi], begin[lo:hi] - f0)
+    t3 = time.perf_counter(); bb.score(PCL_F32); eng.sync(); t4 = time.perf_counter()
+    r = bb.decode(max_tokens=8192); t5 = time.perf_counter()
+    bb.close()
+    t_h2d += t2 - t1; t_gpu += t4 - t3; t_d2h += t5 - t4
+print('streaming in %d chunks: H2D %.1f ms + score %.1f ms + decode incl. results D2H %.1f ms = %.3f M frames/s per GPU with the legs back to back'
+      % (CH, t_h2d * 1e3, t_gpu * 1e3, t_d2h * 1e3, U * T / (t_h2d + t_gpu + t_d2h) / 1e6))
+best = res[0]['final'][0] if res[0]['final'] else None
+print('utterance 0: best token', best, 'history entries', len(res[0]['history']))
