@@ -6,7 +6,7 @@ chunk k is scored and decoded -- here measured as per-chunk phases; the GPU-resi
 quoted on.  The tree is synthetic (the reference ships no word list): words of 1-4 characters drawn from the characters of
 the golden lexicon fixture, read through the reference's Mandarin.dat rules (poccala_amd.Lexicon).
 
-usage: c5_decode_bench.py [utterances] [mixtures] [words] [chunks]"""
+usage: c5_decode_bench.py [utterances] [mixtures] [words] [chunks] [max live tokens per utterance]"""
 import json
 import os
 import sys
@@ -23,6 +23,7 @@ U = int(sys.argv[1]) if len(sys.argv) > 1 else c['U']
 M = int(sys.argv[2]) if len(sys.argv) > 2 else c['M']
 NW = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 CH = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+CAP = int(sys.argv[5]) if len(sys.argv) > 5 else 2048      # live tokens per utterance (the reference's 15 % rule alone lets the set grow with the tree)
 T, D, units_n = c['T'], c['D'], c['units']
 
 g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'G13_lexicon.json')))
@@ -49,13 +50,13 @@ eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); eng.load_lexicon(
 # ---- resident: whole shard in HBM
 eng.load_frames(frames)
 b = eng.all_state_batch(lens, begin)
-b.score(PCL_F32); res = b.decode(max_tokens=8192); eng.sync()
+b.score(PCL_F32); res = b.decode(max_tokens=CAP); eng.sync()
 eng.kernel_time('score'); eng.kernel_time('decode')
 t0 = time.perf_counter()
 reps = 3
 for _ in range(reps):
     b.score(PCL_F32)
-    res = b.decode(max_tokens=8192)
+    res = b.decode(max_tokens=CAP)
 eng.sync()
 wall = (time.perf_counter() - t0) / reps
 sc_ms, k1 = eng.kernel_time('score'); de_ms, k2 = eng.kernel_time('decode')
@@ -84,7 +85,7 @@ for k in range(CH):
     t1 = time.perf_counter(); eng.load_frames(frames[f0:f1]); t2 = time.perf_counter()
     bb = eng.all_state_batch(lens[lo:hi], begin[lo:hi] - f0)
     t3 = time.perf_counter(); bb.score(PCL_F32); eng.sync(); t4 = time.perf_counter()
-    r = bb.decode(max_tokens=8192); t5 = time.perf_counter()
+    r = bb.decode(max_tokens=CAP); t5 = time.perf_counter()
     bb.close()
     t_h2d += t2 - t1; t_gpu += t4 - t3; t_d2h += t5 - t4
 print('streaming in %d chunks: H2D %.1f ms + score %.1f ms + decode incl. results D2H %.1f ms = %.3f M frames/s per GPU with the legs back to back'
