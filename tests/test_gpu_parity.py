@@ -952,3 +952,116 @@ def test_estep_fuzz_default_variant(eng, seed):
     mu_got = stt['mean_acc'][occ] / stt['acc'][occ][:, None] - 100.0
     np.testing.assert_allclose(mu_got, mu_ref, rtol=0, atol=2e-4)
     b.close()
+
+
+# ------------------------------------------------------------------ full-size parity in depth
+def _last_tile_utterances(labels, n_units, how_many):
+    """For `how_many` units: the LAST utterance whose label contains the unit -- the one that owns the tail of the state's
+    frame list (its last scoring tile, the XCD padding behind it, the last accumulate tile)."""
+    last = {}
+    for u, lab in enumerate(labels):
+        for unit in lab:
+            last[int(unit)] = u
+    units = sorted(last, key=lambda k: last[k])[:how_many // 2] + sorted(last, key=lambda k: -last[k])[:how_many - how_many // 2]
+    return sorted({last[k] for k in units}), units
+
+
+def test_c4_shard_deep_parity(eng):
+    """The headline configuration at full size against the oracle, in depth: 16 random utterances + the utterances owning
+    the last tile of 8 states -- every emission row (2048-mix), log P(O) and the normalised posteriors gamma_t(j) of each.
+    The oracle runs on the host cores (about 15 s of NumPy per utterance)."""
+    from poccala_amd import PCL_F32, synth
+    from _oracle_pool import label_jobs
+    c = synth.CONFIGS['C4shard']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
+    labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F32)
+    b.forward_backward(fix_pi=False)
+    B, lp, lg = b.get('B'), b.get('logp'), b.get('lgamma')
+    b.close()
+    tail_utts, _ = _last_tile_utterances(labels, c['units'], 8)
+    pick = sorted(set(np.random.default_rng(77).choice(c['U'], 16, replace=False).tolist()) | set(tail_utts))
+    jobs = []
+    for u in pick:
+        model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)])
+                 for unit in set(labels[u])}
+        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, True))
+    worst_b = worst_g = 0.0
+    for u, (bref, lpref, lgref, _, _) in zip(pick, label_jobs(jobs)):
+        fin_close(B[u], bref, rtol=0, atol=F32_LOGLIK_ATOL)
+        np.testing.assert_allclose(lp[u], lpref, rtol=F32_RTOL)
+        g, gref = np.exp(lg[u]), np.exp(lgref)
+        np.testing.assert_allclose(g, gref, rtol=F32_RTOL, atol=1e-6)          # occupancies: 1e-4 relative (north star), 1e-6 floor
+        worst_b = max(worst_b, float(np.abs(B[u][1:-1] - bref[1:-1]).max()))
+        worst_g = max(worst_g, float(np.abs(g - gref).max()))
+    print('C4 shard, %d utterances vs oracle: max |d ln b| = %.2e, max |d gamma| = %.2e' % (len(pick), worst_b, worst_g))
+
+
+def test_c3_deep_parity_and_flip_rate(eng):
+    """BASELINE config C3 at full size: 16 random utterances + the utterances owning the last tile of 8 states, emissions
+    against the oracle; Viterbi paths bit-exact given the device emissions; and the end-to-end f32 path compared with the
+    oracle's float64 alignment: the frame flip rate is asserted (<= 1 %) and printed."""
+    from poccala_amd import PCL_F32, synth
+    from _oracle_pool import label_jobs
+    c = synth.CONFIGS['C3']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'])
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], ragged=True)
+    labels = synth.make_labels(c['U'], c['L'], c['units'])
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F32)
+    b.viterbi()
+    B, paths, pts = b.get('B'), b.get('path'), b.get('point')
+    b.close()
+    tail_utts, _ = _last_tile_utterances(labels, c['units'], 8)
+    pick = sorted(set(np.random.default_rng(78).choice(c['U'], 16, replace=False).tolist()) | set(tail_utts))
+    jobs = []
+    for u in pick:
+        model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)])
+                 for unit in set(labels[u])}
+        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, False))
+    flips = total = 0
+    for u, (bref, _, _, a, pi) in zip(pick, label_jobs(jobs)):
+        fin_close(B[u], bref, rtol=0, atol=F32_LOGLIK_ATOL)
+        rp, rpath = po.viterbi(a, pi, B[u])                        # same emissions -> bit-exact (LHMM.viterbi's contract)
+        assert np.array_equal(paths[u].astype(np.float64), rpath) and rp == pts[u]
+        _, opath = po.viterbi(a, pi, bref)                         # the float64 reference end to end
+        flips += int((opath != rpath).sum())
+        total += len(rpath)
+    rate = flips / total
+    print('C3, %d utterances: f32-scored alignment differs from the float64 alignment on %d of %d frames (%.4f %%)' % (len(pick), flips, total, 100 * rate))
+    assert rate <= 0.01
+
+
+def test_c5_shard_full_size(eng):
+    """BASELINE config C5's scoring half at its real shape: the per-GPU shard of the 1M-frame corpus, 417 utterances x 300
+    frames, ALL 549 XIF_tone-sized states x 4096 mixtures for every frame.  Properties at full size (entry row 0, exit row
+    -inf, everything finite, states shared by all utterances score identically for identical frames), 2 utterances against
+    the oracle (every state), and the token-passing decode on top runs without overflow at a generous cap."""
+    from poccala_amd import PCL_F32, synth
+    from _oracle_pool import state_rows
+    c = synth.CONFIGS['C5shard']
+    J = c['units'] * 3
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=5)
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=6)
+    frames[begin[9]:begin[9] + lens[9]] = frames[begin[3]:begin[3] + lens[3]]      # two utterances with identical frames
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F32)
+    B = b.get('B')
+    b.close()
+    for u in range(c['U']):
+        assert B[u].shape == (J + 2, c['T']) and np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1])) and np.isfinite(B[u][1:-1]).all()
+    assert np.array_equal(B[3], B[9])                                # same frames, same tile positions or not: same bits
+    gm = [(mean[j], var[j], w[j]) for j in range(J)]
+    for u in (0, c['U'] - 1):
+        ref = state_rows(frames[begin[u]:begin[u] + lens[u]].astype(np.float64), gm)
+        np.testing.assert_allclose(B[u][1:-1], ref, rtol=0, atol=F32_LOGLIK_ATOL)
