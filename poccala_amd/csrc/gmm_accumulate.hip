@@ -623,8 +623,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
     hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
                        b->acc_off, b->acc_list);
-    static const bool acc_bf16 = getenv("PCL_ACC_BF16") && atoi(getenv("PCL_ACC_BF16")) != 0;      // A/B: the round-1 kernel
-    if (mfma && n_good > 0 && ctx->score_variant == 7 && !acc_bf16) {
+    if (mfma && n_good > 0 && ctx->score_variant == 7) {
         // producer / consumer on the f16 + bf16 matrix pipes (gmm_accumulate_f16.hip), in groups of states whose tile
         // images fit the image buffer (worst case: every frame of the state survives)
         static const size_t budget = (size_t)(getenv("PCL_ACC_IMAGE_MB") ? atol(getenv("PCL_ACC_IMAGE_MB")) : 2048) << 20;   // per buffer set, two sets
@@ -708,9 +707,6 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));
             if (!overlap && g + 1 < G) { rc = produce(g + 1); if (rc != PCL_OK) return rc; }
         }
-    } else if (mfma && n_good > 0 && ctx->score_variant >= 4) {
-        const int rc = pcl_launch_accumulate_split(ctx, b, n_good);     // bf16 matrix pipe (gmm_accumulate_split.hip)
-        if (rc != PCL_OK) return rc;
     } else if (mfma && n_good > 0) {
         const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = n_good;
         const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;

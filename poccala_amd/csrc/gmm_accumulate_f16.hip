@@ -1,8 +1,8 @@
 // gmm_accumulate_f16.hip -- E-step sufficient statistics, producer / consumer form (gfx950), the default f32 path.
 //
 // Same reference rows as gmm_accumulate.hip (A13: Clustering.GMM.update_acc, StatisticalModel/Clustering.py:653-680,
-// called from LHMM.update_acc, StatisticalModel/LHMM.py:497-505) and the same two chained contractions as
-// gmm_accumulate_split.hip, per 32-frame x 32-mixture tile of one state's list of surviving frames:
+// called from LHMM.update_acc, StatisticalModel/LHMM.py:497-505): two chained contractions per 32-frame x 32-mixture
+// tile of one state's list of surviving frames,
 //   (1) D1[f][m] = Xe[f,:] . P[:,m]            the scoring GEMM (K = 2D + 2): log2 of w_m N_m(o_f), relative to K0_j
 //       g[f][m]  = exp2(D1 + cf_f)             cf_f = log2e (ln gamma_f(j) - ln b_j(o_f)) + K0_j: gamma_f(j,m)
 //   (2) S[m][:] += sum_f g[f][m] [x'^2_d, x'_d | 1]      raw moments S2, S1, S0 about the state centre
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void acc16_producer_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// consumer: 8 waves = 8 m-tiles of one state; grid as in gmm_accumulate_split.hip (XCD-aware)
+// consumer: 8 waves = 8 m-tiles of one state; the 8 slices of a state sit on block indices with equal residue mod 8 (one XCD's L2)
 template <int D>
 __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     const uint4 *__restrict__ images, const uint4 *__restrict__ pm16f, const float *__restrict__ centers,

@@ -1,9 +1,9 @@
 // model_derive.hip -- device-side model preparation and the GMM M-step (gfx950).
 //
 //   derive: from the float64 master copy (mean, var, weight) build every layout the kernels read:
-//           the VALU scoring rows [s_d c_d ... k2] (f32 + f64), the per-state expansion centres and the
-//           MFMA layout [m-tile][KS4][64][4] of gmm_score_mfma.hip, its split-bf16 twin [m-tile][3][KS8][64][8] of
-//           gmm_score_split.hip, and the f32 means.
+//           the VALU scoring rows [s_d c_d ... k2] (f32 + f64), the per-state expansion centres, the f32-input
+//           MFMA layout [m-tile][KS4][64][4] of gmm_score_mfma.hip, the two-piece f16 layout [m-tile][2][KS8][64][8]
+//           of gmm_score_split.hip / gmm_accumulate_f16.hip with its power-of-two feature scales and K0, and the f32 means.
 //   mstep:  Clustering.GMM.update_param (StatisticalModel/Clustering.py:682-693) for every state at once
 //           from the resident linear statistics:
 //               w = acc / alpha_acc          (= exp(acc - alpha_acc) of the log-domain reference)
@@ -73,8 +73,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      int Mpad, int Mpad32, int D, int Dhost, int row, int flags,
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
-                                                     uint4 *__restrict__ pm16, uint4 *__restrict__ pm16h,
-                                                     uint4 *__restrict__ pm16x, uint4 *__restrict__ pm16f,
+                                                     uint4 *__restrict__ pm16f,
                                                      const double *__restrict__ kzero, int *__restrict__ kz_bits,
                                                      const float *__restrict__ fscale, float *__restrict__ cond, int what) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                 atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
                 // the 16x16x32 kernel keeps the constant in f16 pieces: a real k' beyond their range sends the state to
                 // the direct-form kernels as well
-                if ((what & (PCL_LAYOUT_PM16X | PCL_LAYOUT_PM16F)) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
+                if ((what & PCL_LAYOUT_PM16F) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
                     atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint(1.0e30f));
             }
         }
@@ -186,84 +185,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
         pt[e] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    // split-bf16 layout [piece 3][KS8][64 lanes][8 bf16] of gmm_score_split.hip: the same f32 values, each written as
-    // the exact sum of three bf16 pieces; lane = half * 32 + mixture, element j = feature 8s + j
-    const int KS8 = (D + 8) / 8;
-    uint4 *pq = pm16 + ((size_t)j * nmt + mt) * (3 * KS8 * 64);
-    if (what & PCL_LAYOUT_PM16)
-    for (int e = tid; e < KS8 * 64; e += 256) {           // one thread per (k-step, lane): all three pieces of its 8 values
-        const int s = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
-        const bool real_m = (m0 + cl) < M;
-        unsigned short h[3][8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const int dd = 8 * s + x;
-            float val = 0.f;
-            if (dd < D) {
-                val = half ? fb[cl * D + dd] : fa[cl * D + dd];
-            } else if (dd == D) {
-                val = half ? 1.f : (real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY);
-                if (!(val > -1.0e37f)) val = -3.0e38f;      // "log zero" stays finite: its pieces meet zeros of the other operand
-            }
-            // round-to-nearest-even three-way split
-            float r = val;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                unsigned int u = __float_as_uint(r);
-                u += 0x7fffu + ((u >> 16) & 1u);
-                h[p][x] = (unsigned short)(u >> 16);
-                r -= __uint_as_float((unsigned int)h[p][x] << 16);
-            }
-            if (val < -1.0e37f) h[1][x] = h[2][x] = 0;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            pq[(p * KS8 + s) * 64 + ln] = make_uint4(h[p][0] | ((unsigned)h[p][1] << 16), h[p][2] | ((unsigned)h[p][3] << 16),
-                                                     h[p][4] | ((unsigned)h[p][5] << 16), h[p][6] | ((unsigned)h[p][7] << 16));
-    }
-    // split-f16 layout [piece 2][KS8f][64 lanes][8 f16] + one bf16 constant chunk [64 lanes][8]:
-    // coefficients scaled by 2^-e (fscale holds 2^e), lanes 0-31 of the constant chunk carry k'1 k'2 k'3 1 1 1 0 0
-    const int KS8f = (D + 7) / 8, CHf = 2 * KS8f + 1;
-    uint4 *ph = pm16h + ((size_t)j * nmt + mt) * (CHf * 64);
-    if (what & PCL_LAYOUT_PM16H)
-    for (int e = tid; e < CHf * 64; e += 256) {
-        const int chunk = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
-        const bool real_m = (m0 + cl) < M;
-        unsigned short h[8];
-        if (chunk < 2 * KS8f) {
-            const int p = chunk / KS8f, s = chunk % KS8f;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const int dd = 8 * s + x;
-                float val = 0.f;
-                if (dd < D)      // power-of-two scaling commutes with the f32 rounding of the coefficient
-                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) / fscale[((size_t)j * 2 + half) * (KS8f * 8) + dd];
-                const _Float16 h1 = (_Float16)val;
-                const _Float16 hp = p ? (_Float16)(val - (float)h1) : h1;
-                h[x] = __builtin_bit_cast(unsigned short, hp);
-            }
-        } else {
-            float kc = real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY;
-            const bool zero = !(kc > -1.0e37f);
-            if (zero) kc = -3.0e38f;
-            float r = kc;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                unsigned short piece = 0;
-                if (half == 0 && x < 3) {
-                    unsigned int u = __float_as_uint(r);
-                    u += 0x7fffu + ((u >> 16) & 1u);
-                    piece = (unsigned short)(u >> 16);
-                    r -= __uint_as_float((unsigned int)piece << 16);
-                    if (zero && x > 0) piece = 0;
-                } else if (half == 0 && x < 6) {
-                    piece = 0x3f80;       // bf16 1.0
-                }
-                h[x] = piece;
-            }
-        }
-        ph[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
-    }
+    const int KS8f = (D + 7) / 8;
     // folded-constant f16 layout (variant 7): [piece 2][KS8f][64 lanes][8 f16] as above, and in the spare slot d = D:
     // a1: [k1 | 0], a2: [k2 | 1] with k1 + k2 = k'_m - K0_j in f16 pieces (log zero = -6e4)
     if (what & PCL_LAYOUT_PM16F) {
@@ -297,48 +219,6 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                 h[x] = __builtin_bit_cast(unsigned short, hp);
             }
             pf[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
-        }
-    }
-    // 16x16x32 layout of gmm_score_split.hip (variant 6): one long K axis = [a2 | a1 | a1 | constants | 0], each segment
-    // SEG = 2D rounded up to 8; [mixture sub-tile 2][K-step][64 lanes][8 f16], lane = 16 g + row: row = mixture, block
-    // t = 4 s + g of 8 consecutive K positions.  Constants block: k'1 k'2 k'3 1 1 1 0 0 (f16 pieces; log zero = -6e4).
-    if (what & PCL_LAYOUT_PM16X) {
-        const int SEG8 = (2 * D + 7) / 8, NKS = (3 * SEG8 + 1 + 3) / 4;
-        uint4 *px = pm16x + ((size_t)j * nmt + mt) * (2 * NKS * 64);
-        for (int e = tid; e < 2 * NKS * 64; e += 256) {
-            const int msub = e / (NKS * 64), s = (e >> 6) % NKS, ln = e & 63, g = ln >> 4, cl = msub * 16 + (ln & 15);
-            const bool real_m = (m0 + cl) < M;
-            const int t = 4 * s + g;
-            unsigned short h[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) h[x] = 0;
-            if (t < 3 * SEG8) {
-                const int seg = t / SEG8, tt = t - seg * SEG8;
-#pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    const int i = 8 * tt + x;
-                    if (i < 2 * D) {
-                        const int side = i >= D, dd = i - side * D;
-                        const float val = (side ? fb[cl * D + dd] : fa[cl * D + dd]) / fscale[((size_t)j * 2 + side) * (KS8f * 8) + dd];
-                        const _Float16 h1 = (_Float16)val;
-                        const _Float16 hp = (seg == 0) ? (_Float16)(val - (float)h1) : h1;       // a2 | a1 | a1
-                        h[x] = __builtin_bit_cast(unsigned short, hp);
-                    }
-                }
-            } else if (t == 3 * SEG8) {
-                float kc = real_m ? (float)(k2s[cl] - kqs[cl]) : -INFINITY;
-                const bool zero = !(kc > -5.0e4f);
-                if (zero) kc = -6.0e4f;
-                float r = kc;
-#pragma unroll
-                for (int x = 0; x < 3; ++x) {
-                    const _Float16 hp = (_Float16)r;
-                    r -= (float)hp;
-                    h[x] = (zero && x > 0) ? 0 : __builtin_bit_cast(unsigned short, hp);
-                }
-                h[3] = h[4] = h[5] = 0x3c00;      // f16 1.0
-            }
-            px[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
         }
     }
 }
@@ -401,9 +281,6 @@ int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64
 static int eager_layouts(const pcl_ctx *ctx) {
     int what = PCL_LAYOUT_P32 | PCL_LAYOUT_COND;              // direct-form f32 kernels: fix-up, ill-conditioned states, variant 1
     if (ctx->score_variant == 3) what |= PCL_LAYOUT_PM32;
-    if (ctx->score_variant >= 4) what |= PCL_LAYOUT_PM16;     // variant 4 scoring and the split accumulate kernel
-    if (ctx->score_variant == 5) what |= PCL_LAYOUT_PM16H;
-    if (ctx->score_variant == 6) what |= PCL_LAYOUT_PM16X;
     if (ctx->score_variant == 7) what |= PCL_LAYOUT_PM16F;
     return what;
 }
@@ -412,8 +289,7 @@ static int launch_derive_kernel(pcl_ctx *ctx, int what) {
     const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)(ctx->D + 2 * 32 * ctx->D) * sizeof(float);
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
-                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16),
-                       reinterpret_cast<uint4 *>(ctx->pm16h), reinterpret_cast<uint4 *>(ctx->pm16x), reinterpret_cast<uint4 *>(ctx->pm16f),
+                       ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16f),
                        ctx->kzero, ctx->kz_bits, ctx->fscale, ctx->d_cond, what);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;

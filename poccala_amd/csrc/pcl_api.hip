@@ -65,8 +65,16 @@ int pcl_init(int device, pcl_ctx **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cus = prop.multiProcessorCount;
-    const char *var = getenv("PCL_SCORE_VARIANT");   // 1 = VALU/LDS kernel, 3 = f32 MFMA kernel (default)
+    // PCL_SCORE_VARIANT: 7 (default) = f32-class contraction on the f16 matrix pipe, 3 = strict f32 on the f32-input MFMA,
+    // 1 = direct form on the VALU (the kernels states leave the matrix pipe for: fix-up, ill-conditioned models)
+    const char *var = getenv("PCL_SCORE_VARIANT");
     ctx->score_variant = var ? atoi(var) : 7;
+    if (ctx->score_variant != 1 && ctx->score_variant != 3 && ctx->score_variant != 7) {
+        g_init_error = "pcl_init: PCL_SCORE_VARIANT must be 1, 3 or 7";
+        hipStreamDestroy(ctx->stream); hipStreamDestroy(ctx->stream_dp); hipStreamDestroy(ctx->stream_aux);
+        delete ctx;
+        return PCL_ERR_INVALID;
+    }
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
     if (const char *tm = getenv("PCL_TIMERS")) ctx->timing = atoi(tm) != 0;
@@ -82,9 +90,6 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->var64);
     dev_free(ctx->w64);
     dev_free(ctx->pm32);
-    dev_free(ctx->pm16);
-    dev_free(ctx->pm16h);
-    dev_free(ctx->pm16x);
     dev_free(ctx->pm16f);
     dev_free(ctx->kzero);
     dev_free(ctx->kz_bits);
@@ -220,9 +225,6 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->var64, nm));
     TRY(dev_alloc(ctx, &ctx->w64, nw));
     TRY(dev_alloc(ctx, &ctx->pm32, npm));
-    TRY(dev_alloc(ctx, &ctx->pm16, (size_t)J * (Mp32 / 32) * 3 * ((Dd + 8) / 8) * 64 * 8));
-    TRY(dev_alloc(ctx, &ctx->pm16h, (size_t)J * (Mp32 / 32) * (2 * ((Dd + 7) / 8) + 1) * 64 * 8));
-    TRY(dev_alloc(ctx, &ctx->pm16x, (size_t)J * (Mp32 / 32) * 2 * ((3 * ((2 * Dd + 7) / 8) + 1 + 3) / 4) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->pm16f, (size_t)J * (Mp32 / 32) * 2 * ((Dd + 7) / 8) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->kzero, (size_t)J));
     TRY(dev_alloc(ctx, &ctx->kz_bits, (size_t)J));
@@ -619,7 +621,7 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
 static int build_tiles(pcl_batch *b, int precision) {
     pcl_ctx *ctx = b->ctx;
     const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D);
-    const int tf = mfma ? (ctx->score_variant >= 5 ? pcl_score_split16_tile_frames() : ctx->score_variant == 4 ? pcl_score_split_tile_frames() : pcl_score_mfma_tile_frames())
+    const int tf = mfma ? (ctx->score_variant == 7 ? pcl_score_split16_tile_frames() : pcl_score_mfma_tile_frames())
                         : pcl_score_tile_frames(ctx->D, precision);
     if (b->d_tiles && b->tile_frames == tf && b->tile_gen == ctx->model_gen) return PCL_OK;
     // MFMA mode: states whose centred expansion is ill conditioned go to the direct-form VALU kernel
@@ -663,14 +665,12 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     TRY(build_tiles(b, precision));
     TRY(pcl_launch_fill_virtual_rows(ctx, b));
     if (precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D)) {
-        if (ctx->score_variant >= 5) {
-            if (ctx->score_variant == 6) TRY(pcl_launch_score_split16x(ctx, b, b->d_tiles, b->n_tiles));
-            else TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));
+        if (ctx->score_variant == 7) {
+            TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));
 #ifndef PCL_DIAG_NOFIXUP
             TRY(pcl_launch_score_fixup(ctx, b, b->d_tiles, b->n_tiles, b->d_tile_flags));   // tiles with out-of-range features
 #endif
-        } else if (ctx->score_variant == 4) TRY(pcl_launch_score_split(ctx, b, b->d_tiles, b->n_tiles));
-        else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
+        } else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
         TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
     } else {
         TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));

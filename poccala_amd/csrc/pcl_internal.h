@@ -65,10 +65,7 @@ struct pcl_ctx {
     double *params64 = nullptr;  // same layout, float64
     float *pm32 = nullptr;       // MFMA scoring layout: [J][Mpad32/32][KS4][64 lanes][4], see gmm_score_mfma.hip
     float *centers32 = nullptr;  // J * D per-state expansion centres c_j
-    unsigned short *pm16 = nullptr;   // split-bf16 scoring layout: [J][Mpad32/32][3 pieces][KS8][64 lanes][8], see gmm_score_split.hip
-    unsigned short *pm16h = nullptr;  // split-f16 scoring layout: [J][Mpad32/32][2 pieces x KS8f + 1 constant chunk][64 lanes][8]
-    unsigned short *pm16x = nullptr;  // 16x16x32 split-f16 layout (variant 6): [J][Mpad32/32][2][K-steps][64 lanes][8]
-    unsigned short *pm16f = nullptr;  // folded-constant split-f16 layout (variant 7): [J][Mpad32/32][2][KS8f][64 lanes][8]
+    unsigned short *pm16f = nullptr;  // split-f16 layout with the constants folded into the spare K slot: [J][Mpad32/32][2][KS8f][64 lanes][8], see gmm_score_split.hip
     int *kz_bits = nullptr;           // [J] scratch of the K0 reduction (order-preserving float bits)
     double *kzero = nullptr;          // [J] K0_j = max_m k'_m of that layout
     float *fscale = nullptr;          // [J][2][KS8f*8] power-of-two feature scales of that layout
@@ -77,7 +74,7 @@ struct pcl_ctx {
     hipStream_t stream_dp = nullptr;   // forward-backward runs here, beside the next batch's scoring on `stream`
     hipStream_t stream_aux = nullptr;  // the accumulate pass's tile-image producer runs here, beside its consumer on `stream`
     bool dp_async = true;              // env PCL_DP_STREAM=0: everything on one stream
-    int score_variant = 0;       // 1 = VALU/LDS, 3 = f32-input MFMA, 4 = split-bf16 MFMA, 5 = split-f16 MFMA (32x32x16), 6 = split-f16 MFMA (16x16x32), 7 = split-f16 with the constants folded into the spare K slots
+    int score_variant = 0;       // 7 = two-piece f16 split on the matrix pipe (default), 3 = f32-input MFMA (strict f32), 1 = direct form on the VALU
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
     // the magnitude of the terms that cancel in it.  States above cond_max are scored / accumulated by the
     // direct-form VALU kernels instead (f32 error of the expansion ~ 5e-7 * cond nats).
@@ -241,21 +238,17 @@ void pcl_accumulate_release(pcl_batch *b);
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
 int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
-int pcl_launch_score_split(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
-int pcl_score_split_tile_frames();
-int pcl_launch_accumulate_split(pcl_ctx *ctx, pcl_batch *b, int ns);
 int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int max_tiles, int buf, hipStream_t stream);
 int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, hipStream_t stream);
 size_t pcl_acc16_image_bytes(int D);
 int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
-int pcl_launch_score_split16x(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split16_tile_frames();
 int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);
 int pcl_ensure_layouts(pcl_ctx *ctx, int need);
-enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_PM16 = 8, PCL_LAYOUT_PM16H = 16, PCL_LAYOUT_COND = 32, PCL_LAYOUT_PM16X = 64, PCL_LAYOUT_PM16F = 128, PCL_LAYOUT_KZERO = 256 };
+enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_COND = 32, PCL_LAYOUT_PM16F = 128, PCL_LAYOUT_KZERO = 256 };
 inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) { return !ctx->cond.empty() && ctx->cond[j] > ctx->cond_max; }
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
