@@ -443,6 +443,9 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     # full E-step: score -> forward-backward -> GMM statistics + per-unit transition accumulators -> exchange
     # (reduce-scatter by state range -> M-step on the owned states -> all-gather of the model) -> transition M-step
     payload = PCL_F32 if args.payload == 'f32' else PCL_F64
+    batch.accumulate(P)                       # setup, not measured: the accumulate pass's work lists and tile-image buffers are
+    batch.accumulate_hmm()                    # allocated on first use
+    eng.sync()
     for k in ('accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive', 'score', 'fb'):
         eng.kernel_time(k)
     eng.stats_zero()

@@ -1,50 +1,104 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof (written by tools/gpu_profile.sh on the GPU box) into the committed summary
-profiles/r01_bench_summary.txt + profiles/r01_bench_kernel_stats.csv."""
-import csv, glob, collections, os, shutil, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, 'gpurun_out', 'prof')
-out = []
-stats = glob.glob(P + '/trace/**/*kernel_stats.csv', recursive=True)[0]
-shutil.copy(stats, os.path.join(ROOT, 'profiles', 'r01_bench_kernel_stats.csv'))
-out.append('# rocprofv3 summaries, round 1 (final kernels: split-f16 MFMA scoring with LDS-DMA staging, XCD-aware tile order)')
-out.append('# command: python3 bench.py --steps 3 --warmup 1 --cpu-baseline 0 --extra 0   (one MI355X, C4 shard)')
-out.append('# produced by tools/gpu_profile.sh + tools/make_profile_summary.py; raw CSVs are scratch (gpurun_out/prof)')
-out.append('# the f32-input MFMA kernel this replaced: profiles/r01_f32mfma_bench_summary.txt')
-out.append('')
-out.append('## --kernel-trace --stats (r01_bench_kernel_stats.csv)')
-kt = {}
-for r in csv.DictReader(open(stats)):
-    out.append('%-70s calls=%s avg_ns=%s pct=%s' % (r['Name'][:70], r['Calls'], r['AverageNs'], r['Percentage']))
-    kt[r['Name'][:70]] = float(r['AverageNs'])
-out.append('')
-out.append('## --pmc passes (one counter group per pass, no trace domains), per-dispatch averages')
-val = {}
-for tag in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_clk'):
-    for f in glob.glob('%s/%s/**/*counter_collection.csv' % (P, tag), recursive=True):
-        agg = collections.defaultdict(lambda: [0.0, 0])
-        for r in csv.DictReader(open(f)):
-            agg[(r['Kernel_Name'][:60], r['Counter_Name'])][0] += float(r['Counter_Value'])
-            agg[(r['Kernel_Name'][:60], r['Counter_Name'])][1] += 1
-        for k, v in sorted(agg.items()):
-            if 'split16' in k[0] or 'hmm_fb' in k[0] or 'gmm_score_kernel' in k[0]:
-                out.append('%-62s %-26s n=%d per-dispatch=%.6g' % (k[0], k[1], v[1], v[0] / v[1]))
-            if 'split16' in k[0]:
-                val[k[1]] = v[0] / v[1]
-ms = [v for k, v in kt.items() if 'split16' in k][0] / 1e6
-pairs, M, D = 18432000, 2048, 39
-flop = pairs * M * (3 * D + 4)
-fetch, write = val['FETCH_SIZE'] * 1024, val['WRITE_SIZE'] * 1024
-cyc = val['GRBM_GUI_ACTIVE'] / 8
-out += ['', '## derived (gmm_score_split16_kernel<39,2,true>, 18,432,000 (frame,state) pairs x 2048 mixtures per launch)',
-        'kernel %.2f ms/launch (rocprofv3 trace pass) -> %.1f TFLOP/s algorithmic (%.4f TFLOP/launch) = %.3f of 838.9 (f16 MFMA peak / 3 split products), %.2f x the f32-input MFMA peak 157.3'
-        % (ms, flop / ms / 1e9, flop / 1e12, flop / ms / 1e9 / 838.9, flop / ms / 1e9 / 157.3),
-        'executed MFMA work: 15 x v_mfma_f32_32x32x16 per 1024 Gaussians = %.0f TFLOP/s of f16/bf16 MFMA flops' % (pairs * M * 480 / ms / 1e9),
-        'GRBM_GUI_ACTIVE %.4g (sum of 8 XCDs) -> %.3g cycles -> clock held %.2f GHz over %.2f ms; SQ_VALU_MFMA_BUSY_CYCLES %.4g / 1024 SIMDs = %.3g cycles -> matrix pipe %.0f %% busy'
-        % (val['GRBM_GUI_ACTIVE'], cyc, cyc / ms / 1e6, ms, val['SQ_VALU_MFMA_BUSY_CYCLES'], val['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024, 100 * val['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc),
-        'FETCH_SIZE %.4g KiB/launch = %.2f GB; WRITE_SIZE %.4g KiB = %.2f GB' % (val['FETCH_SIZE'], fetch / 1e9, val['WRITE_SIZE'], write / 1e9),
-        'algorithmic bytes/launch 2.14 GB (parameters 1.97 GB + frames 48 MB + B 147 MB): traffic/algorithmic = %.2f' % ((fetch + write) / 2.1369e9),
-        'HBM %.3f TB/s = %.1f %% of 8 TB/s: compute bound' % ((fetch + write) / ms / 1e9, (fetch + write) / ms / 1e9 / 8 * 100),
-        'traffic_bytes for bench.py --traffic-bytes: %d' % int(fetch + write)]
-open(os.path.join(ROOT, 'profiles', 'r01_bench_summary.txt'), 'w').write('\n'.join(out) + '\n')
-print('\n'.join(out[-10:]))
+"""Condense the rocprofv3 passes of tools/gpu_profile.sh into <dir>/<round>_bench_summary.txt, <round>_bench_kernel_stats.csv,
+<round>_accumulate_summary.txt, <round>_accumulate_kernel_stats.csv (copied to profiles/ afterwards).
+usage: make_profile_summary.py <dir with the passes> <round tag>"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+P, RND = sys.argv[1], sys.argv[2]
+
+
+def kernel_stats(tag, dst):
+    f = glob.glob('%s/%s/**/*kernel_stats.csv' % (P, tag), recursive=True)
+    if not f:
+        return {}, ['(trace pass %s missing)' % tag]
+    shutil.copy(f[0], os.path.join(P, dst))
+    out, kt = [], {}
+    for r in csv.DictReader(open(f[0])):
+        out.append('%-72s calls=%s avg_ns=%s pct=%s' % (r['Name'][:72], r['Calls'], r['AverageNs'], r['Percentage']))
+        kt[r['Name']] = float(r['AverageNs'])
+    return kt, out
+
+
+def counters(tags, keep):
+    out, val = [], collections.defaultdict(dict)
+    for tag in tags:
+        for f in glob.glob('%s/%s/**/*counter_collection.csv' % (P, tag), recursive=True):
+            agg = collections.defaultdict(lambda: [0.0, 0])
+            for r in csv.DictReader(open(f)):
+                k = (r['Kernel_Name'], r['Counter_Name'])
+                agg[k][0] += float(r['Counter_Value'])
+                agg[k][1] += 1
+            for k, v in sorted(agg.items()):
+                if any(s in k[0] for s in keep):
+                    out.append('%-62s %-26s n=%d per-dispatch=%.6g' % (k[0][:62], k[1], v[1], v[0] / v[1]))
+                    val[[s for s in keep if s in k[0]][0]][k[1]] = v[0] / v[1]
+    return out, val
+
+
+def pick(kt, name):
+    return [v for k, v in kt.items() if name in k][0] / 1e6
+
+
+# ---------------------------------------------------------------- bench.py (score + forward-backward)
+out = ['# rocprofv3 summaries, %s: python3 bench.py --steps 3 --warmup 1 --cpu-baseline 0 --extra 0 (one MI355X, C4 shard)' % RND,
+       '# produced by tools/gpu_profile.sh + tools/make_profile_summary.py; one --kernel-trace --stats pass and separate --pmc passes',
+       '', '## --kernel-trace --stats (%s_bench_kernel_stats.csv)' % RND]
+kt, lines = kernel_stats('bench_trace', '%s_bench_kernel_stats.csv' % RND)
+out += lines + ['', '## --pmc passes (<= 4 counters per pass, no trace domains), per-dispatch averages']
+lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fb_kernel'])
+out += lines
+try:
+    v = val['gmm_score_split16_kernel']
+    ms = pick(kt, 'gmm_score_split16_kernel')
+    pairs, M, D = 18432000, 2048, 39
+    flop = pairs * M * (3 * D + 4)
+    fetch, write = v['FETCH_SIZE'] * 1024, v['WRITE_SIZE'] * 1024
+    cyc = v['GRBM_GUI_ACTIVE'] / 8
+    out += ['', '## derived (gmm_score_split16_kernel<39,2>, 18,432,000 (frame,state) pairs x 2048 mixtures per launch)',
+            'kernel %.2f ms/launch (trace pass) -> %.1f TFLOP/s algorithmic (%.4f TFLOP/launch) = %.3f of 838.9 (f16 MFMA peak / 3 split products), %.2f x the f32-input MFMA peak 157.3'
+            % (ms, flop / ms / 1e9, flop / 1e12, flop / ms / 1e9 / 838.9, flop / ms / 1e9 / 157.3),
+            'executed MFMA work: 15 x v_mfma_f32_32x32x16 per 1024 Gaussians = %.0f TFLOP/s of f16 MFMA flops = %.2f of the 2516.6 dense peak' % (pairs * M * 480 / ms / 1e9, pairs * M * 480 / ms / 1e9 / 2516.6),
+            'GRBM_GUI_ACTIVE %.4g (sum of 8 XCDs) -> %.3g cycles -> clock held %.2f GHz over %.2f ms; SQ_VALU_MFMA_BUSY_CYCLES %.4g / 1024 SIMDs = %.3g cycles -> matrix pipe %.0f %% busy'
+            % (v['GRBM_GUI_ACTIVE'], cyc, cyc / ms / 1e6, ms, v['SQ_VALU_MFMA_BUSY_CYCLES'], v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024, 100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc),
+            'FETCH_SIZE %.4g KiB/launch = %.2f GB raw; WRITE_SIZE %.4g KiB = %.2f GB' % (v['FETCH_SIZE'], fetch / 1e9, v['WRITE_SIZE'], write / 1e9),
+            'gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies wide streaming reads (16 B/lane, global_load_lds included: the parameter '
+            'stream) at half their bytes -> traffic = 2 x FETCH_SIZE + WRITE_SIZE = %.2f GB per launch (an upper bound: the 156-B frame rows are narrow reads)' % ((2 * fetch + write) / 1e9),
+            'algorithmic bytes/launch 2.14 GB (parameters 1.97 GB + frames 48 MB + B 147 MB): corrected traffic / algorithmic = %.2f' % ((2 * fetch + write) / 2.1369e9),
+            'HBM %.3f TB/s = %.1f %% of 8 TB/s: compute bound' % ((2 * fetch + write) / ms / 1e9, (2 * fetch + write) / ms / 1e9 / 8 * 100),
+            'traffic_bytes for bench.py: %d' % int(2 * fetch + write)]
+except (KeyError, IndexError) as e:
+    out.append('(derived block incomplete: %r)' % (e,))
+open(os.path.join(P, '%s_bench_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
+
+# ---------------------------------------------------------------- accumulate pass (tools/acc_bench.py)
+out = ['# rocprofv3 summaries, %s: python3 tools/acc_bench.py (one MI355X, C4 shard, flat posteriors: 4 accumulate passes, 7 state groups each)' % RND,
+       '', '## --kernel-trace --stats (%s_accumulate_kernel_stats.csv)' % RND]
+kt, lines = kernel_stats('acc_trace', '%s_accumulate_kernel_stats.csv' % RND)
+out += lines + ['', '## --pmc passes (<= 4 counters per pass), per-dispatch averages']
+lines, val = counters(['acc_fetch', 'acc_write', 'acc_clk', 'acc_sq1', 'acc_sq2', 'acc_lds', 'acc_tcc'], ['acc16_consumer_kernel', 'acc16_producer_kernel'])
+out += lines
+try:
+    v = val['acc16_consumer_kernel']
+    ms = pick(kt, 'acc16_consumer_kernel')
+    calls = [r for r in csv.DictReader(open(os.path.join(P, '%s_accumulate_kernel_stats.csv' % RND))) if 'acc16_consumer' in r['Name']][0]
+    n = int(calls['Calls'])
+    cyc = v['GRBM_GUI_ACTIVE'] / 8
+    mf = v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024
+    wc = v['SQ_WAVE_CYCLES']
+    out += ['', '## derived (acc16_consumer_kernel<39>, per dispatch = one state group; %d dispatches in 4 passes)' % n,
+            'consumer %.2f ms/dispatch, producer %.2f ms/dispatch; per pass: %d groups' % (ms, pick(kt, 'acc16_producer_kernel'), n // 4),
+            'GRBM_GUI_ACTIVE %.4g (sum of 8 XCDs) -> clock held %.2f GHz; SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs = %.3g cycles -> matrix pipe %.0f %% busy'
+            % (v['GRBM_GUI_ACTIVE'], cyc / ms / 1e6, mf, 100 * mf / cyc),
+            'wave time: SQ_WAIT_ANY %.0f %% (s_waitcnt / barrier), SQ_WAIT_INST_ANY %.0f %% (issue stalls: pipe, dependencies), SQ_ACTIVE_INST_ANY %.0f %% of SQ_WAVE_CYCLES'
+            % (100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, 100 * v['SQ_ACTIVE_INST_ANY'] / wc),
+            'LDS: SQ_LDS_IDX_ACTIVE / 256 CUs = %.3g cycles = %.0f %% of the dispatch, bank conflicts %.3g' % (v['SQ_LDS_IDX_ACTIVE'] / 256, 100 * v['SQ_LDS_IDX_ACTIVE'] / 256 / cyc, v['SQ_LDS_BANK_CONFLICT']),
+            'L2: hit rate %.0f %% (TCC_HIT / (HIT + MISS)); FETCH_SIZE %.2f GB raw (x 2 for 16-B-per-lane streaming reads = %.2f GB), WRITE_SIZE %.2f GB per dispatch'
+            % (100 * v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']), v['FETCH_SIZE'] * 1024 / 1e9, 2 * v['FETCH_SIZE'] * 1024 / 1e9, v['WRITE_SIZE'] * 1024 / 1e9)]
+except (KeyError, IndexError, ZeroDivisionError) as e:
+    out.append('(derived block incomplete: %r)' % (e,))
+open(os.path.join(P, '%s_accumulate_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
