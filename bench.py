@@ -610,7 +610,53 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
                                     'the posteriors of aligned speech; score + forward-backward + accumulate + per-unit merge, no exchange')
     bp.close()
     ep.close()
+    out['zero_change_route'] = zero_change_route()
     return out
+
+
+def zero_change_route(n_utts=3):
+    """The reference's own per-utterance worker (AcousticModel.multi_embedded_training_1, AcousticModel.py:884-916) written against
+    the drop-in classes exactly as the reference writes it against its own -- per label unit cal_observation_pro, then embedded,
+    LHMM(...).baulm_welch() with its update_acc into every unit's GMMs -- on BASELINE config 2's shapes (39-dim, 256-mix, 50 units,
+    20 units per utterance).  This is the route a user takes by changing nothing but the import; the batched entry points
+    (estep_batch) are the fast one."""
+    from poccala_amd import synth
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd.Exceptions import NullLog
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    from poccala_amd.StatisticalModel.LHMM import LHMM
+    c = synth.CONFIGS['C2']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=3)
+    frames, lens, begin = synth.make_frames(n_utts, c['T'], c['D'], seed=4)
+    labels = synth.make_labels(n_utts, c['L'], c['units'], seed=5)
+    log = NullLog()
+    am = AcousticModel(log, 'XIF_tone', state_num=5)
+
+    def unit_hmm(u):
+        gm = [Clustering.GMM(log, dimension=c['D'], mix_level=c['M'], alpha=w[u * 3 + k], mean=mean[u * 3 + k],
+                             covariance=var[u * 3 + k], gmm_id=k, precision='f32') for k in range(3)]
+        prof = [AcousticModel.VirtualState(1.)] + gm + [AcousticModel.VirtualState(0.)]
+        return LHMM({i: str(u) for i in range(5)}, 5, log, transmat=trans[u].copy(), profunc=prof)
+    t_all = 0.0
+    for rep in range(2):                                    # the first pass warms the contexts
+        t0 = time.perf_counter()
+        for n in range(n_utts):
+            x = frames[begin[n]:begin[n] + lens[n]].astype(np.float64)
+            label = [str(int(u)) for u in labels[n]]
+            hmm_list = [unit_hmm(int(u)) for u in labels[n]]          # init_unit + init_parameter per label position (:897-899)
+            for h in hmm_list:
+                h.cal_observation_pro([x], [len(x)])                  # :901
+                h.clear_data()
+            states, a, b, pi = am.embedded(label, hmm_list, 0, 15)   # :903
+            embed = LHMM(states, 5, log, transmat=a, probmat=[b], pi=pi, hmm_list=hmm_list, fix_code=0)   # :906
+            embed.add_data([x])
+            embed.add_T([len(x)])
+            embed.baulm_welch()                                       # :910 (incl. update_acc: 60 GMM.update_acc calls)
+        t_all = time.perf_counter() - t0
+    nf = int(lens.sum())
+    return dict(frames_per_s=nf / t_all, ms_per_utterance=t_all / n_utts * 1e3, utterances=n_utts,
+                what='per-utterance drop-in worker on config-2 shapes (39-dim, 256-mix, L = 20): 20 cal_observation_pro + embedded + '
+                     'baulm_welch + 60 GMM.update_acc, every call through the C-ABI on a private context')
 
 
 if __name__ == '__main__':

@@ -15,9 +15,20 @@ import numpy as np
 
 from ..Exceptions import DataDimensionError, NullLog
 from .._lib import PCL_F32, PCL_F64
-from ..runtime import default_engine
+from ..runtime import scratch_engine
 from .DataInitialization import DataInitialization
 from .util import log_sum_exp
+
+
+def _lse2(a, b):
+    """Elementwise util.log_sum_exp of two arrays (util.py:54-77): max + ln(sum exp(. - max)), the max itself where it is
+    infinite (quirk Q4).  Same arithmetic as the reference's per-row calls, without the Python loop over mixtures."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    top = np.maximum(a, b)
+    safe = np.where(np.isinf(top), 0.0, top)
+    with np.errstate(all='ignore'):
+        out = safe + np.log(np.exp(a - safe) + np.exp(b - safe))
+    return np.where(np.isinf(top), top, out)
 
 
 def _diag_of(covariance, m, d):
@@ -121,7 +132,7 @@ class Clustering(DataInitialization):
             frames = np.asarray(frames, dtype=np.float64)
             if frames.ndim != 2 or frames.shape[1] != self.dimension:
                 raise DataDimensionError(self.dimension, frames.shape[-1], self.log)
-            eng = default_engine()
+            eng = scratch_engine()
             mean, var, w = self.model_arrays()
             eng.load_model(mean[None], var[None], w[None])
             eng.load_frames(frames)
@@ -139,7 +150,7 @@ class Clustering(DataInitialization):
             b_value = np.asarray(b_value, dtype=np.float64)
             o_value = np.asarray(o_value, dtype=np.float64)
             t = o_value.shape[0]
-            eng = default_engine()
+            eng = scratch_engine()
             mean, var, w = self.model_arrays()
             eng.load_model(mean[None], var[None], w[None])
             eng.load_frames(o_value)
@@ -153,15 +164,12 @@ class Clustering(DataInitialization):
             st = eng.stats_download()
             b.close()
             with np.errstate(divide='ignore'):
-                self.__acc = log_sum_exp(np.stack([np.log(st['acc'][0]), self.__acc], axis=1), vector=True)
+                self.__acc = _lse2(np.log(st['acc'][0]), self.__acc)
                 # alpha_acc: the reference adds ln gamma_t(j) of EVERY frame (Clustering.py:667); the device
                 # sums only frames that do not underflow, identical to the last bit of the float64 sum
                 self.__alpha_acc = log_sum_exp(np.append(l_value, self.__alpha_acc))
-                lm = np.log(st['mean_acc'][0])
-                lc = np.log(st['cov_acc'][0])
-            for i in range(self.__mix_level):
-                self.__mean_acc[i] = log_sum_exp(np.stack([lm[i], self.__mean_acc[i]], axis=1), vector=True)
-                self.__covariance_acc[i] = log_sum_exp(np.stack([lc[i], self.__covariance_acc[i]], axis=1), vector=True)
+                self.__mean_acc = _lse2(np.log(st['mean_acc'][0]), self.__mean_acc)
+                self.__covariance_acc = list(_lse2(np.log(st['cov_acc'][0]), np.asarray(self.__covariance_acc)))
             self.__record_frames = 0
 
         # ---------------------------------------------------------------- A15  update_param (Clustering.py:682-693)

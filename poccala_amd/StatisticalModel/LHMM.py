@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-from ..runtime import default_engine
+from ..runtime import scratch_engine
 from .._lib import PCL_F64
 from .DataInitialization import DataInitialization
 from .util import log_sum_exp, matrix_log_sum_exp
@@ -117,7 +117,7 @@ class LHMM(DataInitialization):
         gmm_rows = [i for i in range(n) if hasattr(self.__profunction[i], 'model_arrays')]
         out = [np.empty((n, lens[d])) for d in range(len(data))]
         if gmm_rows:
-            eng = default_engine()
+            eng = scratch_engine()
             arrs = [self.__profunction[i].model_arrays() for i in gmm_rows]
             frames = np.concatenate([np.asarray(data[d], dtype=np.float64)[:lens[d]] for d in range(len(data))], axis=0)
             if frames.shape[1] != arrs[0][0].shape[1]:
@@ -148,7 +148,7 @@ class LHMM(DataInitialization):
 
     # ------------------------------------------------------------------ A8..A11 + A10 baulm_welch (LHMM.py:526-544)
     def _device_pass(self, log_pi, fix_pi, threshold):
-        eng = default_engine()
+        eng = scratch_engine()
         n_utt = self.datasize if self.datasize else len(self.__result_p)
         n = self.__hmm_size
         ts = [self.__result_p[d].shape[1] for d in range(n_utt)]
@@ -238,7 +238,7 @@ class LHMM(DataInitialization):
         prob = np.asarray(prob, dtype=np.float64)
         s_len, t = prob.shape
         assert s_len == len(states), 'number of states does not match the score matrix'     # LHMM.py:563
-        eng = default_engine()
+        eng = scratch_engine()
         b = eng.batch([s_len], [t])
         b.set_transitions([_np_log(transmat)], [_np_log(pi)])     # np.log on the host: bit-identical operands
         b.set_emissions([prob])

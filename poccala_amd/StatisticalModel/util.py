@@ -12,9 +12,9 @@ import numpy as np
 def gaussian_function(y, mean, cov, dimension, log=False, standard=False):
     if not log or standard:
         raise NotImplementedError('only log=True, standard=False is on the hot path (SURVEY quirk Q3)')
-    from ..runtime import default_engine
+    from ..runtime import scratch_engine
     from .._lib import PCL_F64
-    eng = default_engine()
+    eng = scratch_engine()
     y = np.asarray(y, dtype=np.float64).reshape(1, -1)
     diag = np.asarray(cov, dtype=np.float64)
     diag = diag.diagonal() if diag.ndim == 2 else diag            # util.py:23

@@ -40,6 +40,7 @@ class Engine(object):
         self.J = self.M = self.D = 0
         self.n_units = self.S = 0
         self.F = 0
+        self._model_key = self._frames_key = None
         self._batches = []   # weak refs to live batches: destroyed before the context
 
     # ------------------------------------------------------------------ plumbing
@@ -94,9 +95,27 @@ class Engine(object):
         if mean.ndim != 3 or var.shape != mean.shape or weight.shape != mean.shape[:2]:
             raise ValueError('model shapes: mean %s var %s weight %s' % (mean.shape, var.shape, weight.shape))
         J, M, D = mean.shape
+        key = self._digest((mean, var, weight), ('model', bool(logdet)))
+        if key is not None and key == self._model_key:
+            return                                   # the same content is resident (and no M-step has touched it)
         self._check(self._lib.pcl_model_upload(self._ctx, J, M, D, ptr(mean), ptr(var), ptr(weight),
                                                1 if logdet else 0))
         self.J, self.M, self.D = J, M, D
+        self._model_key = key
+
+    _DIGEST_MAX = 64 << 20
+
+    @staticmethod
+    def _digest(arrays, tag):
+        """Content key of small uploads (the drop-in classes re-send the same unit model / utterance for every call);
+        None above 64 MB, where hashing would cost more than it saves."""
+        import hashlib
+        if sum(a.nbytes for a in arrays) > Engine._DIGEST_MAX:
+            return None
+        h = hashlib.blake2b(repr((tag, [(a.shape, str(a.dtype)) for a in arrays])).encode(), digest_size=16)
+        for a in arrays:
+            h.update(memoryview(np.ascontiguousarray(a)).cast('B'))
+        return h.digest()
 
     def load_frames(self, frames):
         """(F,D) float32 or float64 MFCC rows of every utterance of the shard, concatenated."""
@@ -107,8 +126,12 @@ class Engine(object):
             f, dt = as_c(frames, np.float32), PCL_F32
         else:
             f, dt = as_c(frames, np.float64), PCL_F64
+        key = self._digest((f,), 'frames')
+        if key is not None and key == self._frames_key:
+            return
         self._check(self._lib.pcl_frames_upload(self._ctx, f.shape[0], f.shape[1], ptr(f), dt))
         self.F = f.shape[0]
+        self._frames_key = key
 
     def batch(self, N, T, frame_begin=None):
         return Batch(self, N, T, frame_begin)
@@ -186,6 +209,7 @@ class Engine(object):
     def mstep(self, c_covariance=1e-3):
         """GMM.update_param for every state on the device (Clustering.py:682-693); rebuilds the scoring layouts."""
         self._check(self._lib.pcl_mstep(self._ctx, float(c_covariance)))
+        self._model_key = None                       # the resident model is no longer what was uploaded
 
     def model_download(self):
         """(mean (J,M,D), var (J,M,D), weight (J,M)) float64 master copy."""
@@ -257,6 +281,7 @@ class Engine(object):
         """reduce-scatter of the statistics by state range -> M-step on the owned states -> all-gather of the model
         (+ merge of the per-unit HMM accumulators, + the transition update on request).  One rank: the M-step."""
         self._check(self._lib.pcl_em_exchange(self._ctx, float(c_covariance), int(payload), 1 if update_transitions else 0))
+        self._model_key = None
 
 
 class Batch(object):

@@ -310,3 +310,44 @@ def test_regroup_batch_equals_discriminate_and_get_gmmdata(golden, tmp_path):
     assert [u for u, _ in saved] == list(G12['e_units'])
     for i, (_, blk) in enumerate(saved):
         np.testing.assert_array_equal(blk, G12['e_block_%d' % i])
+
+
+def test_per_gmm_calls_do_not_disturb_a_batched_estep_in_flight(golden):
+    """GMM.update_acc / point used to zero and re-upload on the shared engine.  Now the per-object
+    calls run in their own context (runtime.scratch_engine): a batched E-step's statistics, model and frames on the default
+    engine survive any number of interleaved per-GMM calls, and the per-GMM results are what they are without the batch."""
+    from poccala_amd import PCL_F64, synth
+    from poccala_amd.runtime import default_engine
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    mean, var, w, trans = synth.make_model(3, 4, 13, seed=91)
+    frames, lens, begin = synth.make_frames(6, 40, 13, seed=92)
+    labels = synth.make_labels(6, 2, 3, seed=93)
+    eng = default_engine()
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
+    eng.load_frames(frames)
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F64)
+    b.forward_backward()
+    eng.stats_zero()
+    b.accumulate(PCL_F64)
+    before = eng.stats_download()
+    # per-GMM traffic in between (a different model, different frames, its own statistics)
+    rng = np.random.default_rng(94)
+    g = Clustering.GMM(RecLog(), dimension=13, mix_level=5, alpha=np.full(5, 0.2), mean=rng.standard_normal((5, 13)),
+                       covariance=np.array([np.diag(v) for v in rng.uniform(0.5, 2.0, (5, 13))]))
+    x = rng.standard_normal((30, 13))
+    p1 = np.array([g.point(x[t], log=True) for t in range(5)])
+    lb = g.point_frames(x)
+    np.testing.assert_array_equal(p1, lb[:5])                    # the cached upload serves every frame
+    g.update_acc(np.log(np.full(30, 0.5)), lb, x)
+    acc1 = g.acc.copy()
+    g.update_acc(np.log(np.full(30, 0.5)), lb, x)                # log-adds onto its own running accumulator
+    np.testing.assert_allclose(g.acc, acc1 + np.log(2.0), rtol=1e-12)
+    after = eng.stats_download()
+    for k in before:
+        np.testing.assert_array_equal(after[k], before[k])
+    b.accumulate(PCL_F64)                                        # and the batch can go on accumulating
+    twice = eng.stats_download()
+    np.testing.assert_allclose(twice['acc'], 2 * before['acc'], rtol=1e-12)
+    b.close()
