@@ -19,6 +19,8 @@
 // a sentence HMM built by AcousticModel.embedded has <= 2 non-zeros per row.  The running
 // alpha/beta vectors are exchanged through LDS; emission rows are read time-major (one
 // coalesced N-vector per step).
+#include <stdlib.h>
+
 #include "pcl_internal.h"
 
 namespace {
@@ -350,6 +352,196 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same pass loop for sentence HMMs of at most 64 states with at most two predecessors / successors per state (every HMM
+// AcousticModel.embedded builds), on TWO wavefronts: within a pass the forward and the backward recursion do not depend on
+// each other (the reference runs them one after the other, LHMM.py:388-392), so wave 0 runs alpha while wave 1 runs beta --
+// each exchanges its running vector through its own LDS buffer, wave-synchronously, with no workgroup barrier per frame --
+// and what needs both (xi, gamma, the per-frame posteriors of the final pass; LHMM.py:394-405,431-445,486-500) is computed
+// afterwards in parallel over t by both waves with online log-sum-exps that are merged at the end.  The T-long dependent
+// chain is walked 3 times per utterance instead of 6.  log(e^a + e^b) is taken as max + log1p(exp(min - max)): one exp
+// and one log1p per state and frame instead of two exps and a log.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lse2(double a, double b) {
+    const double m = fmax(a, b);
+    if (isinf(m)) return m;                                   // util.log_sum_exp, quirk Q4
+    return m + log1p(exp(fmin(a, b) - m));
+}
+__device__ __forceinline__ void online_lse(double x, double &m, double &s) {
+    if (x > m) {
+        s = s * exp(m - x) + 1.0;                             // exp(-inf) = 0 on the first finite value
+        m = x;
+    } else if (x > -INFINITY) {
+        s += exp(x - m);
+    }
+}
+__device__ __forceinline__ double wave_lse(double v) {
+    const double m = wave_max(v);
+    if (isinf(m)) return m;
+    return m + log(wave_sum(exp(v - m)));
+}
+
+__global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                                     const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                     const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
+                                                     const int *__restrict__ row_idx, const double *__restrict__ csc_val,
+                                                     const double *__restrict__ logpi_in, double *__restrict__ alpha,
+                                                     double *__restrict__ beta, double *__restrict__ lgam, double *__restrict__ ksai,
+                                                     double *__restrict__ gamma_out, double *__restrict__ pi_out, double *__restrict__ logp,
+                                                     double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
+                                                     double threshold) {
+    __shared__ double vF[2][64], vB[2][64], a0s[64], b0s[64], lpi[64];
+    __shared__ double s_q;
+    const UttDesc d = utts[blockIdx.x];
+    const int N = d.N, T = d.T;
+    const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
+    const bool act = i < N;
+    const double *B = Bt + d.b_off;
+    double *A_ = alpha + d.b_off, *Bv = beta + d.b_off, *G = lgam + d.b_off;
+    int pidx[2] = {0, 0}, sidx[2] = {0, 0}, nsucc = 0;
+    double pval[2] = {-INFINITY, -INFINITY}, sval[2] = {-INFINITY, -INFINITY};
+    if (act) {
+        const int pc0 = col_ptr[d.ptr_off + i] + d.nnz_off, pc1 = col_ptr[d.ptr_off + i + 1] + d.nnz_off;
+        const int sr0 = row_ptr[d.ptr_off + i] + d.nnz_off, sr1 = row_ptr[d.ptr_off + i + 1] + d.nnz_off;
+        nsucc = sr1 - sr0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < pc1 - pc0) { pidx[k] = row_idx[pc0 + k]; pval[k] = csc_val[pc0 + k]; }
+            if (k < sr1 - sr0) { sidx[k] = col_idx[sr0 + k]; sval[k] = csr_val[sr0 + k]; }
+        }
+    }
+    if (w == 0) lpi[i] = act ? logpi_in[d.vec_off + i] : -INFINITY;
+    for (long long e = threadIdx.x; e < (long long)N * N; e += 128) ksai[d.mat_off + e] = -INFINITY;   // LHMM.py:404: ln 0 entries
+    __syncthreads();
+    // the LDS vectors are exchanged inside ONE wave: its ds_write and the ds_reads after it are executed in order
+#define WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    double q = -INFINITY;
+    int npass = 0;
+    for (;;) {
+        if (w == 0) {
+            // ---------------------------------------------------------------- forward (LHMM.py:335-351)
+            double bnext = act ? B[i] : 0.0, a = -INFINITY;
+            if (act) {
+                a = lpi[i] + bnext;
+                A_[i] = a;
+            }
+            a0s[i] = a;
+            vF[0][i] = a;
+            bnext = (act && T > 1) ? B[(long long)N + i] : 0.0;
+            WAVE_LDS_FENCE();
+            for (int t = 1; t < T; ++t) {
+                const double *prev = vF[(t - 1) & 1];
+                const double bcur = bnext;
+                if (act && t + 1 < T) bnext = B[(long long)(t + 1) * N + i];     // in flight during this step
+                if (act) {
+                    a = lse2(prev[pidx[0]] + pval[0], prev[pidx[1]] + pval[1]) + bcur;
+                    A_[(long long)t * N + i] = a;
+                }
+                vF[t & 1][i] = a;
+                WAVE_LDS_FENCE();
+            }
+            const double qn = wave_lse(act ? a : -INFINITY);                     // Q (LHMM.py:412-422, datasize == 1 on this path)
+            if (i == 0) s_q = qn;
+        } else {
+            // ---------------------------------------------------------------- backward (LHMM.py:353-366); beta_{T-1} = 0 (quirk Q8)
+            if (act) Bv[(long long)(T - 1) * N + i] = 0.0;
+            vB[(T - 1) & 1][i] = act ? B[(long long)(T - 1) * N + i] + 0.0 : -INFINITY;      // w_j = b_j(o_{t+1}) + beta_{t+1}(j)
+            double b_t = (act && T > 1) ? B[(long long)(T - 2) * N + i] : 0.0, bcur = 0.0;
+            WAVE_LDS_FENCE();
+            for (int t = T - 2; t >= 0; --t) {
+                const double *nxt = vB[(t + 1) & 1];
+                const double bt = b_t;
+                if (act && t > 0) b_t = B[(long long)(t - 1) * N + i];
+                if (act) {
+                    bcur = lse2(sval[0] + nxt[sidx[0]], sval[1] + nxt[sidx[1]]);
+                    Bv[(long long)t * N + i] = bcur;
+                }
+                vB[t & 1][i] = act ? bt + bcur : -INFINITY;
+                WAVE_LDS_FENCE();
+            }
+            b0s[i] = (T > 1) ? bcur : 0.0;
+        }
+        __syncthreads();
+        const double qnew = s_q;
+        bool final_pass = !(qnew - q > threshold) || (npass + 1 >= PCL_MAX_PASS);   // LHMM.py:539
+        if (threadIdx.x == 0) qtrace[(long long)blockIdx.x * PCL_MAX_PASS + npass] = qnew;
+        ++npass;
+        if (fix_pi && !final_pass && threshold >= 0.0 && npass < PCL_MAX_PASS) {
+            // quirk Q6: with pi locked the next pass would reproduce this one bit for bit and then stop
+            if (threadIdx.x == 0) qtrace[(long long)blockIdx.x * PCL_MAX_PASS + npass] = qnew;
+            ++npass;
+            final_pass = true;
+        }
+        // ---------------------------------------------------------------- pi (LHMM.py:447-452,470-471), wave 0
+        if (w == 0) {
+            if (!fix_pi) {
+                const double p0 = act ? a0s[i] + b0s[i] : -INFINITY;
+                const double n0 = wave_lse(p0);
+                const double pv = exp(p0 - n0);                  // the reference stores pi = exp(.) and takes np.log of it again
+                lpi[i] = act ? log(pv) : -INFINITY;
+                if (final_pass && act) pi_out[d.vec_off + i] = pv;
+            } else if (final_pass && act) {
+                pi_out[d.vec_off + i] = exp(lpi[i]);
+            }
+        }
+        if (final_pass) {
+            // ---------------------------------------------------------------- xi / gamma / posteriors, parallel over t
+            double gm = -INFINITY, gs = 0.0, xm[2] = {-INFINITY, -INFINITY}, xs[2] = {0.0, 0.0};
+            for (int t = w; t < T; t += 2) {
+                const double at = act ? A_[(long long)t * N + i] : -INFINITY, bt = act ? Bv[(long long)t * N + i] : 0.0;
+                const double l = at + bt;
+                const double norm = wave_lse(act ? l : -INFINITY);               // sum_value[t] (LHMM.py:488)
+                if (act) G[(long long)t * N + i] = l - norm;                     // l[:,t] - sum_value[t] (:486-500)
+                if (act && t < T - 1) {
+                    online_lse(l, gm, gs);                                       // gamma_i over t < T-1 (:442-445)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (k < nsucc) {
+                            // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
+                            const long long o = (long long)(t + 1) * N + sidx[k];
+                            online_lse(at + (sval[k] + (B[o] + Bv[o])), xm[k], xs[k]);
+                        }
+                }
+            }
+            // merge the two waves' partial log-sum-exps: (m, s) pairs through LDS
+            __shared__ double ms[3][2][2][64];
+            ms[0][w][0][i] = gm; ms[0][w][1][i] = gs;
+            ms[1][w][0][i] = xm[0]; ms[1][w][1][i] = xs[0];
+            ms[2][w][0][i] = xm[1]; ms[2][w][1][i] = xs[1];
+            __syncthreads();
+            if (w == 0 && act) {
+                double outv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double m0 = ms[c][0][0][i], s0 = ms[c][0][1][i], m1 = ms[c][1][0][i], s1 = ms[c][1][1][i];
+                    const double M = fmax(m0, m1);
+                    double v = -INFINITY;
+                    if (M > -INFINITY) {
+                        double tsum = 0.0;
+                        if (m0 > -INFINITY) tsum += s0 * exp(m0 - M);
+                        if (m1 > -INFINITY) tsum += s1 * exp(m1 - M);
+                        v = M + log(tsum);
+                    }
+                    outv[c] = v;
+                }
+                gamma_out[d.vec_off + i] = outv[0];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (k < nsucc) ksai[d.mat_off + (long long)i * N + sidx[k]] = outv[1 + k];
+            }
+            if (threadIdx.x == 0) {
+                logp[blockIdx.x] = qnew;
+                npass_out[blockIdx.x] = npass;
+                for (int k = npass; k < PCL_MAX_PASS; ++k) qtrace[(long long)blockIdx.x * PCL_MAX_PASS + k] = NAN;
+            }
+            break;
+        }
+        q = qnew;
+        __syncthreads();
+    }
+#undef WAVE_LDS_FENCE
+}
+
+// ------------------------------------------------------------------------------------------------
 // Viterbi (LHMM.py:546-609).  Bit-exact in float64: adds in the reference's order
 // (p_i + ln A_ij) -> max with first-index tie-break -> + prob[j,t].
 // ------------------------------------------------------------------------------------------------
@@ -455,7 +647,12 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);
     const size_t shm = (size_t)3 * NP * sizeof(double);
     pcl_timer_begin(ctx, "fb");
-    if (b->max_indeg <= 2 && b->max_outdeg <= 2)
+    static const bool one_wave = getenv("PCL_FB_ONE_WAVE") && atoi(getenv("PCL_FB_ONE_WAVE")) != 0;      // A/B: the round-1 kernel
+    if (b->max_indeg <= 2 && b->max_outdeg <= 2 && NP == 64 && !one_wave)
+        hipLaunchKernelGGL(hmm_fb2_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
+                           b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->ksai,
+                           b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
+    else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
         hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
                            b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Forward-backward alone (no scoring beside it): 1024 sentence HMMs of 62 states x 300 frames, random emissions.
+env PCL_FB_ONE_WAVE=1 selects the round-1 one-wave kernel."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from poccala_amd import Engine, synth
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+mean, var, w, trans = synth.make_model(50, 4, 13)
+labels = synth.make_labels(U, 20, 50)
+eng = Engine(0); eng.enable_timing(True)
+eng.load_model(mean, var, w); eng.load_units(np.stack(trans))
+frames, lens, begin = synth.make_frames(U, 300, 13)
+eng.load_frames(frames)
+b = eng.label_batch(labels, lens, begin)
+b.score(1)
+for fix in (False, True):
+    b.forward_backward(fix_pi=fix); eng.sync(); eng.kernel_time('fb')
+    for _ in range(5):
+        b.forward_backward(fix_pi=fix)
+    ms, k = eng.kernel_time('fb')
+    print('%s U=%d fix_pi=%s: %.3f ms per launch (%d passes), logP[0] = %.10f' % ('one-wave' if os.environ.get('PCL_FB_ONE_WAVE') else 'two-wave', U, fix, ms / k, b.get('npass')[0], b.get('logp')[0]))
