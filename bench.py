@@ -552,6 +552,27 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
         source='rocm-smi --showclocks --showpower sampled every ~0.1 s while gmm_score_split16_kernel runs back to back; the in-kernel clock from '
                'GRBM_GUI_ACTIVE is in profiles/ (rocm-smi reads up to ~10 % above it)')
     b0.close()
+    # ---- forced alignment, f32-class scoring against float64 scoring on the device (near-ties may flip), 64 utterances
+    from poccala_amd import PCL_F64
+    nu = min(64, cfg['U'])
+    ba = eng.label_batch(labels[:nu], np.full(nu, cfg['T'], dtype=np.int32), np.arange(nu, dtype=np.int64) * cfg['T'])
+    ba.score(PCL_F32); ba.viterbi()
+    p32 = ba.get('path')
+    ba.score(PCL_F64); eng.sync()
+    t1 = time.perf_counter()
+    ba.score(PCL_F64); eng.sync()
+    t64 = time.perf_counter() - t1
+    ba.viterbi()
+    p64 = ba.get('path')
+    t1 = time.perf_counter()
+    ba.score(PCL_F32); eng.sync()
+    t32 = time.perf_counter() - t1
+    ba.close()
+    nfr = sum(len(a) for a in p64)
+    nflip = int(sum((a != b_).sum() for a, b_ in zip(p32, p64)))
+    out['alignment_flip_rate'] = dict(utterances=nu, frames=nfr, flipped=nflip, rate=nflip / nfr, score_f32_ms=t32 * 1e3, score_f64_ms=t64 * 1e3,
+                                      what='Viterbi paths under the default f32-class scoring against the same kernel chain under float64 scoring '
+                                           '(PCL_F64, direct form): the float64 scoring removes every flip at score_f64_ms / score_f32_ms the cost')
     # ---- strict f32: v_mfma_f32_32x32x2_f32 (bit for bit an f32 FMA chain), same batch
     old = os.environ.get('PCL_SCORE_VARIANT')
     os.environ['PCL_SCORE_VARIANT'] = '3'

@@ -1043,8 +1043,8 @@ def test_c3_deep_parity_and_flip_rate(eng):
 def test_c5_shard_full_size(eng):
     """BASELINE config C5's scoring half at its real shape: the per-GPU shard of the 1M-frame corpus, 417 utterances x 300
     frames, ALL 549 XIF_tone-sized states x 4096 mixtures for every frame.  Properties at full size (entry row 0, exit row
-    -inf, everything finite, states shared by all utterances score identically for identical frames), 2 utterances against
-    the oracle (every state), and the token-passing decode on top runs without overflow at a generous cap."""
+    -inf, everything finite, states shared by all utterances score identically for identical frames) and 2 utterances against
+    the oracle (every state).  The decode half on this shard is timed by tools/c5_decode_bench.py and tested in test_gpu_decode.py."""
     from poccala_amd import PCL_F32, synth
     from _oracle_pool import state_rows
     c = synth.CONFIGS['C5shard']
