@@ -109,6 +109,19 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean /* J*
  * argument of cal_observation_pro).  dtype: PCL_F32 or PCL_F64 host element type. */
 int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dtype);
 
+/* Streaming form for a corpus that is fed chunk by chunk (BASELINE config 5; the reference reads one utterance at a time
+ * from disk inside its worker, AcousticModel.py:723-768).  Two device slots: pcl_frames_stage queues the H2D copy of the
+ * NEXT chunk (float32, row-major (F,D)) on the library's copy stream, into the slot that is not current, behind the
+ * last kernels that read that slot, and returns at once; pcl_frames_swap waits for that copy (after it returns the
+ * caller's buffer is free again) and makes the staged chunk the current frame matrix for batches created afterwards.
+ * Batches of the previous chunk stay valid for everything that does not read frames (decode, forward-backward, Viterbi,
+ * downloads); scoring / accumulating them again fails the row check unless the new chunk is at least as long.
+ * pcl_host_alloc returns page-locked host memory (the copy is then truly asynchronous); any host pointer works. */
+int pcl_frames_stage(pcl_ctx *ctx, int64_t F, int D, const float *frames);
+int pcl_frames_swap(pcl_ctx *ctx);
+int pcl_host_alloc(pcl_ctx *ctx, size_t bytes, void **out);
+int pcl_host_free(pcl_ctx *ctx, void *ptr);
+
 /* ------------------------------------------------------------------ batch
  * A batch = U sentence-level HMMs (AcousticModel.embedded, AcousticModel.py:957-1014), utterance u
  * having N[u] states and T[u] frames starting at row frame_begin[u] of the uploaded frame matrix

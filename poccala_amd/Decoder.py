@@ -27,18 +27,9 @@ def load_inventory(engine, unit_names, means, variances, weights, unit_trans, le
     return tree
 
 
-def decode_batch(data_list, tree, engine=None, precision=PCL_F32, beam_=None, candidate=5, max_tokens=4096):
-    """data_list: MFCC matrices (T_u, D).  Scores every GMM state for every frame (the decoder has no label) and runs the
-    token passing.  Returns per utterance (words, score, detail): `words` = the word sequence behind the best final
-    token -- each entry the list of homophones of a word-end node -- as transfer() reports it (Decoder.py:183-186)."""
-    engine = engine or default_engine()
-    lens = np.array([len(d) for d in data_list], dtype=np.int32)
-    begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
-    engine.load_frames(np.concatenate([np.asarray(d) for d in data_list], axis=0))
-    b = engine.all_state_batch(lens, begin)
-    b.score(precision)
-    res = b.decode(beam if beam_ is None else beam_, 8, candidate, max_tokens)
-    b.close()
+def _report(res, tree):
+    """Per utterance (words, score, detail): the word sequence behind the best final token, as transfer() reports it
+    (Decoder.py:183-186) -- each entry the list of homophones of a word-end node."""
     out = []
     for r in res:
         words, score = [], -np.inf
@@ -52,3 +43,76 @@ def decode_batch(data_list, tree, engine=None, precision=PCL_F32, beam_=None, ca
                 words.append(tree['words'][node])
         out.append((words, score, r))
     return out
+
+
+def decode_batch(data_list, tree, engine=None, precision=PCL_F32, beam_=None, candidate=5, max_tokens=4096):
+    """data_list: MFCC matrices (T_u, D).  Scores every GMM state for every frame (the decoder has no label) and runs the
+    token passing.  Returns per utterance (words, score, detail)."""
+    engine = engine or default_engine()
+    lens = np.array([len(d) for d in data_list], dtype=np.int32)
+    begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+    engine.load_frames(np.concatenate([np.asarray(d) for d in data_list], axis=0))
+    b = engine.all_state_batch(lens, begin)
+    b.score(precision)
+    res = b.decode(beam if beam_ is None else beam_, 8, candidate, max_tokens)
+    b.close()
+    return _report(res, tree)
+
+
+def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, candidate=5, max_tokens=4096):
+    """The streaming form (BASELINE config 5: a corpus that is fed chunk by chunk).  `chunks` yields lists of (T_u, D)
+    float32 MFCC matrices; for every chunk, in order, decode_batch's result list is yielded.  Three legs overlap:
+      copy stream    frames of chunk k+1 travel into the frame slot that is not being scored (Engine.stage_frames)
+      main stream    every GMM state x every frame of chunk k is scored
+      second stream  chunk k-1 is decoded (token passing), its results come down
+    and the host packs chunk k+1 into page-locked memory meanwhile.  Batches are kept per chunk shape (the lengths of its
+    utterances) and reused alternately, so a stream of equal-shaped chunks allocates nothing after the second one; a new
+    shape costs one batch creation, which waits for the device."""
+    engine = engine or default_engine()
+    bm = beam if beam_ is None else beam_
+    pool, pinned = {}, [None]
+
+    def pack(chunk):
+        lens = np.array([len(d) for d in chunk], dtype=np.int32)
+        begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+        rows, dim = int(lens.sum()), int(np.asarray(chunk[0]).shape[1])
+        if pinned[0] is None or pinned[0].shape[0] < rows or pinned[0].shape[1] != dim:
+            pinned[0] = engine.pinned_empty((rows, dim), np.float32)
+        view = pinned[0][:rows]
+        np.concatenate([np.asarray(d, dtype=np.float32) for d in chunk], axis=0, out=view)
+        engine.stage_frames(view)
+        return lens, begin
+
+    def batch_for(lens, begin, k):
+        key = lens.tobytes()
+        pair = pool.setdefault(key, [None, None])
+        if pair[k & 1] is None:
+            pair[k & 1] = engine.all_state_batch(lens, begin)
+        return pair[k & 1]
+
+    it = iter(chunks)
+    nxt = next(it, None)
+    if nxt is None:
+        return
+    try:
+        layout = pack(nxt)
+        prev, k = None, 0
+        while nxt is not None:
+            engine.swap_frames()                                   # chunk k is the current frame matrix
+            b = batch_for(layout[0], layout[1], k)
+            b.score(precision)
+            nxt = next(it, None)
+            if nxt is not None:
+                layout = pack(nxt)                                 # host packing + H2D of chunk k+1 beside the GPU work
+            raw = prev.decode_fetch() if prev is not None else None    # waits for the decoder of chunk k-1 only
+            b.decode_launch(bm, 8, candidate, max_tokens)
+            if raw is not None:
+                yield _report(b.decode_unpack(raw), tree)          # host work (and the consumer's) beside decode(k) / score(k+1)
+            prev = b
+            k += 1
+        yield _report(prev.decode_results(), tree)
+    finally:
+        for pair in pool.values():
+            for b in pair:
+                if b is not None:
+                    b.close()

@@ -28,6 +28,10 @@ PROTOTYPES = {
     'pcl_kernel_time': (_i, [_vp, C.c_char_p, C.POINTER(C.c_float), C.POINTER(_i)]),
     'pcl_model_upload': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i]),
     'pcl_frames_upload': (_i, [_vp, C.c_int64, _i, _vp, _i]),
+    'pcl_frames_stage': (_i, [_vp, C.c_int64, _i, _vp]),
+    'pcl_frames_swap': (_i, [_vp]),
+    'pcl_host_alloc': (_i, [_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'pcl_host_free': (_i, [_vp, _vp]),
     'pcl_batch_create': (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(_vp)]),
     'pcl_batch_destroy': (_i, [_vp]),
     'pcl_batch_set_transitions': (_i, [_vp, _vp, _vp]),

@@ -18,15 +18,21 @@
 // against the reference itself -- nothing executable exists there.
 //
 // Mapping.  The emissions are the all-state matrix of a scoring batch (rows entry, 0..J-1, exit: pcl_batch_score), time
-// major, so a frame's J values are contiguous.  A token is 8 lanes (N = two units x three emitting states + 2 <= 8):
-// lane j holds p_j; ln A is built on the fly from the unit matrices (183 units x 25 doubles: cache resident).  All
-// float64: scores reach -1e5.  Per frame the workgroup runs
-//   step -> donors (finished tokens) and the best word-end donor -> prefix sum of the creations -> merge / create ->
-//   first step of the new tokens -> prune (radix select on the order-preserving bits of the scores, ties by token
-//   order) -> stable compaction into the other token buffer,
-// with workgroup barriers between phases; a tree node has at most one live token and one parent, so no hand-over needs
-// an atomic and the result does not depend on timing.
+// major, so a frame's J values are contiguous; the frame's row and the unit matrices (183 x 25 doubles) are staged in
+// LDS.  A token is 8 lanes in its step (N = two units x three emitting states + 2 <= 8: lane j holds p_j, two tokens per
+// lane group in flight) and one lane in the bookkeeping phases; its state lives in separate arrays (score, p[8], node,
+// history, unit pair), so every pass is coalesced.  All float64: scores reach -1e5.  Per frame the workgroup runs
+//   step -> donors (finished tokens), the best word-end donor, and the donors' children as ONE flattened list of
+//   (donor, target) pairs -> merge / create, a pair per thread (a node with hundreds of children is spread over the
+//   workgroup) -> first step of the new tokens -> prune (one pass for the width, the key range and a hashed occupancy map
+//   that settles the "8 distinct scores" rule; radix select below the keys' common prefix; ties by token order) ->
+//   stable compaction of the small fields into the other set of arrays (the 64 bytes of p stay where the step wrote them:
+//   the next step reads them through a source map and writes the other p buffer in the new order),
+// with workgroup barriers between phases; ordered prefix sums are a ballot per 64 tokens plus one exchange of 16 wave
+// totals.  A tree node has at most one live token and one parent, so no hand-over needs an atomic and the result does not
+// depend on timing.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -36,27 +42,35 @@
 
 namespace {
 
-constexpr int DW = 1024;            // threads per workgroup
+#ifndef PCL_DEC_DW
+#define PCL_DEC_DW 1024
+#endif
+constexpr int DW = PCL_DEC_DW;      // threads per workgroup
+constexpr int NWV = DW / 64;        // wavefronts per workgroup
 constexpr int NS = 8;               // lanes per token = states of its HMM at most
+constexpr int TG = DW / NS;         // tokens stepped per pass of the workgroup
+constexpr int SEG_LDS = 4096;       // donor segments whose offsets are searched in LDS (more: searched in HBM)
+constexpr int NONE = 0x7fffffff;
+[[maybe_unused]] constexpr int N_STAMP = 8;
 
-struct DecTok {
-    double score;
-    double p[NS];
-    int node, hist, fin, drop;      // fin: finished this frame; drop: pruned this frame
-};
-
+// Token state is kept as separate arrays (coalesced passes), two buffers of each: a frame ends with a stable compaction
+// from one into the other.  upair = the node's units, u0 | u1 << 16 (u1 = 0xffff: a one-unit node).
 struct DecArgs {
     const UttDesc *utts;
     const double *Bt;
     const double *unit_logtrans;    // [n_units][S][S]
     const int *node_units, *node_nunits, *child_ptr, *child_idx, *node_word, *roots;
-    int n_nodes, n_roots, S, cap, candidate, min_distinct, Tmax;
+    int n_nodes, n_roots, n_units, S, cap, candidate, min_distinct, Tmax;
     double beam, lpi1, lpi2;        // ln(1/N) for one- and two-unit nodes, from the caller's np.log
-    DecTok *tok;                    // [U][2][cap]
+    double *score, *p;              // [U][2][cap], [U][2][cap][NS]
+    int *node, *hist, *upair;       // [U][2][cap]
+    int *flag, *dst;                // [U][cap]: bit 0 finished, bit 1 pruned (this frame); where a token's p sits in the other p buffer
+    int *seg_ofs, *seg_cptr, *seg_hist;   // [U][cap + 2]: the frame's donors as segments of the flattened (donor, child) list
+    double *seg_score;
     int *slot;                      // [U][n_nodes]: live token of a node, or -1
-    int *work;                      // [U][cap + n_roots]: creation counts / prefix sums
     int *out_n, *out_node, *out_hist, *hist_n, *hist_prev, *hist_node, *trace, *overflow;
     double *out_score;
+    long long *stamps;              // PCL_DEC_STAMPS: [N_STAMP] clock ticks per phase, utterance 0
 };
 
 __device__ __forceinline__ unsigned long long okey(double s) {       // order-preserving bits
@@ -64,37 +78,37 @@ __device__ __forceinline__ unsigned long long okey(double s) {       // order-pr
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// ln A[i][j] of the node's embedded HMM (AcousticModel.py:979-989)
-__device__ __forceinline__ double log_a(const double *lt, const int *units, int nu, int S, int i, int j) {
-    const int e = S - 2, N = e * nu + 2;
-    if (i >= N - 1) return -INFINITY;
-    const int pos = (i == 0) ? 0 : (i - 1) / e, r = (i == 0) ? 0 : 1 + (i - 1) % e, c = j - pos * e;
-    if (c < 0 || c >= S) return -INFINITY;
-    return lt[((size_t)units[pos] * S + r) * S + c];
-}
+// What a lane (state j = sub of its token) needs of ln A of the embedded HMM (AcousticModel.py:979-989), fixed per thread:
+// predecessor i reaches j through entry rc[i] of its unit's (S,S) matrix, or not at all.
+struct LaneCtx {
+    int e, SS, mypos, myk;
+    int rc[NS];                     // entry r S + c of the unit matrix, + 256 when the predecessor sits in the second unit; -1: none
+    double lpi1, lpi2;
+};
 
-// One step of one token on the frame whose emissions start at Bf, by the token's 8 lanes (sub = state j; the 8 lanes sit
-// in one wave and run in lockstep: every lane has read the old p before any lane stores the new one).
-// first: p = ln pi + B[:,t] (Decoder.py:270); else the max recursion (:278-283).  score += max_j p_j (:285); fin (D1).
-__device__ __forceinline__ void token_step(const DecArgs &a, DecTok *tk, const double *Bf, int sub, bool first) {
-    const int *units = a.node_units + (size_t)tk->node * 2;
-    const int nu = a.node_nunits[tk->node], e = a.S - 2, N = e * nu + 2;
+// One step of one token by its 8 lanes (they sit in one wave and run in lockstep).  FIRST: p = ln pi + B[:,t]
+// (Decoder.py:270); else the max recursion (:278-283).  best = max_j p_j and fin (D1) come back on every lane.
+template <bool FIRST>
+__device__ __forceinline__ void token_step(const LaneCtx &c, const double *lt, const double *Bs, int up, double pold, int sub, double &pj,
+                                           double &best, int &fin) {
+    const int u0 = up & 0xffff, u1 = (int)((unsigned int)up >> 16);
+    const int nu = (u1 == 0xffff) ? 1 : 2, N = c.e * nu + 2;
     double bj = -INFINITY;
     if (sub == 0) bj = 0.0;                                        // entry VirtualState: ln 1 (AcousticModel.py:218)
-    else if (sub < N - 1) bj = Bf[1 + units[(sub - 1) / e] * e + (sub - 1) % e];   // (exit VirtualState: ln 0, :219)
-    double pj = -INFINITY;
-    if (first) {
-        if (sub < N) pj = (nu == 1 ? a.lpi1 : a.lpi2) + bj;
+    else if (sub < N - 1) bj = Bs[1 + (c.mypos ? u1 : u0) * c.e + c.myk];    // (exit VirtualState: ln 0, :219)
+    pj = -INFINITY;
+    if (FIRST) {
+        if (sub < N) pj = (nu == 1 ? c.lpi1 : c.lpi2) + bj;
     } else {
-        const double pold = tk->p[sub];                            // every lane's old value travels by shuffle: no lane reads
-        double m = -INFINITY;                                      // p from memory after another lane has stored its new one
-        for (int i = 0; i < N; ++i) {
+        double m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {                             // every lane's old value travels by shuffle
             const double pi = __shfl(pold, i, NS);
-            if (sub < N) m = fmax(m, pi + log_a(a.unit_logtrans, units, nu, a.S, i, sub));
+            if (i < N - 1 && c.rc[i] >= 0 && sub < N) m = fmax(m, pi + lt[((c.rc[i] & 256) ? u1 : u0) * c.SS + (c.rc[i] & 255)]);
         }
         if (sub < N) pj = m + bj;
     }
-    double best = pj;
+    best = pj;
     int arg = (sub < N) ? sub : NS;
 #pragma unroll
     for (int o = 1; o < NS; o <<= 1) {                             // max and FIRST argmax over the token's lanes (:263-268)
@@ -105,279 +119,442 @@ __device__ __forceinline__ void token_step(const DecArgs &a, DecTok *tk, const d
             arg = oa;
         }
     }
-    tk->p[sub] = pj;
-    if (sub == 0) {
-        tk->score += best;
-        tk->fin = arg >= N - 2;
-        tk->drop = 0;
+    fin = arg >= N - 2;
+}
+
+// tokens [lo, hi) take a step, two per 8-lane group and pass, software-pipelined over the passes: while pass k computes,
+// the old p of pass k+1 and the indices of pass k+2 are on their way (the old p of token i sits at src[i] of the other p
+// buffer: the compaction at the end of a frame only writes that map).
+struct StepIn {
+    int up[2], at[2];
+    double sc[2];
+};
+template <bool FIRST>
+__device__ __forceinline__ void step_range(const LaneCtx &c, const double *lt, const double *Bs, int lo, int hi, const int *up, const double *pin,
+                                           const int *src, double *p, double *sc, int *flag, int tk8, int sub) {
+    auto fetch = [&](int i0, StepIn &in) {                         // indices, unit pairs, scores of the pass that starts at i0
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int i = i0 + tk8 + x * TG;
+            const bool ok = i < hi;
+            in.up[x] = ok ? up[i] : (int)0xffff0000;
+            in.at[x] = (!FIRST && ok) ? src[i] : 0;
+            in.sc[x] = (ok && sub == 0) ? sc[i] : 0.0;
+        }
+    };
+    auto fetch_p = [&](int i0, const StepIn &in, double (&po)[2]) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) po[x] = (!FIRST && i0 + tk8 + x * TG < hi) ? pin[(size_t)in.at[x] * NS + sub] : 0.0;
+    };
+    if (lo >= hi) return;
+    StepIn in0, in1, in2;
+    double po0[2], po1[2];
+    fetch(lo, in0);
+    fetch(lo + 2 * TG, in1);
+    fetch_p(lo, in0, po0);
+    for (int i0 = lo; i0 < hi; i0 += 2 * TG) {
+        fetch(i0 + 4 * TG, in2);
+        fetch_p(i0 + 2 * TG, in1, po1);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int i = i0 + tk8 + x * TG;
+            double pj, best;
+            int fin;
+            token_step<FIRST>(c, lt, Bs, in0.up[x], po0[x], sub, pj, best, fin);
+            if (i < hi) {
+                p[(size_t)i * NS + sub] = pj;
+                if (sub == 0) {
+                    sc[i] = in0.sc[x] + best;                      // score += max_j p_j (Decoder.py:285)
+                    flag[i] = fin;
+                }
+            }
+        }
+        in0 = in1;
+        in1 = in2;
+        po0[0] = po1[0];
+        po0[1] = po1[1];
     }
 }
 
-// exclusive prefix sum of v[0..n) in place (workgroup-wide); returns the total.  sh: DW + 1 ints of LDS.
-__device__ int block_scan(int *v, int n, int *sh) {
-    const int tid = threadIdx.x, per = (n + DW - 1) / DW, lo = min(tid * per, n), hi = min(lo + per, n);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += v[i];
-    sh[tid] = s;
-    __syncthreads();
-    if (tid < 64) {                                                // one wave scans the DW partials, 16 per lane
-        constexpr int PER = DW / 64;
-        int loc[PER], run = 0;
+__device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            loc[k] = run;
-            run += sh[tid * PER + k];
-        }
-        int inc = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int w = __shfl_up(inc, o, 64);
-            if (tid >= o) inc += w;
-        }
-        const int base = inc - run;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) sh[tid * PER + k] = base + loc[k];
-        if (tid == 63) sh[DW] = inc;
-    }
-    __syncthreads();
-    int run = sh[tid];
-    for (int i = lo; i < hi; ++i) {
-        const int x = v[i];
-        v[i] = run;
-        run += x;
-    }
-    const int total = sh[DW];
-    __syncthreads();
-    return total;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-__global__ __launch_bounds__(DW) void hmm_decode_kernel(DecArgs a) {
-    __shared__ int sh[DW + 1];
+// TLDS: the unit matrices and the frame's emission row are staged in LDS (dynamic: (n_units S S + N) doubles).
+// Light phases use a wave-blocked ownership of the tokens: wave w owns [w C, (w+1) C), lane l its tokens w C + 64 k + l --
+// coalesced, and an ORDERED prefix over the tokens is a ballot per 64 tokens plus one exchange of 16 wave totals.
+// KMAX: a lane owns at most KMAX old tokens (cap <= DW KMAX): their sort keys stay in registers through the pruning phase.
+#ifdef PCL_DEC_WAVES
+#define PCL_DEC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PCL_DEC_WAVES, PCL_DEC_WAVES)))
+#else
+#define PCL_DEC_WAVES_ATTR
+#endif
+template <bool TLDS, int KMAX>
+__global__ __launch_bounds__(DW) PCL_DEC_WAVES_ATTR void hmm_decode_kernel(DecArgs a) {
+    extern __shared__ double dyn[];
+    __shared__ int seg_l[SEG_LDS + 1];
     __shared__ unsigned int hist256[256];
-    __shared__ double red_d[DW / 64];
-    __shared__ int red_i[DW / 64];
+    __shared__ int wsum[2][NWV];
+    __shared__ double red_d[NWV];
+    __shared__ unsigned long long red_u[2][NWV];
+    __shared__ int red_i[2][NWV];
     __shared__ unsigned long long s_sel;
     __shared__ int s_i[4];
-    __shared__ double s_d[2];
+    __shared__ double s_d[1];
     const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const UttDesc d = a.utts[u];
     const int T = d.T, Nb = d.N, cap = a.cap;
     const double *B = a.Bt + d.b_off;
-    DecTok *buf[2] = {a.tok + (size_t)u * 2 * cap, a.tok + ((size_t)u * 2 + 1) * cap};
+    double *scb[2] = {a.score + (size_t)u * 2 * cap, a.score + ((size_t)u * 2 + 1) * cap};
+    double *pb[2] = {a.p + (size_t)u * 2 * cap * NS, a.p + ((size_t)u * 2 + 1) * cap * NS};
+    int *ndb[2] = {a.node + (size_t)u * 2 * cap, a.node + ((size_t)u * 2 + 1) * cap};
+    int *hsb[2] = {a.hist + (size_t)u * 2 * cap, a.hist + ((size_t)u * 2 + 1) * cap};
+    int *upb[2] = {a.upair + (size_t)u * 2 * cap, a.upair + ((size_t)u * 2 + 1) * cap};
+    int *flag = a.flag + (size_t)u * cap, *src = a.dst + (size_t)u * cap;
+    int *seg_ofs = a.seg_ofs + (size_t)u * (cap + 2), *seg_cptr = a.seg_cptr + (size_t)u * (cap + 2), *seg_hist = a.seg_hist + (size_t)u * (cap + 2);
+    double *seg_score = a.seg_score + (size_t)u * (cap + 2);
     int *slot = a.slot + (size_t)u * a.n_nodes;
-    int *work = a.work + (size_t)u * (cap + a.n_roots);
     int *hprev = a.hist_prev + (size_t)u * a.Tmax, *hnode = a.hist_node + (size_t)u * a.Tmax;
     const int tk8 = tid >> 3, sub = tid & 7;                       // token group of 8 lanes
 
+    LaneCtx c;
+    c.e = a.S - 2;
+    c.SS = a.S * a.S;
+    c.mypos = (sub == 0) ? 0 : (sub - 1) / c.e;
+    c.myk = (sub == 0) ? 0 : (sub - 1) % c.e;
+    c.lpi1 = a.lpi1;
+    c.lpi2 = a.lpi2;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int pos = (i == 0) ? 0 : (i - 1) / c.e, r = (i == 0) ? 0 : 1 + (i - 1) % c.e, col = sub - pos * c.e;
+        c.rc[i] = (col >= 0 && col < a.S) ? (r * a.S + col) | (pos ? 256 : 0) : -1;
+    }
+    const double *lt;
+    double *Bs_l = nullptr;
+    if (TLDS) {
+        for (int k = tid; k < a.n_units * c.SS; k += DW) dyn[k] = a.unit_logtrans[k];
+        lt = dyn;
+        Bs_l = dyn + a.n_units * c.SS;
+    } else {
+        lt = a.unit_logtrans;
+    }
+    auto pack_units = [&](int node) -> int {
+        const int u0 = a.node_units[2 * node];
+        const int u1 = (a.node_nunits[node] == 2) ? a.node_units[2 * node + 1] : 0xffff;
+        return u0 | (u1 << 16);
+    };
+#ifdef PCL_DEC_STAMPS
+    long long st_acc[N_STAMP] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = wall_clock64();
+#define STAMP(k)                                  \
+    if (u == 0 && tid == 0) {                     \
+        const long long now_ = wall_clock64();    \
+        st_acc[k] += now_ - st_t;                 \
+        st_t = now_;                              \
+    }
+#else
+#define STAMP(k)
+#endif
+
     // ---- frame 0: every first-character node starts (D3)
     int cur = 0, n = min(a.n_roots, cap), ovf = a.n_roots > cap, nh = 0;
-    for (int i0 = 0; i0 < n; i0 += DW / NS) {
-        const int i = i0 + tk8;
-        if (i < n) {
-            DecTok *tk = &buf[0][i];
-            if (sub == 0) {
-                tk->node = a.roots[i];
-                tk->hist = -1;
-                tk->score = 0.0;
-                slot[a.roots[i]] = i;
-            }
-        }
+    for (int i = tid; i < n; i += DW) {
+        const int node = a.roots[i];
+        ndb[0][i] = node;
+        hsb[0][i] = -1;
+        scb[0][i] = 0.0;
+        upb[0][i] = pack_units(node);
+        slot[node] = i;
     }
+    if (TLDS)
+        for (int k = tid; k < Nb; k += DW) Bs_l[k] = B[k];
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += DW / NS) {
-        const int i = i0 + tk8;
-        if (i < n) token_step(a, &buf[0][i], B, sub, true);
-    }
+    step_range<true>(c, lt, TLDS ? Bs_l : B, 0, n, upb[0], nullptr, nullptr, pb[0], scb[0], flag, tk8, sub);
+    for (int i = tid; i < n; i += DW) src[i] = i;
     __syncthreads();
     if (tid == 0) a.trace[(size_t)u * a.Tmax] = n;
+    int pcur = 0;                                                  // the p buffer the tokens' values are in (at src[])
 
     for (int t = 1; t < T; ++t) {
-        DecTok *tok = buf[cur], *nxt = buf[cur ^ 1];
+        double *sc = scb[cur], *p = pb[pcur ^ 1];
+        const double *pin = pb[pcur];
+        int *nd = ndb[cur], *hs = hsb[cur], *up = upb[cur];
         const double *Bf = B + (size_t)t * Nb;
-        // ---- (1) every live token takes its step
-        for (int i0 = 0; i0 < n; i0 += DW / NS) {
-            const int i = i0 + tk8;
-            if (i < n) token_step(a, &tok[i], Bf, sub, false);
+        if (TLDS) {
+            for (int k = tid; k < Nb; k += DW) Bs_l[k] = Bf[k];
+            __syncthreads();
         }
+        const double *Bs = TLDS ? Bs_l : Bf;
+        const int C = ((n + DW - 1) / DW) * 64, w0 = wave * C;     // this frame's ownership of the old tokens
+        // ---- (1) every live token takes its step
+        step_range<false>(c, lt, Bs, 0, n, up, pin, src, p, sc, flag, tk8, sub);
         __syncthreads();
-        // ---- (2) donors.  The best finished word-end token (earliest on ties) re-seeds the first characters (D4);
-        //      first_w = the first finished word-end token: the roots it makes are created right after its children
+        STAMP(0)
+        // ---- (2) donors = finished tokens.  The best finished word-end token (earliest on ties) re-seeds the first
+        //      characters (D4); first_w = the first finished word-end token: the roots are created right after its children
+        int nd_cnt = 0, ch_cnt = 0, bw_i = NONE, fw = NONE;
         double bw = -INFINITY;
-        int bw_i = 0x7fffffff, fw = 0x7fffffff;
-        for (int i = tid; i < n; i += DW)
-            if (tok[i].fin && a.node_word[tok[i].node]) {
-                fw = min(fw, i);
-                if (tok[i].score > bw || (tok[i].score == bw && i < bw_i) || bw_i == 0x7fffffff) {
-                    bw = tok[i].score;
-                    bw_i = i;
+        for (int k = 0; k < C; k += 64) {
+            const int i = w0 + k + lane;
+            if (i < n && (flag[i] & 1)) {
+                const int node = nd[i];
+                ++nd_cnt;
+                ch_cnt += a.child_ptr[node + 1] - a.child_ptr[node];
+                if (a.node_word[node]) {
+                    fw = min(fw, i);
+                    const double s = sc[i];
+                    if (bw_i == NONE || s > bw) {                  // (a thread's tokens come in ascending order)
+                        bw = s;
+                        bw_i = i;
+                    }
                 }
             }
+        }
+        nd_cnt = wave_sum(nd_cnt);
+        ch_cnt = wave_sum(ch_cnt);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(bw, o, 64);
             const int oi = __shfl_xor(bw_i, o, 64);
-            if (oi != 0x7fffffff && (bw_i == 0x7fffffff || ob > bw || (ob == bw && oi < bw_i))) {
+            if (oi != NONE && (bw_i == NONE || ob > bw || (ob == bw && oi < bw_i))) {
                 bw = ob;
                 bw_i = oi;
             }
             fw = min(fw, __shfl_xor(fw, o, 64));
         }
         if (lane == 0) {
+            wsum[0][wave] = nd_cnt;
+            wsum[1][wave] = ch_cnt;
             red_d[wave] = bw;
-            red_i[wave] = bw_i;
-            sh[wave] = fw;
+            red_i[0][wave] = bw_i;
+            red_i[1][wave] = fw;
         }
         __syncthreads();
         if (tid == 0) {
             double b = -INFINITY;
-            int bi = 0x7fffffff, f = 0x7fffffff;
-            for (int w = 0; w < DW / 64; ++w) {
-                if (red_i[w] != 0x7fffffff && (bi == 0x7fffffff || red_d[w] > b || (red_d[w] == b && red_i[w] < bi))) {
+            int bi = NONE, f = NONE;
+            for (int w = 0; w < NWV; ++w) {
+                if (red_i[0][w] != NONE && (bi == NONE || red_d[w] > b || (red_d[w] == b && red_i[0][w] < bi))) {
                     b = red_d[w];
-                    bi = red_i[w];
+                    bi = red_i[0][w];
                 }
-                f = min(f, sh[w]);
+                f = min(f, red_i[1][w]);
             }
             s_d[0] = b;
             s_i[0] = bi;
             s_i[1] = f;
             s_i[2] = -1;
-            if (bi != 0x7fffffff) {                                // one history entry per frame: the winning donor's word
+            if (bi != NONE) {                                      // one history entry per frame: the winning donor's word
                 if (nh < a.Tmax) {
-                    hprev[nh] = tok[bi].hist;
-                    hnode[nh] = tok[bi].node;
+                    hprev[nh] = hs[bi];
+                    hnode[nh] = nd[bi];
                 }
                 s_i[2] = nh;
             }
         }
+        int dbase = 0, cbase = 0, nd_tot = 0, ch_tot = 0;
+        for (int w = 0; w < NWV; ++w) {
+            const int x = wsum[0][w], y = wsum[1][w];
+            if (w < wave) {
+                dbase += x;
+                cbase += y;
+            }
+            nd_tot += x;
+            ch_tot += y;
+        }
         __syncthreads();
         const double w_score = s_d[0];
         const int w_i = s_i[0], first_w = s_i[1], w_hist = s_i[2];
-        if (w_i != 0x7fffffff) ++nh;
-        // a target is "live" when its node has a token that did not finish in this frame
-        auto live_slot = [&](int node) -> int {
-            const int s = slot[node];
-            return (s >= 0 && !tok[s].fin) ? s : -1;
-        };
-        // creation counts: work[i] for donor i = its children without a live token; work[n + r] for root r (only if a
-        // word ended), laid out so that the prefix sum gives the reference's creation order: donors in token order, each
-        // donor's children in child order, the roots right after the children of the first word-end donor
-        for (int i = tid; i < n; i += DW) {
-            int c = 0;
-            if (tok[i].fin) {
-                const int nd = tok[i].node;
-                for (int k = a.child_ptr[nd]; k < a.child_ptr[nd + 1]; ++k) c += live_slot(a.child_idx[k]) < 0;
-            }
-            work[i] = c;
-        }
-        for (int r = tid; r < a.n_roots; r += DW) work[n + r] = (w_i != 0x7fffffff) ? (live_slot(a.roots[r]) < 0) : 0;
-        __syncthreads();
-        const int n_child_new = block_scan(work, n, sh);
-        const int n_root_new = block_scan(work + n, a.n_roots, sh);
-        // position of donor i's first creation: its prefix, plus the roots if the first word-end donor comes before it
-        // ---- (3) merges and creations
-        for (int i = tid; i < n; i += DW) {
-            if (!tok[i].fin) continue;
-            const int nd = tok[i].node;
-            int pos = n + work[i] + ((first_w < i) ? n_root_new : 0);
-            for (int k = a.child_ptr[nd]; k < a.child_ptr[nd + 1]; ++k) {      // passing_in_word (Decoder.py:114-143)
-                const int c = a.child_idx[k], s = live_slot(c);
-                if (s >= 0) {
-                    if (tok[i].score > tok[s].score) {                          // :126-134: the recursion state is kept
-                        tok[s].score = tok[i].score;
-                        tok[s].hist = tok[i].hist;
-                    }
-                } else {
-                    if (pos < cap) {
-                        DecTok *nt = &tok[pos];                                 // (slots n .. cap-1 of the current buffer)
-                        nt->node = c;
-                        nt->hist = tok[i].hist;
-                        nt->score = tok[i].score;
-                    }
-                    ++pos;
+        const bool has_w = w_i != NONE;
+        if (has_w) ++nh;
+        // the frame's hand-overs as ONE flattened list of (donor, target) pairs in the order the restated rules create
+        // tokens: donors in token order, each donor's children in child order, the first characters as the children of a
+        // pseudo-donor right behind the first word-end donor.  seg_ofs = where each donor's pairs start.
+        const int nseg = nd_tot + (has_w ? 1 : 0), Q = ch_tot + (has_w ? a.n_roots : 0);
+        const bool use_l = nseg <= SEG_LDS;
+        {
+            int drun = dbase, crun = cbase;
+            for (int k = 0; k < C; k += 64) {
+                const int i = w0 + k + lane;
+                const bool fin = i < n && (flag[i] & 1);
+                int cptr = 0, cnt = 0;
+                if (fin) {
+                    const int node = nd[i];
+                    cptr = a.child_ptr[node];
+                    cnt = a.child_ptr[node + 1] - cptr;
                 }
-            }
-        }
-        if (w_i != 0x7fffffff) {
-            const int base = n + work[first_w] + ((first_w + 1 < n) ? (work[first_w + 1] - work[first_w]) : (n_child_new - work[first_w]));
-            for (int r = tid; r < a.n_roots; r += DW) {
-                const int node = a.roots[r], s = live_slot(node);
-                if (s >= 0) {
-                    if (w_score > tok[s].score) {
-                        tok[s].score = w_score;
-                        tok[s].hist = w_hist;
-                    }
-                } else {
-                    const int pos = base + work[n + r];
-                    if (pos < cap) {
-                        DecTok *nt = &tok[pos];
-                        nt->node = node;
-                        nt->hist = w_hist;
-                        nt->score = w_score;
-                    }
-                }
-            }
-        }
-        const int n_new_all = n_child_new + n_root_new;
-        const int n_new = min(n_new_all, cap - n);
-        if (n_new_all > cap - n) ovf = 1;
-        __syncthreads();
-        // the new tokens take their first step at once (Decoder.py:138-139)
-        for (int i0 = 0; i0 < n_new; i0 += DW / NS) {
-            const int i = n + i0 + tk8;
-            if (i < n + n_new) token_step(a, &tok[i], Bf, sub, true);
-        }
-        // ---- (4) pruning over the tokens that were alive before the frame and did not finish (Decoder.py:159-167)
-        //      n_old, the number of distinct scores (up to min_distinct), then the m-th smallest by radix select
-        int cnt = 0;
-        for (int i = tid; i < n; i += DW) cnt += !tok[i].fin;
+                const unsigned long long mask = __ballot(fin);
+                const int r = drun + __popcll(mask & lt_mask);
+                int inc = cnt;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        if (lane == 0) red_i[wave] = cnt;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int x = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += x;
+                }
+                if (fin) {
+                    const int after = (has_w && i > first_w) ? 1 : 0, seg = r + after;
+                    const int ofs = crun + inc - cnt + (after ? a.n_roots : 0);
+                    seg_ofs[seg] = ofs;
+                    if (use_l) seg_l[seg] = ofs;
+                    seg_cptr[seg] = cptr;
+                    seg_hist[seg] = hs[i];
+                    seg_score[seg] = sc[i];
+                    if (has_w && i == first_w) {
+                        seg_ofs[seg + 1] = ofs + cnt;
+                        if (use_l) seg_l[seg + 1] = ofs + cnt;
+                        seg_cptr[seg + 1] = -1;
+                        seg_hist[seg + 1] = w_hist;
+                        seg_score[seg + 1] = w_score;
+                    }
+                }
+                drun += __popcll(mask);
+                crun += __shfl(inc, 63, 64);
+            }
+        }
         __syncthreads();
+        STAMP(1)
+        // ---- (3) merges and creations, one pair per thread (passing_in_word, Decoder.py:114-143).  A target is "live"
+        //      when its node has a token that did not finish in this frame: it keeps its recursion and takes the score if
+        //      strictly better (:126-134); otherwise a new token is made behind the old ones, in pair order.
+        int created = 0;
+        for (int q0 = 0; q0 < Q; q0 += DW) {
+            const int q = q0 + tid;
+            bool isnew = false;
+            int child = 0, dh = 0;
+            double ds = 0.0;
+            if (q < Q) {
+                int lo = 0, hi = nseg;                             // the last segment that starts at or before q
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = use_l ? seg_l[mid] : seg_ofs[mid];
+                    if (v <= q) lo = mid + 1;
+                    else hi = mid;
+                }
+                const int seg = lo - 1, o = use_l ? seg_l[seg] : seg_ofs[seg], cptr = seg_cptr[seg];
+                ds = seg_score[seg];
+                dh = seg_hist[seg];
+                child = (cptr < 0) ? a.roots[q - o] : a.child_idx[cptr + q - o];
+                const int s = slot[child];
+                if (s >= 0 && !(flag[s] & 1)) {
+                    if (ds > sc[s]) {
+                        sc[s] = ds;
+                        hs[s] = dh;
+                    }
+                } else {
+                    isnew = true;
+                }
+            }
+            const unsigned long long mask = __ballot(isnew);
+            if (lane == 0) wsum[0][wave] = __popcll(mask);
+            __syncthreads();
+            int base = 0, tot = 0;
+            for (int w = 0; w < NWV; ++w) {
+                const int x = wsum[0][w];
+                if (w < wave) base += x;
+                tot += x;
+            }
+            if (isnew) {
+                const int pos = n + created + base + __popcll(mask & lt_mask);
+                if (pos < cap) {                                   // (slots n .. cap-1 of the current buffer)
+                    nd[pos] = child;
+                    hs[pos] = dh;
+                    sc[pos] = ds;
+                    up[pos] = pack_units(child);
+                }
+            }
+            created += tot;
+            __syncthreads();
+        }
+        const int n_new = min(created, cap - n);
+        if (created > cap - n) ovf = 1;
+        STAMP(2)
+        // the new tokens take their first step at once (Decoder.py:138-139)
+        step_range<true>(c, lt, Bs, n, n + n_new, up, nullptr, nullptr, p, sc, flag, tk8, sub);
+        STAMP(3)
+        // ---- (4) pruning over the tokens that were alive before the frame and did not finish (Decoder.py:159-167):
+        //      nothing below min_distinct different scores, else the int(width (1 - beam)) lowest go (stable ascending
+        //      order: ties by token order).  One pass gives the width, the key range and a hashed occupancy map (different
+        //      bins => different scores); the m-th smallest key by radix select below the range's common prefix.
+        if (tid < 256) hist256[tid] = 0u;
+        __syncthreads();
+        constexpr unsigned long long NOKEY = ~0ull;                             // not an old unfinished token
+        unsigned long long keys[KMAX];
+        int cnt = 0;
+        unsigned long long kmn = ~0ull, kmx = 0ull;
+#pragma unroll
+        for (int kk = 0; kk < KMAX; ++kk) {
+            const int i = w0 + kk * 64 + lane;
+            keys[kk] = NOKEY;
+            if (kk * 64 < C && i < n && !(flag[i] & 1)) {
+                const unsigned long long key = okey(sc[i]);
+                keys[kk] = key;
+                ++cnt;
+                kmn = min(kmn, key);
+                kmx = max(kmx, key);
+                atomicOr(&hist256[(unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 56)], 1u);
+            }
+        }
+        cnt = wave_sum(cnt);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmn = min(kmn, (unsigned long long)__shfl_xor((long long)kmn, o, 64));
+            kmx = max(kmx, (unsigned long long)__shfl_xor((long long)kmx, o, 64));
+        }
+        if (lane == 0) {
+            wsum[0][wave] = cnt;
+            red_u[0][wave] = kmn;
+            red_u[1][wave] = kmx;
+        }
+        __syncthreads();
+        const int bins = __syncthreads_count(tid < 256 && hist256[tid] != 0u);
         int n_old = 0;
-        for (int w = 0; w < DW / 64; ++w) n_old += red_i[w];
-        __syncthreads();
+        unsigned long long kmin = ~0ull, kmax = 0ull;
+        for (int w = 0; w < NWV; ++w) {
+            n_old += wsum[0][w];
+            kmin = min(kmin, red_u[0][w]);
+            kmax = max(kmax, red_u[1][w]);
+        }
         const int m = (int)((double)n_old * (1.0 - a.beam));                   // int(width * (1 - beam))
         bool prune = m > 0 && n_old >= a.min_distinct;
-        if (prune) {                                                            // at least min_distinct different scores?
+        if (prune && bins < a.min_distinct) {                                   // few bins: count the distinct scores exactly
             unsigned long long prev = 0ull;
             bool have_prev = false;
             int distinct = 0;
-            for (int round = 0; round < a.min_distinct; ++round) {
+            for (int round = 0; round < a.min_distinct; ++round) {              // the next larger key, min_distinct times
                 unsigned long long mn = ~0ull;
                 bool any = false;
-                for (int i = tid; i < n; i += DW)
-                    if (!tok[i].fin) {
-                        const unsigned long long k = okey(tok[i].score);
-                        if ((!have_prev || k > prev) && (!any || k < mn)) {
-                            mn = k;
-                            any = true;
-                        }
+#pragma unroll
+                for (int kk = 0; kk < KMAX; ++kk) {
+                    const unsigned long long key = keys[kk];
+                    if (key != NOKEY && (!have_prev || key > prev) && (!any || key < mn)) {
+                        mn = key;
+                        any = true;
                     }
-                // reduce (min over the lanes that found something)
+                }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned long long om = __shfl_xor(mn, o, 64);
+                    const unsigned long long om = (unsigned long long)__shfl_xor((long long)mn, o, 64);
                     const int oa = __shfl_xor((int)any, o, 64);
                     if (oa && (!any || om < mn)) {
                         mn = om;
                         any = true;
                     }
                 }
+                __syncthreads();
                 if (lane == 0) {
-                    reinterpret_cast<unsigned long long *>(red_d)[wave] = mn;
-                    red_i[wave] = any;
+                    red_u[0][wave] = mn;
+                    red_i[0][wave] = any;
                 }
                 __syncthreads();
                 unsigned long long g = ~0ull;
                 bool gany = false;
-                for (int w = 0; w < DW / 64; ++w)
-                    if (red_i[w] && (!gany || reinterpret_cast<unsigned long long *>(red_d)[w] < g)) {
-                        g = reinterpret_cast<unsigned long long *>(red_d)[w];
+                for (int w = 0; w < NWV; ++w)
+                    if (red_i[0][w] && (!gany || red_u[0][w] < g)) {
+                        g = red_u[0][w];
                         gany = true;
                     }
-                __syncthreads();
                 if (!gany) break;
                 prev = g;
                 have_prev = true;
@@ -386,107 +563,170 @@ __global__ __launch_bounds__(DW) void hmm_decode_kernel(DecArgs a) {
             prune = distinct >= a.min_distinct;
         }
         if (prune) {
-            // radix select, most significant byte first: the key of rank m-1 (0-based) among the old unfinished tokens
-            unsigned long long prefix = 0ull;
+            unsigned long long sel = kmin;
             int rank = m - 1;
-            for (int byte = 7; byte >= 0; --byte) {
-                for (int k = tid; k < 256; k += DW) hist256[k] = 0u;
-                __syncthreads();
-                const unsigned long long hi_mask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
-                for (int i = tid; i < n; i += DW)
-                    if (!tok[i].fin) {
-                        const unsigned long long k = okey(tok[i].score);
-                        if ((k & hi_mask) == prefix) atomicAdd(&hist256[(k >> (8 * byte)) & 255u], 1u);
+            const unsigned long long diff = kmin ^ kmax;
+            if (diff != 0ull) {
+                const int b0 = (63 - __clzll((long long)diff)) >> 3;           // the first byte in which the keys differ
+                unsigned long long prefix = (b0 == 7) ? 0ull : (kmin & (~0ull << (8 * (b0 + 1))));
+                for (int byte = b0; byte >= 0; --byte) {
+                    if (tid < 256) hist256[tid] = 0u;
+                    __syncthreads();
+                    const unsigned long long hi_mask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
+#pragma unroll
+                    for (int kk = 0; kk < KMAX; ++kk) {
+                        const unsigned long long key = keys[kk];
+                        if (key != NOKEY && (key & hi_mask) == prefix) atomicAdd(&hist256[(unsigned int)(key >> (8 * byte)) & 255u], 1u);
                     }
-                __syncthreads();
-                if (tid == 0) {
-                    int acc = 0, b = 0;
-                    for (; b < 256; ++b) {
-                        if (acc + (int)hist256[b] > rank) break;
-                        acc += hist256[b];
+                    __syncthreads();
+                    if (wave == 0) {                                            // 4 bins per lane: the bin holding rank
+                        int h[4], s4 = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            h[j] = (int)hist256[4 * lane + j];
+                            s4 += h[j];
+                        }
+                        int inc = s4;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int x = __shfl_up(inc, o, 64);
+                            if (lane >= o) inc += x;
+                        }
+                        const unsigned long long hit = __ballot(inc > rank);
+                        if (hit != 0ull && lane == __ffsll((long long)hit) - 1) {
+                            int acc = inc - s4, j = 0;
+                            for (; j < 3; ++j) {
+                                if (acc + h[j] > rank) break;
+                                acc += h[j];
+                            }
+                            s_sel = (unsigned long long)(4 * lane + j);
+                            s_i[3] = rank - acc;
+                        }
                     }
-                    s_sel = (unsigned long long)b;
-                    s_i[3] = rank - acc;
+                    __syncthreads();
+                    prefix |= s_sel << (8 * byte);
+                    rank = s_i[3];
                 }
-                __syncthreads();
-                prefix |= s_sel << (8 * byte);
-                rank = s_i[3];
-                __syncthreads();
+                sel = prefix;
             }
             // everything below the selected key goes, and of the tokens equal to it the first (rank + 1) in token order
-            const unsigned long long sel = prefix;
-            for (int i = tid; i < n; i += DW) work[i] = (!tok[i].fin && okey(tok[i].score) == sel) ? 1 : 0;
+            int eq = 0;
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk) eq += keys[kk] == sel;
+            eq = wave_sum(eq);
             __syncthreads();
-            block_scan(work, n, sh);
-            for (int i = tid; i < n; i += DW)
-                if (!tok[i].fin) {
-                    const unsigned long long k = okey(tok[i].score);
-                    if (k < sel || (k == sel && work[i] <= rank)) tok[i].drop = 1;
-                }
+            if (lane == 0) wsum[0][wave] = eq;
             __syncthreads();
+            int run = 0;
+            for (int w = 0; w < wave; ++w) run += wsum[0][w];
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk) {
+                const unsigned long long key = keys[kk];
+                const bool is_eq = key == sel;                                 // (sel is a real key, never NOKEY)
+                const unsigned long long mask = __ballot(is_eq);
+                if (key != NOKEY && (key < sel || (is_eq && run + __popcll(mask & lt_mask) <= rank))) flag[w0 + kk * 64 + lane] |= 2;
+                run += __popcll(mask);
+            }
         }
+        __syncthreads();
+        STAMP(4)
         // ---- (5) stable compaction: the survivors of the old tokens, then the new ones; the node -> token map follows
-        for (int i = tid; i < n; i += DW) {
-            const int keep = !tok[i].fin && !tok[i].drop;
-            work[i] = keep;
-            if (!keep && slot[tok[i].node] == i) slot[tok[i].node] = -1;
-        }
-        __syncthreads();
-        const int n_keep = block_scan(work, n, sh);
-        for (int i = tid; i < n + n_new; i += DW) {
-            int dst = -1;
+        double *scn = scb[cur ^ 1];
+        int *ndn = ndb[cur ^ 1], *hsn = hsb[cur ^ 1], *upn = upb[cur ^ 1];
+        int keep_cnt = 0;
+        for (int k = 0; k < C; k += 64) {
+            const int i = w0 + k + lane;
             if (i < n) {
-                if (!tok[i].fin && !tok[i].drop) dst = work[i];
-            } else {
-                dst = n_keep + (i - n);
-            }
-            if (dst >= 0) {
-                nxt[dst] = tok[i];
-                slot[tok[i].node] = dst;
+                if (flag[i] & 3) {
+                    const int node = nd[i];
+                    if (slot[node] == i) slot[node] = -1;
+                } else {
+                    ++keep_cnt;
+                }
             }
         }
+        keep_cnt = wave_sum(keep_cnt);
+        if (lane == 0) wsum[1][wave] = keep_cnt;
         __syncthreads();
+        int krun = 0, n_keep = 0;
+        for (int w = 0; w < NWV; ++w) {
+            const int x = wsum[1][w];
+            if (w < wave) krun += x;
+            n_keep += x;
+        }
+        for (int k = 0; k < C; k += 64) {
+            const int i = w0 + k + lane;
+            const bool keep = i < n && !(flag[i] & 3);
+            const unsigned long long mask = __ballot(keep);
+            {
+                if (keep) {
+                    const int to = krun + __popcll(mask & lt_mask);
+                    const int node = nd[i];
+                    scn[to] = sc[i];
+                    ndn[to] = node;
+                    hsn[to] = hs[i];
+                    upn[to] = up[i];
+                    src[to] = i;                                   // where the token's p sits in this frame's p buffer
+                    slot[node] = to;
+                }
+            }
+            krun += __popcll(mask);
+        }
+        for (int j = tid; j < n_new; j += DW) {
+            const int i = n + j, to = n_keep + j, node = nd[i];
+            scn[to] = sc[i];
+            ndn[to] = node;
+            hsn[to] = hs[i];
+            upn[to] = up[i];
+            src[to] = i;
+            slot[node] = to;
+        }
+        __syncthreads();
+        STAMP(5)
         n = n_keep + n_new;
         cur ^= 1;
+        pcur ^= 1;
         if (tid == 0) a.trace[(size_t)u * a.Tmax + t] = n;
     }
     // ---- transfer (Decoder.py:175-187): the `candidate` best tokens, ties in token order
-    DecTok *tok = buf[cur];
+    const double *sc = scb[cur];
+    for (int i = tid; i < n; i += DW) flag[i] = 0;                 // 4 = taken
+    __syncthreads();
     int n_out = 0;
-    for (int c = 0; c < a.candidate && c < n; ++c) {
+    for (int cc = 0; cc < a.candidate && cc < n; ++cc) {
         double b = -INFINITY;
-        int bi = 0x7fffffff;
+        int bi = NONE;
         for (int i = tid; i < n; i += DW)
-            if (tok[i].drop != 2 && (bi == 0x7fffffff || tok[i].score > b)) {   // (strictly greater keeps the earliest on ties)
-                b = tok[i].score;
+            if (flag[i] != 4 && (bi == NONE || sc[i] > b)) {        // (strictly greater keeps the earliest on ties)
+                b = sc[i];
                 bi = i;
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(b, o, 64);
             const int oi = __shfl_xor(bi, o, 64);
-            if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > b || (ob == b && oi < bi))) {
+            if (oi != NONE && (bi == NONE || ob > b || (ob == b && oi < bi))) {
                 b = ob;
                 bi = oi;
             }
         }
         if (lane == 0) {
             red_d[wave] = b;
-            red_i[wave] = bi;
+            red_i[0][wave] = bi;
         }
         __syncthreads();
         if (tid == 0) {
             double g = -INFINITY;
-            int gi = 0x7fffffff;
-            for (int w = 0; w < DW / 64; ++w)
-                if (red_i[w] != 0x7fffffff && (gi == 0x7fffffff || red_d[w] > g || (red_d[w] == g && red_i[w] < gi))) {
+            int gi = NONE;
+            for (int w = 0; w < NWV; ++w)
+                if (red_i[0][w] != NONE && (gi == NONE || red_d[w] > g || (red_d[w] == g && red_i[0][w] < gi))) {
                     g = red_d[w];
-                    gi = red_i[w];
+                    gi = red_i[0][w];
                 }
-            a.out_node[(size_t)u * a.candidate + c] = tok[gi].node;
-            a.out_score[(size_t)u * a.candidate + c] = tok[gi].score;
-            a.out_hist[(size_t)u * a.candidate + c] = tok[gi].hist;
-            tok[gi].drop = 2;                                                   // taken
+            a.out_node[(size_t)u * a.candidate + cc] = ndb[cur][gi];
+            a.out_score[(size_t)u * a.candidate + cc] = sc[gi];
+            a.out_hist[(size_t)u * a.candidate + cc] = hsb[cur][gi];
+            flag[gi] = 4;
         }
         ++n_out;
         __syncthreads();
@@ -495,6 +735,10 @@ __global__ __launch_bounds__(DW) void hmm_decode_kernel(DecArgs a) {
         a.out_n[u] = n_out;
         a.hist_n[u] = min(nh, a.Tmax);
         a.overflow[u] = ovf;
+#ifdef PCL_DEC_STAMPS
+        if (u == 0 && a.stamps)
+            for (int k = 0; k < N_STAMP; ++k) a.stamps[k] = st_acc[k];
+#endif
     }
 }
 
@@ -512,7 +756,7 @@ void pcl_lexicon_release(pcl_ctx *ctx) {
 }
 
 void pcl_batch_decode_release(pcl_batch *b) {
-    dev_free(b->dec_tok);
+    dev_free(b->dec_f64);
     dev_free(b->dec_slot);
     dev_free(b->dec_work);
     dev_free(b->dec_int);
@@ -531,6 +775,7 @@ int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, con
     const int e = ctx->S - 2;
     for (int i = 0; i < n_nodes; ++i) {
         const int nu = node_nunits[i];
+        if (ctx->n_units >= 0xffff) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: %d units (the decoder packs unit ids into 16 bits)", ctx->n_units);
         if (nu < 1 || nu > 2 || e * nu + 2 > NS) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: node %d has %d units (1 or 2; %d-state units need %d <= %d HMM states)", i, nu, ctx->S, e * nu + 2, NS);
         for (int k = 0; k < nu; ++k)
             if (node_units[2 * i + k] < 0 || node_units[2 * i + k] >= ctx->n_units) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: node %d unit %d outside [0,%d)", i, node_units[2 * i + k], ctx->n_units);
@@ -575,6 +820,7 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_decode: no emissions (pcl_batch_score first)");
     if (!(beam > 0.0 && beam <= 1.0) || min_distinct < 1 || candidate < 1 || max_tokens < 1)
         PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_decode: beam %g, min_distinct %d, candidate %d, max_tokens %d", beam, min_distinct, candidate, max_tokens);
+    if (max_tokens > 16 * DW) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_decode: max_tokens %d > %d (a lane keeps the sort keys of its tokens in registers)", max_tokens, 16 * DW);
     // the emission rows must be [entry, state 0 .. J-1, exit]: the all-state matrix
     const int J = ctx->n_units * (ctx->S - 2);
     for (int u = 0; u < b->U; ++u) {
@@ -588,12 +834,29 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_dp, 0));
         b->dp_pending = false;
     }
+    // Like the forward-backward recursion, the decoder does no matrix work and is latency / bandwidth bound: it runs on
+    // the second stream, beside the scoring of the next chunk on the main one (every later call on this batch joins it).
+    hipStream_t main_stream = ctx->stream;
+    if (ctx->dp_async) {
+        if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
+        if (!b->ev_main) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(b->ev_main, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0));
+    }
+    struct StreamSwap {                                                        // the launches below and their timer use ctx->stream
+        pcl_ctx *c;
+        hipStream_t keep;
+        ~StreamSwap() { c->stream = keep; }
+    } swap_back{ctx, main_stream};
+    if (ctx->dp_async) ctx->stream = ctx->stream_dp;
     const int cap = max_tokens, U = b->U, Tm = b->Tmax;
     if (b->dec_cap != cap || b->dec_cand != candidate || b->dec_nodes != ctx->lex_nodes) {
         pcl_batch_decode_release(b);
-        TRY(dev_alloc(ctx, &b->dec_tok, (size_t)U * 2 * cap * sizeof(DecTok)));
+        // doubles per utterance: score 2 cap | p 2 cap NS | seg_score cap + 2;  ints: node, hist, upair 2 cap each | flag, dst cap each |
+        // seg_ofs, seg_cptr, seg_hist cap + 2 each
+        TRY(dev_alloc(ctx, &b->dec_f64, (size_t)U * (2 * (size_t)cap * (1 + NS) + cap + 2)));
+        TRY(dev_alloc(ctx, &b->dec_work, (size_t)U * (8 * (size_t)cap + 3 * ((size_t)cap + 2))));
         TRY(dev_alloc(ctx, &b->dec_slot, (size_t)U * ctx->lex_nodes));
-        TRY(dev_alloc(ctx, &b->dec_work, (size_t)U * (cap + ctx->lex_nroots)));
         // ints: out_n U | out_node U*cand | out_hist U*cand | hist_n U | hist_prev U*Tm | hist_node U*Tm | trace U*Tm | overflow U
         TRY(dev_alloc(ctx, &b->dec_int, (size_t)U * (3 + 2 * candidate + 3 * Tm)));
         TRY(dev_alloc(ctx, &b->dec_score, (size_t)U * candidate));
@@ -609,11 +872,25 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     a.unit_logtrans = ctx->d_unit_logtrans;
     a.node_units = ctx->lex_units; a.node_nunits = ctx->lex_nunits; a.child_ptr = ctx->lex_child_ptr; a.child_idx = ctx->lex_child_idx;
     a.node_word = ctx->lex_word; a.roots = ctx->lex_roots;
-    a.n_nodes = ctx->lex_nodes; a.n_roots = ctx->lex_nroots; a.S = ctx->S; a.cap = cap; a.candidate = candidate; a.min_distinct = min_distinct; a.Tmax = Tm;
+    a.n_nodes = ctx->lex_nodes; a.n_roots = ctx->lex_nroots; a.n_units = ctx->n_units; a.S = ctx->S; a.cap = cap; a.candidate = candidate;
+    a.min_distinct = min_distinct; a.Tmax = Tm;
     a.beam = beam; a.lpi1 = logpi_one_unit; a.lpi2 = logpi_two_units;
-    a.tok = reinterpret_cast<DecTok *>(b->dec_tok);
+    {
+        double *q = b->dec_f64;
+        a.score = q; q += (size_t)U * 2 * cap;
+        a.p = q; q += (size_t)U * 2 * cap * NS;
+        a.seg_score = q;
+        int *w = b->dec_work;
+        a.node = w; w += (size_t)U * 2 * cap;
+        a.hist = w; w += (size_t)U * 2 * cap;
+        a.upair = w; w += (size_t)U * 2 * cap;
+        a.flag = w; w += (size_t)U * cap;
+        a.dst = w; w += (size_t)U * cap;
+        a.seg_ofs = w; w += (size_t)U * (cap + 2);
+        a.seg_cptr = w; w += (size_t)U * (cap + 2);
+        a.seg_hist = w;
+    }
     a.slot = b->dec_slot;
-    a.work = b->dec_work;
     int *p = b->dec_int;
     a.out_n = p; p += U;
     a.out_node = p; p += (size_t)U * candidate;
@@ -624,10 +901,43 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     a.trace = p; p += (size_t)U * Tm;
     a.overflow = p;
     a.out_score = b->dec_score;
+    a.stamps = nullptr;
+#ifdef PCL_DEC_STAMPS
+    long long *d_stamps = nullptr;
+    TRY(dev_alloc(ctx, &d_stamps, (size_t)N_STAMP));
+    HIPCHK(ctx, hipMemsetAsync(d_stamps, 0, N_STAMP * sizeof(long long), ctx->stream));
+    a.stamps = d_stamps;
+#endif
+    // the unit matrices and one emission row in LDS when they fit beside the kernel's static 18 KB
+    const size_t table_bytes = ((size_t)ctx->n_units * ctx->S * ctx->S + (size_t)(J + 2)) * sizeof(double);
+    const bool tlds = table_bytes <= 44u * 1024u;
     pcl_timer_begin(ctx, "decode");
-    hipLaunchKernelGGL(hmm_decode_kernel, dim3(U), dim3(DW), 0, ctx->stream, a);
+#define PCL_DEC_LAUNCH(K)                                                                                                  \
+    do {                                                                                                                   \
+        if (tlds) hipLaunchKernelGGL((hmm_decode_kernel<true, K>), dim3(U), dim3(DW), table_bytes, ctx->stream, a);       \
+        else hipLaunchKernelGGL((hmm_decode_kernel<false, K>), dim3(U), dim3(DW), 0, ctx->stream, a);                      \
+    } while (0)
+    if (cap <= DW) PCL_DEC_LAUNCH(1);
+    else if (cap <= 2 * DW) PCL_DEC_LAUNCH(2);
+    else if (cap <= 4 * DW) PCL_DEC_LAUNCH(4);
+    else if (cap <= 8 * DW) PCL_DEC_LAUNCH(8);
+    else PCL_DEC_LAUNCH(16);
+#undef PCL_DEC_LAUNCH
     pcl_timer_end(ctx, "decode");
     HIPCHK(ctx, hipGetLastError());
+#ifdef PCL_DEC_STAMPS
+    {
+        long long h[N_STAMP];
+        HIPCHK(ctx, hipMemcpyAsync(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "decode stamps (utterance 0, 100 MHz ticks): step %lld donors %lld pairs %lld first %lld prune %lld compact %lld\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+        dev_free(d_stamps);
+    }
+#endif
+    if (ctx->dp_async) {
+        HIPCHK(ctx, hipEventRecord(b->ev_dp, ctx->stream_dp));
+        b->dp_pending = true;
+    }
     b->have_dec = true;
     return PCL_OK;
 }
@@ -640,8 +950,11 @@ int pcl_batch_decode_get(pcl_batch *b, int32_t *n_final, int32_t *node, double *
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int U = b->U, c = b->dec_cand, Tm = b->Tmax;
     const int *p = b->dec_int;
+    // the results come down on the stream the decoder ran on, and only that stream is waited for: the scoring of the next
+    // chunk, queued on the main stream meanwhile, keeps running
+    hipStream_t st = b->dp_pending ? ctx->stream_dp : ctx->stream;
     auto get = [&](void *dst, const void *src, size_t bytes) -> int {
-        if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
         return PCL_OK;
     };
     TRY(get(n_final, p, (size_t)U * 4)); p += U;
@@ -653,7 +966,8 @@ int pcl_batch_decode_get(pcl_batch *b, int32_t *n_final, int32_t *node, double *
     TRY(get(n_tokens, p, (size_t)U * Tm * 4)); p += (size_t)U * Tm;
     TRY(get(overflow, p, (size_t)U * 4));
     TRY(get(score, b->dec_score, (size_t)U * c * 8));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    b->dp_pending = false;                                                     // (complete: nothing left to join)
     return PCL_OK;
 }
 

@@ -101,6 +101,16 @@ static void free_model(pcl_ctx *ctx) {
     ctx->J = ctx->M = ctx->Mpad = 0;
 }
 
+// frames32 is either a plain upload (owned) or a view of a streaming slot
+static void release_frames32(pcl_ctx *ctx) {
+    if (ctx->frames_front >= 0) {
+        ctx->frames32 = nullptr;
+        ctx->frames_front = -1;
+    } else {
+        dev_free(ctx->frames32);
+    }
+}
+
 int pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return PCL_OK;
     hipSetDevice(ctx->device);
@@ -111,8 +121,12 @@ int pcl_destroy(pcl_ctx *ctx) {
     drop_timers(ctx);
     free_model(ctx);
     pcl_units_release(ctx);
-    dev_free(ctx->frames32);
+    release_frames32(ctx);
     dev_free(ctx->frames64);
+    dev_free(ctx->frames_slot[0]);
+    dev_free(ctx->frames_slot[1]);
+    if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
+    if (ctx->ev_slot_free) hipEventDestroy(ctx->ev_slot_free);
     hipStreamDestroy(ctx->stream);
     hipStreamDestroy(ctx->stream_dp);
     hipStreamDestroy(ctx->stream_aux);
@@ -262,7 +276,7 @@ int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dt
     const int Dd = device_dim(D);
     if (Dd < 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_upload: feature dimension %d > 64 is not supported", D);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    dev_free(ctx->frames32);
+    release_frames32(ctx);
     dev_free(ctx->frames64);
     const size_t n = (size_t)F * Dd;
     // Direct PCIe copy in the host element type (padded on the host only when D has no exact kernel);
@@ -287,6 +301,62 @@ int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dt
     ctx->F = F;
     ctx->FD = Dd;
     ctx->FDhost = D;
+    return PCL_OK;
+}
+
+// Streaming (BASELINE config 5: the corpus does not fit a batch): the next chunk's frames travel on the copy stream
+// into the slot that is not being scored, so the H2D leg runs beside the scoring / decoding of the current chunk.
+int pcl_frames_stage(pcl_ctx *ctx, int64_t F, int D, const float *frames) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (F <= 0 || D <= 0 || !frames) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_stage: bad shape F=%lld D=%d", (long long)F, D);
+    if (device_dim(D) != D) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_stage: feature dimension %d needs host padding; use pcl_frames_upload", D);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int back = ctx->frames_front == 0 ? 1 : 0;
+    const size_t n = (size_t)F * D;
+    if (n > ctx->frames_slot_cap[back]) {                          // (grows only: a steady stream of equal chunks allocates twice)
+        dev_free(ctx->frames_slot[back]);
+        ctx->frames_slot_cap[back] = 0;
+        TRY(dev_alloc(ctx, &ctx->frames_slot[back], n));
+        ctx->frames_slot_cap[back] = n;
+    }
+    if (!ctx->ev_stage) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming));
+    if (ctx->have_slot_free) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_slot_free, 0));   // its last readers
+    HIPCHK(ctx, hipMemcpyAsync(ctx->frames_slot[back], frames, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream_aux));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_stage, ctx->stream_aux));
+    ctx->staged_slot = back;
+    ctx->staged_F = F;
+    ctx->staged_D = D;
+    return PCL_OK;
+}
+
+int pcl_frames_swap(pcl_ctx *ctx) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (ctx->staged_slot < 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_frames_swap: nothing staged (pcl_frames_stage first)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_stage));               // the copy is done: the caller's buffer is free again
+    release_frames32(ctx);
+    dev_free(ctx->frames64);
+    if (!ctx->ev_slot_free) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_slot_free, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_slot_free, ctx->stream));   // everything queued so far read the old slot
+    ctx->have_slot_free = true;
+    ctx->frames_front = ctx->staged_slot;
+    ctx->frames32 = ctx->frames_slot[ctx->frames_front];
+    ctx->F = ctx->staged_F;
+    ctx->FD = ctx->FDhost = ctx->staged_D;
+    ctx->staged_slot = -1;
+    return PCL_OK;
+}
+
+int pcl_host_alloc(pcl_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out || !bytes) return PCL_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return PCL_OK;
+}
+
+int pcl_host_free(pcl_ctx *ctx, void *ptr) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (ptr) HIPCHK(ctx, hipHostFree(ptr));
     return PCL_OK;
 }
 

@@ -90,6 +90,14 @@ struct pcl_ctx {
     int FD = 0, FDhost = 0;
     float *frames32 = nullptr;
     double *frames64 = nullptr;
+    // streaming: two frame slots; frames32 points into slot frames_front (or is a plain upload when frames_front < 0);
+    // pcl_frames_stage copies the next chunk into the other slot on stream_aux, pcl_frames_swap makes it current
+    float *frames_slot[2] = {nullptr, nullptr};
+    size_t frames_slot_cap[2] = {0, 0};
+    int frames_front = -1, staged_slot = -1, staged_D = 0;
+    int64_t staged_F = 0;
+    hipEvent_t ev_stage = nullptr, ev_slot_free = nullptr;
+    bool have_slot_free = false;
     // E-step statistics (device, float64, linear domain)
     double *stats = nullptr;  // one allocation: [acc J*Mpad | alpha J | mean J*Mpad*D | cov J*Mpad*D]
     size_t stats_len = 0;
@@ -168,7 +176,7 @@ struct pcl_batch {
     hipEvent_t acc16_ev_prod[2] = {nullptr, nullptr}, acc16_ev_cons[2] = {nullptr, nullptr}, acc16_ev_start = nullptr;
     size_t acc16_cap_tiles = 0, acc16_cap_states = 0;
     // decoder state (hmm_decode.hip): token buffers, node -> token map, scratch, results
-    char *dec_tok = nullptr;
+    double *dec_f64 = nullptr;
     int *dec_slot = nullptr, *dec_work = nullptr, *dec_int = nullptr;
     double *dec_score = nullptr;
     int dec_cap = 0, dec_cand = 0, dec_nodes = 0;

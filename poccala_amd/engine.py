@@ -42,6 +42,8 @@ class Engine(object):
         self.F = 0
         self._model_key = self._frames_key = None
         self._batches = []   # weak refs to live batches: destroyed before the context
+        self._pinned = []    # page-locked host allocations (pinned_empty)
+        self._staged = None
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -55,6 +57,9 @@ class Engine(object):
                 if b is not None:
                     b.close()
             self._batches = []
+            for p in self._pinned:
+                self._lib.pcl_host_free(self._ctx, p)
+            self._pinned = []
             self._lib.pcl_destroy(self._ctx)
             self._ctx = None
 
@@ -132,6 +137,33 @@ class Engine(object):
         self._check(self._lib.pcl_frames_upload(self._ctx, f.shape[0], f.shape[1], ptr(f), dt))
         self.F = f.shape[0]
         self._frames_key = key
+
+    # ------------------------------------------------------------------ streaming (BASELINE config 5: a corpus fed chunk by chunk)
+    def stage_frames(self, frames):
+        """Queue the H2D copy of the NEXT chunk's (F,D) float32 rows on the copy stream, into the frame slot that is not
+        current; returns at once.  The array must stay untouched until swap_frames() returns (a pinned_empty() array makes
+        the copy truly asynchronous)."""
+        f = np.asarray(frames)
+        if f.ndim != 2 or f.dtype != np.float32 or not f.flags['C_CONTIGUOUS']:
+            raise ValueError('stage_frames: a C-contiguous (F,D) float32 array')
+        self._check(self._lib.pcl_frames_stage(self._ctx, f.shape[0], f.shape[1], ptr(f)))
+        self._staged = f
+
+    def swap_frames(self):
+        """Wait for the staged copy and make that chunk the current frame matrix (batches created from now on index it)."""
+        self._check(self._lib.pcl_frames_swap(self._ctx))
+        self.F = self._staged.shape[0]
+        self._staged = None
+        self._frames_key = None
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """A NumPy array over page-locked host memory (freed with the engine)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._lib.pcl_host_alloc(self._ctx, n, C.byref(p)))
+        self._pinned.append(p)
+        buf = (C.c_char * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def batch(self, N, T, frame_begin=None):
         return Batch(self, N, T, frame_begin)
@@ -394,20 +426,38 @@ class Batch(object):
         """Token passing over the loaded pronunciation tree (Decoder.py:91-167, 250-288) for every utterance of an all-state
         batch.  Returns a list (one dict per utterance): final = [(node, score, hist)] best first, history = [(prev, node)],
         n_tokens (T,) live tokens after every frame, overflow."""
+        self.decode_launch(beam, min_distinct, candidate, max_tokens)
+        return self.decode_results()
+
+    def decode_launch(self, beam=0.85, min_distinct=8, candidate=5, max_tokens=4096):
+        """Queue the token passing (on the library's second stream, behind this batch's scoring) and return at once."""
         e = self.eng.S - 2
         lp = np.log(np.array([1.0 / (e + 2), 1.0 / (2 * e + 2)]))               # np.log(np.ones(N) / N), AcousticModel.py:1005
         self._check(self._lib.pcl_batch_decode(self._b, float(beam), int(min_distinct), int(candidate), int(max_tokens), float(lp[0]), float(lp[1])))
-        U, c, tm = self.U, int(candidate), int(self.T.max())
+        self._dec_candidate = int(candidate)
+
+    def decode_fetch(self):
+        """Wait for the queued token passing of THIS batch (nothing else) and bring its result arrays to the host."""
+        U, c, tm = self.U, self._dec_candidate, int(self.T.max())
         nf = np.empty(U, np.int32); node = np.empty((U, c), np.int32); score = np.empty((U, c)); hist = np.empty((U, c), np.int32)
         hn = np.empty(U, np.int32); hp = np.empty((U, tm), np.int32); hnode = np.empty((U, tm), np.int32)
         nt = np.empty((U, tm), np.int32); ov = np.empty(U, np.int32)
         self._check(self._lib.pcl_batch_decode_get(self._b, ptr(nf), ptr(node), ptr(score), ptr(hist), ptr(hn), ptr(hp), ptr(hnode), ptr(nt), ptr(ov)))
+        return nf, node, score, hist, hn, hp, hnode, nt, ov, self.T.copy()
+
+    @staticmethod
+    def decode_unpack(raw):
+        """decode_fetch's arrays as the per-utterance dicts decode() returns (host work only)."""
+        nf, node, score, hist, hn, hp, hnode, nt, ov, T = raw
         out = []
-        for u in range(U):
-            out.append(dict(final=[(int(node[u, k]), float(score[u, k]), int(hist[u, k])) for k in range(nf[u])],
-                            history=[(int(hp[u, k]), int(hnode[u, k])) for k in range(hn[u])],
-                            n_tokens=nt[u, :self.T[u]].copy(), overflow=bool(ov[u])))
+        for u in range(len(nf)):
+            out.append(dict(final=list(zip(node[u, :nf[u]].tolist(), score[u, :nf[u]].tolist(), hist[u, :nf[u]].tolist())),
+                            history=list(zip(hp[u, :hn[u]].tolist(), hnode[u, :hn[u]].tolist())),
+                            n_tokens=nt[u, :T[u]].copy(), overflow=bool(ov[u])))
         return out
+
+    def decode_results(self):
+        return self.decode_unpack(self.decode_fetch())
 
     def refresh_transitions(self):
         """Take the engine's CURRENT unit transitions (after mstep_transitions / em_exchange); label-built batches only."""

@@ -137,3 +137,29 @@ def test_decode_batch_dropin_and_errors(eng, lex):
     with pytest.raises(PoccalaHipError):
         b.decode()
     b.close()
+
+
+def test_decode_stream_equals_chunk_by_chunk(eng, lex):
+    """The streaming pipeline (frames of chunk k+1 on the copy stream, scoring of chunk k on the main stream, token passing
+    of chunk k-1 on the second stream, batches reused per chunk shape) returns, chunk by chunk, exactly what decode_batch
+    returns for that chunk alone -- including a chunk of a different shape in the middle and a one-utterance tail."""
+    from poccala_amd import Decoder, PCL_F32, synth
+    lx, units, tree0 = lex
+    mean, var, w, trans = model_for(units, 3, 13, 41)
+    tree = Decoder.load_inventory(eng, units, mean, var, w, trans, lx)
+    rng = np.random.default_rng(42)
+    shapes = [[40, 40, 40], [40, 40, 40], [25, 60], [40, 40, 40], [40, 40, 40], [33]]
+    chunks = [[rng.standard_normal((t, 13)).astype(np.float32) for t in sh] for sh in shapes]
+    ref = [Decoder.decode_batch(ch, tree, engine=eng, precision=PCL_F32, candidate=4, max_tokens=600) for ch in chunks]
+    got = list(Decoder.decode_stream(iter(chunks), tree, engine=eng, precision=PCL_F32, candidate=4, max_tokens=600))
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert len(g) == len(r)
+        for (gw, gs, gd), (rw, rs, rd) in zip(g, r):
+            assert gw == rw and gs == rs
+            assert gd['final'] == rd['final'] and gd['history'] == rd['history'] and gd['overflow'] == rd['overflow']
+            assert np.array_equal(gd['n_tokens'], rd['n_tokens'])
+    # the resident path is untouched by the slots: a plain upload afterwards scores as before
+    one = Decoder.decode_batch(chunks[0], tree, engine=eng, precision=PCL_F32, candidate=4, max_tokens=600)
+    assert [x[1] for x in one] == [x[1] for x in ref[0]]
+    assert list(Decoder.decode_stream(iter([]), tree, engine=eng)) == []

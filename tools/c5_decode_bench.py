@@ -69,26 +69,37 @@ print('resident: %.1f ms/shard = %.3f M frames/s per GPU | score %.1f ms (%.0f T
       '(%.1f M token-steps/s, mean %.0f / max %d live tokens, overflow %d utterances)'
       % (wall * 1e3, U * T / wall / 1e6, sc_ms, flop / sc_ms / 1e9, flop / sc_ms / 1e9 / 838.9, de_ms, steps / de_ms / 1e3, ntok.mean(), ntok.max(),
          sum(r['overflow'] for r in res)))
-# decode traffic: a token step reads and writes its 88-byte record and reads <= 6 emissions; compaction copies it once more
-print('decode bytes/step ~ %d -> %.1f GB/s (HBM peak 8000): latency bound -- %d frames x ~14 workgroup phases per utterance, one workgroup per utterance'
-      % (88 * 4 + 48, steps * (88 * 4 + 48) / de_ms / 1e6, T))
+print('decode ~%d bytes per token step (step: p in + out 128, score / flags / units 32; prune ~6 passes over score + flag 72; compaction 60) -> %.0f GB/s of 8000'
+      % (292, steps * 292 / de_ms / 1e6))
 b.close()
 
-# ---- streaming: chunks of the shard, frames uploaded per chunk, results downloaded per chunk (synchronous legs, timed apart)
+# ---- streaming: the shard arrives in CH chunks through poccala_amd.Decoder.decode_stream -- H2D of chunk k+1 on the copy stream,
+#      scoring of chunk k on the main stream, token passing of chunk k-1 (and its results D2H) on the second stream
+from poccala_amd import Decoder
 per = (U + CH - 1) // CH
-t_h2d = t_gpu = t_d2h = 0.0
-for k in range(CH):
-    lo, hi = k * per, min(U, (k + 1) * per)
-    if lo >= hi:
-        break
-    f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
-    t1 = time.perf_counter(); eng.load_frames(frames[f0:f1]); t2 = time.perf_counter()
-    bb = eng.all_state_batch(lens[lo:hi], begin[lo:hi] - f0)
+chunks = [[frames[begin[u]:begin[u] + lens[u]] for u in range(k * per, min(U, (k + 1) * per))] for k in range(CH)]
+chunks = [c_ for c_ in chunks if c_]
+for rep in range(2):                                               # the first pass creates the two batches and the slots
+    t0 = time.perf_counter()
+    outs = list(Decoder.decode_stream(iter(chunks), tree, engine=eng, precision=PCL_F32, max_tokens=CAP))
+    eng.sync()
+    t_stream = time.perf_counter() - t0
+same = all(o[2]['final'] == r['final'] for o, r in zip([x for ch in outs for x in ch], res))
+print('streaming in %d chunks of %d utterances (copy / score / decode legs on three streams): %.1f ms/shard = %.3f M frames/s per GPU; results %s the resident run'
+      % (len(chunks), per, t_stream * 1e3, U * T / t_stream / 1e6, 'equal' if same else 'DIFFER FROM'))
+# the legs one after the other, for comparison
+t_h2d = t_sc = t_de = 0.0
+for ch in chunks:
+    fl = np.concatenate(ch, axis=0)
+    ln = np.array([len(x) for x in ch], dtype=np.int32)
+    bg = np.concatenate([[0], np.cumsum(ln[:-1].astype(np.int64))]).astype(np.int64)
+    t1 = time.perf_counter(); eng.load_frames(fl); t2 = time.perf_counter()
+    bb = eng.all_state_batch(ln, bg)
     t3 = time.perf_counter(); bb.score(PCL_F32); eng.sync(); t4 = time.perf_counter()
-    r = bb.decode(max_tokens=CAP); t5 = time.perf_counter()
+    bb.decode(max_tokens=CAP); t5 = time.perf_counter()
     bb.close()
-    t_h2d += t2 - t1; t_gpu += t4 - t3; t_d2h += t5 - t4
-print('streaming in %d chunks: H2D %.1f ms + score %.1f ms + decode incl. results D2H %.1f ms = %.3f M frames/s per GPU with the legs back to back'
-      % (CH, t_h2d * 1e3, t_gpu * 1e3, t_d2h * 1e3, U * T / (t_h2d + t_gpu + t_d2h) / 1e6))
+    t_h2d += t2 - t1; t_sc += t4 - t3; t_de += t5 - t4
+print('the same chunks with the legs back to back: H2D %.1f ms + score %.1f ms + decode incl. results D2H %.1f ms = %.3f M frames/s per GPU'
+      % (t_h2d * 1e3, t_sc * 1e3, t_de * 1e3, U * T / (t_h2d + t_sc + t_de) / 1e6))
 best = res[0]['final'][0] if res[0]['final'] else None
 print('utterance 0: best token', best, 'history entries', len(res[0]['history']))
