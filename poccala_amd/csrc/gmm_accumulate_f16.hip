@@ -285,39 +285,36 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     // The fragment reads of a product are issued a whole phase before its MFMAs and pinned there with sched_barrier:
     // left to itself the compiler reads each fragment right in front of the MFMA that needs it, and every MFMA of the
     // dependent chain then waits out an LDS round trip (the round-1 kernel's loss: matrix pipe 43 % busy).
-    auto load1 = [&](int t, h8v (&a1)[KS], h8v (&a2)[KS]) {
+    // (the frame fragments travel from one iteration to the next as plain 128-bit integers: carried as half vectors the
+    //  compiler splits them into 16-bit halves at the loop edge and re-packs them with v_perm_b32, 40 VALU ops per tile)
+    auto load1 = [&](int t, uint4 (&a1)[KS], uint4 (&a2)[KS]) {
 #ifdef PCL_ACC16_DIAG_NOLDS
         const uint4 fake = make_uint4(t, lane, t ^ lane, 0x3c003c00u);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { a1[s] = __builtin_bit_cast(h8v, fake); a2[s] = __builtin_bit_cast(h8v, fake); }
+        for (int s = 0; s < KS; ++s) { a1[s] = fake; a2[s] = fake; }
         return;
 #endif
         const uint4 *x1 = &slot[t % NSLOT][I::B1 * 64];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a2[s] = __builtin_bit_cast(h8v, x1[(1 * KS + s) * 64 + lane]);
+        for (int s = 0; s < KS; ++s) a2[s] = x1[(1 * KS + s) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a1[s] = __builtin_bit_cast(h8v, x1[(0 * KS + s) * 64 + lane]);
+        for (int s = 0; s < KS; ++s) a1[s] = x1[(0 * KS + s) * 64 + lane];
     };
-    auto mfma1 = [&](const h8v (&a1)[KS], const h8v (&a2)[KS]) -> f16v {
-        // two independent accumulation chains (the small cross terms | the leading term), added at the end: when the
-        // partner wave of the SIMD stalls, a lone dependent chain of this MFMA runs at about half the pipe rate
-        f16v d, e;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] = e[r] = 0.f;
+    // The chain starts from the frames' coefficients cf (ln gamma - ln b in log2 units, -inf for a frame that is not in the
+    // image): the posterior's exponent comes out of the matrix pipe complete, no VALU add per value.  (Two chains added at
+    // the end measured the same as one; every VALU op in this loop competes with the MFMAs for the issue port.)
+    // d comes in holding cf (load_cf writes the very registers the chain accumulates in) and goes out as D1.
+    auto mfma1 = [&](const uint4 (&a1)[KS], const uint4 (&a2)[KS], f16v &d) {
 #ifdef PCL_ACC16_DIAG_NOP1
-        d[0] = (float)a1[0][0] + (float)a2[KS - 1][7];
-        return d;
+        d[0] += (float)a1[0].x + (float)a2[KS - 1].w;
+        return;
 #endif
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[s], pf[0][s], d, 0, 0, 0);   // x2 a1
-            e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], pf[0][s], e, 0, 0, 0);   // x1 a1
-        }
+        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a2[s]), pf[0][s], d, 0, 0, 0);   // x2 a1
 #pragma unroll
-        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[s], pf[1][s], d, 0, 0, 0);   // x1 a2
+        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[1][s], d, 0, 0, 0);   // x1 a2
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] += e[r];
-        return d;
+        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[0][s], d, 0, 0, 0);   // x1 a1
     };
     auto load2 = [&](int t, int sp, bf8v (&bq)[3][NCT]) {
 #ifdef PCL_ACC16_DIAG_NOLDS
@@ -365,24 +362,26 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     // otherwise it re-waits for them (vmcnt(0)) at their first use inside the loop, every iteration, and drains the DMA
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();                                             // everyone's have
-    f16v d1;
+    // Two accumulator sets take turns (the tile loop is unrolled by two): while the posteriors of tile t are read out of one,
+    // the chain of tile t + 1 runs in the other, which was loaded with that tile's cf a phase earlier -- no register copies.
+    f16v dA, dB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[r] = 0.f;
-    float cfr[16];
-    h8v a1[KS], a2[KS];
-    auto load_cf = [&](int t) {                                  // cf of tile t in the register order of D1 (lane half h, register r)
+    for (int r = 0; r < 16; ++r) dA[r] = dB[r] = 0.f;
+    uint4 a1[KS], a2[KS];
+    auto load_cf = [&](int t, f16v &c) {                         // cf of tile t in the register order of D1 (lane half h, register r)
         const float4 *cfp = reinterpret_cast<const float4 *>(&slot[t % NSLOT][I::BM * 64]) + half * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = cfp[q];
-            cfr[4 * q] = v.x; cfr[4 * q + 1] = v.y; cfr[4 * q + 2] = v.z; cfr[4 * q + 3] = v.w;
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
         }
     };
     if (live) {
         load1(t0, a1, a2);
-        d1 = mfma1(a1, a2);
-        load_cf(t0);
-        load1(t0 + 1, a1, a2);                                   // (past the last tile: whatever the slot holds, nobody reads the product)
+        load_cf(t0, dA);
+        mfma1(a1, a2, dA);
+        load_cf(t0 + 1, dB);                                     // (past the last tile: whatever the slot holds, nobody reads the product)
+        load1(t0 + 1, a1, a2);
     }
 #ifdef PCL_ACC16_PRIO_LATE
     if (wave >= AW / 2) __builtin_amdgcn_s_setprio(PCL_ACC16_PRIO_LATE);
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     unsigned long long st_busy = 0, st_vm = 0, st_bar = 0, st_prev = __builtin_amdgcn_s_memtime();
     unsigned int st_n = 0;
 #endif
-    for (int t = t0; t < t1; ++t) {
+    auto tile_step = [&](int t, f16v &d1, f16v &dn) __attribute__((always_inline)) {
 #ifdef PCL_ACC16_DIAG_NODMA
         const bool ahead = false;
 #else
@@ -410,13 +409,13 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
 #ifdef PCL_ACC16_DIAG_NOV
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    u1[r] = __float_as_uint(d1[2 * r] + cfr[2 * r]);
-                    u2[r] = __float_as_uint(d1[2 * r + 1] + cfr[2 * r + 1]);
+                    u1[r] = __float_as_uint(d1[2 * r]);
+                    u2[r] = __float_as_uint(d1[2 * r + 1]);
                 }
 #else
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float ga = __builtin_amdgcn_exp2f(d1[2 * r] + cfr[2 * r]), gb = __builtin_amdgcn_exp2f(d1[2 * r + 1] + cfr[2 * r + 1]);
+                    const float ga = __builtin_amdgcn_exp2f(d1[2 * r]), gb = __builtin_amdgcn_exp2f(d1[2 * r + 1]);
                     const bf2v c = bf2v{(__bf16)ga, (__bf16)gb};                   // v_cvt_pk_bf16_f32
                     u1[r] = __builtin_bit_cast(unsigned int, c);
                     const bf2v e = bf2v{(__bf16)(ga - __uint_as_float(u1[r] << 16)), (__bf16)(gb - __uint_as_float(u1[r] & 0xffff0000u))};
@@ -428,7 +427,7 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
                 g2[0] = __builtin_bit_cast(bf8v, make_uint4(u2[0], u2[1], u2[2], u2[3]));
                 g2[1] = __builtin_bit_cast(bf8v, make_uint4(u2[4], u2[5], u2[6], u2[7]));
             }
-            const f16v dn = mfma1(a1, a2);                       // product (1) of tile t + 1
+            mfma1(a1, a2, dn);                                   // product (1) of tile t + 1, from its frames' coefficients
             load2(t, 0, bq0);
             load2(t, 1, bq1);
             // ---- region Y
@@ -438,9 +437,8 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
 #else
             S[0][0] += (float)g1[0][0] + (float)g2[1][1] + (float)bq0[0][0][0] + (float)bq1[2][NCT - 1][3];
 #endif
-            load_cf(t + 1);
+            load_cf(t + 2, d1);                                  // (the posteriors of tile t have been read out of d1)
             load1(t + 2, a1, a2);
-            d1 = dn;
 #ifdef PCL_ACC16_DIAG_DUMMYLDS   // the reads are issued but nobody waits for their data (until the end of the tile)
             {
                 const unsigned int ad = lds_addr(cur) + lane * 16u;
@@ -509,6 +507,10 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
         st_busy += st_a - st_prev; st_vm += st_b - st_a; st_bar += st_c - st_b; st_prev = st_c; ++st_n;
 #endif
+    };
+    for (int t = t0; t < t1; t += 2) {
+        tile_step(t, dA, dB);
+        if (t + 1 < t1) tile_step(t + 1, dB, dA);
     }
 #ifdef PCL_ACC16_STAMPS
     if ((blockIdx.x == 40 || blockIdx.x == 1000) && lane == 0 && st_n)
