@@ -701,7 +701,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             const int buf = g & 1;
             if (overlap && g + 1 < G) { const int rc = produce(g + 1); if (rc != PCL_OK) return rc; }
             if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->acc16_ev_prod[buf], 0));
-            int rc = pcl_launch_acc16_consume(ctx, b, gfirst[g], gcount[g], buf, ctx->stream);
+            int rc = pcl_launch_acc16_consume(ctx, b, gfirst[g], gcount[g], buf, ctx->stats_fresh, ctx->stream);
             if (rc != PCL_OK) return rc;
             launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
             if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));

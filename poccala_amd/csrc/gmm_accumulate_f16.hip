@@ -33,10 +33,14 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
-#ifndef PCL_ACC16_AW
-#define PCL_ACC16_AW 8
+#ifndef PCL_ACC16_MT
+#define PCL_ACC16_MT 1
 #endif
-constexpr int AW = PCL_ACC16_AW;       // waves (32-mixture tiles) per consumer workgroup
+#ifndef PCL_ACC16_AW
+#define PCL_ACC16_AW (PCL_ACC16_MT == 1 ? 8 : 4)
+#endif
+constexpr int MT = PCL_ACC16_MT;       // 32-mixture tiles per consumer wave
+constexpr int AW = PCL_ACC16_AW;       // waves per consumer workgroup
 constexpr float FMAXH = 6.0e4f;        // what an f16 piece may hold (gmm_score_split.hip)
 constexpr double LOG2E = 1.4426950408889634074;
 
@@ -237,9 +241,13 @@ __global__ __launch_bounds__(256) void acc16_producer_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// consumer: 8 waves = 8 m-tiles of one state; the 8 slices of a state sit on block indices with equal residue mod 8 (one XCD's L2)
-template <int D>
-__global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
+// consumer: AW waves x MT m-tiles = AW MT x 32 mixtures of one state per workgroup; the slices of a state sit on block
+// indices with equal residue mod 8 (one XCD's L2).  MT = 2 at one wave per SIMD: every fragment read from LDS feeds two
+// MFMAs, product (1) runs two independent chains and product (2) six.
+// FRESH: the statistics are all zero (first pass after pcl_stats_zero) and every (state, mixture) belongs to exactly one wave:
+// the flush stores instead of read-modify-writing 7.7 GB of float64.
+template <int D, bool FRESH>
+__global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kernel(
     const uint4 *__restrict__ images, const uint4 *__restrict__ pm16f, const float *__restrict__ centers,
     const double *__restrict__ means64, int M, int Mpad, int n_mtiles, int n_states, const int *__restrict__ work_states,
     const int *__restrict__ tile_off, int tile_base, double bias, double *__restrict__ st_acc, double *__restrict__ st_alpha,
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     constexpr int NSLOT = 5;                                     // tile t in slot t % 5: t .. t + 2 being read, t + 3 and t + 4 landing
     __shared__ __attribute__((aligned(16))) uint4 slot[NSLOT][NB * 64];
 
-    const int nslice = (n_mtiles + AW - 1) / AW;
+    const int nslice = (n_mtiles + AW * MT - 1) / (AW * MT);
     const int b = blockIdx.x;
     const int w = (b & 7) + 8 * (b / (8 * nslice));              // block b runs on XCD b % 8: all slices of a state on one XCD
     const int slice = (b >> 3) % nslice;
@@ -258,35 +266,36 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     if (t0 == t1) return;
     const int j = work_states[w];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
-    const int mt = slice * AW + wave;
-    const bool live = mt < n_mtiles;
+    const int mt0 = (slice * AW + wave) * MT;                    // this wave's m-tiles: mt0 .. mt0 + MT - 1
+    const bool live = mt0 < n_mtiles;                            // (a tile past the end repeats the last one and is not flushed)
 
-    // parameters of this wave's m-tile: the scoring layout of variant 7 as it is (B operand of product (1))
-    h8v pf[2][KS];
-    {
+    // parameters of this wave's m-tiles: the scoring layout of variant 7 as it is (B operand of product (1))
+    h8v pf[MT][2][KS];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int mt = min(mt0 + i, n_mtiles - 1);
         const uint4 *pq = pm16f + ((size_t)j * n_mtiles + (live ? mt : 0)) * (2 * KS * 64) + lane;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) pf[p][s] = __builtin_bit_cast(h8v, pq[(p * KS + s) * 64]);
+            for (int s = 0; s < KS; ++s) pf[i][p][s] = __builtin_bit_cast(h8v, pq[(p * KS + s) * 64]);
     }
-    f16v S[NCT];
+    f16v S[MT][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[ct][r] = 0.f;
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[i][ct][r] = 0.f;
     double galpha = 0.0;
 
-    auto dma = [&](int t) {                                      // tile t -> slot t % NSLOT; the NB blocks are dealt to the 8 waves
+    auto dma = [&](int t) {                                      // tile t -> slot t % NSLOT; the NB blocks are dealt to the waves
         const uint4 *src = images + (size_t)t * (NB * 64);
         const unsigned int dst = __builtin_amdgcn_readfirstlane(lds_addr(&slot[t % NSLOT][0]));
         for (int p = wave; p < NB; p += AW) glds16(src + p * 64 + lane, dst + (unsigned int)p * 1024u);
     };
-    // The fragment reads of a product are issued a whole phase before its MFMAs and pinned there with sched_barrier:
-    // left to itself the compiler reads each fragment right in front of the MFMA that needs it, and every MFMA of the
-    // dependent chain then waits out an LDS round trip (the round-1 kernel's loss: matrix pipe 43 % busy).
     // (the frame fragments travel from one iteration to the next as plain 128-bit integers: carried as half vectors the
-    //  compiler splits them into 16-bit halves at the loop edge and re-packs them with v_perm_b32, 40 VALU ops per tile)
+    //  compiler splits them into 16-bit halves at the loop edge and re-packs them with v_perm_b32, 80 VALU ops per tile)
     auto load1 = [&](int t, uint4 (&a1)[KS], uint4 (&a2)[KS]) {
 #ifdef PCL_ACC16_DIAG_NOLDS
         const uint4 fake = make_uint4(t, lane, t ^ lane, 0x3c003c00u);
@@ -300,21 +309,26 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
 #pragma unroll
         for (int s = 0; s < KS; ++s) a1[s] = x1[(0 * KS + s) * 64 + lane];
     };
-    // The chain starts from the frames' coefficients cf (ln gamma - ln b in log2 units, -inf for a frame that is not in the
-    // image): the posterior's exponent comes out of the matrix pipe complete, no VALU add per value.  (Two chains added at
-    // the end measured the same as one; every VALU op in this loop competes with the MFMAs for the issue port.)
-    // d comes in holding cf (load_cf writes the very registers the chain accumulates in) and goes out as D1.
-    auto mfma1 = [&](const uint4 (&a1)[KS], const uint4 (&a2)[KS], f16v &d) {
+    // The chains start from the frames' coefficients cf (ln gamma - ln b in log2 units, -inf for a frame that is not in the
+    // image): the posterior's exponent comes out of the matrix pipe complete, no VALU add per value; d comes in holding cf
+    // (load_cf writes the very registers the chain accumulates in) and goes out as D1.  Small cross terms first.
+    auto mfma1 = [&](const uint4 (&a1)[KS], const uint4 (&a2)[KS], f16v (&d)[MT]) {
 #ifdef PCL_ACC16_DIAG_NOP1
-        d[0] += (float)a1[0].x + (float)a2[KS - 1].w;
+        d[0][0] += (float)a1[0].x + (float)a2[KS - 1].w;
         return;
 #endif
 #pragma unroll
-        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a2[s]), pf[0][s], d, 0, 0, 0);   // x2 a1
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[1][s], d, 0, 0, 0);   // x1 a2
+            for (int i = 0; i < MT; ++i) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a2[s]), pf[i][0][s], d[i], 0, 0, 0);   // x2 a1
 #pragma unroll
-        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[0][s], d, 0, 0, 0);   // x1 a1
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[i][1][s], d[i], 0, 0, 0);   // x1 a2
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[i][0][s], d[i], 0, 0, 0);   // x1 a1
     };
     auto load2 = [&](int t, int sp, bf8v (&bq)[3][NCT]) {
 #ifdef PCL_ACC16_DIAG_NOLDS
@@ -331,27 +345,33 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) bq[p][ct] = __builtin_bit_cast(bf8v, x2[((p * NCT + ct) * 2 + sp) * 64 + lane]);
     };
-    auto mfma2 = [&](const bf8v &g1, const bf8v &g2, const bf8v (&bq)[3][NCT]) {
-        // the NCT column tiles are independent accumulators, issued round robin; small cross terms first
+    auto mfma2 = [&](const bf8v (&g1)[MT], const bf8v (&g2)[MT], const bf8v (&bq)[3][NCT]) {
+        // the MT x NCT accumulators are independent, issued round robin; small cross terms first
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bq[2][ct], S[ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2, bq[1][ct], S[ct], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[i], bq[2][ct], S[i][ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2, bq[0][ct], S[ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bq[1][ct], S[ct], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[i], bq[1][ct], S[i][ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) S[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bq[0][ct], S[ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[i], bq[0][ct], S[i][ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[i], bq[1][ct], S[i][ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[i], bq[0][ct], S[i][ct], 0, 0, 0);
     };
 
     // Software pipeline, per wave, one basic block per tile t (the waves of a workgroup meet at ONE barrier per tile):
-    //   region X   product (1) of tile t + 1 (15 MFMAs)  ||  VALU: D1 of tile t -> posteriors  ||  reads: product (2) fragments of tile t
-    //   region Y   product (2) of tile t (30 MFMAs)       ||  reads: cf of tile t + 1, product (1) fragments of tile t + 2
-    // so the matrix pipe always has this wave's next MFMA while its VALU work and LDS reads ride in the 24 of 32 cycles an
-    // MFMA leaves the issue port free; sched_group_barrier pins the interleave.  (Measured before: with the phases back to
-    // back -- reads, VALU, MFMAs -- the 19 ms of MFMA work, 8 ms of LDS reads, 4 ms of DMA and 3 ms of VALU simply ADDED UP:
-    // the two waves of a SIMD run in lockstep behind the per-tile barrier and stall together.)
+    //   region X   product (1) of tile t + 1  ||  VALU: D1 of tile t -> posteriors  ||  reads: product (2) fragments of tile t
+    //   region Y   product (2) of tile t      ||  reads: cf and product (1) fragments of tile t + 2
     // LDS-DMA: tile t + 4 is issued at the top of tile t and waited for (counted vmcnt, leaving the newest tile in flight)
     // at the end of tile t + 1, two barriers before its first read: issued -> landed takes microseconds when every CU streams.
     constexpr int MYB_HI = (NB + AW - 1) / AW, MYB_LO = NB / AW;  // blocks per tile this wave issues: waves < NB % AW one more
@@ -363,17 +383,20 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();                                             // everyone's have
     // Two accumulator sets take turns (the tile loop is unrolled by two): while the posteriors of tile t are read out of one,
-    // the chain of tile t + 1 runs in the other, which was loaded with that tile's cf a phase earlier -- no register copies.
-    f16v dA, dB;
+    // the chains of tile t + 1 run in the other, which was loaded with that tile's cf a phase earlier -- no register copies.
+    f16v dA[MT], dB[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dA[r] = dB[r] = 0.f;
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dA[i][r] = dB[i][r] = 0.f;
     uint4 a1[KS], a2[KS];
-    auto load_cf = [&](int t, f16v &c) {                         // cf of tile t in the register order of D1 (lane half h, register r)
+    auto load_cf = [&](int t, f16v (&c)[MT]) {                   // cf of tile t in the register order of D1 (lane half h, register r)
         const float4 *cfp = reinterpret_cast<const float4 *>(&slot[t % NSLOT][I::BM * 64]) + half * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = cfp[q];
-            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { c[i][4 * q] = v.x; c[i][4 * q + 1] = v.y; c[i][4 * q + 2] = v.z; c[i][4 * q + 3] = v.w; }
         }
     };
     if (live) {
@@ -383,14 +406,11 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
         load_cf(t0 + 1, dB);                                     // (past the last tile: whatever the slot holds, nobody reads the product)
         load1(t0 + 1, a1, a2);
     }
-#ifdef PCL_ACC16_PRIO_LATE
-    if (wave >= AW / 2) __builtin_amdgcn_s_setprio(PCL_ACC16_PRIO_LATE);
-#endif
 #ifdef PCL_ACC16_STAMPS          // diagnostic build: where a wave's time goes (s_memtime at points where no LDS read is pending)
     unsigned long long st_busy = 0, st_vm = 0, st_bar = 0, st_prev = __builtin_amdgcn_s_memtime();
     unsigned int st_n = 0;
 #endif
-    auto tile_step = [&](int t, f16v &d1, f16v &dn) __attribute__((always_inline)) {
+    auto tile_step = [&](int t, f16v (&d1)[MT], f16v (&dn)[MT]) __attribute__((always_inline)) {
 #ifdef PCL_ACC16_DIAG_NODMA
         const bool ahead = false;
 #else
@@ -401,84 +421,46 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
         if (slice == 0 && wave == 0 && lane < 32) galpha += reinterpret_cast<const double *>(cur + I::BM * 64)[32 + lane];   // byte 256: gamma_f(j)
         if (live) {
             bf8v bq0[3][NCT], bq1[3][NCT];
-            bf8v g1[2], g2[2];
+            bf8v g1a[MT], g1b[MT], g2a[MT], g2b[MT];
             // ---- region X
-            {   // posteriors gamma_t(j,m) (Clustering.py:660-661) of tile t in two bf16 pieces = the A fragments of product (2)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                // posteriors gamma_t(j,m) (Clustering.py:660-661) of tile t in two bf16 pieces = the A fragments of product (2)
                 typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
                 unsigned int u1[8], u2[8];
 #ifdef PCL_ACC16_DIAG_NOV
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    u1[r] = __float_as_uint(d1[2 * r]);
-                    u2[r] = __float_as_uint(d1[2 * r + 1]);
+                    u1[r] = __float_as_uint(d1[i][2 * r]);
+                    u2[r] = __float_as_uint(d1[i][2 * r + 1]);
                 }
 #else
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float ga = __builtin_amdgcn_exp2f(d1[2 * r]), gb = __builtin_amdgcn_exp2f(d1[2 * r + 1]);
+                    const float ga = __builtin_amdgcn_exp2f(d1[i][2 * r]), gb = __builtin_amdgcn_exp2f(d1[i][2 * r + 1]);
                     const bf2v c = bf2v{(__bf16)ga, (__bf16)gb};                   // v_cvt_pk_bf16_f32
                     u1[r] = __builtin_bit_cast(unsigned int, c);
                     const bf2v e = bf2v{(__bf16)(ga - __uint_as_float(u1[r] << 16)), (__bf16)(gb - __uint_as_float(u1[r] & 0xffff0000u))};
                     u2[r] = __builtin_bit_cast(unsigned int, e);
                 }
 #endif
-                g1[0] = __builtin_bit_cast(bf8v, make_uint4(u1[0], u1[1], u1[2], u1[3]));
-                g1[1] = __builtin_bit_cast(bf8v, make_uint4(u1[4], u1[5], u1[6], u1[7]));
-                g2[0] = __builtin_bit_cast(bf8v, make_uint4(u2[0], u2[1], u2[2], u2[3]));
-                g2[1] = __builtin_bit_cast(bf8v, make_uint4(u2[4], u2[5], u2[6], u2[7]));
+                g1a[i] = __builtin_bit_cast(bf8v, make_uint4(u1[0], u1[1], u1[2], u1[3]));
+                g1b[i] = __builtin_bit_cast(bf8v, make_uint4(u1[4], u1[5], u1[6], u1[7]));
+                g2a[i] = __builtin_bit_cast(bf8v, make_uint4(u2[0], u2[1], u2[2], u2[3]));
+                g2b[i] = __builtin_bit_cast(bf8v, make_uint4(u2[4], u2[5], u2[6], u2[7]));
             }
             mfma1(a1, a2, dn);                                   // product (1) of tile t + 1, from its frames' coefficients
             load2(t, 0, bq0);
             load2(t, 1, bq1);
             // ---- region Y
 #ifndef PCL_ACC16_DIAG_NOP2      // (timing diagnostics: wrong results)
-            mfma2(g1[0], g2[0], bq0);                            // product (2) of tile t: S[mixture][feature] += g^T . Xe
-            mfma2(g1[1], g2[1], bq1);
+            mfma2(g1a, g2a, bq0);                                // product (2) of tile t: S[mixture][feature] += g^T . Xe
+            mfma2(g1b, g2b, bq1);
 #else
-            S[0][0] += (float)g1[0][0] + (float)g2[1][1] + (float)bq0[0][0][0] + (float)bq1[2][NCT - 1][3];
+            S[0][0][0] += (float)g1a[0][0] + (float)g2b[MT - 1][1] + (float)bq0[0][0][0] + (float)bq1[2][NCT - 1][3];
 #endif
             load_cf(t + 2, d1);                                  // (the posteriors of tile t have been read out of d1)
             load1(t + 2, a1, a2);
-#ifdef PCL_ACC16_DIAG_DUMMYLDS   // the reads are issued but nobody waits for their data (until the end of the tile)
-            {
-                const unsigned int ad = lds_addr(cur) + lane * 16u;
-                uint4 dm0, dm1, dm2, dm3;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                                 : "=v"(dm0), "=v"(dm1), "=v"(dm2), "=v"(dm3) : "v"(ad + q * 4096u));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-#endif
-#ifdef PCL_ACC16_SCHED            // (pinning the interleave by hand measured no better than the compiler's own: 46.3 vs 45.7 ms)
-            // the interleave: X = 15 x {1 MFMA, 1-2 fragment reads, 6 VALU}, Y = 30 x {1 MFMA, 0-1 reads, 1 VALU}
-            constexpr int NX = 3 * KS, RX = 6 * NCT, NX2 = RX > NX ? RX - NX : 0;   // MFMAs and reads of region X; steps that take two reads
-            constexpr int NY = 10 * NCT, RY = 4 + 2 * KS;
-            static_assert(RX <= 2 * NX && RY <= NY, "reads fit the MFMA steps");
-#pragma unroll
-            for (int i = 0; i < NX2; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // DS read
-                __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);       // VALU | TRANS
-            }
-#pragma unroll
-            for (int i = NX2; i < NX; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < RY; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 1, 0);
-            }
-#pragma unroll
-            for (int i = RY; i < NY; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 1, 0);
-            }
-#endif
         }
 #ifdef PCL_ACC16_STAMPS
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
@@ -520,24 +502,37 @@ __global__ __launch_bounds__(AW * 64, 2) void acc16_consumer_kernel(
 
     // ---- flush: lane = feature column, register = mixture row; cov = S2 - 2 d S1 + d^2 S0, mean = S1 + (c + bias) S0
     const float *cen = centers + (size_t)j * D;
-    if (live) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int mt = mt0 + i;
+        if (mt >= n_mtiles) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float s0 = __shfl(S[(2 * D) >> 5][r], (lane & 32) + ((2 * D) & 31), 64);   // column 2D = the constant feature
+            const float s0 = __shfl(S[i][(2 * D) >> 5][r], (lane & 32) + ((2 * D) & 31), 64);   // column 2D = the constant feature
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const float s1 = __shfl_xor(S[ct][r], 1, 64);                              // odd neighbour: x' column of the same d
+                const float s1 = __shfl_xor(S[i][ct][r], 1, 64);                           // odd neighbour: x' column of the same d
                 const int cidx = ct * 32 + col;
                 if (m < M && !(cidx & 1) && cidx < 2 * D) {
                     const int d = cidx >> 1;
                     const size_t o = ((size_t)j * Mpad + m) * D + d;
                     const double c = (double)cen[d], dl = means64[o] - c;
-                    const double S0 = (double)s0, S1 = (double)s1, S2 = (double)S[ct][r];
-                    st_mean[o] += S1 + (c + bias) * S0;                            // Clustering.py:669-672
-                    st_cov[o] += S2 - 2.0 * dl * S1 + dl * dl * S0;                // Clustering.py:674-678
+                    const double S0 = (double)s0, S1 = (double)s1, S2 = (double)S[i][ct][r];
+                    const double vm = S1 + (c + bias) * S0;                        // Clustering.py:669-672
+                    const double vc = S2 - 2.0 * dl * S1 + dl * dl * S0;           // Clustering.py:674-678
+                    if (FRESH) {
+                        st_mean[o] = vm;
+                        st_cov[o] = vc;
+                    } else {
+                        st_mean[o] += vm;
+                        st_cov[o] += vc;
+                    }
                 }
-                if (m < M && cidx == 2 * D) st_acc[(size_t)j * Mpad + m] += (double)S[ct][r];   // Clustering.py:665
+                if (m < M && cidx == 2 * D) {                                      // Clustering.py:665
+                    if (FRESH) st_acc[(size_t)j * Mpad + m] = (double)S[i][ct][r];
+                    else st_acc[(size_t)j * Mpad + m] += (double)S[i][ct][r];
+                }
             }
         }
     }
@@ -583,16 +578,21 @@ int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
 }
 
 // ... and the consumer of the same group
-int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, hipStream_t stream) {
+int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, bool fresh, hipStream_t stream) {
     if (ns == 0) return PCL_OK;
-    const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW;
+    const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW * MT - 1) / (AW * MT);
     const int nblocks = ((ns + 7) / 8) * 8 * nslice;
     const int *ws = b->d_work_states + first;
-#define CONSUME16(DD)                                                                                                         \
-    hipLaunchKernelGGL((acc16_consumer_kernel<DD>), dim3(nblocks), dim3(AW * 64), 0, stream,                                  \
+#define CONSUME16F(DD, FR)                                                                                                    \
+    hipLaunchKernelGGL((acc16_consumer_kernel<DD, FR>), dim3(nblocks), dim3(AW * 64), 0, stream,                              \
                        reinterpret_cast<const uint4 *>(b->acc16_images[buf]), reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->centers32, \
                        ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, ws, b->acc16_tile_off[buf], 0, 100.0, ctx->st_acc, ctx->st_alpha,      \
                        ctx->st_mean, ctx->st_cov)
+#define CONSUME16(DD)                     \
+    do {                                  \
+        if (fresh) CONSUME16F(DD, true);  \
+        else CONSUME16F(DD, false);       \
+    } while (0)
     switch (ctx->D) {
         case 39: CONSUME16(39); break;
         case 26: CONSUME16(26); break;
@@ -600,6 +600,7 @@ int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
         default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f16 accumulate kernel for D=%d", ctx->D);
     }
 #undef CONSUME16
+#undef CONSUME16F
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

@@ -882,6 +882,7 @@ int pcl_stats_zero(pcl_ctx *ctx) {
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_zero: no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->stats, 0, ctx->stats_len * sizeof(double), ctx->stream));
+    ctx->stats_fresh = true;
     if (ctx->hmm_ksai) return pcl_hmm_acc_zero(ctx);      // the per-unit transition accumulators restart at ln 0 (LHMM.py:84-85)
     return PCL_OK;
 }
@@ -902,7 +903,9 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
         TRY(ensure_frames64(ctx));
         TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P64));
     }
-    return pcl_launch_accumulate(ctx, b, precision);
+    const int rc = pcl_launch_accumulate(ctx, b, precision);
+    ctx->stats_fresh = false;
+    return rc;
 }
 
 int pcl_mstep(pcl_ctx *ctx, double c_covariance) {

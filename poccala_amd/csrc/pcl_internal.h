@@ -102,6 +102,7 @@ struct pcl_ctx {
     double *stats = nullptr;  // one allocation: [acc J*Mpad | alpha J | mean J*Mpad*D | cov J*Mpad*D]
     size_t stats_len = 0;
     double *st_acc = nullptr, *st_alpha = nullptr, *st_mean = nullptr, *st_cov = nullptr;
+    bool stats_fresh = false;    // all zero since pcl_stats_zero: the first accumulate pass may store instead of read-modify-write
     // unit inventory (hmm_units.hip): n_units HMMs of S states, unit i owns GMM states i*(S-2) .. i*(S-2)+S-3
     int n_units = 0, S = 0;
     std::vector<double> unit_trans, unit_logtrans;   // host copies [n_units][S][S]: transmat and np.log(transmat)
@@ -247,7 +248,7 @@ int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *
 int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int max_tiles, int buf, hipStream_t stream);
-int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, hipStream_t stream);
+int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, bool fresh, hipStream_t stream);
 size_t pcl_acc16_image_bytes(int D);
 int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split16_tile_frames();

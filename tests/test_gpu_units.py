@@ -531,3 +531,31 @@ def test_accumulate_outlier_frames_take_the_direct_form_fixup(eng):
             np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-6 * ref.max(), err_msg='%s state %d' % (key, j))
         np.testing.assert_allclose(st['alpha_acc'][j], np.exp(acc['alpha_acc']), rtol=1e-6)
     np.testing.assert_allclose(lb[1], po.gmm_point(xx, mean[0], var[0], w[0]), rtol=1e-5, atol=2e-4)
+
+
+def test_accumulate_first_pass_stores_later_passes_add(eng):
+    """The first accumulate after stats_zero stores the statistics (every (state, mixture) belongs to one wave, the buffer is
+    zero), later ones read-modify-write: the same batch accumulated twice gives exactly twice the statistics, states the
+    batch does not contain stay zero, and a second stats_zero starts over."""
+    from poccala_amd import PCL_F32
+    mean, var, w, trans, frames, lens, begin, labels = problem(17, units=4, M=40, D=39, U=6, T=70, L=2)
+    labels = [np.array([0, 2]) for _ in labels]                 # units 1 and 3 are never seen
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F32)
+    b.forward_backward()
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    one = eng.stats_download()
+    b.accumulate(PCL_F32)
+    two = eng.stats_download()
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    again = eng.stats_download()
+    b.close()
+    for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+        assert np.array_equal(two[key], 2.0 * one[key]), key
+        assert np.array_equal(again[key], one[key]), key
+    assert one['alpha_acc'][0] > 0 and (one['alpha_acc'][3:6] == 0).all() and (one['acc'][9:] == 0).all()
