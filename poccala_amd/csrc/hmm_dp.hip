@@ -366,18 +366,67 @@ __device__ __forceinline__ double lse2(double a, double b) {
     if (isinf(m)) return m;                                   // util.log_sum_exp, quirk Q4
     return m + log1p(exp(fmin(a, b) - m));
 }
+// The same through a table in LDS: the two-term log-sum-exp IS the step of the T-long dependent chain, and exp + log1p in
+// float64 are ~140 dependent instructions of it.  f(d) = log1p(exp(-d)), d = |a - b| >= 0, is smooth and every derivative is a
+// polynomial in s = 1 / (1 + e^d): f1 = -s, f2 = q = s (1 - s), f3 = -q (1 - 2s), f4 = q (1 - 6q), f5 = -q (1 - 2s)(1 - 12q),
+// f6 = q (1 - 30q + 120q^2).  The table holds (f, s) at d_k = k / 32 (host libm, float64); a sixth-order Taylor step of at most
+// 1/64 leaves < 1e-17 -- ~25 instructions.  Past d = 40, f < 5e-18 is dropped.
+constexpr int SP_N = 1281;
+constexpr double SP_MAX = 39.98;
+__device__ __forceinline__ double lse2_tab(double a, double b, const double2 *tab) {
+    const double m = fmax(a, b);
+    if (isinf(m)) return m;                                   // util.log_sum_exp, quirk Q4
+    const double d = m - fmin(a, b);
+    if (!(d < SP_MAX)) return m;
+    const int k = __double2int_rn(d * 32.0);
+    const double x = fma(-(double)k, 1.0 / 32.0, d);
+    const double2 e = tab[k];
+    const double sg = e.y, q = fma(-sg, sg, sg), h = fma(-2.0, sg, 1.0), qh = q * h;
+    const double c6 = q * fma(q, fma(120.0, q, -30.0), 1.0) * (1.0 / 720.0);
+    const double c5 = qh * fma(-12.0, q, 1.0) * (-1.0 / 120.0);
+    const double c4 = q * fma(-6.0, q, 1.0) * (1.0 / 24.0);
+    const double c3 = qh * (-1.0 / 6.0);
+    double r = fma(x, c6, c5);
+    r = fma(x, r, c4);
+    r = fma(x, r, c3);
+    r = fma(x, r, 0.5 * q);
+    r = fma(x, r, -sg);
+    return m + fma(x, r, e.x);
+}
+// exp(x) for x <= 0 (every log-sum-exp term is taken relative to a maximum): k = rint(x log2 e), r = x - k ln 2 in two pieces,
+// a degree-12 Taylor polynomial on |r| <= ln 2 / 2 (remainder 1.7e-16 relative), v_ldexp_f64 -- 19 instructions where the
+// library's takes ~40; below -745 the result is 0, as the library's.
+__device__ __forceinline__ double exp_neg(double x) {
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return (x > -745.0) ? ldexp(p, (int)k) : 0.0;
+}
 __device__ __forceinline__ void online_lse(double x, double &m, double &s) {
     if (x > m) {
-        s = s * exp(m - x) + 1.0;                             // exp(-inf) = 0 on the first finite value
+        s = s * exp_neg(m - x) + 1.0;                         // exp(-inf) = 0 on the first finite value
         m = x;
     } else if (x > -INFINITY) {
-        s += exp(x - m);
+        s += exp_neg(x - m);
     }
 }
 __device__ __forceinline__ double wave_lse(double v) {
     const double m = wave_max(v);
     if (isinf(m)) return m;
-    return m + log(wave_sum(exp(v - m)));
+    return m + log(wave_sum(exp_neg(v - m)));
 }
 
 __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
@@ -388,8 +437,10 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                                                      double *__restrict__ beta, double *__restrict__ lgam, double *__restrict__ ksai,
                                                      double *__restrict__ gamma_out, double *__restrict__ pi_out, double *__restrict__ logp,
                                                      double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
-                                                     double threshold) {
+                                                     double threshold, const double2 *__restrict__ softplus) {
     __shared__ double vF[2][64], vB[2][64], a0s[64], b0s[64], lpi[64];
+    __shared__ double2 sp[SP_N];
+    for (int k = threadIdx.x; k < SP_N; k += 128) sp[k] = softplus[k];
     __shared__ double s_q;
     const UttDesc d = utts[blockIdx.x];
     const int N = d.N, T = d.T;
@@ -433,7 +484,7 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                 const double bcur = bnext;
                 if (act && t + 1 < T) bnext = B[(long long)(t + 1) * N + i];     // in flight during this step
                 if (act) {
-                    a = lse2(prev[pidx[0]] + pval[0], prev[pidx[1]] + pval[1]) + bcur;
+                    a = lse2_tab(prev[pidx[0]] + pval[0], prev[pidx[1]] + pval[1], sp) + bcur;
                     A_[(long long)t * N + i] = a;
                 }
                 vF[t & 1][i] = a;
@@ -452,7 +503,7 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                 const double bt = b_t;
                 if (act && t > 0) b_t = B[(long long)(t - 1) * N + i];
                 if (act) {
-                    bcur = lse2(sval[0] + nxt[sidx[0]], sval[1] + nxt[sidx[1]]);
+                    bcur = lse2_tab(sval[0] + nxt[sidx[0]], sval[1] + nxt[sidx[1]], sp);
                     Bv[(long long)t * N + i] = bcur;
                 }
                 vB[t & 1][i] = act ? bt + bcur : -INFINITY;
@@ -486,8 +537,30 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
         if (final_pass) {
             // ---------------------------------------------------------------- xi / gamma / posteriors, parallel over t
             double gm = -INFINITY, gs = 0.0, xm[2] = {-INFINITY, -INFINITY}, xs[2] = {0.0, 0.0};
+            // (the loads of frame t + 2 are issued before frame t is worked on: each iteration is otherwise a chain of an L2 round
+            //  trip, two wave reductions and three exponentials)
+            auto fetch = [&](int t, double &at, double &bt, double (&nx)[2]) {
+                at = -INFINITY;
+                bt = 0.0;
+                nx[0] = nx[1] = 0.0;
+                if (act && t < T) {
+                    at = A_[(long long)t * N + i];
+                    bt = Bv[(long long)t * N + i];
+                    if (t < T - 1) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            if (k < nsucc) {
+                                const long long o = (long long)(t + 1) * N + sidx[k];
+                                nx[k] = B[o] + Bv[o];
+                            }
+                    }
+                }
+            };
+            double at_n, bt_n, nx_n[2];
+            fetch(w, at_n, bt_n, nx_n);
             for (int t = w; t < T; t += 2) {
-                const double at = act ? A_[(long long)t * N + i] : -INFINITY, bt = act ? Bv[(long long)t * N + i] : 0.0;
+                const double at = at_n, bt = bt_n, nx[2] = {nx_n[0], nx_n[1]};
+                fetch(t + 2, at_n, bt_n, nx_n);
                 const double l = at + bt;
                 const double norm = wave_lse(act ? l : -INFINITY);               // sum_value[t] (LHMM.py:488)
                 if (act) G[(long long)t * N + i] = l - norm;                     // l[:,t] - sum_value[t] (:486-500)
@@ -495,11 +568,8 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                     online_lse(l, gm, gs);                                       // gamma_i over t < T-1 (:442-445)
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
-                        if (k < nsucc) {
-                            // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
-                            const long long o = (long long)(t + 1) * N + sidx[k];
-                            online_lse(at + (sval[k] + (B[o] + Bv[o])), xm[k], xs[k]);
-                        }
+                        if (k < nsucc)                                           // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
+                            online_lse(at + (sval[k] + nx[k]), xm[k], xs[k]);
                 }
             }
             // merge the two waves' partial log-sum-exps: (m, s) pairs through LDS
@@ -646,12 +716,24 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     const int NP = (b->Nmax + 63) / 64 * 64;
     if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);
     const size_t shm = (size_t)3 * NP * sizeof(double);
+    if (!ctx->d_softplus) {                                      // (f, s) of log1p(exp(-d)) at d = k / 32, host libm
+        std::vector<double> tab(2 * SP_N);
+        for (int k = 0; k < SP_N; ++k) {
+            const double d = k / 32.0;
+            tab[2 * k] = log1p(exp(-d));
+            tab[2 * k + 1] = 1.0 / (1.0 + exp(d));
+        }
+        TRY(dev_alloc(ctx, &ctx->d_softplus, tab.size()));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_softplus, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     pcl_timer_begin(ctx, "fb");
     static const bool one_wave = getenv("PCL_FB_ONE_WAVE") && atoi(getenv("PCL_FB_ONE_WAVE")) != 0;      // A/B: the round-1 kernel
     if (b->max_indeg <= 2 && b->max_outdeg <= 2 && NP == 64 && !one_wave)
         hipLaunchKernelGGL(hmm_fb2_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->ksai,
-                           b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
+                           b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold,
+                           reinterpret_cast<const double2 *>(ctx->d_softplus));
     else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
         hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,

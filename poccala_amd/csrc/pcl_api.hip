@@ -123,6 +123,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     pcl_units_release(ctx);
     release_frames32(ctx);
     dev_free(ctx->frames64);
+    dev_free(ctx->d_softplus);
     dev_free(ctx->frames_slot[0]);
     dev_free(ctx->frames_slot[1]);
     if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);

@@ -102,6 +102,7 @@ struct pcl_ctx {
     double *stats = nullptr;  // one allocation: [acc J*Mpad | alpha J | mean J*Mpad*D | cov J*Mpad*D]
     size_t stats_len = 0;
     double *st_acc = nullptr, *st_alpha = nullptr, *st_mean = nullptr, *st_cov = nullptr;
+    double *d_softplus = nullptr;   // table of log1p(exp(-d)) for the forward-backward recursion (hmm_dp.hip)
     bool stats_fresh = false;    // all zero since pcl_stats_zero: the first accumulate pass may store instead of read-modify-write
     // unit inventory (hmm_units.hip): n_units HMMs of S states, unit i owns GMM states i*(S-2) .. i*(S-2)+S-3
     int n_units = 0, S = 0;
