@@ -631,6 +631,36 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
                                     'the posteriors of aligned speech; score + forward-backward + accumulate + per-unit merge, no exchange')
     bp.close()
     ep.close()
+    # ---- the accumulate pass in its approximate mode (pcl_accumulate_prune) on the bench's own flat posteriors: a fresh context
+    #      with the ORIGINAL model (the main one has been through an M-step by now), pairs with gamma_t(j) < 2^-40 left out
+    ef = Engine(eng.device)
+    ef.enable_timing(True)
+    ef.load_model(mean, var, w)
+    ef.load_units(np.stack(trans))
+    ef.load_frames(frames0)
+    bf = ef.label_batch(labels, lens0, begin0)
+    bf.score(PCL_F32); bf.forward_backward(fix_pi=False)
+    ms_acc, st_acc = {}, {}
+    for name, thr in (('exact', -1e300), ('pruned', -40.0)):
+        ef.accumulate_prune(thr)
+        ef.stats_zero(); bf.accumulate(PCL_F32); ef.sync(); ef.kernel_time('accumulate')
+        ef.stats_zero(); bf.accumulate(PCL_F32)
+        ms_acc[name] = ef.kernel_time('accumulate')[0]
+        st_acc[name] = ef.stats_download(moments=False)
+    lg0 = bf.get('lgamma')
+    seen = st_acc['exact']['alpha_acc'] > 0
+    out['accumulate_pruned'] = dict(
+        log2_threshold=-40, accumulate_ms=ms_acc['pruned'], accumulate_exact_ms=ms_acc['exact'],
+        surviving_pair_fraction=float(np.mean([np.mean(l[1:-1] >= -40 * np.log(2)) for l in lg0[::16]])),
+        surviving_pair_fraction_exact=float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lg0[::16]])),
+        max_rel_dev_alpha_acc=float(np.max(np.abs(st_acc['pruned']['alpha_acc'][seen] - st_acc['exact']['alpha_acc'][seen]) / st_acc['exact']['alpha_acc'][seen])),
+        max_dev_acc_rel_to_state_occupancy=float(np.max(np.abs(st_acc['pruned']['acc'][seen] - st_acc['exact']['acc'][seen]) / st_acc['exact']['alpha_acc'][seen][:, None])),
+        what='OFF by default.  The default pass leaves out only (frame, state) pairs whose every term is exactly 0 in f32 (gamma_t(j) < 2^-150); '
+             'here pairs below 2^-40 (1e-12 of a frame) are left out too -- the deviations are measured against the exact pass of the same batch '
+             '(state occupancies are float64 sums; the mixture sums also carry the f32 regrouping noise of different tiles)')
+    del lg0, st_acc
+    bf.close()
+    ef.close()
     out['zero_change_route'] = zero_change_route()
     return out
 

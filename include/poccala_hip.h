@@ -238,6 +238,13 @@ int pcl_batch_get(pcl_batch *b, int what, void *host);
 int pcl_stats_zero(pcl_ctx *ctx);
 int pcl_batch_accumulate(pcl_batch *b, int precision);
 /* J*M, J, J*M*D, J*M*D doubles */
+/* Approximate mode of pcl_batch_accumulate (off by default): (frame, state) pairs with gamma_t(j) < 2^log2_threshold are
+ * left out of the statistics.  The default leaves out only pairs whose every term is EXACTLY zero in the kernel's arithmetic
+ * (2^-150 in f32, 2^-1076 in f64), which changes no bit; a threshold such as -40 drops contributions below 1e-12 of a frame
+ * -- far inside the f32 path's own rounding -- and shortens the pass when the posteriors are flat.  The reference has no
+ * such cut (it sums everything in the log domain, Clustering.py:653-680). */
+int pcl_accumulate_prune(pcl_ctx *ctx, double log2_threshold);
+
 int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc);
 
 /* A15: Clustering.GMM.update_param (Clustering.py:682-693) for every state, on the device, from the resident

@@ -44,6 +44,7 @@ PROTOTYPES = {
     'pcl_batch_get': (_i, [_vp, _i, _vp]),
     'pcl_stats_zero': (_i, [_vp]),
     'pcl_batch_accumulate': (_i, [_vp, _i]),
+    'pcl_accumulate_prune': (_i, [_vp, C.c_double]),
     'pcl_stats_download': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pcl_mstep': (_i, [_vp, _d]),
     'pcl_model_download': (_i, [_vp, _vp, _vp, _vp]),

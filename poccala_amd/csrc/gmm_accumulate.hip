@@ -615,7 +615,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     // a frame survives unless every gamma_t(j,m) <= gamma_t(j) underflows to exactly 0 in the
     // kernel's arithmetic (f32: 2^-149, f64: 2^-1074)
     const double LN2 = 0.693147180559945309417232121458;
-    const double thr = (precision == PCL_F64 ? -1076.0 : -150.0) * LN2;
+    const double thr = std::max(precision == PCL_F64 ? -1076.0 : -150.0, ctx->acc_prune_log2) * LN2;
     pcl_timer_begin(ctx, "accumulate");
     const int wpb = 4;
     dim3 gseg((b->n_segs + wpb - 1) / wpb);

@@ -946,12 +946,21 @@ int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight) 
     return r;
 }
 
+int pcl_accumulate_prune(pcl_ctx *ctx, double log2_threshold) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (log2_threshold > 0.0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_accumulate_prune: threshold 2^%g > 1", log2_threshold);
+    ctx->acc_prune_log2 = log2_threshold;
+    return PCL_OK;
+}
+
 int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_download: no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<double> h(ctx->stats_len);
-    HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->stats, ctx->stats_len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // [acc | alpha | mean | cov]: only as far as the caller asks (the two moment blocks are 99 % of the bytes)
+    const size_t need = cov_acc ? ctx->stats_len : mean_acc ? (size_t)(ctx->st_cov - ctx->stats) : (size_t)(ctx->st_mean - ctx->stats);
+    std::vector<double> h(need);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->stats, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int J = ctx->J, M = ctx->M, Mp = ctx->Mpad, D = ctx->Dhost, Dd = ctx->D;
     const double *a = h.data(), *al = a + (size_t)J * Mp, *me = al + J, *co = me + (size_t)J * Mp * Dd;

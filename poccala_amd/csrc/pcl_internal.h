@@ -103,7 +103,8 @@ struct pcl_ctx {
     size_t stats_len = 0;
     double *st_acc = nullptr, *st_alpha = nullptr, *st_mean = nullptr, *st_cov = nullptr;
     double *d_softplus = nullptr;   // table of log1p(exp(-d)) for the forward-backward recursion (hmm_dp.hip)
-    bool stats_fresh = false;    // all zero since pcl_stats_zero: the first accumulate pass may store instead of read-modify-write
+    bool stats_fresh = false;
+    double acc_prune_log2 = -1e300;   // pcl_accumulate_prune: frames with gamma_t(j) below 2^this are left out (default: only exact zeros)    // all zero since pcl_stats_zero: the first accumulate pass may store instead of read-modify-write
     // unit inventory (hmm_units.hip): n_units HMMs of S states, unit i owns GMM states i*(S-2) .. i*(S-2)+S-3
     int n_units = 0, S = 0;
     std::vector<double> unit_trans, unit_logtrans;   // host copies [n_units][S][S]: transmat and np.log(transmat)

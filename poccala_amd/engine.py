@@ -229,14 +229,22 @@ class Engine(object):
     def stats_zero(self):
         self._check(self._lib.pcl_stats_zero(self._ctx))
 
-    def stats_download(self):
-        """Linear-domain sums: acc (J,M), alpha_acc (J,), mean_acc (J,M,D), cov_acc (J,M,D)."""
+    def stats_download(self, moments=True):
+        """Linear-domain sums: acc (J,M), alpha_acc (J,), and unless moments=False mean_acc (J,M,D), cov_acc (J,M,D)."""
         acc = np.empty((self.J, self.M))
         al = np.empty((self.J,))
+        if not moments:
+            self._check(self._lib.pcl_stats_download(self._ctx, ptr(acc), ptr(al), None, None))
+            return dict(acc=acc, alpha_acc=al)
         me = np.empty((self.J, self.M, self.D))
         co = np.empty((self.J, self.M, self.D))
         self._check(self._lib.pcl_stats_download(self._ctx, ptr(acc), ptr(al), ptr(me), ptr(co)))
         return dict(acc=acc, alpha_acc=al, mean_acc=me, cov_acc=co)
+
+    def accumulate_prune(self, log2_threshold):
+        """Approximate mode of Batch.accumulate: leave out (frame, state) pairs with gamma_t(j) < 2^log2_threshold
+        (default: only pairs that are exactly zero in the kernel's arithmetic)."""
+        self._check(self._lib.pcl_accumulate_prune(self._ctx, float(log2_threshold)))
 
     def mstep(self, c_covariance=1e-3):
         """GMM.update_param for every state on the device (Clustering.py:682-693); rebuilds the scoring layouts."""

@@ -559,3 +559,36 @@ def test_accumulate_first_pass_stores_later_passes_add(eng):
         assert np.array_equal(two[key], 2.0 * one[key]), key
         assert np.array_equal(again[key], one[key]), key
     assert one['alpha_acc'][0] > 0 and (one['alpha_acc'][3:6] == 0).all() and (one['acc'][9:] == 0).all()
+
+
+def test_accumulate_prune_is_off_by_default_and_bounded(eng):
+    """pcl_accumulate_prune: the default (exact zeros only) is what every parity test runs under; with a threshold of 2^-40 the
+    state occupancies (float64 sums) move by less than the left-out mass (pairs x 2^-40), the f32 mixture sums by that plus their
+    own regrouping noise, and everything comes back bit for bit when the mode is switched off."""
+    from poccala_amd import PCL_F32, PoccalaHipError
+    mean, var, w, trans, frames, lens, begin, labels = problem(23, units=5, M=40, D=39, U=8, T=80, L=3)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    b = eng.label_batch(labels, lens, begin)
+    b.score(PCL_F32)
+    b.forward_backward()
+    eng.stats_zero(); b.accumulate(PCL_F32)
+    exact = eng.stats_download()
+    eng.accumulate_prune(-40.0)
+    eng.stats_zero(); b.accumulate(PCL_F32)
+    cut = eng.stats_download()
+    eng.accumulate_prune(-1e300)
+    eng.stats_zero(); b.accumulate(PCL_F32)
+    back = eng.stats_download()
+    with pytest.raises(PoccalaHipError):
+        eng.accumulate_prune(1.0)
+    lg = b.get('lgamma')
+    b.close()
+    n_cut = sum(int(((l[1:-1] < -40 * np.log(2)) & (l[1:-1] >= -150 * np.log(2))).sum()) for l in lg)
+    assert n_cut > 0                                            # the threshold does leave pairs out on this problem
+    for key in exact:
+        assert np.array_equal(back[key], exact[key]), key
+    assert np.abs(cut['alpha_acc'] - exact['alpha_acc']).max() <= n_cut * 2.0 ** -40
+    # (the f32 sums also regroup: leaving frames out moves the others to different 32-frame tiles -> f32 rounding noise)
+    np.testing.assert_allclose(cut['acc'], exact['acc'], rtol=2e-6, atol=n_cut * 2.0 ** -40 + 1e-9)
