@@ -450,8 +450,8 @@ __global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kerne
                 g2b[i] = __builtin_bit_cast(bf8v, make_uint4(u2[4], u2[5], u2[6], u2[7]));
             }
             mfma1(a1, a2, dn);                                   // product (1) of tile t + 1, from its frames' coefficients
-            load2(t, 0, bq0);
-            load2(t, 1, bq1);
+            load2(t, 0, bq0);                                    // (asked for at the top of the tile and pinned there with a sched_barrier,
+            load2(t, 1, bq1);                                    //  the 18 reads make the first MFMA wait for all of them: 43.7 vs 41.9 ms)
             // ---- region Y
 #ifndef PCL_ACC16_DIAG_NOP2      // (timing diagnostics: wrong results)
             mfma2(g1a, g2a, bq0);                                // product (2) of tile t: S[mixture][feature] += g^T . Xe
