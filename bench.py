@@ -27,6 +27,7 @@ import secrets
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -55,6 +56,7 @@ def parse():
                         'scoring of step k+1; 1 = every step re-scores the same batch and the two phases serialise')
     p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
+    p.add_argument('--extra-timeout', type=int, default=600, help='seconds the untimed extras (and the shutdown) may take before rank 0 prints the line without them')
     p.add_argument('--traffic-bytes', type=float, default=None,
                    help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md '
                         'prescribes (2 x FETCH_SIZE for the wide streaming reads + WRITE_SIZE); default: the figure committed in '
@@ -352,12 +354,9 @@ def main():
                     hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_n else None,
                     fb_kernel_avg_ms=fb_ms / max(fb_n, 1))
 
-    extra = None
-    if args.extra:
-        extra = extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans)
+    info = eng.device_info()                   # (not from the watchdog thread: the main thread may be inside the runtime)
 
-    if rank == 0:
-        info = eng.device_info()
+    def make_line(extra):
         out = {
             'metric': 'frames/sec GMM-score+fwd-bwd, 39-d MFCC, 2048-mix',
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -388,14 +387,40 @@ def main():
         if cpu:
             out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value'],
                                    'vs_blas_gemm_formulation': value / cpu['gemm_value']}
-        print(json.dumps(out))
+        return json.dumps(out)
+
+    # The timed number is final here.  What follows (the E-step with its exchange, side measurements) is outside the timed region and
+    # must not be able to take the line with it: an exception is reported inside `extra`, and if the extras or the shutdown do not come
+    # back within --extra-timeout seconds (a collective that never completes on some node), rank 0 prints the line without them.
+    printed = threading.Event()
+
+    def give_up():
+        if rank == 0 and not printed.is_set():
+            print(make_line(dict(error='extras did not finish within %d s' % args.extra_timeout)))
+            sys.stdout.flush()
+        os._exit(0)
+    dog = threading.Timer(args.extra_timeout, give_up)
+    dog.daemon = True
+    dog.start()
+    extra = None
+    if args.extra:
+        try:
+            extra = extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans)
+        except Exception as e:                 # noqa: the headline does not depend on the extras
+            import traceback
+            traceback.print_exc()
+            extra = dict(error='%s: %s' % (type(e).__name__, e))
+    if rank == 0:
+        print(make_line(extra))
         sys.stdout.flush()
+        printed.set()
     barrier()
     for bt in batches:
         bt.close()
     eng._lib.pcl_comm_destroy(eng._ctx)
     ctl.close()
     eng.close()
+    dog.cancel()
 
 
 def committed_traffic():

@@ -99,3 +99,29 @@ def test_gmm_dropin_parameter_files_without_gpu(tmp_path):
     np.testing.assert_allclose(h.acc, g.acc + np.log(2), rtol=1e-12)           # two identical files merged
     np.testing.assert_allclose(h.alpha_acc, 0.3 + np.log(2), rtol=1e-12)
     assert h.covariance_acc == 100.0                        # the reference's getter returns the bias (T2)
+
+
+def test_decode_result_unpacking_and_word_chain_without_gpu():
+    """Batch.decode_unpack (raw result arrays -> per-utterance dicts) and Decoder._report (history chain -> words, as
+    transfer() reports them, Decoder.py:183-186) are host-only; crafted arrays: two utterances, one with a two-word history
+    and a final token on a word-end node, one whose best token has no history and sits inside a word."""
+    from poccala_amd import Decoder
+    from poccala_amd.engine import Batch
+    tree = dict(words={3: ['ni', 'ni2'], 5: ['hao'], 7: ['ma']}, node_word=np.array([0, 0, 0, 1, 0, 1, 0, 1]))
+    nf = np.array([2, 1], np.int32)
+    node = np.array([[7, 2], [4, 0]], np.int32)
+    score = np.array([[-10.5, -11.0], [-3.25, 0.0]])
+    hist = np.array([[1, 0], [-1, 0]], np.int32)
+    hn = np.array([2, 0], np.int32)
+    hp = np.array([[-1, 0, 0], [0, 0, 0]], np.int32)              # entry 1 -> entry 0 -> start
+    hnode = np.array([[3, 5, 0], [0, 0, 0]], np.int32)
+    nt = np.array([[4, 5, 6], [2, 9, 9]], np.int32)
+    ov = np.array([0, 1], np.int32)
+    T = np.array([3, 1], np.int32)
+    res = Batch.decode_unpack((nf, node, score, hist, hn, hp, hnode, nt, ov, T))
+    assert res[0]['final'] == [(7, -10.5, 1), (2, -11.0, 0)] and res[0]['history'] == [(-1, 3), (0, 5)]
+    assert res[0]['n_tokens'].tolist() == [4, 5, 6] and res[0]['overflow'] is False
+    assert res[1]['final'] == [(4, -3.25, -1)] and res[1]['history'] == [] and res[1]['n_tokens'].tolist() == [2] and res[1]['overflow'] is True
+    rep = Decoder._report(res, tree)
+    assert rep[0][0] == [['ni', 'ni2'], ['hao'], ['ma']] and rep[0][1] == -10.5
+    assert rep[1][0] == [] and rep[1][1] == -3.25

@@ -27,7 +27,13 @@ run acc_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $R/tool
 run acc_sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" $R/tools/acc_bench.py
 run acc_lds "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" $R/tools/acc_bench.py
 run acc_tcc "TCC_HIT_sum TCC_MISS_sum" $R/tools/acc_bench.py
+DEC="$R/tools/c5_decode_bench.py 417 4096 20000 3 8192"
+run dec_trace "" $DEC
+run dec_fetch "FETCH_SIZE" $DEC
+run dec_write "WRITE_SIZE" $DEC
+run dec_clk "GRBM_GUI_ACTIVE" $DEC
+run dec_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $DEC
 python3 $R/tools/make_profile_summary.py $OUT r02
 find $OUT -name "*.csv" -size +1M -delete
 cat $OUT/failures.log 2>/dev/null
-tail -22 $OUT/r02_bench_summary.txt; tail -22 $OUT/r02_accumulate_summary.txt
+tail -22 $OUT/r02_bench_summary.txt; tail -22 $OUT/r02_accumulate_summary.txt; tail -12 $OUT/r02_decode_summary.txt

@@ -50,7 +50,7 @@ out = ['# rocprofv3 summaries, %s: python3 bench.py --steps 3 --warmup 1 --cpu-b
        '', '## --kernel-trace --stats (%s_bench_kernel_stats.csv)' % RND]
 kt, lines = kernel_stats('bench_trace', '%s_bench_kernel_stats.csv' % RND)
 out += lines + ['', '## --pmc passes (<= 4 counters per pass, no trace domains), per-dispatch averages']
-lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fb_kernel'])
+lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fb'])
 out += lines
 try:
     v = val['gmm_score_split16_kernel']
@@ -102,3 +102,24 @@ try:
 except (KeyError, IndexError, ZeroDivisionError) as e:
     out.append('(derived block incomplete: %r)' % (e,))
 open(os.path.join(P, '%s_accumulate_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
+
+# ---------------------------------------------------------------- C5 shard: all-state scoring + token passing (tools/c5_decode_bench.py)
+out = ['# rocprofv3 summaries, %s: python3 tools/c5_decode_bench.py 417 4096 20000 3 8192 (one MI355X: BASELINE config 5 per-GPU shard, 417 x 300 frames,' % RND,
+       '# 549 states x 4096 mixtures, 20 k-word tree, at most 8192 live tokens per utterance; resident runs + a streamed run in 3 chunks)',
+       '', '## --kernel-trace --stats (%s_decode_kernel_stats.csv)' % RND]
+kt, lines = kernel_stats('dec_trace', '%s_decode_kernel_stats.csv' % RND)
+out += lines + ['', '## --pmc passes (<= 4 counters per pass), per-dispatch averages (all launches: full shard and chunks)']
+lines, val = counters(['dec_fetch', 'dec_write', 'dec_clk', 'dec_sq1'], ['hmm_decode_kernel'])
+out += lines
+try:
+    v = val['hmm_decode_kernel']
+    ms = pick(kt, 'hmm_decode_kernel')
+    cyc = v['GRBM_GUI_ACTIVE'] / 8
+    wc = v['SQ_WAVE_CYCLES']
+    out += ['', '## derived (hmm_decode_kernel, averages over the launches above)',
+            'FETCH_SIZE %.2f GB raw + WRITE_SIZE %.2f GB per launch of %.1f ms average -> %.2f TB/s raw (the token arrays are read with 8- and 4-byte lanes: no x 2)'
+            % (v['FETCH_SIZE'] * 1024 / 1e9, v['WRITE_SIZE'] * 1024 / 1e9, ms, (v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 / ms / 1e9),
+            'clock held %.2f GHz; wave time: SQ_WAIT_ANY %.0f %%, SQ_WAIT_INST_ANY %.0f %% of SQ_WAVE_CYCLES' % (cyc / ms / 1e6, 100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc)]
+except (KeyError, IndexError, ZeroDivisionError) as e:
+    out.append('(derived block incomplete: %r)' % (e,))
+open(os.path.join(P, '%s_decode_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
