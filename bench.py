@@ -55,6 +55,8 @@ def parse():
                         'data loader would: the forward-backward of step k runs on the library\'s second stream beside the '
                         'scoring of step k+1; 1 = every step re-scores the same batch and the two phases serialise')
     p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
+    p.add_argument('--words', type=int, default=20000, help='--workload C5shard: random words added to the synthetic lexicon')
+    p.add_argument('--max-tokens', type=int, default=8192, help='--workload C5shard: live tokens per utterance')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
     p.add_argument('--extra-timeout', type=int, default=600, help='seconds the untimed extras (and the shutdown) may take before rank 0 prints the line without them')
     p.add_argument('--traffic-bytes', type=float, default=None,
@@ -222,6 +224,83 @@ KERNELS = {
 
 
 # ------------------------------------------------------------------------------------------------
+def bench_decode(args, rank, world, local):
+    """--workload C5shard: BASELINE config 5 per GPU -- 417 utterances x 300 frames (1/8 of the 1M-frame corpus), every one of the
+    549 GMM states x 4096 mixtures scored for every frame, then frame-synchronous token passing over a synthetic 20 k-word
+    pronunciation tree (the reference ships no word list), at most --max-tokens live tokens per utterance.  A step = score +
+    decode + results on the host for one resident shard; the ranks work on their own shards with no collective (weak scaling)."""
+    from poccala_amd import Engine, PCL_F32, synth
+    from poccala_amd.distributed import Control
+    from poccala_amd.engine import device_count
+    c = dict(synth.CONFIGS['C5shard'])
+    if args.utts:
+        c['U'] = args.utts
+    U, T, D, M, units_n = c['U'], c['T'], c['D'], c['M'], c['units']
+    t_setup = time.perf_counter()
+    tree, lx = synth.make_pronunciation_tree(args.words, units_n)
+    mean, var, w, trans = synth.make_model(units_n, M, D)
+    frames, lens, begin = synth.make_frames(U, T, D, seed=1000 * rank)
+    ndev = device_count()
+    dev = int(os.environ.get('POCCALA_DEVICE', local))
+    if bool(os.environ.get('POCCALA_SHARE_DEVICE')) and 0 < ndev < world:
+        dev = dev % ndev
+    eng = Engine(dev)
+    eng.enable_timing(True)
+    ctl = Control(rank, world)
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        b.score(PCL_F32)
+        return b.decode(max_tokens=args.max_tokens)
+    step()
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.kernel_time('score'); eng.kernel_time('decode')
+    ctl.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    eng.sync()
+    ctl.barrier()
+    elapsed = ctl.allreduce_max(time.perf_counter() - t0)
+    sc_ms, k1 = eng.kernel_time('score')
+    de_ms, k2 = eng.kernel_time('decode')
+    sc_ms, de_ms = sc_ms / max(k1, 1), de_ms / max(k2, 1)
+    pairs = U * T * units_n * 3
+    flop = pairs * M * (3 * D + 4)
+    ntok = np.concatenate([r['n_tokens'] for r in res])
+    if rank == 0:
+        info = eng.device_info()
+        print(json.dumps({
+            'metric': 'frames/sec all-state GMM-score + lexicon token-passing decode, 39-d MFCC, 4096-mix', 'value': U * T * world * args.steps / elapsed,
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C5shard: %d utterances/GPU x %d frames, D=%d, all %d GMM states x %d mixtures for every frame; token passing over a '
+                                   'synthetic tree of %d words (%d nodes, %d first-character nodes), <= %d live tokens per utterance, beam 0.85 (Decoder.py:34)'
+                                   % (U, T, D, units_n * 3, M, lx.size, len(tree['names']), len(tree['roots']), args.max_tokens),
+                       'device': info['name'], 'cus': info['cus'], 'setup_s': t_setup},
+            'roofline': dict(bound='mfma', kernel='gmm_score_split16_kernel<39,2>', achieved=flop / (sc_ms * 1e-3) / 1e12, peak=BF16_MFMA_PEAK_TFLOPS / 3, unit='TFLOP/s',
+                             frac=flop / (sc_ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3), kernel_avg_ms=sc_ms, traffic=None,
+                             note='the scoring half; the decode half is latency / bandwidth bound: see decode'),
+            'decode': dict(kernel='hmm_decode_kernel', kernel_avg_ms=de_ms, token_steps_per_s=float(ntok.sum()) / (de_ms * 1e-3), live_tokens_mean=float(ntok.mean()),
+                           live_tokens_max=int(ntok.max()), utterances_at_the_cap=int(sum(r['overflow'] for r in res)),
+                           approx_bytes_per_token_step=292, approx_gb_per_s=float(ntok.sum()) * 292 / (de_ms * 1e-3) / 1e9,
+                           parity='bit-exact against oracle/decoder_oracle.py (tests/test_gpu_decode.py); PARITY UNPINNED against the reference, whose Decoder.py cannot run'),
+            'cpu_baseline': None}))
+        sys.stdout.flush()
+    ctl.barrier()
+    b.close()
+    ctl.close()
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -235,6 +314,8 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ['POCCALA_HANG_DUMP']), repeat=True, file=sys.stderr)
 
     from poccala_amd import synth
+    if args.workload == 'C5shard':                # BASELINE config 5: all-state scoring + lexicon token-passing decode
+        return bench_decode(args, rank, world, local)
     P_name = args.precision
     cfg = dict(synth.CONFIGS[args.workload])
     if args.utts:

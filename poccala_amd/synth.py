@@ -54,3 +54,32 @@ def make_frames(U, T, D, seed=0, ragged=False):
 def make_labels(U, L, units, seed=2):
     rng = np.random.default_rng(seed)
     return [rng.integers(0, units, size=L) for _ in range(U)]
+
+
+def make_pronunciation_tree(n_words, units_n, seed=55, fixture=None):
+    """A synthetic pronunciation tree for BASELINE config 5 (the reference ships no word list): the words of the golden
+    lexicon fixture plus n_words random strings of 1-4 of its characters, read through the reference's Mandarin.dat rules
+    (poccala_amd.Lexicon), compiled against units_n unit ids.  Returns (tree, lexicon)."""
+    import json
+    import os
+    import tempfile
+    from .Lexicon import PinYin, PronunciationLexicon
+    if fixture is None:
+        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'G13_lexicon.json')
+    g = json.load(open(fixture))
+    with tempfile.NamedTemporaryFile('w', suffix='.dat', delete=False) as f:
+        for k, v in g['table'].items():
+            f.write('%s\t%s\n' % (k, v))
+        tab = f.name
+    try:
+        py = PinYin(tab)
+    finally:
+        os.unlink(tab)
+    chars = sorted({ch for w in g['words'] for ch in w})
+    rng = np.random.default_rng(seed)
+    words = list(g['words']) + [''.join(rng.choice(chars, size=rng.integers(1, 5))) for _ in range(n_words)]
+    lx = PronunciationLexicon()
+    lx.generate_lexicon(words=words, pinyin=py)
+    names = sorted({u for w in words for r in (py.word2pinyin(w) or []) for x in r for u in x.split(',')})
+    names = names[:units_n] + ['pad%d' % i for i in range(max(0, units_n - len(names)))]
+    return lx.compile({u: i for i, u in enumerate(names)}), lx

@@ -15,7 +15,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from poccala_amd import Engine, PCL_F32, synth
-from poccala_amd.Lexicon import PinYin, PronunciationLexicon
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 c = dict(synth.CONFIGS['C5shard'])
@@ -26,20 +25,7 @@ CH = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 CAP = int(sys.argv[5]) if len(sys.argv) > 5 else 2048      # live tokens per utterance (the reference's 15 % rule alone lets the set grow with the tree)
 T, D, units_n = c['T'], c['D'], c['units']
 
-g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'G13_lexicon.json')))
-tab = '/tmp/pcl_c5_mandarin.dat'
-with open(tab, 'w') as f:
-    for k, v in g['table'].items():
-        f.write('%s\t%s\n' % (k, v))
-py = PinYin(tab)
-chars = sorted({ch for w in g['words'] for ch in w})
-rng = np.random.default_rng(55)
-words = list(g['words']) + [''.join(rng.choice(chars, size=rng.integers(1, 5))) for _ in range(NW)]
-lx = PronunciationLexicon()
-lx.generate_lexicon(words=words, pinyin=py)
-names = sorted({u for w in words for r in (py.word2pinyin(w) or []) for x in r for u in x.split(',')})
-names = names[:units_n] + ['pad%d' % i for i in range(max(0, units_n - len(names)))]       # J = 549 states as in config 5
-tree = lx.compile({u: i for i, u in enumerate(names)})
+tree, lx = synth.make_pronunciation_tree(NW, units_n)
 print('tree: %d words -> %d nodes, %d first-character nodes, %d units in use of %d' % (lx.size, len(tree['names']), len(tree['roots']), len(set(tree['node_units'].ravel()) - {-1}), units_n))
 
 mean, var, w, trans = synth.make_model(units_n, M, D)
