@@ -355,7 +355,7 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
 // The same pass loop for sentence HMMs of at most 64 states with at most two predecessors / successors per state (every HMM
 // AcousticModel.embedded builds), on TWO wavefronts: within a pass the forward and the backward recursion do not depend on
 // each other (the reference runs them one after the other, LHMM.py:388-392), so wave 0 runs alpha while wave 1 runs beta --
-// each exchanges its running vector through its own LDS buffer, wave-synchronously, with no workgroup barrier per frame --
+// each keeps its running vector in registers and reads its two neighbours' values with cross-lane reads, no barrier per frame --
 // and what needs both (xi, gamma, the per-frame posteriors of the final pass; LHMM.py:394-405,431-445,486-500) is computed
 // afterwards in parallel over t by both waves with online log-sum-exps that are merged at the end.  The T-long dependent
 // chain is walked 3 times per utterance instead of 6.  log(e^a + e^b) is taken as max + log1p(exp(min - max)): one exp
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                                                      double *__restrict__ gamma_out, double *__restrict__ pi_out, double *__restrict__ logp,
                                                      double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
                                                      double threshold, const double2 *__restrict__ softplus) {
-    __shared__ double vF[2][64], vB[2][64], a0s[64], b0s[64], lpi[64];
+    __shared__ double a0s[64], b0s[64], lpi[64];
     __shared__ double2 sp[SP_N];
     for (int k = threadIdx.x; k < SP_N; k += 128) sp[k] = softplus[k];
     __shared__ double s_q;
@@ -463,8 +463,6 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
     if (w == 0) lpi[i] = act ? logpi_in[d.vec_off + i] : -INFINITY;
     for (long long e = threadIdx.x; e < (long long)N * N; e += 128) ksai[d.mat_off + e] = -INFINITY;   // LHMM.py:404: ln 0 entries
     __syncthreads();
-    // the LDS vectors are exchanged inside ONE wave: its ds_write and the ds_reads after it are executed in order
-#define WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     double q = -INFINITY;
     int npass = 0;
     for (;;) {
@@ -476,38 +474,34 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                 A_[i] = a;
             }
             a0s[i] = a;
-            vF[0][i] = a;
             bnext = (act && T > 1) ? B[(long long)N + i] : 0.0;
-            WAVE_LDS_FENCE();
             for (int t = 1; t < T; ++t) {
-                const double *prev = vF[(t - 1) & 1];
+                // the running vector stays in registers: a lane fetches its two predecessors' values with a cross-lane read
+                // (ds_bpermute) -- no LDS write, fence and read per step of the chain
+                const double p0 = __shfl(a, pidx[0], 64), p1 = __shfl(a, pidx[1], 64);
                 const double bcur = bnext;
                 if (act && t + 1 < T) bnext = B[(long long)(t + 1) * N + i];     // in flight during this step
                 if (act) {
-                    a = lse2_tab(prev[pidx[0]] + pval[0], prev[pidx[1]] + pval[1], sp) + bcur;
+                    a = lse2_tab(p0 + pval[0], p1 + pval[1], sp) + bcur;
                     A_[(long long)t * N + i] = a;
                 }
-                vF[t & 1][i] = a;
-                WAVE_LDS_FENCE();
             }
             const double qn = wave_lse(act ? a : -INFINITY);                     // Q (LHMM.py:412-422, datasize == 1 on this path)
             if (i == 0) s_q = qn;
         } else {
             // ---------------------------------------------------------------- backward (LHMM.py:353-366); beta_{T-1} = 0 (quirk Q8)
             if (act) Bv[(long long)(T - 1) * N + i] = 0.0;
-            vB[(T - 1) & 1][i] = act ? B[(long long)(T - 1) * N + i] + 0.0 : -INFINITY;      // w_j = b_j(o_{t+1}) + beta_{t+1}(j)
+            double wv = act ? B[(long long)(T - 1) * N + i] + 0.0 : -INFINITY;                // w_j = b_j(o_{t+1}) + beta_{t+1}(j)
             double b_t = (act && T > 1) ? B[(long long)(T - 2) * N + i] : 0.0, bcur = 0.0;
-            WAVE_LDS_FENCE();
             for (int t = T - 2; t >= 0; --t) {
-                const double *nxt = vB[(t + 1) & 1];
+                const double n0 = __shfl(wv, sidx[0], 64), n1 = __shfl(wv, sidx[1], 64);
                 const double bt = b_t;
                 if (act && t > 0) b_t = B[(long long)(t - 1) * N + i];
                 if (act) {
-                    bcur = lse2_tab(sval[0] + nxt[sidx[0]], sval[1] + nxt[sidx[1]], sp);
+                    bcur = lse2_tab(sval[0] + n0, sval[1] + n1, sp);
                     Bv[(long long)t * N + i] = bcur;
                 }
-                vB[t & 1][i] = act ? bt + bcur : -INFINITY;
-                WAVE_LDS_FENCE();
+                wv = act ? bt + bcur : -INFINITY;
             }
             b0s[i] = (T > 1) ? bcur : 0.0;
         }
@@ -608,7 +602,6 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
         q = qnew;
         __syncthreads();
     }
-#undef WAVE_LDS_FENCE
 }
 
 // ------------------------------------------------------------------------------------------------
