@@ -36,6 +36,8 @@ restated line by line; where the source cannot run, the gap is filled with the s
              keeps its recursion and takes the score if it is STRICTLY better (:126-134), several donors -> the best,
              the earliest on ties; (3) finished tokens are deleted; (4) pruning over the tokens that were alive before
              the frame (new ones are exempt, as in the source where they are not in score_list).
+  capacity   (not in the source) the device holds at most max_tokens live tokens per utterance: a creation that would exceed
+             it is dropped and reported (info['overflow']); at frame 0 only the first max_tokens first-character nodes start.
 """
 import numpy as np
 
@@ -101,6 +103,10 @@ def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5,
     tokens = []                                                                # live tokens in creation order
     history = []
     for r in roots:                                                            # D3
+        if max_tokens is not None and len(tokens) >= max_tokens:               # device capacity: the first max_tokens first-character
+            if info is not None:                                               # nodes start, the rest is reported as overflow
+                info['overflow'] = True
+            break
         tok = Token(0.0, r, units_of[r], unit_trans, s)
         tok.hist = -1
         tok.viterbi(emission_column(tok.units, b_all, 0, s))

@@ -52,7 +52,7 @@ def model_for(units, M, D, seed, dense=False):
     return mean, var, w, np.stack(trans)
 
 
-@pytest.mark.parametrize('dense,beam,cap', [(False, 0.85, 4096), (True, 0.85, 4096), (False, 1.0, 4096), (False, 0.5, 4096), (False, 0.85, 230)])
+@pytest.mark.parametrize('dense,beam,cap', [(False, 0.85, 4096), (True, 0.85, 4096), (False, 1.0, 4096), (False, 0.5, 4096), (False, 0.85, 230), (True, 0.7, 5)])
 def test_decode_matches_cpu_restatement_bit_for_bit(eng, lex, dense, beam, cap):
     from poccala_amd import PCL_F64, synth
     lx, units, tree = lex
