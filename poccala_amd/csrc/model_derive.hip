@@ -17,53 +17,112 @@ namespace {
 
 constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
 
-// one workgroup per state: centre c_j[d] = (float) mean_m mu[j,m,d]
-__global__ void centers_kernel(const double *__restrict__ mean64, int M, int Mpad, int D, float *__restrict__ centers) {
-    const int j = blockIdx.x;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        double s = 0.0;
-        for (int m = 0; m < M; ++m) s += mean64[((size_t)j * Mpad + m) * D + d];
-        centers[(size_t)j * D + d] = (float)(s / M);
-    }
-}
-
-// one workgroup per state: exact power-of-two scale of every feature of the split-f16 layout (gmm_score_split.hip):
-// fscale[j][h][d] = 2^e with e = floor(log2 max_m |coef_m,h,d|), coef = -log2e/(2 var) (h = 0) or log2e (mu - c)/var
-// (h = 1), so that the scaled coefficients fill [1, 2) and the frame features carry the range
-__global__ void fscale_kernel(const double *__restrict__ mean64, const double *__restrict__ var64, const float *__restrict__ centers,
-                              int M, int Mpad, int D, int Dhost, int KS8, float *__restrict__ fscale) {
-    const int j = blockIdx.x;
-    for (int t = threadIdx.x; t < 2 * KS8 * 8; t += blockDim.x) {
-        const int h = t / (KS8 * 8), d = t % (KS8 * 8);
-        double mx = 0.0;
-        if (d < Dhost) {
-            const double c = (double)centers[(size_t)j * D + d];
-            for (int m = 0; m < M; ++m) {
-                const size_t o = ((size_t)j * Mpad + m) * D + d;
-                const double var = var64[o], coef = h ? LOG2E * (mean64[o] - c) / var : LOG2E / (2.0 * var);
-                mx = fmax(mx, fabs(coef));
-            }
-        }
-        int ex = 1;
-        if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)
-        ex = min(max(ex - 1, -60), 60);
-        fscale[((size_t)j * 2 + h) * (KS8 * 8) + d] = (float)ldexp(1.0, ex);
-    }
-}
-
-// K0_j = max_m k'_m (log2 units) of the centred expansion, for the folded-constant layout (gmm_score_split.hip variant 7
-// keeps k'_m - K0_j in two f16 pieces and adds K0_j back in f64).  A first, write-free pass of derive_kernel
-// (PCL_LAYOUT_KZERO) takes the maximum with an integer atomicMax on order-preserving float bits; this turns them back.
 __device__ __forceinline__ int ordered_bits(float f) {
     const int i = __float_as_int(f);
     return i >= 0 ? i : i ^ 0x7fffffff;
 }
-__global__ void kzero_finish_kernel(const int *__restrict__ bits, int J, double *__restrict__ kzero) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= J) return;
-    const int i = bits[j];
-    const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
-    kzero[j] = (i == (int)0x80000000 || !(f > -3.0e38f)) ? 0.0 : (double)f;      // no real mixture at all: anything
+
+// One workgroup per state, one visit: what the layouts need to know about a state as a whole before any of them can be
+// written -- its expansion centre c_j[d] = (float) mean_m mu[j,m,d]; the exact power-of-two scale of every feature of the
+// split-f16 layout (gmm_score_split.hip): fscale[j][h][d] = 2^e, e = floor(log2 max_m |coef_m,h,d|), coef = -log2e/(2 var)
+// (h = 0) or log2e (mu - c)/var (h = 1), so that the scaled coefficients fill [1, 2) and the frame features carry the range;
+// and K0_j = max_m k'_m (log2 units) of the centred expansion, which the folded-constant layout keeps k'_m relative to
+// (k'_m - K0_j in two f16 pieces, K0_j added back in f64).  Two phases over the state's 1.3 MB (the second finds them in L2):
+//   (A) centres: thread = (row group r, dimension d), blockDim = D x R threads read R whole rows per step, contiguously;
+//   (B) 8 lanes per mixture, 64 mixtures per step, the per-mixture sums in derive_kernel's order (so k'_m has its bits).
+// (Round 1 did this with three launches of 39..128 busy threads per state and a write-free pass of derive_kernel: 5.0 ms.)
+constexpr int PRE_T = 512;
+__global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
+                                                             const double *__restrict__ w64, int M, int Mpad, int D, int Dhost, int KS8,
+                                                             int flags, float *__restrict__ centers, float *__restrict__ fscale,
+                                                             double *__restrict__ kzero) {
+    __shared__ double part[64 * 40];
+    __shared__ float cen[64];
+    __shared__ unsigned long long fbits[2][64];
+    __shared__ int kbits;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const double *mu = mean64 + (size_t)j * Mpad * D, *vr = var64 + (size_t)j * Mpad * D;
+    // ---- (A)
+    const int R = min(PRE_T / D, 40), d = tid % D, r = tid / D;
+    if (r < R) {
+        double s = 0.0;
+        for (int m = r; m < M; m += R) s += mu[(size_t)m * D + d];
+        part[r * 64 + d] = s;
+    }
+    if (tid < 128) fbits[tid >> 6][tid & 63] = 0ull;
+    if (tid == 0) kbits = (int)0x80808080;                       // below every real value
+    __syncthreads();
+    if (tid < D) {
+        double s = 0.0;
+        for (int q = 0; q < R; ++q) s += part[q * 64 + tid];
+        const float c = (float)(s / M);
+        centers[(size_t)j * D + tid] = c;
+        cen[tid] = c;
+    }
+    __syncthreads();
+    // ---- (B)
+    const int ml = tid >> 3, sub = tid & 7;
+    double mx0[8], mx1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mx0[k] = mx1[k] = 0.0;
+    float kmax = -INFINITY;
+    bool any = false;
+    for (int m0 = 0; m0 < M; m0 += PRE_T / 8) {
+        const int m = m0 + ml;
+        const bool real_m = m < M;
+        double sumvar = 0.0, sumlog = 0.0, kq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dd = sub + 8 * k;
+            if (dd < D && dd < Dhost && real_m) {
+                const double v = vr[(size_t)m * D + dd], dm = mu[(size_t)m * D + dd] - (double)cen[dd];
+                sumvar += v;
+                if (flags & PCL_MODEL_LOGDET) sumlog += log(v);
+                kq += dm * dm / (2.0 * v);
+                mx0[k] = fmax(mx0[k], LOG2E / (2.0 * v));
+                mx1[k] = fmax(mx1[k], fabs(LOG2E * dm / v));
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            sumvar += __shfl_xor(sumvar, o, 64);
+            sumlog += __shfl_xor(sumlog, o, 64);
+            kq += __shfl_xor(kq, o, 64);
+        }
+        if (sub == 0 && real_m) {
+            // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var); textbook log-determinant only on request
+            const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
+            const double k2 = LOG2E * (log(w64[(size_t)j * Mpad + m]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
+            if (k2 > -INFINITY) {
+                const float kp = (float)(k2 - LOG2E * kq);
+                kmax = any ? fmaxf(kmax, kp) : kp;
+                any = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dd = sub + 8 * k;                              // (non-negative doubles order like their bit patterns)
+        if (dd < D) {
+            atomicMax(&fbits[0][dd], (unsigned long long)__double_as_longlong(mx0[k]));
+            atomicMax(&fbits[1][dd], (unsigned long long)__double_as_longlong(mx1[k]));
+        }
+    }
+    if (any) atomicMax(&kbits, ordered_bits(kmax));
+    __syncthreads();
+    for (int t = tid; t < 2 * KS8 * 8; t += PRE_T) {
+        const int h = t / (KS8 * 8), dd = t % (KS8 * 8);
+        const double mx = (dd < Dhost && dd < 64) ? __longlong_as_double((long long)fbits[h][dd]) : 0.0;
+        int ex = 1;
+        if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)
+        ex = min(max(ex - 1, -60), 60);
+        fscale[((size_t)j * 2 + h) * (KS8 * 8) + dd] = (float)ldexp(1.0, ex);
+    }
+    if (tid == 0) {
+        const int i = kbits;
+        const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
+        kzero[j] = (i == (int)0x80808080 || !(f > -3.0e38f)) ? 0.0 : (double)f;      // no real mixture at all: anything
+    }
 }
 
 // one workgroup per (state, 32-mixture tile): the tile's mean/var rows are staged in LDS with coalesced
@@ -74,7 +133,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      float *__restrict__ params32, double *__restrict__ params64,
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
                                                      uint4 *__restrict__ pm16f,
-                                                     const double *__restrict__ kzero, int *__restrict__ kz_bits,
+                                                     const double *__restrict__ kzero,
                                                      const float *__restrict__ fscale, float *__restrict__ cond, int what) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
@@ -126,7 +185,6 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             }
             k2s[ml] = k2;
             kqs[ml] = LOG2E * kq;
-            if ((what & PCL_LAYOUT_KZERO) && real_m && k2 > -INFINITY) atomicMax(kz_bits + j, ordered_bits((float)(k2 - LOG2E * kq)));
             // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats
             // order like their bit patterns, so an integer atomicMax works)
             if (real_m && (what & PCL_LAYOUT_COND)) {
@@ -139,7 +197,6 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         }
     }
     __syncthreads();
-    if (what == PCL_LAYOUT_KZERO) return;
     // VALU scoring rows [s_d c_d ... k2 pad] and the f32 means (only mixtures inside the Mpad grid)
     const bool w32 = what & PCL_LAYOUT_P32, wr64 = what & PCL_LAYOUT_P64;
     if (w32 || wr64)
@@ -290,24 +347,17 @@ static int launch_derive_kernel(pcl_ctx *ctx, int what) {
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16f),
-                       ctx->kzero, ctx->kz_bits, ctx->fscale, ctx->d_cond, what);
+                       ctx->kzero, ctx->fscale, ctx->d_cond, what);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }
 
 int pcl_launch_derive(pcl_ctx *ctx) {
-    hipLaunchKernelGGL(centers_kernel, dim3(ctx->J), dim3(64), 0, ctx->stream, ctx->mean64, ctx->M, ctx->Mpad, ctx->D, ctx->centers32);
     const int KS8f = (ctx->D + 7) / 8;
-    hipLaunchKernelGGL(fscale_kernel, dim3(ctx->J), dim3(128), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->centers32, ctx->M, ctx->Mpad,
-                       ctx->D, ctx->Dhost, KS8f, ctx->fscale);
+    hipLaunchKernelGGL(state_prepass_kernel, dim3(ctx->J), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
+                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     const int what = eager_layouts(ctx);
-    if (what & PCL_LAYOUT_PM16F) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->kz_bits, 0x80, (size_t)ctx->J * sizeof(int), ctx->stream));      // 0x80808080: below every real value
-        const int rk = launch_derive_kernel(ctx, PCL_LAYOUT_KZERO);
-        if (rk != PCL_OK) return rk;
-        hipLaunchKernelGGL(kzero_finish_kernel, dim3((ctx->J + 255) / 256), dim3(256), 0, ctx->stream, ctx->kz_bits, ctx->J, ctx->kzero);
-    }
     const int rc = launch_derive_kernel(ctx, what);
     if (rc != PCL_OK) return rc;
     ctx->layouts_valid = what;

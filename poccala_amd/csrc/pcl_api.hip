@@ -92,7 +92,6 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->pm32);
     dev_free(ctx->pm16f);
     dev_free(ctx->kzero);
-    dev_free(ctx->kz_bits);
     dev_free(ctx->fscale);
     dev_free(ctx->centers32);
     dev_free(ctx->d_cond);
@@ -242,7 +241,6 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->pm32, npm));
     TRY(dev_alloc(ctx, &ctx->pm16f, (size_t)J * (Mp32 / 32) * 2 * ((Dd + 7) / 8) * 64 * 8));
     TRY(dev_alloc(ctx, &ctx->kzero, (size_t)J));
-    TRY(dev_alloc(ctx, &ctx->kz_bits, (size_t)J));
     TRY(dev_alloc(ctx, &ctx->fscale, (size_t)J * 2 * ((Dd + 7) / 8) * 8));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));

@@ -66,7 +66,6 @@ struct pcl_ctx {
     float *pm32 = nullptr;       // MFMA scoring layout: [J][Mpad32/32][KS4][64 lanes][4], see gmm_score_mfma.hip
     float *centers32 = nullptr;  // J * D per-state expansion centres c_j
     unsigned short *pm16f = nullptr;  // split-f16 layout with the constants folded into the spare K slot: [J][Mpad32/32][2][KS8f][64 lanes][8], see gmm_score_split.hip
-    int *kz_bits = nullptr;           // [J] scratch of the K0 reduction (order-preserving float bits)
     double *kzero = nullptr;          // [J] K0_j = max_m k'_m of that layout
     float *fscale = nullptr;          // [J][2][KS8f*8] power-of-two feature scales of that layout
     int Mpad32 = 0;              // M rounded up to a multiple of 32
@@ -259,7 +258,7 @@ int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);
 int pcl_ensure_layouts(pcl_ctx *ctx, int need);
-enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_COND = 32, PCL_LAYOUT_PM16F = 128, PCL_LAYOUT_KZERO = 256 };
+enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_COND = 32, PCL_LAYOUT_PM16F = 128 };
 inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) { return !ctx->cond.empty() && ctx->cond[j] > ctx->cond_max; }
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
