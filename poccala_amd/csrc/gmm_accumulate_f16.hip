@@ -461,6 +461,9 @@ __global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kerne
 #endif
             load_cf(t + 2, d1);                                  // (the posteriors of tile t have been read out of d1)
             load1(t + 2, a1, a2);
+#ifdef PCL_ACC16_IGLP
+            __builtin_amdgcn_iglp_opt(PCL_ACC16_IGLP);
+#endif
         }
 #ifdef PCL_ACC16_STAMPS
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
