@@ -65,9 +65,10 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
       copy stream    frames of chunk k+1 travel into the frame slot that is not being scored (Engine.stage_frames)
       main stream    every GMM state x every frame of chunk k is scored
       second stream  chunk k-1 is decoded (token passing), its results come down
-    and the host packs chunk k+1 into page-locked memory meanwhile.  Batches are kept per chunk shape (the lengths of its
-    utterances) and reused alternately, so a stream of equal-shaped chunks allocates nothing after the second one; a new
-    shape costs one batch creation, which waits for the device."""
+    and the host packs chunk k+1 into page-locked memory meanwhile.  Batches are kept for the last few chunk shapes (the
+    lengths of a chunk's utterances) and reused alternately; a new shape costs a batch creation, which takes its buffers from
+    the library's device-memory pool and copies its descriptors on the main stream -- it does not wait for the decoder
+    running on the second stream."""
     engine = engine or default_engine()
     bm = beam if beam_ is None else beam_
     pool, pinned = {}, [None]
@@ -83,9 +84,15 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
         engine.stage_frames(view)
         return lens, begin
 
-    def batch_for(lens, begin, k):
+    def batch_for(lens, begin, k, busy):
         key = lens.tobytes()
-        pair = pool.setdefault(key, [None, None])
+        pair = pool.pop(key, None) or [None, None]
+        pool[key] = pair                                           # (most recently used last)
+        for old in [q for q in pool if q != key][:max(0, len(pool) - 4)]:
+            if not any(x is busy for x in pool[old] if x is not None):      # never the batch whose decoder is still running
+                for x in pool.pop(old):
+                    if x is not None:
+                        x.close()
         if pair[k & 1] is None:
             pair[k & 1] = engine.all_state_batch(lens, begin)
         return pair[k & 1]
@@ -99,7 +106,7 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
         prev, k = None, 0
         while nxt is not None:
             engine.swap_frames()                                   # chunk k is the current frame matrix
-            b = batch_for(layout[0], layout[1], k)
+            b = batch_for(layout[0], layout[1], k, prev)
             b.score(precision)
             nxt = next(it, None)
             if nxt is not None:

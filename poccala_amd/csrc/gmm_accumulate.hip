@@ -535,17 +535,17 @@ bool device_dim_supported(int D) { return D == 13 || D == 26 || D == 39 || D == 
 }  // namespace
 
 void pcl_accumulate_release(pcl_batch *b) {
-    if (b->acc_cnt) (void)hipFree(b->acc_cnt);
-    if (b->acc_off) (void)hipFree(b->acc_off);
-    if (b->acc_list) (void)hipFree(b->acc_list);
-    if (b->d_work_states) (void)hipFree(b->d_work_states);
-    if (b->d_seg_lo) (void)hipFree(b->d_seg_lo);
-    if (b->d_seg_hi) (void)hipFree(b->d_seg_hi);
+    dev_free(b->acc_cnt);
+    dev_free(b->acc_off);
+    dev_free(b->acc_list);
+    dev_free(b->d_work_states);
+    dev_free(b->d_seg_lo);
+    dev_free(b->d_seg_hi);
     for (int k = 0; k < 2; ++k) {
-        if (b->acc16_images[k]) (void)hipFree(b->acc16_images[k]);
-        if (b->acc16_tile_off[k]) (void)hipFree(b->acc16_tile_off[k]);
-        if (b->acc16_tile_mask[k]) (void)hipFree(b->acc16_tile_mask[k]);
-        if (b->acc16_state_flag[k]) (void)hipFree(b->acc16_state_flag[k]);
+        dev_free(b->acc16_images[k]);
+        dev_free(b->acc16_tile_off[k]);
+        dev_free(b->acc16_tile_mask[k]);
+        dev_free(b->acc16_state_flag[k]);
         if (b->acc16_ev_prod[k]) (void)hipEventDestroy(b->acc16_ev_prod[k]);
         if (b->acc16_ev_cons[k]) (void)hipEventDestroy(b->acc16_ev_cons[k]);
         b->acc16_images[k] = nullptr; b->acc16_tile_off[k] = nullptr; b->acc16_tile_mask[k] = nullptr; b->acc16_state_flag[k] = nullptr;
@@ -567,28 +567,28 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         cap += (size_t)last.vstart + last.len;
     }
     if (b->acc_cap_segs < (size_t)b->n_segs + 1) {
-        if (b->acc_cnt) (void)hipFree(b->acc_cnt);
-        if (b->acc_off) (void)hipFree(b->acc_off);
+        dev_free(b->acc_cnt);
+        dev_free(b->acc_off);
         b->acc_cnt = nullptr; b->acc_off = nullptr;
-        HIPCHK(ctx, hipMalloc((void **)&b->acc_cnt, ((size_t)b->n_segs + 1) * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void **)&b->acc_off, ((size_t)b->n_segs + 1) * sizeof(long long)));
+        TRY(dev_alloc(ctx, &b->acc_cnt, (size_t)(((size_t)b->n_segs + 1))));
+        TRY(dev_alloc(ctx, &b->acc_off, (size_t)b->n_segs + 1));
         b->acc_cap_segs = (size_t)b->n_segs + 1;
     }
     if (b->acc_cap_list < cap) {
-        if (b->acc_list) (void)hipFree(b->acc_list);
+        dev_free(b->acc_list);
         b->acc_list = nullptr;
-        HIPCHK(ctx, hipMalloc((void **)&b->acc_list, cap * sizeof(ActiveFrame)));
+        TRY(dev_alloc(ctx, &b->acc_list, (size_t)(cap)));
         b->acc_cap_list = cap;
     }
     const size_t ns = b->work_states.size();
     if (b->acc_cap_states < ns) {
-        if (b->d_work_states) (void)hipFree(b->d_work_states);
-        if (b->d_seg_lo) (void)hipFree(b->d_seg_lo);
-        if (b->d_seg_hi) (void)hipFree(b->d_seg_hi);
+        dev_free(b->d_work_states);
+        dev_free(b->d_seg_lo);
+        dev_free(b->d_seg_hi);
         b->d_work_states = b->d_seg_lo = b->d_seg_hi = nullptr;
-        HIPCHK(ctx, hipMalloc((void **)&b->d_work_states, ns * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void **)&b->d_seg_lo, ns * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void **)&b->d_seg_hi, ns * sizeof(int)));
+        TRY(dev_alloc(ctx, &b->d_work_states, (size_t)(ns)));
+        TRY(dev_alloc(ctx, &b->d_seg_lo, (size_t)(ns)));
+        TRY(dev_alloc(ctx, &b->d_seg_hi, (size_t)(ns)));
         b->acc_cap_states = ns;
     }
     // MFMA mode: well-conditioned states first (MFMA kernel), then the ill-conditioned ones (direct-form VALU kernel)
@@ -647,21 +647,22 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         else cap_tiles = std::max(cap_tiles, std::min(cap_tiles + cap_tiles / 4, std::max(by_budget, biggest)));   // grow with headroom
         if (b->acc16_cap_tiles < cap_tiles) {
             for (int k = 0; k < 2; ++k) {
-                if (b->acc16_images[k]) (void)hipFree(b->acc16_images[k]);
-                if (b->acc16_tile_mask[k]) (void)hipFree(b->acc16_tile_mask[k]);
+                dev_free(b->acc16_images[k]);
+                dev_free(b->acc16_tile_mask[k]);
                 b->acc16_images[k] = nullptr; b->acc16_tile_mask[k] = nullptr;
-                HIPCHK(ctx, hipMalloc(&b->acc16_images[k], cap_tiles * ib));
-                HIPCHK(ctx, hipMalloc((void **)&b->acc16_tile_mask[k], cap_tiles * sizeof(unsigned int)));
+                b->acc16_images[k] = pcl_pool_alloc(ctx->device, cap_tiles * ib);
+                if (!b->acc16_images[k]) PCL_FAIL(ctx, PCL_ERR_NOMEM, "device memory: %zu bytes of tile images", cap_tiles * ib);
+                TRY(dev_alloc(ctx, &b->acc16_tile_mask[k], cap_tiles));
             }
             b->acc16_cap_tiles = cap_tiles;
         }
         if (b->acc16_cap_states < (size_t)n_good + 1) {
             for (int k = 0; k < 2; ++k) {
-                if (b->acc16_tile_off[k]) (void)hipFree(b->acc16_tile_off[k]);
-                if (b->acc16_state_flag[k]) (void)hipFree(b->acc16_state_flag[k]);
+                dev_free(b->acc16_tile_off[k]);
+                dev_free(b->acc16_state_flag[k]);
                 b->acc16_tile_off[k] = b->acc16_state_flag[k] = nullptr;
-                HIPCHK(ctx, hipMalloc((void **)&b->acc16_tile_off[k], ((size_t)n_good + 1) * sizeof(int)));
-                HIPCHK(ctx, hipMalloc((void **)&b->acc16_state_flag[k], ((size_t)n_good + 1) * sizeof(int)));
+                TRY(dev_alloc(ctx, &b->acc16_tile_off[k], (size_t)(((size_t)n_good + 1))));
+                TRY(dev_alloc(ctx, &b->acc16_state_flag[k], (size_t)(((size_t)n_good + 1))));
             }
             b->acc16_cap_states = (size_t)n_good + 1;
         }

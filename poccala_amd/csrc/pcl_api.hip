@@ -8,6 +8,10 @@
 
 #include <algorithm>
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 #include "pcl_internal.h"
 
 static std::string g_init_error;
@@ -41,6 +45,84 @@ static void drop_timers(pcl_ctx *ctx) {
         }
         kv.second.ev.clear();
     }
+}
+
+// ================================================================ device memory pool
+// Size classes: powers of two up to 1 MiB, eighths of a power of two above (a block wastes < 12.5 %), so that batches of
+// similar shape -- the chunks of a ragged stream, the one-utterance batches of the drop-in classes -- reuse each other's
+// blocks.  The cache is trimmed (largest blocks first) when it exceeds PCL_POOL_MAX_MB (default 65536), and released
+// altogether before an allocation is reported as failed.
+thread_local int pcl_tls_free_synced = 0;
+namespace {
+struct PoolBlock { size_t bytes; int device; };
+std::mutex g_pool_mu;
+std::unordered_map<void *, PoolBlock> g_pool_live;                 // every block handed out or cached
+std::multimap<std::pair<int, size_t>, void *> g_pool_free;           // (device, class bytes) -> cached block
+size_t g_pool_cached = 0;
+size_t pool_class(size_t n) {
+    if (n <= 256) return 256;
+    size_t p2 = 256;
+    while (p2 < n) p2 <<= 1;
+    if (p2 <= (1u << 20)) return p2;
+    const size_t step = p2 >> 4;                                    // eighths of the lower power of two
+    return (n + step - 1) / step * step;
+}
+size_t pool_limit() {
+    static const size_t lim = (size_t)(getenv("PCL_POOL_MAX_MB") ? atol(getenv("PCL_POOL_MAX_MB")) : 65536) << 20;
+    return lim;
+}
+void pool_release_locked(size_t keep) {                              // hipFree cached blocks, largest first, down to `keep` bytes
+    while (g_pool_cached > keep && !g_pool_free.empty()) {
+        auto best = g_pool_free.begin();
+        for (auto it = g_pool_free.begin(); it != g_pool_free.end(); ++it)
+            if (it->first.second > best->first.second) best = it;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != best->first.first) (void)hipSetDevice(best->first.first);
+        (void)hipFree(best->second);
+        if (cur != best->first.first) (void)hipSetDevice(cur);
+        g_pool_cached -= best->first.second;
+        g_pool_live.erase(best->second);
+        g_pool_free.erase(best);
+    }
+}
+}  // namespace
+
+void *pcl_pool_alloc(int device, size_t bytes) {
+    const size_t cls = pool_class(bytes);
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto it = g_pool_free.find(std::make_pair(device, cls));
+    if (it != g_pool_free.end()) {
+        void *p = it->second;
+        g_pool_free.erase(it);
+        g_pool_cached -= cls;
+        return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, cls) != hipSuccess) {
+        (void)hipGetLastError();
+        pool_release_locked(0);                                      // give the cache back and try once more
+        if (hipMalloc(&p, cls) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    g_pool_live[p] = PoolBlock{cls, device};
+    return p;
+}
+
+void pcl_pool_free(void *p) {
+    if (!p) return;
+    if (pcl_tls_free_synced <= 0) (void)hipDeviceSynchronize();     // what hipFree did: nobody on the device still uses the block
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) {                                   // not ours (never happens): the runtime's problem
+        (void)hipFree(p);
+        return;
+    }
+    g_pool_free.emplace(std::make_pair(it->second.device, it->second.bytes), p);
+    g_pool_cached += it->second.bytes;
+    if (g_pool_cached > pool_limit()) pool_release_locked(pool_limit() / 2);
 }
 
 extern "C" {
@@ -424,9 +506,12 @@ int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, co
 int pcl_batch_destroy(pcl_batch *b) {
     if (!b) return PCL_OK;
     hipSetDevice(b->ctx->device);
+    // the GPU must be done with THIS batch: everything on the main and the copy stream, and on the second stream what the batch
+    // itself queued there and nobody has joined yet -- not another batch's recursion or decoder that is still running there
     hipStreamSynchronize(b->ctx->stream);
-    hipStreamSynchronize(b->ctx->stream_dp);
     hipStreamSynchronize(b->ctx->stream_aux);
+    if (b->dp_pending && b->ev_dp) hipEventSynchronize(b->ev_dp);
+    pcl_free_synced_scope done;                              // the frees below skip their device-wide wait
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
     pcl_accumulate_release(b);
@@ -463,16 +548,16 @@ int pcl_batch_upload_sparse(pcl_batch *b, const std::vector<int> &row_ptr, const
     TRY(dev_alloc(ctx, &b->csc_val, nz));
     TRY(dev_alloc(ctx, &b->xi_m, nz));
     TRY(dev_alloc(ctx, &b->xi_s, nz));
-    HIPCHK(ctx, hipMemcpy(b->row_ptr, row_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(b->col_ptr, col_ptr.data(), np * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, pcl_h2d(ctx, b->row_ptr, row_ptr.data(), np * sizeof(int)));
+    HIPCHK(ctx, pcl_h2d(ctx, b->col_ptr, col_ptr.data(), np * sizeof(int)));
     if (nz) {
-        HIPCHK(ctx, hipMemcpy(b->col_idx, col_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(b->row_idx, row_idx.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(b->csr_val, csr_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(b->csc_val, csc_val.data(), nz * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(ctx, pcl_h2d(ctx, b->col_idx, col_idx.data(), nz * sizeof(int)));
+        HIPCHK(ctx, pcl_h2d(ctx, b->row_idx, row_idx.data(), nz * sizeof(int)));
+        HIPCHK(ctx, pcl_h2d(ctx, b->csr_val, csr_val.data(), nz * sizeof(double)));
+        HIPCHK(ctx, pcl_h2d(ctx, b->csc_val, csc_val.data(), nz * sizeof(double)));
     }
-    HIPCHK(ctx, hipMemcpy(b->logpi, logpi, (size_t)b->sumN * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    HIPCHK(ctx, pcl_h2d(ctx, b->logpi, logpi, (size_t)b->sumN * sizeof(double)));
+    HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     b->have_trans = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;
@@ -590,9 +675,9 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     dev_free(b->d_tiles_v);
     b->tile_frames = 0;
     TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
-    if (b->n_segs) HIPCHK(ctx, hipMemcpy(b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    if (b->n_segs) HIPCHK(ctx, pcl_h2d(ctx, b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg)));
+    HIPCHK(ctx, pcl_h2d(ctx, b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t)));
+    HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     b->have_states = true;
     b->max_state = max_state;
     b->model_J = ctx->J;
@@ -625,7 +710,7 @@ int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
     if (!B) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_emissions: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(ensure_tmp(b));
-    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     HIPCHK(ctx, hipMemcpyAsync(b->tmp, B, (size_t)b->sumNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(pcl_launch_transpose(ctx, b, b->tmp, b->Bt, 1));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -642,7 +727,7 @@ int pcl_batch_set_posteriors(pcl_batch *b, const double *lgamma) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(ensure_tmp(b));
     if (!b->lgam) TRY(dev_alloc(ctx, &b->lgam, (size_t)b->sumNT));
-    HIPCHK(ctx, hipMemcpy(b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc), hipMemcpyHostToDevice));
+    HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     HIPCHK(ctx, hipMemcpyAsync(b->tmp, lgamma, (size_t)b->sumNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(pcl_launch_transpose(ctx, b, b->tmp, b->lgam, 1));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -707,10 +792,10 @@ static int build_tiles(pcl_batch *b, int precision) {
     b->tile_frames = tf;
     b->tile_gen = ctx->model_gen;
     TRY(dev_alloc(ctx, &b->d_tiles, tiles.size()));
-    if (!tiles.empty()) HIPCHK(ctx, hipMemcpy(b->d_tiles, tiles.data(), tiles.size() * sizeof(ScoreTile), hipMemcpyHostToDevice));
+    if (!tiles.empty()) HIPCHK(ctx, pcl_h2d(ctx, b->d_tiles, tiles.data(), tiles.size() * sizeof(ScoreTile)));
     if (!tiles_v.empty()) {
         TRY(dev_alloc(ctx, &b->d_tiles_v, tiles_v.size()));
-        HIPCHK(ctx, hipMemcpy(b->d_tiles_v, tiles_v.data(), tiles_v.size() * sizeof(ScoreTile), hipMemcpyHostToDevice));
+        HIPCHK(ctx, pcl_h2d(ctx, b->d_tiles_v, tiles_v.data(), tiles_v.size() * sizeof(ScoreTile)));
     }
     return PCL_OK;
 }

@@ -207,24 +207,43 @@ struct pcl_batch {
 
 void pcl_set_error(pcl_ctx *ctx, const char *msg);
 
+// Device memory comes from a process-wide caching pool (pcl_api.hip): hipMalloc / hipFree cost 0.1-1 ms each and hipFree
+// waits for the whole device, which a library that creates and drops a batch per utterance (the drop-in classes) or per
+// chunk (streaming) cannot afford.  A freed block goes back to the pool; dev_free first waits for the device, as hipFree
+// did, unless the caller has already made sure the GPU is done with the block (pcl_free_synced_scope).
+void *pcl_pool_alloc(int device, size_t bytes);           // nullptr: out of memory even after the cache was released
+void pcl_pool_free(void *p);
+extern thread_local int pcl_tls_free_synced;              // > 0: dev_free skips its device-wide wait
+struct pcl_free_synced_scope {
+    pcl_free_synced_scope() { ++pcl_tls_free_synced; }
+    ~pcl_free_synced_scope() { --pcl_tls_free_synced; }
+};
 template <typename T>
 static inline int dev_alloc(pcl_ctx *ctx, T **p, size_t n) {
-    *p = nullptr;
     if (n == 0) n = 1;
-    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
-    if (e != hipSuccess) PCL_FAIL(ctx, PCL_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    *p = static_cast<T *>(pcl_pool_alloc(ctx->device, n * sizeof(T)));
+    if (!*p) PCL_FAIL(ctx, PCL_ERR_NOMEM, "device memory: %zu bytes", n * sizeof(T));
     return PCL_OK;
 }
 template <typename T>
 static inline void dev_free(T *&p) {
-    if (p) (void)hipFree(p);
+    if (p) pcl_pool_free((void *)p);
     p = nullptr;
 }
+// Host -> device copy on the context's main stream, complete on return: unlike hipMemcpy (legacy null stream) it does not
+// wait for the work of the other streams (a decoder running on the second stream while the next chunk's batch is built).
+static inline hipError_t pcl_h2d(pcl_ctx *ctx, void *dst, const void *src, size_t bytes);
 #define TRY(x)                    \
     do {                          \
         int _r = (x);             \
         if (_r != PCL_OK) return _r; \
     } while (0)
+
+static inline hipError_t pcl_h2d(pcl_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
 
 // shared by pcl_api.hip and hmm_units.hip (C linkage, internal)
 extern "C" {

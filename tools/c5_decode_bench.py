@@ -87,5 +87,22 @@ for ch in chunks:
     t_h2d += t2 - t1; t_sc += t4 - t3; t_de += t5 - t4
 print('the same chunks with the legs back to back: H2D %.1f ms + score %.1f ms + decode incl. results D2H %.1f ms = %.3f M frames/s per GPU'
       % (t_h2d * 1e3, t_sc * 1e3, t_de * 1e3, U * T / (t_h2d + t_sc + t_de) / 1e6))
+# a ragged stream: every utterance a different length, so every chunk is a new shape -- a batch is created (and an old one dropped)
+# per chunk, out of the device-memory pool, while the previous chunk's decoder runs
+rl = np.random.default_rng(77).integers(150, T + 1, size=U)
+rchunks = [[frames[begin[u]:begin[u] + rl[u]] for u in range(k * per, min(U, (k + 1) * per))] for k in range(CH)]
+rchunks = [c_ for c_ in rchunks if c_]
+for rep in range(2):
+    t0 = time.perf_counter()
+    routs = list(Decoder.decode_stream(iter(rchunks), tree, engine=eng, precision=PCL_F32, max_tokens=CAP))
+    eng.sync()
+    t_rag = time.perf_counter() - t0
+t_b2b = 0.0
+for ch in rchunks:
+    t1 = time.perf_counter()
+    Decoder.decode_batch(ch, tree, engine=eng, precision=PCL_F32, max_tokens=CAP)
+    t_b2b += time.perf_counter() - t1
+print('ragged stream (%d chunks, utterances of 150-%d frames, %d frames): %.1f ms through decode_stream = %.3f M frames/s; chunk by chunk with decode_batch: %.1f ms'
+      % (len(rchunks), T, int(rl.sum()), t_rag * 1e3, rl.sum() / t_rag / 1e6, t_b2b * 1e3))
 best = res[0]['final'][0] if res[0]['final'] else None
 print('utterance 0: best token', best, 'history entries', len(res[0]['history']))
