@@ -15,8 +15,10 @@ eng.load_frames(frames)
 b = eng.label_batch(labels, lens, begin)
 b.score(1)
 for fix in (False, True):
-    b.forward_backward(fix_pi=fix); eng.sync(); eng.kernel_time('fb')
-    for _ in range(5):
+    for _ in range(60):                        # (a kernel this short, launched after host work, otherwise runs at idle clocks)
+        b.forward_backward(fix_pi=fix)
+    eng.sync(); eng.kernel_time('fb')
+    for _ in range(20):
         b.forward_backward(fix_pi=fix)
     ms, k = eng.kernel_time('fb')
     print('%s U=%d fix_pi=%s: %.3f ms per launch (%d passes), logP[0] = %.10f' % ('one-wave' if os.environ.get('PCL_FB_ONE_WAVE') else 'two-wave', U, fix, ms / k, b.get('npass')[0], b.get('logp')[0]))
