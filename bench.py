@@ -240,6 +240,25 @@ def bench_decode(args, rank, world, local):
     tree, lx = synth.make_pronunciation_tree(args.words, units_n)
     mean, var, w, trans = synth.make_model(units_n, M, D)
     frames, lens, begin = synth.make_frames(U, T, D, seed=1000 * rank)
+    # CPU baseline (rank 0, N = 1): the float64 restatement of the same two halves on ONE host core, bounded -- all 549 states x M
+    # mixtures of the first frames of one utterance (vectorised NumPy), then the pure-Python token passing over the same tree
+    cpu = None
+    if args.cpu_baseline and rank == 0 and world == 1:
+        from oracle import decoder_oracle as dco
+        from oracle import poccala_oracle as po
+        nfr = 12
+        x = frames[begin[0]:begin[0] + nfr].astype(np.float64)
+        t1 = time.perf_counter()
+        b_all = np.stack([po.gmm_point(x, mean[j], var[j], w[j]) for j in range(units_n * 3)])
+        t_sc = time.perf_counter() - t1
+        ndec, ntr = 48, []
+        t1 = time.perf_counter()                   # (the decoder's cost does not depend on the values: the scored frames repeat)
+        dco.decode(tree, list(trans), np.tile(b_all, (1, ndec // nfr)), beam=0.85, candidate=5, max_tokens=args.max_tokens, trace=ntr)
+        t_de = time.perf_counter() - t1
+        cpu = dict(value=1.0 / (t_sc / nfr + t_de / ndec), unit='frames/s', cores=1, kind='port',
+                   sample='one core: vectorised float64 scoring of all %d states x %d mixtures for the first %d frames of one utterance (%.1f s) + the '
+                          'pure-Python restatement of the token passing over the same tree for %d frames (%.1f s, %d live tokens at the end); '
+                          'value = 1 / (scoring s per frame + decoding s per frame)' % (units_n * 3, M, nfr, t_sc, ndec, t_de, ntr[-1]))
     ndev = device_count()
     dev = int(os.environ.get('POCCALA_DEVICE', local))
     if bool(os.environ.get('POCCALA_SHARE_DEVICE')) and 0 < ndev < world:
@@ -292,7 +311,7 @@ def bench_decode(args, rank, world, local):
                            live_tokens_max=int(ntok.max()), utterances_at_the_cap=int(sum(r['overflow'] for r in res)),
                            approx_bytes_per_token_step=292, approx_gb_per_s=float(ntok.sum()) * 292 / (de_ms * 1e-3) / 1e9,
                            parity='bit-exact against oracle/decoder_oracle.py (tests/test_gpu_decode.py); PARITY UNPINNED against the reference, whose Decoder.py cannot run'),
-            'cpu_baseline': None}))
+            'cpu_baseline': cpu}))
         sys.stdout.flush()
     ctl.barrier()
     b.close()
