@@ -128,6 +128,8 @@ class AcousticModel(DataInitialization):
     class VirtualState(object):
         """Constant-score pdf of the non-emitting entry/exit states (AcousticModel.py:1029-1043)."""
 
+        constant_score = True                  # point() does not look at the frame: callers may evaluate it once per utterance
+
         def __init__(self, p=0.):
             self.__p = p
 

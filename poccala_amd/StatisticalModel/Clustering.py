@@ -71,7 +71,7 @@ class Clustering(DataInitialization):
             # accumulators, log domain, initial -inf (Clustering.py:96-101)
             self.__alpha_acc = -np.inf
             self.__mean_acc = np.full((mix_level, dimension), -np.inf)
-            self.__covariance_acc = [np.full((dimension,), -np.inf) for _ in range(mix_level)]
+            self.__covariance_acc = list(np.full((mix_level, dimension), -np.inf))     # a list of per-mixture rows, as in the reference
             self.__acc = np.full((mix_level,), -np.inf)
 
         # ---------------------------------------------------------------- properties (Clustering.py:122-229)

@@ -140,7 +140,10 @@ class LHMM(DataInitialization):
                 continue
             prof = self.__profunction[i]           # any object with .point (VirtualState: constant ln p)
             for d in range(len(data)):
-                out[d][i] = [prof.point(data[d][f], log=True, standard=standard, record=True) for f in range(lens[d])]
+                if getattr(prof, 'constant_score', False) and lens[d]:      # the reference calls it once per frame (LHMM.py:176-180)
+                    out[d][i] = prof.point(data[d][0], log=True, standard=standard, record=True)
+                else:
+                    out[d][i] = [prof.point(data[d][f], log=True, standard=standard, record=True) for f in range(lens[d])]
         if normalize:
             for d in range(len(data)):
                 out[d] = out[d] - np.array([[log_sum_exp(out[d][j])] for j in range(n)])

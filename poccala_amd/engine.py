@@ -114,10 +114,15 @@ class Engine(object):
     def _digest(arrays, tag):
         """Content key of small uploads (the drop-in classes re-send the same unit model / utterance for every call);
         None above 64 MB, where hashing would cost more than it saves."""
-        import hashlib
         if sum(a.nbytes for a in arrays) > Engine._DIGEST_MAX:
             return None
-        h = hashlib.blake2b(repr((tag, [(a.shape, str(a.dtype)) for a in arrays])).encode(), digest_size=16)
+        head = repr((tag, [(a.shape, str(a.dtype)) for a in arrays])).encode()
+        try:                                   # a 128-bit non-cryptographic hash at memory speed where it is installed
+            import xxhash
+            h = xxhash.xxh3_128(head)
+        except ImportError:
+            import hashlib
+            h = hashlib.blake2b(head, digest_size=16)
         for a in arrays:
             h.update(memoryview(np.ascontiguousarray(a)).cast('B'))
         return h.digest()
