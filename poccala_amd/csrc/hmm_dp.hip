@@ -556,7 +556,13 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                 const double at = at_n, bt = bt_n, nx[2] = {nx_n[0], nx_n[1]};
                 fetch(t + 2, at_n, bt_n, nx_n);
                 const double l = at + bt;
-                const double norm = wave_lse(act ? l : -INFINITY);               // sum_value[t] (LHMM.py:488)
+                // sum_value[t] = LSE_i l[i,t] (LHMM.py:488).  Every one of them is ln P(O) up to rounding, so the log-sum-exp is
+                // taken with THAT as its shift -- no maximum over the wave, and the logarithm of a sum within 1e-4 of 1 is three
+                // terms of its series; anything else (an impossible utterance: -inf) takes the general path
+                double norm;
+                const double ssum = wave_sum(act ? exp_neg(l - qnew) : 0.0), u1 = ssum - 1.0;
+                if (qnew > -INFINITY && fabs(u1) < 1.0e-4) norm = qnew + u1 * (1.0 - u1 * (0.5 - u1 * (1.0 / 3.0)));
+                else norm = wave_lse(act ? l : -INFINITY);
                 if (act) G[(long long)t * N + i] = l - norm;                     // l[:,t] - sum_value[t] (:486-500)
                 if (act && t < T - 1) {
                     online_lse(l, gm, gs);                                       // gamma_i over t < T-1 (:442-445)
