@@ -374,10 +374,10 @@ __device__ __forceinline__ double lse2(double a, double b) {
 constexpr int SP_N = 1281;
 constexpr double SP_MAX = 39.98;
 __device__ __forceinline__ double lse2_tab(double a, double b, const double2 *tab) {
+    // (branch-free: two conditional branches in every step of a latency-bound chain cost more than the arithmetic they skip)
     const double m = fmax(a, b);
-    if (isinf(m)) return m;                                   // util.log_sum_exp, quirk Q4
-    const double d = m - fmin(a, b);
-    if (!(d < SP_MAX)) return m;
+    const bool plain = isinf(m) || !(m - fmin(a, b) < SP_MAX);   // util.log_sum_exp, quirk Q4: the maximum itself; or nothing to add
+    const double d = plain ? 0.0 : m - fmin(a, b);
     const int k = __double2int_rn(d * 32.0);
     const double x = fma(-(double)k, 1.0 / 32.0, d);
     const double2 e = tab[k];
@@ -391,7 +391,7 @@ __device__ __forceinline__ double lse2_tab(double a, double b, const double2 *ta
     r = fma(x, r, c3);
     r = fma(x, r, 0.5 * q);
     r = fma(x, r, -sg);
-    return m + fma(x, r, e.x);
+    return plain ? m : m + fma(x, r, e.x);
 }
 // exp(x) for x <= 0 (every log-sum-exp term is taken relative to a maximum): k = rint(x log2 e), r = x - k ln 2 in two pieces,
 // a degree-12 Taylor polynomial on |r| <= ln 2 / 2 (remainder 1.7e-16 relative), v_ldexp_f64 -- 19 instructions where the
