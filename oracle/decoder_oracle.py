@@ -1,11 +1,30 @@
-"""CPU restatement of the reference's token-passing decoder -- TEST INFRASTRUCTURE, PARITY UNPINNED.
+"""CPU restatement of the reference's token-passing decoder -- TEST INFRASTRUCTURE.
+PARITY: recursion + pruning + frame loop + in-word hand-over PINNED (golden G14); the rules D1-D5 below UNPINNED.
 
 Only tests/, __graft_entry__.smoke() and bench tools may import this; the product (poccala_amd/) never does.
 
-The reference's Decoder.py is dead code: it imports a module that does not exist (`LanguageModel.Ngram`, Decoder.py:17)
-and calls AcousticModel / LHMM methods of an older API (`am.initialize_unit`, `am.unit`, `hmm.change_T`,
-`hmm.q_function`, Decoder.py:73-75,195-197), so nothing executable pins it.  What CAN be restated from the source is
-restated line by line; where the source cannot run, the gap is filled with the smallest well-defined rule and listed:
+The reference's Decoder.py is dead code as a program: it imports a module that does not exist (`LanguageModel.Ngram`,
+Decoder.py:17) and its `main` / `generate_first_word` call AcousticModel / LHMM methods of an older API
+(`am.initialize_unit`, `hmm.change_T`, `hmm.q_function`, Decoder.py:73-75,195-197).  With a stand-in for the missing
+module its pieces DO run (tests/golden/make_golden_decoder.py, build container only), and golden G14 holds what the
+reference itself produced for them; tests/test_decoder_golden.py holds this file to G14:
+
+  pinned     Token.viterbi (Decoder.py:250-288) -> `Token.viterbi`: p, score, mark per frame for one- and two-unit
+             tokens over 40 frames (rtol 1e-12; marks exact), driven through the reference's own AcousticModel.embedded;
+  pinned     pruning (Decoder.py:159-167) -> `prune`: 17 constructed score lists (fewer than 8 distinct scores, the
+             int(width * (1 - beam)) edges, ties across the cut, one shared score): surviving sets exact;
+  pinned     token_passing (Decoder.py:91-111) -> `decode(finished='source')` on a flat tree: the per-frame ascending
+             score lists and the surviving token sets of 14 tokens over 24 frames, exact keys / rtol 1e-12 scores;
+  pinned     passing_in_word (Decoder.py:114-143) -> `hand_over`: an existing token takes the donor's score only when it
+             is STRICTLY better and keeps its own recursion state; a missing one is created with the donor's score and
+             takes its first step at once; the return flag = "words end here";
+  D1         is the one INTENTIONAL deviation from executable source, with its golden counter-example: in G14 the best
+             state reaches the last emitting state of every token and the source's rule (`mark == len(states) - 1`)
+             never fires (tok*_ret are all None), so no token would ever be handed over.
+  unpinned   D2-D5 (what the source cannot do at all: node keys, first-word seeding, word-to-word hand-over, the order of
+             steps and hand-overs inside a frame) and the capacity rule.
+
+What is restated, line by line, and where the source cannot run, the smallest well-defined rule that fills the gap:
 
   restated   Token.viterbi (Decoder.py:250-288): first frame p = ln pi + B[:,0]; later p_j = max_i(p_i + ln A_ij) + B_j;
              score += max_j p_j; `mark` = first argmax.  The token's HMM is AcousticModel.embedded of the node's units
@@ -68,6 +87,8 @@ def emission_column(units, b_all, t, s=5):
 
 
 class Token(object):
+    finished_rule = 'D1'
+
     def __init__(self, score, node, units, unit_trans, s=5):
         self.score = score
         self.node = node
@@ -89,11 +110,36 @@ class Token(object):
         point = self.p.max()                                                   # info(), :263-268
         self.mark = int(np.where(self.p == point)[0][0])
         self.score += point                                                    # :285
-        return self.mark >= n - 2
+        if self.finished_rule == 'source':                                     # :276,:287 -- never true under the live API
+            return self.mark == n - 1
+        return self.mark >= n - 2                                              # D1
 
 
-def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5, max_tokens=None, trace=None, info=None):
-    """tree: the dict PronunciationLexicon.compile returns; b_all (J,T): ln b_j(o_t) of every GMM state.
+def prune(scores, beam=0.85, min_distinct=8):
+    """Decoder.pruning (:159-167) over the scores of the tokens alive before the frame, in token order.
+    Returns the set of token positions that are deleted: none while fewer than `min_distinct` distinct scores exist,
+    otherwise the int(width * (1 - beam)) first of the stable ascending sort (:108)."""
+    if len(set(scores)) < min_distinct:
+        return set()
+    ranked = sorted(range(len(scores)), key=lambda i: scores[i])
+    return set(ranked[:int(len(scores) * (1 - beam))])
+
+
+def hand_over(score, live_score):
+    """passing_in_word's rule for ONE target (:123-140).  `live_score` is the target's live token score or None.
+    Returns 'create' (no live token: a new one starts from `score` and steps at once), 'take' (the live token takes the
+    score, its recursion state stays) or 'keep'."""
+    if live_score is None:
+        return 'create'
+    return 'take' if score > live_score else 'keep'
+
+
+def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5, max_tokens=None, trace=None, info=None,
+           finished='D1', frame_log=None):
+    """`finished`: 'D1' (default) or 'source' = the source's own test, under which no token ever finishes and the loop is
+    exactly token_passing (:91-111) -- the form golden G14 pins.  `frame_log`, if a list, receives per frame the ascending
+    [(node, score)] list of the tokens that stepped and did not finish (what the source prints at :111).
+    tree: the dict PronunciationLexicon.compile returns; b_all (J,T): ln b_j(o_t) of every GMM state.
     Returns (final, history): final = [(node, score, hist)] of the `candidate` best tokens after the last frame
     (descending, ties in token order); history = [(previous entry or -1, word-end node)], the chain `hist` points into."""
     T = b_all.shape[1]
@@ -102,12 +148,17 @@ def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5,
     kids = lambda n: [int(c) for c in tree['child_idx'][tree['child_ptr'][n]:tree['child_ptr'][n + 1]]]
     tokens = []                                                                # live tokens in creation order
     history = []
+
+    def Token_(*a):
+        tok = Token(*a)
+        tok.finished_rule = finished
+        return tok
     for r in roots:                                                            # D3
         if max_tokens is not None and len(tokens) >= max_tokens:               # device capacity: the first max_tokens first-character
             if info is not None:                                               # nodes start, the rest is reported as overflow
                 info['overflow'] = True
             break
-        tok = Token(0.0, r, units_of[r], unit_trans, s)
+        tok = Token_(0.0, r, units_of[r], unit_trans, s)
         tok.hist = -1
         tok.viterbi(emission_column(tok.units, b_all, 0, s))
         tokens.append(tok)
@@ -142,23 +193,25 @@ def decode(tree, unit_trans, b_all, beam=0.85, candidate=5, min_distinct=8, s=5,
         created = []
         for node in order:
             score, hist = offers[node]
-            if node in live:
-                if score > live[node].score:                                   # :126-134 (the recursion state is kept)
-                    live[node].score = score
-                    live[node].hist = hist
+            rule = hand_over(score, live[node].score if node in live else None)
+            if rule == 'take':                                                 # :126-134 (the recursion state is kept)
+                live[node].score = score
+                live[node].hist = hist
+            elif rule == 'keep':
+                pass
             elif max_tokens is not None and n_start + len(created) >= max_tokens:
                 if info is not None:
                     info['overflow'] = True                                    # device capacity: the frame's token slots are used up
             else:
-                new = Token(score, node, units_of[node], unit_trans, s)
+                new = Token_(score, node, units_of[node], unit_trans, s)
                 new.hist = hist
                 new.viterbi(emission_column(new.units, b_all, t, s))           # :138-139
                 created.append(new)
         old = [tok for tok, d in zip(tokens, done) if not d]                   # (3)
-        ranked = sorted(range(len(old)), key=lambda i: old[i].score)           # (4) pruning, :159-167: ascending, stable
-        if len(set(tok.score for tok in old)) >= min_distinct:
-            drop = set(ranked[:int(len(old) * (1 - beam))])
-            old = [tok for i, tok in enumerate(old) if i not in drop]
+        if frame_log is not None:
+            frame_log.append(sorted(((tok.node, tok.score) for tok in old), key=lambda q: q[1]))
+        drop = prune([tok.score for tok in old], beam, min_distinct)           # (4) pruning, :159-167
+        old = [tok for i, tok in enumerate(old) if i not in drop]
         tokens = old + created
         if trace is not None:
             trace.append(len(tokens))

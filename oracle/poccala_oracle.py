@@ -8,9 +8,10 @@ and bench.py's cpu_baseline leg may import it; the product package
 
 Pinning: every function below is checked in tests/test_oracle_golden.py against
 golden vectors produced by running the reference itself in the build container
-(tests/golden/make_golden.py, groups G1..G9), rtol <= 1e-10.  The one exception
-is `token_viterbi_step` (A16): the reference module it restates (Decoder.py)
-cannot be imported, so that function is "parity unpinned".
+(tests/golden/make_golden.py, groups G1..G9), rtol <= 1e-10.  `token_viterbi_step`
+(A16) is pinned through golden G14 (tests/golden/make_golden_decoder.py runs the
+reference's Decoder.Token.viterbi with a stand-in for the one module it cannot
+import; tests/test_decoder_golden.py + test_decoder_oracle.py).
 
 Each function cites the reference file:line it follows (paths relative to the
 reference checkout).  Reference quirks Q1..Q9 are kept.
@@ -427,13 +428,13 @@ def discriminate(unit, sequence):
 
 
 # --------------------------------------------------------------------------
-# A16  token-passing max recursion  --  PARITY UNPINNED   Decoder.py:250-288
+# A16  token-passing max recursion  --  pinned by golden G14   Decoder.py:250-288
 # --------------------------------------------------------------------------
 def token_viterbi_step(p, la, b_col, first):
     """One frame of Decoder.Token.viterbi: first frame p = ln pi + B[:,0]
     (the caller passes ln pi as `p`), later p_j = max_i(p_i + ln A_ij) + B_j;
-    returns (new p, max_j p_j).  Restated from source only; nothing executable
-    in the reference pins it (Decoder.py cannot be imported)."""
+    returns (new p, max_j p_j).  Held to the reference's own Token.viterbi
+    through decoder_oracle.Token (golden G14)."""
     if first:
         new = p + b_col
     else:

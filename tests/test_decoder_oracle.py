@@ -1,6 +1,6 @@
-"""CPU checks of the decoder's restatement (oracle/decoder_oracle.py, PARITY UNPINNED: the reference's Decoder.py cannot
-run) -- the properties its recursion guarantees, so that the GPU kernel is compared against something that is itself
-held to account."""
+"""CPU checks of the decoder's restatement (oracle/decoder_oracle.py) beyond what golden G14 pins (test_decoder_golden.py:
+recursion, pruning, frame loop, in-word hand-over) -- the properties of the whole decode incl. the unpinned rules D1-D5,
+so that the GPU kernel is compared against something that is itself held to account."""
 import json
 import os
 
