@@ -741,15 +741,7 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
     b3.close()
     e3.close()
     # ---- the E-step on peaked posteriors: features sampled from the model along each utterance's label (aligned speech)
-    T, D, L = cfg['T'], cfg['D'], cfg['L']
-    rng = np.random.default_rng(5)
-    per = T // (3 * L)
-    fr = np.empty((cfg['U'] * T, D), dtype=np.float32)
-    for u, lab in enumerate(labels):
-        st = np.repeat(np.asarray(lab)[:, None] * 3 + np.arange(3)[None, :], per).reshape(-1)[:T]
-        st = np.concatenate([st, np.full(T - len(st), st[-1])])
-        mix = rng.integers(0, cfg['M'], size=T)
-        fr[u * T:(u + 1) * T] = mean[st, mix] + np.sqrt(var[st, mix]) * rng.standard_normal((T, D))
+    fr = synth.make_peaked_frames(labels, cfg['T'], mean, var, seed=5)
     ep = Engine(eng.device)
     ep.enable_timing(True)
     ep.load_model(mean, var, w)

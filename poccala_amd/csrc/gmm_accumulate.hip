@@ -626,7 +626,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     if (mfma && n_good > 0 && ctx->score_variant == 7) {
         // producer / consumer on the f16 + bf16 matrix pipes (gmm_accumulate_f16.hip), in groups of states whose tile
         // images fit the image buffer (worst case: every frame of the state survives)
-        static const size_t budget = (size_t)(getenv("PCL_ACC_IMAGE_MB") ? atol(getenv("PCL_ACC_IMAGE_MB")) : 2048) << 20;   // per buffer set, two sets
+        const size_t budget = (size_t)(getenv("PCL_ACC_IMAGE_MB") ? std::max(1L, atol(getenv("PCL_ACC_IMAGE_MB"))) : 2048) << 20;   // per buffer set, two sets; read per call (tests lower it to force many groups)
         const size_t ib = pcl_acc16_image_bytes(D);
         // group by the ACTUAL tile counts: the scan result comes back (n_segs + 1 offsets, one short copy behind the scan
         // kernel) -- on peaked posteriors a tenth of the frames survive, and sizing the groups for the worst case made
@@ -702,7 +702,9 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             const int buf = g & 1;
             if (overlap && g + 1 < G) { const int rc = produce(g + 1); if (rc != PCL_OK) return rc; }
             if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->acc16_ev_prod[buf], 0));
+            pcl_timer_begin(ctx, "acc_consume");                                 // one entry per state group (timing mode only)
             int rc = pcl_launch_acc16_consume(ctx, b, gfirst[g], gcount[g], buf, ctx->stats_fresh, ctx->stream);
+            pcl_timer_end(ctx, "acc_consume");
             if (rc != PCL_OK) return rc;
             launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
             if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));

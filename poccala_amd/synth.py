@@ -51,6 +51,22 @@ def make_frames(U, T, D, seed=0, ragged=False):
     return frames, lens, begin
 
 
+def make_peaked_frames(labels, T, mean, var, seed=5, s=S):
+    """Features sampled from the model ALONG each utterance's label (one Gaussian of the state the frame is aligned to):
+    the peaked posteriors of aligned speech, where a tenth of the (frame, state) pairs survive the E-step's underflow cut."""
+    rng = np.random.default_rng(seed)
+    e = s - 2
+    M, D = mean.shape[1], mean.shape[2]
+    fr = np.empty((len(labels) * T, D), dtype=np.float32)
+    for u, lab in enumerate(labels):
+        per = max(1, T // (e * len(lab)))
+        st = np.repeat(np.asarray(lab)[:, None] * e + np.arange(e)[None, :], per).reshape(-1)[:T]
+        st = np.concatenate([st, np.full(T - len(st), st[-1])])
+        mix = rng.integers(0, M, size=T)
+        fr[u * T:(u + 1) * T] = mean[st, mix] + np.sqrt(var[st, mix]) * rng.standard_normal((T, D))
+    return fr
+
+
 def make_labels(U, L, units, seed=2):
     rng = np.random.default_rng(seed)
     return [rng.integers(0, units, size=L) for _ in range(U)]

@@ -46,3 +46,33 @@ def state_rows(x, gmms, block=8):
     jobs = [(x, gmms[i:i + block]) for i in range(0, len(gmms), block)]
     with mp.get_context('spawn').Pool(min(workers(), len(jobs))) as pool:
         return np.concatenate(pool.map(_rows_job, jobs, chunksize=1), axis=0)
+
+
+def _acc_job(args):
+    """A13 for ONE occurrence of a state (Clustering.GMM.update_acc, Clustering.py:653-680) through the oracle, the
+    mixtures in slices (every mixture's accumulators are independent of the others; bounds the (M,D,T) temporaries).
+    Returns the occurrence's contribution in the LINEAR domain: acc (M,), alpha_acc, mean_acc (M,D), cov_acc (M,D)."""
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import poccala_oracle as po
+    x, l_value, b_value, mean, var, w, step = args
+    m, d = mean.shape
+    out = dict(acc=np.zeros(m), alpha_acc=0.0, mean_acc=np.zeros((m, d)), cov_acc=np.zeros((m, d)))
+    for lo in range(0, m, step):
+        hi = min(m, lo + step)
+        a = dict(acc=np.full(hi - lo, -np.inf), alpha_acc=-np.inf, mean_acc=np.full((hi - lo, d), -np.inf),
+                 cov_acc=np.full((hi - lo, d), -np.inf))
+        po.gmm_update_acc(a, l_value, b_value, x, mean[lo:hi], var[lo:hi], w[lo:hi])
+        with np.errstate(all='ignore'):
+            out['acc'][lo:hi] = np.exp(a['acc'])
+            out['mean_acc'][lo:hi] = np.exp(a['mean_acc'])
+            out['cov_acc'][lo:hi] = np.exp(a['cov_acc'])
+            out['alpha_acc'] = float(np.exp(a['alpha_acc']))
+    return out
+
+
+def state_statistics(jobs, step=128):
+    """jobs: [(x (T,D) f64, ln gamma_t(j) (T,), ln b_j(o_t) (T,), mean, var, w)] -- the occurrences of one or more
+    states; returns one linear-domain contribution per job (see _acc_job)."""
+    jobs = [tuple(j) + (step,) for j in jobs]
+    with mp.get_context('spawn').Pool(min(workers(), len(jobs))) as pool:
+        return pool.map(_acc_job, jobs, chunksize=1)

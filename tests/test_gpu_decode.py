@@ -1,6 +1,7 @@
 """The token-passing decoder (BASELINE config 5's decode half) on the GPU against its CPU restatement
-(oracle/decoder_oracle.py; PARITY UNPINNED against the reference, whose Decoder.py cannot run): bit-exact scores, nodes,
-histories and token counts given identical emissions, plus the properties the recursion guarantees."""
+(oracle/decoder_oracle.py: recursion, pruning, frame loop and in-word hand-over pinned by golden G14 from the reference's
+own Decoder.py; the completion rules D1-D5 unpinned): bit-exact scores, nodes, histories and token counts given identical
+emissions, plus the properties the recursion guarantees."""
 import json
 import os
 
@@ -163,3 +164,72 @@ def test_decode_stream_equals_chunk_by_chunk(eng, lex):
     one = Decoder.decode_batch(chunks[0], tree, engine=eng, precision=PCL_F32, candidate=4, max_tokens=600)
     assert [x[1] for x in one] == [x[1] for x in ref[0]]
     assert list(Decoder.decode_stream(iter([]), tree, engine=eng)) == []
+
+
+def test_c5_decode_at_shard_shape(eng):
+    """BASELINE config 5's decode half at its real shape (Decoder.py:91-167): the per-GPU shard of 417 utterances x 300 frames,
+    all 549 states x 4096 mixtures scored, a 20 k-word / 90 k-node pronunciation tree, 8192 live tokens per utterance.
+    Too big for the CPU restatement as a whole, so: properties at full size -- live tokens within the cap, the overflow
+    flag consistent (an utterance that never overflowed decodes identically under a larger cap), acyclic word-ending
+    history chains, two runs bit-identical, the streamed pipeline equal to the resident run -- and one utterance x 72 frames
+    bit for bit against oracle/decoder_oracle.py (recursion / pruning / loop pinned by golden G14; D1-D5 the builder's
+    completion of the reference's dead code)."""
+    from poccala_amd import Decoder, PCL_F32, synth
+    c = synth.CONFIGS['C5shard']
+    cap = 8192
+    tree, lx = synth.make_pronunciation_tree(20000, c['units'])
+    assert len(tree['names']) > 80000
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=5)
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=6)
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F32)
+    one = b.decode(max_tokens=cap, candidate=5)
+    two = b.decode(max_tokens=cap, candidate=5)
+    big = b.decode(max_tokens=16384, candidate=5)
+    b.close()
+    n_roots = len(tree['roots'])
+    calm = 0
+    for u in range(c['U']):
+        r = one[u]
+        assert r['final'] == two[u]['final'] and r['history'] == two[u]['history'] and np.array_equal(r['n_tokens'], two[u]['n_tokens'])
+        nt = r['n_tokens']
+        assert len(nt) == c['T'] and nt[0] == min(n_roots, cap) and nt.min() > 0 and nt.max() <= cap
+        assert len(r['final']) == min(5, int(nt[-1]))
+        sc = [s for _, s, _ in r['final']]
+        assert sc == sorted(sc, reverse=True) and np.isfinite(sc).all()
+        for i, (prev, node) in enumerate(r['history']):              # chains point backwards (acyclic) and end words
+            assert -1 <= prev < i and tree['node_word'][node]
+        assert all(-1 <= h < len(r['history']) for _, _, h in r['final'])
+        if not r['overflow']:                                        # the capacity never bound: a larger one changes nothing
+            calm += 1
+            assert not big[u]['overflow'] and r['final'] == big[u]['final'] and np.array_equal(nt, big[u]['n_tokens'])
+    print('C5 shard decode: %d of %d utterances within %d tokens, mean %.0f / max %d live tokens'
+          % (calm, c['U'], cap, np.mean([r['n_tokens'].mean() for r in one]), max(r['n_tokens'].max() for r in one)))
+    # streamed == resident (three chunks, the pipeline of Decoder.decode_stream)
+    per = (c['U'] + 2) // 3
+    chunks = [[frames[begin[u]:begin[u] + lens[u]] for u in range(k * per, min(c['U'], (k + 1) * per))] for k in range(3)]
+    got = [x for ch in Decoder.decode_stream(iter(chunks), tree, engine=eng, precision=PCL_F32, max_tokens=cap, candidate=5) for x in ch]
+    assert len(got) == c['U']
+    for u in range(c['U']):
+        assert got[u][2]['final'] == one[u]['final'] and got[u][2]['history'] == one[u]['history']
+        assert np.array_equal(got[u][2]['n_tokens'], one[u]['n_tokens'])
+    # one utterance against the restatement, from the emissions the device decoded
+    tcut = 72
+    eng.load_frames(frames)
+    b = eng.all_state_batch(np.array([tcut], dtype=np.int32), np.array([begin[7]], dtype=np.int64))
+    b.score(PCL_F32)
+    B = b.get('B')[0]
+    g = b.decode(max_tokens=cap, candidate=5)[0]
+    b.close()
+    trace, info = [], {}
+    fin, hist = do.decode(tree, list(trans), B[1:-1], max_tokens=cap, candidate=5, trace=trace, info=info)
+    assert np.array_equal(g['n_tokens'], np.array(trace))
+    assert g['history'] == [(int(p), int(n)) for p, n in hist]
+    assert [(n, h) for n, _, h in g['final']] == [(n, h) for n, _, h in fin]
+    assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]
+    assert g['overflow'] == bool(info.get('overflow'))
+    assert np.array_equal(g['n_tokens'], one[7]['n_tokens'][:tcut])           # a prefix of the full-length run
