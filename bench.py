@@ -36,7 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CPU_SAMPLE_FRAMES = 64            # frames per utterance in the CPU baseline sample (about 20-30 s of CPU work per leg)
+T_PROCESS_START = time.perf_counter()
+CPU_SAMPLE_FRAMES = 16            # frames per utterance in the CPU baseline sample (the vectorised leg is DRAM bound with every core busy: ~1.2 s per frame)
+CPU_FAITHFUL_ROWS = 12            # label states (of 60) the reference's per-mixture loop nest is timed on, scaled to all of them
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 HBM_PEAK_GBS = 8000.0
@@ -104,32 +106,48 @@ def spawn_ranks(args):
 # ------------------------------------------------------------------------------------------------
 # CPU baseline leg: the oracle (a port of the reference's arithmetic) timed on the host cores.
 # ------------------------------------------------------------------------------------------------
-def _cpu_vectorised_utt(args):
-    """One utterance of score + forward-backward with the vectorised float64 oracle."""
-    os.environ['OMP_NUM_THREADS'] = '1'
+_CPU_JOBS = None      # set by cpu_baseline() BEFORE the pool forks: the workers read their job by index, nothing is pickled
+
+
+def _cpu_job(u):
+    """(frames (T,D) f64, [(mean, var, w)] of the label's states, A, pi) of sample utterance u, from the forked globals."""
+    from poccala_amd.engine import embedded_structure
+    cfg, mean, var, w, trans, frames, lens, begin, labels = _CPU_JOBS
+    e = 3
+    lab = labels[u]
+    x = frames[begin[u]:begin[u] + min(int(lens[u]), CPU_SAMPLE_FRAMES)].astype(np.float64)   # bounded sample
+    gm = [(mean[i * e + k], var[i * e + k], w[i * e + k]) for i in lab for k in range(e)]
+    a, pi = embedded_structure(len(lab), [trans[i] for i in lab])
+    return x, gm, a, pi
+
+
+def _cpu_vectorised_utt(u):
+    """One utterance of score + forward-backward with the vectorised float64 oracle; returns its own elapsed time."""
+    from threadpoolctl import threadpool_limits
     from oracle import poccala_oracle as po
-    x, gmms_per_row, a, pi = args
-    t0 = time.perf_counter()
-    rows = [np.zeros(x.shape[0])]
-    for (mean, var, w) in gmms_per_row:
-        out = np.empty(x.shape[0])
-        for s in range(0, x.shape[0], 25):                      # chunked: bounds the (T,M,D) temporary
-            out[s:s + 25] = po.gmm_point(x[s:s + 25], mean, var, w)
-        rows.append(out)
-    rows.append(np.full(x.shape[0], -np.inf))
-    b = np.array(rows)
-    po.baum_welch(a, pi, [b])
-    return time.perf_counter() - t0
+    x, gmms_per_row, a, pi = _cpu_job(u)
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        rows = [np.zeros(x.shape[0])]
+        for (mean, var, w) in gmms_per_row:
+            out = np.empty(x.shape[0])
+            for s in range(0, x.shape[0], 25):                      # chunked: bounds the (T,M,D) temporary
+                out[s:s + 25] = po.gmm_point(x[s:s + 25], mean, var, w)
+            rows.append(out)
+        rows.append(np.full(x.shape[0], -np.inf))
+        b = np.array(rows)
+        po.baum_welch(a, pi, [b])
+        return time.perf_counter() - t0, x.shape[0]
 
 
-def _cpu_gemm_utt(args):
+def _cpu_gemm_utt(u):
     """Informational third figure: the same log-likelihoods through the expanded quadratic form as ONE float64
     GEMM per state on the host BLAS (single thread per worker) + the vectorised forward-backward.  This is not
     the reference's arithmetic (it is the formulation the GPU kernel uses); it shows what an optimised CPU
     implementation of the same mathematics would do on these cores."""
     from threadpoolctl import threadpool_limits
     from oracle import poccala_oracle as po
-    x, gmms_per_row, a, pi = args
+    x, gmms_per_row, a, pi = _cpu_job(u)
     with threadpool_limits(limits=1):
         t0 = time.perf_counter()
         xe = np.concatenate([x * x, x, np.ones((x.shape[0], 1))], axis=1)             # (T, 2D+1)
@@ -142,64 +160,74 @@ def _cpu_gemm_utt(args):
             rows.append(po.lse(xe @ p.T, axis=1))
         rows.append(np.full(x.shape[0], -np.inf))
         po.baum_welch(a, pi, [np.array(rows)])
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, x.shape[0]
 
 
-def _cpu_faithful_sample(args):
+def _cpu_faithful_sample(u):
     """The reference's own loop nest (per frame x per mixture NumPy calls; per-(t,j) LSE) on a tiny
-    sample: `nf` frames of scoring for every row + one full forward/backward lattice."""
-    os.environ['OMP_NUM_THREADS'] = '1'
+    sample: 1 frame of scoring for every row + one full forward/backward lattice.  Returns seconds per frame."""
+    from threadpoolctl import threadpool_limits
     from oracle import poccala_oracle as po
-    x, gmms_per_row, a, pi, nf = args
-    t0 = time.perf_counter()
-    for (mean, var, w) in gmms_per_row:
-        for t in range(nf):
-            po.faithful_gmm_point(x[t], mean, var, w)
-    t_score = (time.perf_counter() - t0) / nf                   # seconds per frame (all rows)
-    n, T = a.shape[0], x.shape[0]
-    b = np.random.default_rng(0).standard_normal((n, T)) - 60.0
-    b[0] = 0.0
-    b[-1] = -np.inf
-    t0 = time.perf_counter()
-    po.faithful_forward_backward(a, pi, b)
-    t_fb = 3 * (time.perf_counter() - t0) / T                    # 3 passes (quirk Q6), seconds per frame
+    x, gmms_per_row, a, pi = _cpu_job(u)
+    nf = 1
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        sub = gmms_per_row[::max(1, len(gmms_per_row) // CPU_FAITHFUL_ROWS)]
+        for (mean, var, w) in sub:
+            for t in range(nf):
+                po.faithful_gmm_point(x[t], mean, var, w)
+        t_score = (time.perf_counter() - t0) / nf * len(gmms_per_row) / len(sub)     # seconds per frame, scaled to all rows
+        n, T = a.shape[0], x.shape[0]
+        b = np.random.default_rng(0).standard_normal((n, T)) - 60.0
+        b[0] = 0.0
+        b[-1] = -np.inf
+        t0 = time.perf_counter()
+        po.faithful_forward_backward(a, pi, b)
+        t_fb = 3 * (time.perf_counter() - t0) / T                    # 3 passes (quirk Q6), seconds per frame
     return t_score + t_fb
 
 
 def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
+    """The oracle timed on the host cores: one sample utterance per core.  The job data sits in a module global BEFORE the
+    pool forks, the workers receive an index and time themselves; a leg's rate = frames of the sample / the slowest worker's
+    time (what the job would take with every core busy), so neither pickling nor the pool's dispatch is in the figure."""
     import multiprocessing as mp
-    from poccala_amd.engine import embedded_structure
+    global _CPU_JOBS
     cores = os.cpu_count() or 1
-    e = 3
-    jobs_v, jobs_f = [], []
     n_utt = min(cores, len(labels))
-    for u in range(n_utt):
-        lab = labels[u]
-        x = frames[begin[u]:begin[u] + min(int(lens[u]), CPU_SAMPLE_FRAMES)].astype(np.float64)   # bounded sample
-        gm = [(mean[i * e + k], var[i * e + k], w[i * e + k]) for i in lab for k in range(e)]
-        a, pi = embedded_structure(len(lab), [trans[i] for i in lab])
-        jobs_v.append((x, gm, a, pi))
-        jobs_f.append((x, gm, a, pi, 1))
-    with mp.get_context('fork').Pool(min(cores, n_utt)) as pool:
+    _CPU_JOBS = (cfg, mean, var, w, trans, frames, lens, begin, labels)
+    os.environ.setdefault('OMP_NUM_THREADS', '1')
+    t_leg = {}
+    with mp.get_context('fork').Pool(n_utt) as pool:
+        idx = list(range(n_utt))
         t0 = time.perf_counter()
-        pool.map(_cpu_vectorised_utt, jobs_v, chunksize=1)
-        wall = time.perf_counter() - t0
-        per_frame = pool.map(_cpu_faithful_sample, jobs_f, chunksize=1)
+        vec = pool.map(_cpu_vectorised_utt, idx, chunksize=1)
+        t_leg['vectorised'] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        pool.map(_cpu_gemm_utt, jobs_v, chunksize=1)
-        wall_gemm = time.perf_counter() - t0
-    frames_done = int(sum(len(j[0]) for j in jobs_v))
-    vec = frames_done / wall
-    faithful = len(per_frame) / float(np.mean(per_frame)) if n_utt == cores else cores / float(np.mean(per_frame))
-    return dict(value=vec, unit='frames/s', cores=min(cores, n_utt), kind='port',
-                sample='first %d frames of %d utterances (one utterance per core, multiprocessing), vectorised float64 NumPy oracle: '
-                       'score %d label states x %d mixtures + 3-pass forward-backward' % (len(jobs_v[0][0]), n_utt, len(jobs_v[0][1]), cfg['M']),
-                gemm_value=frames_done / wall_gemm,
+        per_frame = pool.map(_cpu_faithful_sample, idx, chunksize=1)
+        t_leg['faithful'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        gemm = pool.map(_cpu_gemm_utt, idx, chunksize=1)
+        t_leg['gemm'] = time.perf_counter() - t0
+    _CPU_JOBS = None
+    frames_done = int(sum(n for _, n in vec))
+    nfr, nrows = vec[0][1], 3 * len(labels[0])
+    faithful = n_utt / float(max(per_frame))                       # every core one frame at a time, the slowest core sets the rate
+    return dict(value=frames_done / max(t for t, _ in vec), unit='frames/s', cores=n_utt, kind='port', ipc_excluded=True,
+                sample='first %d frames of %d utterances (one utterance per core, forked workers reading the job from inherited memory, '
+                       'timed inside the workers: frames / slowest worker), vectorised float64 NumPy oracle: score %d label states x %d '
+                       'mixtures + 3-pass forward-backward' % (nfr, n_utt, nrows, cfg['M']),
+                worker_s=dict(vectorised_max=max(t for t, _ in vec), vectorised_mean=float(np.mean([t for t, _ in vec])),
+                              gemm_max=max(t for t, _ in gemm), gemm_mean=float(np.mean([t for t, _ in gemm])),
+                              faithful_s_per_frame_max=float(max(per_frame)), faithful_s_per_frame_mean=float(np.mean(per_frame))),
+                leg_wall_s=t_leg,
+                gemm_value=frames_done / max(t for t, _ in gemm),
                 gemm_sample='same sample, expanded quadratic form as one float64 BLAS GEMM per state (1 thread per worker): an '
                             'optimised CPU formulation, not the reference arithmetic',
                 faithful_value=faithful,
-                faithful_sample='reference loop nest (per frame x per mixture NumPy calls, per-(t,j) LSE): 1 frame x %d states '
-                                'of scoring + one faithful forward/backward lattice per core, scaled to frames/s over %d cores' % (len(jobs_v[0][1]), cores))
+                faithful_sample='reference loop nest (per frame x per mixture NumPy calls, per-(t,j) LSE): 1 frame x %d of the %d label states '
+                                'of scoring (scaled to all of them) + one faithful forward/backward lattice of %d frames per core, frames/s = cores / '
+                                'slowest core\'s seconds per frame' % (len(labels[0]) * 3 // max(1, len(labels[0]) * 3 // CPU_FAITHFUL_ROWS), nrows, nfr))
 
 
 # per scoring kernel: name, the peak its arithmetic is priced against, and what that peak means
@@ -310,7 +338,11 @@ def bench_decode(args, rank, world, local):
             'decode': dict(kernel='hmm_decode_kernel', kernel_avg_ms=de_ms, token_steps_per_s=float(ntok.sum()) / (de_ms * 1e-3), live_tokens_mean=float(ntok.mean()),
                            live_tokens_max=int(ntok.max()), utterances_at_the_cap=int(sum(r['overflow'] for r in res)),
                            approx_bytes_per_token_step=292, approx_gb_per_s=float(ntok.sum()) * 292 / (de_ms * 1e-3) / 1e9,
-                           parity='bit-exact against oracle/decoder_oracle.py (tests/test_gpu_decode.py); PARITY UNPINNED against the reference, whose Decoder.py cannot run'),
+                           parity='bit-exact against oracle/decoder_oracle.py (tests/test_gpu_decode.py, incl. this shape).  The reference\'s Decoder.py is dead code: '
+                                  'its Token.viterbi recursion, pruning rule, token_passing loop and in-word hand-over are pinned by golden G14 (produced by '
+                                  'running those pieces of the reference); first-word seeding, word-to-word hand-over, node-keyed tokens, the finished test '
+                                  'on the last emitting state and the order of steps and hand-overs in a frame (rules D1-D5) are the builder\'s '
+                                  'completion of that dead code, not the reference\'s semantics'),
             'cpu_baseline': cpu}))
         sys.stdout.flush()
     ctl.barrier()
@@ -320,6 +352,63 @@ def bench_decode(args, rank, world, local):
 
 
 # ------------------------------------------------------------------------------------------------
+def timed_steps(eng, batches, P, align, warmup, steps, barrier):
+    """The timed region: W untimed warm-up steps, then exactly K steps between barrier + device sync on both sides.  A step =
+    scoring of one resident batch (main stream) + its forward-backward pass loop (second stream, beside the next step's
+    scoring); successive steps alternate between the resident batches.  Returns (elapsed s, score kernel ms, launches,
+    forward-backward kernel ms, launches) -- the kernel times from HIP events on the library's streams."""
+    nb = len(batches)
+    step_no = [0]
+
+    def step():
+        bt = batches[step_no[0] % nb]
+        step_no[0] += 1
+        bt.score(P)                                   # main stream
+        if align:
+            bt.viterbi()                              # BASELINE config 3: forced alignment instead of the Baum-Welch pass
+        else:
+            bt.forward_backward(fix_pi=False)         # second stream: runs beside the next step's scoring
+
+    # setup, not a step: every resident batch once, so that lazy allocations (tile lists, alpha/beta/xi buffers) never land
+    # in a timed step whatever --warmup is
+    for bt in batches:
+        bt.score(P)
+        if align:
+            bt.viterbi()
+        else:
+            bt.forward_backward(fix_pi=False)
+    eng.sync()
+    for _ in range(warmup):
+        step()
+    eng.sync()
+    eng.kernel_time('score')
+    eng.kernel_time('fb')
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    score_ms, score_n = eng.kernel_time('score')
+    fb_ms, fb_n = eng.kernel_time('fb')
+    return elapsed, score_ms, score_n, fb_ms, fb_n
+
+
+def engine_with_variant(device, variant):
+    """A fresh context whose scoring kernel is PCL_SCORE_VARIANT=variant (read by pcl_init)."""
+    from poccala_amd import Engine
+    old = os.environ.get('PCL_SCORE_VARIANT')
+    os.environ['PCL_SCORE_VARIANT'] = str(variant)
+    try:
+        return Engine(device)
+    finally:
+        if old is None:
+            os.environ.pop('PCL_SCORE_VARIANT', None)
+        else:
+            os.environ['PCL_SCORE_VARIANT'] = old
+
+
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -340,16 +429,22 @@ def main():
     if args.utts:
         cfg['U'] = args.utts
     t_setup = time.perf_counter()
+    tl = {}                                           # where the wall-clock of this run goes (extra.timeline_s)
+    t_mark = time.perf_counter()
     mean, var, w, trans = synth.make_model(cfg['units'], cfg['M'], cfg['D'], seed=1)
     nb = max(1, args.batches)
     frames, lens_all, begin_all = synth.make_frames(cfg['U'] * nb, cfg['T'], cfg['D'], seed=1000 * rank)      # each rank its own shard
     labels_all = synth.make_labels(cfg['U'] * nb, cfg['L'], cfg['units'], seed=2 + 7919 * rank)
     lens, begin, labels = lens_all[:cfg['U']], begin_all[:cfg['U']], labels_all[:cfg['U']]      # batch 0: accounting and the CPU leg
+    tl['synthetic_model_and_frames_s'] = time.perf_counter() - t_mark
+    t_mark = time.perf_counter()
 
     # CPU baseline leg first: its worker pool is forked BEFORE this process initialises HIP
     cpu = None
     if args.cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels)
+    tl['cpu_baseline_s'] = time.perf_counter() - t_mark
+    t_mark = time.perf_counter()
 
     from poccala_amd import Engine, PCL_F32, PCL_F64
     from poccala_amd.engine import device_count
@@ -386,45 +481,16 @@ def main():
             eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
     comm = eng.comm_info()
     t_setup = time.perf_counter() - t_setup
+    tl['upload_and_batches_s'] = time.perf_counter() - t_mark
+    t_mark = time.perf_counter()
 
-    step_no = [0]
     align = args.workload == 'C3'                     # score + Viterbi forced alignment (the task BASELINE config 3 names)
     if align:
         args.extra = 0                                # (the extras measure the E-step)
-
-    def step():
-        bt = batches[step_no[0] % nb]
-        step_no[0] += 1
-        bt.score(P)                                   # main stream
-        if align:
-            bt.viterbi()                              # BASELINE config 3: forced alignment instead of the Baum-Welch pass
-        else:
-            bt.forward_backward(fix_pi=False)         # second stream: runs beside the next step's scoring
-
-    # setup, not a step: every resident batch once, so that lazy allocations (tile lists, alpha/beta/xi buffers) never land
-    # in a timed step whatever --warmup is
-    for bt in batches:
-        bt.score(P)
-        if align:
-            bt.viterbi()
-        else:
-            bt.forward_backward(fix_pi=False)
-    eng.sync()
-    for _ in range(args.warmup):
-        step()
-    eng.sync()
-    eng.kernel_time('score')
-    eng.kernel_time('fb')
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    score_ms, score_n = eng.kernel_time('score')
-    fb_ms, fb_n = eng.kernel_time('fb')
+    elapsed, score_ms, score_n, fb_ms, fb_n = timed_steps(eng, batches, P, align, args.warmup, args.steps, barrier)
     elapsed = ctl.allreduce_max(elapsed)
+    tl['timed_loop_s'] = time.perf_counter() - t_mark
+    t_mark = time.perf_counter()
 
     frames_per_rank = int(lens.sum())
     total_frames = frames_per_rank * world
@@ -494,6 +560,10 @@ def main():
             out['extra'] = extra
             if extra.get('roofline_estep'):
                 out['roofline_estep'] = extra.pop('roofline_estep')
+            sf = extra.get('strict_f32')
+            if sf and sf.get('value'):             # the same timed loop on the strict-f32 kernel (a second engine, PCL_SCORE_VARIANT=3)
+                out['value_strict_f32'] = sf['value']
+                out['ms_per_step_strict_f32'] = sf['ms_per_step']
         if cpu:
             out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value'],
                                    'vs_blas_gemm_formulation': value / cpu['gemm_value']}
@@ -508,14 +578,15 @@ def main():
         if rank == 0 and not printed.is_set():
             print(make_line(dict(error='extras did not finish within %d s' % args.extra_timeout)))
             sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)                            # the line is out, but the job did NOT complete: launchers must see a failure
     dog = threading.Timer(args.extra_timeout, give_up)
     dog.daemon = True
     dog.start()
     extra = None
     if args.extra:
         try:
-            extra = extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans)
+            extra = extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans,
+                           dict(labels_all=labels_all, lens_all=lens_all, begin_all=begin_all, tl=tl, t_mark=t_mark))
         except Exception as e:                 # noqa: the headline does not depend on the extras
             import traceback
             traceback.print_exc()
@@ -535,23 +606,36 @@ def main():
 
 def committed_traffic():
     """HBM bytes per scoring launch from the committed PMC passes of this command (counters cannot be read from inside the
-    run): (corrected bytes, {'FETCH_SIZE_bytes', 'WRITE_SIZE_bytes', 'file'}) or (None, None)."""
-    for name in ('r02_bench_summary.txt', 'r01_bench_summary.txt'):
+    run): (corrected bytes, {'FETCH_SIZE_bytes', 'WRITE_SIZE_bytes', 'file', ...}) or (None, {'stale': ...}).  The summary
+    records the sha256 of the scoring kernel's source it was taken from; when the source has changed since, the figure is
+    withheld (traffic = null) instead of being passed off as a measurement of the current kernel."""
+    import hashlib
+    src = os.path.join(ROOT, 'poccala_amd', 'csrc', 'gmm_score_split.hip')
+    try:
+        now = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        now = None
+    for name in ('r03_bench_summary.txt', 'r02_bench_summary.txt'):
         try:
-            fetch = write = None
+            fetch = write = sha = None
             for line in open(os.path.join(ROOT, 'profiles', name)):
                 if 'gmm_score_split16_kernel' in line and 'FETCH_SIZE' in line:
                     fetch = float(line.split('per-dispatch=')[1]) * 1024.0            # rocprofv3 reports KiB
                 if 'gmm_score_split16_kernel' in line and 'WRITE_SIZE' in line:
                     write = float(line.split('per-dispatch=')[1]) * 1024.0
+                if line.startswith('kernel_source_sha16'):
+                    sha = line.split()[-1]
             if fetch is not None and write is not None:
-                return 2.0 * fetch + write, dict(FETCH_SIZE_bytes=fetch, WRITE_SIZE_bytes=write, file='profiles/' + name)
+                if sha is not None and now is not None and sha != now:
+                    return None, dict(stale='profiles/%s was taken from gmm_score_split.hip %s, the source is now %s: re-run tools/gpu_profile.sh'
+                                            % (name, sha, now))
+                return 2.0 * fetch + write, dict(FETCH_SIZE_bytes=fetch, WRITE_SIZE_bytes=write, file='profiles/' + name, kernel_source_sha16=sha)
         except (OSError, ValueError, IndexError):
             pass
     return None, None
 
 
-def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans):
+def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans, more):
     """Untimed-region measurements: forced alignment, the full E-step with the statistics exchange and both M-steps, PCIe legs."""
     from poccala_amd import PCL_F32, PCL_F64
     barrier = ctl.barrier
@@ -637,7 +721,10 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
                                           'the SURVIVING pairs.  Bench features are random N(0,1): flat posteriors, ~78 % of the pairs survive the exact '
                                           'underflow compaction; aligned speech is peaked: extra.estep_peaked'))
     if ctl.world == 1 and P == PCL_F32 and not args.utts:
-        extra.update(side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs))
+        more['frames'] = frames
+        extra.update(side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs, more))
+        more['tl']['total_before_line_s'] = time.perf_counter() - T_PROCESS_START
+        extra['timeline_s'] = more['tl']
     return extra
 
 
@@ -655,12 +742,19 @@ def smi_sample():
         return None
 
 
-def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs):
+def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs, more):
     """What the judge asked to see beside the headline, all outside the timed region, N = 1 only:
     strict-f32 scoring on the f32-input MFMA, the E-step on peaked (model-sampled) features, clock / power while scoring."""
     import threading
     from poccala_amd import Engine, PCL_F32, synth
     out = {}
+    tl = more['tl']
+    t_sec = [time.perf_counter()]
+
+    def mark(name):
+        now = time.perf_counter()
+        tl[name] = now - t_sec[0]
+        t_sec[0] = now
     # ---- clock and power while the scoring kernel runs back to back for ~2 s (the 'power limited' claim)
     samples, stop = [], threading.Event()
 
@@ -692,6 +786,7 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
         source='rocm-smi --showclocks --showpower sampled every ~0.1 s while gmm_score_split16_kernel runs back to back; the in-kernel clock from '
                'GRBM_GUI_ACTIVE is in profiles/ (rocm-smi reads up to ~10 % above it)')
     b0.close()
+    mark('clock_power_s')
     # ---- forced alignment, f32-class scoring against float64 scoring on the device (near-ties may flip), 64 utterances
     from poccala_amd import PCL_F64
     nu = min(64, cfg['U'])
@@ -713,33 +808,32 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
     out['alignment_flip_rate'] = dict(utterances=nu, frames=nfr, flipped=nflip, rate=nflip / nfr, score_f32_ms=t32 * 1e3, score_f64_ms=t64 * 1e3,
                                       what='Viterbi paths under the default f32-class scoring against the same kernel chain under float64 scoring '
                                            '(PCL_F64, direct form): the float64 scoring removes every flip at score_f64_ms / score_f32_ms the cost')
-    # ---- strict f32: v_mfma_f32_32x32x2_f32 (bit for bit an f32 FMA chain), same batch
-    old = os.environ.get('PCL_SCORE_VARIANT')
-    os.environ['PCL_SCORE_VARIANT'] = '3'
-    try:
-        e3 = Engine(eng.device)
-    finally:
-        if old is None:
-            os.environ.pop('PCL_SCORE_VARIANT', None)
-        else:
-            os.environ['PCL_SCORE_VARIANT'] = old
+    mark('alignment_flip_rate_s')
+    # ---- strict f32: v_mfma_f32_32x32x2_f32 (bit for bit an f32 FMA chain) through the SAME timed loop as the headline: a
+    #      fresh engine with PCL_SCORE_VARIANT=3, the same resident batches, the same warm-up and step counts
+    t_mark = time.perf_counter()
+    e3 = engine_with_variant(eng.device, 3)
     e3.enable_timing(True)
     e3.load_model(mean, var, w)
     e3.load_units(np.stack(trans))
-    frames0, lens0, begin0 = synth.make_frames(cfg['U'], cfg['T'], cfg['D'], seed=0)
-    e3.load_frames(frames0)
-    b3 = e3.label_batch(labels, lens0, begin0)
-    b3.score(PCL_F32); e3.sync(); e3.kernel_time('score')
-    for _ in range(3):
-        b3.score(PCL_F32)
-    ms3, k3 = e3.kernel_time('score')
+    e3.load_frames(more['frames'])
+    nb = max(1, args.batches)
+    b3 = [e3.label_batch(more['labels_all'][cfg['U'] * k:cfg['U'] * (k + 1)], more['lens_all'][cfg['U'] * k:cfg['U'] * (k + 1)],
+                         more['begin_all'][cfg['U'] * k:cfg['U'] * (k + 1)]) for k in range(nb)]
+    el3, ms3, k3, fb3, kf3 = timed_steps(e3, b3, PCL_F32, False, args.warmup, args.steps, lambda: None)
     ms3 /= max(k3, 1)
     flop = pairs * cfg['M'] * (3 * cfg['D'] + 4)
-    out['strict_f32'] = dict(kernel='gmm_score_mfma_kernel<39,2> (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3)', score_ms=ms3,
+    out['strict_f32'] = dict(kernel='gmm_score_mfma_kernel<39,2> (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3)',
+                             value=frames_per_rank * args.steps / el3, ms_per_step=el3 / args.steps * 1e3, steps=args.steps, warmup=args.warmup,
+                             score_ms=ms3, fb_kernel_avg_ms=fb3 / max(kf3, 1),
                              tflops=flop / (ms3 * 1e-3) / 1e12, peak=FP32_VECTOR_PEAK_TFLOPS, frac=flop / (ms3 * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                             score_only_frames_per_s=frames_per_rank / (ms3 * 1e-3))
-    b3.close()
+                             what='the headline\'s timed loop (score + forward-backward, %d resident batches, same steps / warm-up) with every Gaussian '
+                                  'product an f32 FMA chain on the f32-input matrix pipe; value = frames/s of that loop on this GPU' % nb)
+    for bt in b3:
+        bt.close()
     e3.close()
+    frames0, lens0, begin0 = synth.make_frames(cfg['U'], cfg['T'], cfg['D'], seed=0)
+    mark('strict_f32_loop_s')
     # ---- the E-step on peaked posteriors: features sampled from the model along each utterance's label (aligned speech)
     fr = synth.make_peaked_frames(labels, cfg['T'], mean, var, seed=5)
     ep = Engine(eng.device)
@@ -763,6 +857,7 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
                                     'the posteriors of aligned speech; score + forward-backward + accumulate + per-unit merge, no exchange')
     bp.close()
     ep.close()
+    mark('estep_peaked_s')
     # ---- the accumulate pass in its approximate mode (pcl_accumulate_prune) on the bench's own flat posteriors: a fresh context
     #      with the ORIGINAL model (the main one has been through an M-step by now), pairs with gamma_t(j) < 2^-40 left out
     ef = Engine(eng.device)
@@ -793,7 +888,81 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
     del lg0, st_acc
     bf.close()
     ef.close()
+    mark('accumulate_pruned_s')
     out['zero_change_route'] = zero_change_route()
+    mark('zero_change_route_s')
+    out['configs'] = other_configs(args, eng.device)
+    mark('other_configs_s')
+    return out
+
+
+def other_configs(args, device):
+    """One-line summaries of the other BASELINE configurations on this GPU (they are parity-test cases, not bench lines; the
+    driver's record should still carry what they run at): C2 (score + forward-backward), C3 (score + Viterbi forced alignment)
+    through the headline's timed loop, and the C5 shard (all-state scoring + token-passing decode).  Fresh engines, models of
+    each configuration's own shape; `python bench.py --workload C3|C5shard` prints the full lines."""
+    from poccala_amd import Engine, PCL_F32, synth
+    out = {}
+    for name in ('C2', 'C3'):
+        c = synth.CONFIGS[name]
+        align = name == 'C3'
+        mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+        nb = max(1, args.batches)
+        frames, lens, begin = synth.make_frames(c['U'] * nb, c['T'], c['D'], seed=0)
+        labels = synth.make_labels(c['U'] * nb, c['L'], c['units'], seed=2)
+        e = Engine(device)
+        e.enable_timing(True)
+        e.load_model(mean, var, w)
+        e.load_units(np.stack(trans))
+        e.load_frames(frames)
+        bs = [e.label_batch(labels[c['U'] * k:c['U'] * (k + 1)], lens[c['U'] * k:c['U'] * (k + 1)], begin[c['U'] * k:c['U'] * (k + 1)]) for k in range(nb)]
+        e.kernel_time('viterbi')
+        steps = max(args.steps, 10)
+        el, sc_ms, sc_n, fb_ms, fb_n = timed_steps(e, bs, PCL_F32, align, args.warmup, steps, lambda: None)
+        vit_ms, vit_n = e.kernel_time('viterbi')
+        nfr = int(lens[:c['U']].sum())
+        out[name] = dict(task='score + Viterbi forced alignment' if align else 'score + forward-backward',
+                         shape='%d utterances x %d frames, M=%d, %d units, L=%d' % (c['U'], c['T'], c['M'], c['units'], c['L']),
+                         value=nfr * steps / el, unit='frames/s', ms_per_step=el / steps * 1e3, steps=steps,
+                         score_kernel_ms=sc_ms / max(sc_n, 1),
+                         dp_kernel='hmm_viterbi_kernel' if align else 'hmm_fb2_kernel',
+                         dp_kernel_ms=vit_ms / max(vit_n, 1) if align else fb_ms / max(fb_n, 1))
+        for bt in bs:
+            bt.close()
+        e.close()
+    c = synth.CONFIGS['C5shard']
+    tree, lx = synth.make_pronunciation_tree(args.words, c['units'])
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'])
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
+    e = Engine(device)
+    e.enable_timing(True)
+    e.load_model(mean, var, w)
+    e.load_units(np.stack(trans))
+    e.load_lexicon(tree)
+    e.load_frames(frames)
+    b = e.all_state_batch(lens, begin)
+    b.score(PCL_F32); b.decode(max_tokens=args.max_tokens); e.sync()
+    e.kernel_time('score'); e.kernel_time('decode')
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.score(PCL_F32)
+        res = b.decode(max_tokens=args.max_tokens)
+    e.sync()
+    el = time.perf_counter() - t0
+    sc_ms, k1 = e.kernel_time('score')
+    de_ms, k2 = e.kernel_time('decode')
+    ntok = np.concatenate([r['n_tokens'] for r in res])
+    out['C5shard'] = dict(task='all-state scoring + lexicon token-passing decode (results on the host)',
+                          shape='%d utterances x %d frames, %d states x %d mixtures, tree of %d words / %d nodes, <= %d live tokens'
+                                % (c['U'], c['T'], c['units'] * 3, c['M'], lx.size, len(tree['names']), args.max_tokens),
+                          value=c['U'] * c['T'] * steps / el, unit='frames/s', ms_per_step=el / steps * 1e3, steps=steps,
+                          score_kernel_ms=sc_ms / max(k1, 1), decode_kernel_ms=de_ms / max(k2, 1), live_tokens_mean=float(ntok.mean()),
+                          decoder='the reference\'s Decoder.py is dead code: Token.viterbi / pruning / token_passing / passing_in_word are pinned by golden '
+                                  'G14 from the reference itself; first-word seeding, word-to-word hand-over, node-keyed tokens, the finished test on the '
+                                  'last emitting state and the frame order (rules D1-D5) are the builder\'s completion, not the reference\'s')
+    b.close()
+    e.close()
     return out
 
 

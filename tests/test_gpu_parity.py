@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 S = 5
 F32_RTOL = 1e-4      # the north-star bound
-F32_LOGLIK_ATOL = 2e-4   # absolute bound on ln b_j(o_t) (|ln b| ~ 50..150 -> ~2e-6 relative)
+F32_LOGLIK_ATOL = 5e-5   # absolute bound on ln b_j(o_t): 3x the measured worst case (1.5e-5 at |ln b| ~ 85, ~2e-7 relative)
 
 
 @pytest.fixture(scope='module')
@@ -630,8 +630,11 @@ def test_ill_conditioned_states_use_direct_form(eng):
     err = np.abs(got - ref)
     own = np.zeros_like(err, dtype=bool)
     own[st, np.arange(T)] = True                      # the (state, frame) pairs that carry posterior mass
-    assert err[own].max() < F32_LOGLIK_ATOL
-    np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)
+    # the frames carry the states' offset of 60 (270 sigma of the tight states): the f32 roundings of the parameters and of
+    # the centred frame move the exponent by more than the centred-data allowance -- the analytical bound prices exactly that
+    bound = f32_evaluation_bound(mean, var, w, x)
+    assert (err[own] < F32_LOGLIK_ATOL + bound[own]).all()
+    assert_f32_class(got, ref, bound, what='ill-conditioned mix:')
     b.close()
 
     # E-step statistics with both kernels contributing to one statistics buffer; every utterance is sampled from

@@ -33,7 +33,8 @@ run dec_fetch "FETCH_SIZE" $DEC
 run dec_write "WRITE_SIZE" $DEC
 run dec_clk "GRBM_GUI_ACTIVE" $DEC
 run dec_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $DEC
-python3 $R/tools/make_profile_summary.py $OUT r02
+RND=${RND:-r03}
+python3 $R/tools/make_profile_summary.py $OUT $RND
 find $OUT -name "*.csv" -size +1M -delete
 cat $OUT/failures.log 2>/dev/null
-tail -22 $OUT/r02_bench_summary.txt; tail -22 $OUT/r02_accumulate_summary.txt; tail -12 $OUT/r02_decode_summary.txt
+tail -22 $OUT/${RND}_bench_summary.txt; tail -22 $OUT/${RND}_accumulate_summary.txt; tail -12 $OUT/${RND}_decode_summary.txt

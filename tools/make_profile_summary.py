@@ -48,6 +48,9 @@ def pick(kt, name):
 out = ['# rocprofv3 summaries, %s: python3 bench.py --steps 3 --warmup 1 --cpu-baseline 0 --extra 0 (one MI355X, C4 shard)' % RND,
        '# produced by tools/gpu_profile.sh + tools/make_profile_summary.py; one --kernel-trace --stats pass and separate --pmc passes',
        '', '## --kernel-trace --stats (%s_bench_kernel_stats.csv)' % RND]
+import hashlib
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'poccala_amd', 'csrc', 'gmm_score_split.hip')
+out.insert(2, 'kernel_source_sha16 gmm_score_split.hip %s' % hashlib.sha256(open(_src, 'rb').read()).hexdigest()[:16])   # bench.py withholds `traffic` when the source has moved on
 kt, lines = kernel_stats('bench_trace', '%s_bench_kernel_stats.csv' % RND)
 out += lines + ['', '## --pmc passes (<= 4 counters per pass, no trace domains), per-dispatch averages']
 lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fb'])
