@@ -7,7 +7,8 @@ recursion and score (:250-288), token_passing / passing_in_word / pruning (:91-1
 device, for many utterances at once (hmm_decode.hip through pcl_batch_decode).  The gaps that had to be filled because the
 source cannot run (D1-D5: exit test on the last emitting state, tokens keyed by tree node, all first characters start,
 word ends re-seed the first characters with a uniform language model, "all step, then all hand over" frames) are listed in
-include/poccala_hip.h and in the tests' CPU restatement.  PARITY UNPINNED against the reference.
+include/poccala_hip.h and in the tests' CPU restatement.  Parity: recursion, pruning, frame loop and in-word hand-over are pinned
+by golden G14 (the reference's own pieces, run with a stand-in for the missing import); D1-D5 are the builder's completion.
 """
 import numpy as np
 

@@ -5,23 +5,32 @@
 // tile of one state's list of surviving frames,
 //   (1) D1[f][m] = Xe[f,:] . P[:,m]            the scoring GEMM (K = 2D + 2): log2 of w_m N_m(o_f), relative to K0_j
 //       g[f][m]  = exp2(D1 + cf_f)             cf_f = log2e (ln gamma_f(j) - ln b_j(o_f)) + K0_j: gamma_f(j,m)
-//   (2) S[m][:] += sum_f g[f][m] [x'^2_d, x'_d | 1]      raw moments S2, S1, S0 about the state centre
-// What changed against the round-1 kernel (48 ms on the bench shard, matrix pipe 43 % busy):
-//   * product (1) runs in the scoring kernel's two-piece f16 scheme (gmm_score_split.hip, variant 7: operands scaled by
-//     exact powers of two per (state, feature), x = h1 + h2 carries 22 bits, products a2x1 + a1x2 + a1x1, the constant
-//     k'_m - K0_j folded into the spare K slot): 15 MFMAs instead of 30.  cf is added on the VALU in f32 (it is a
-//     per-frame scalar of magnitude ~100: two f16 pieces would not hold it).  Product (2) is unchanged: posteriors in
-//     two bf16 pieces, features in three, five cross terms (30 MFMAs) -- the statistics are the exact moments of the
-//     frames under posteriors perturbed by < 2^-16 relative, and bf16 keeps the range of a rarely responsible mixture.
-//   * the operand images of a tile are built ONCE by a producer kernel (gather of the 32 frame rows, centring, scaling,
-//     splitting, both fragment layouts) and written to HBM in LDS-image order; the 8 workgroups that own the 8 x 256
-//     mixtures of the state stream them in by LDS-DMA (global_load_lds, no VGPRs, no VALU).  Round 1 staged every tile
-//     in each of the 8 workgroups with ~105 VALU instructions per thread per tile.
-//   * the consumer is software pipelined across tiles: while the VALU turns D1 of tile t into posteriors, the matrix
-//     pipe already runs product (1) of tile t+1, then product (2) of tile t; three LDS slots, one barrier per tile.
-//   * a frame whose scaled feature leaves the f16 range (|x - c| beyond ~300 sigma of the tightest mixture) is taken
-//     out of the image (g = 0) and marked in its tile's mask; the direct-form VALU kernel adds exactly those frames
-//     afterwards (gmm_accumulate.hip, masked mode), so no input sees a clamped posterior.
+//   (2) S^T[:][m] += sum_f [x'^2_d, x'_d | 1]^T g[f][m]      raw moments S2, S1, S0 about the state centre
+// Round 3: BOTH products run in the scoring kernel's two-piece f16 scheme on ONE operand image (round 2: product (2) in
+// bf16, posteriors in two pieces and features in three, five cross terms = 30 MFMAs, and a second, feature-major copy of
+// the tile in the image):
+//   * product (1) as before (gmm_score_split.hip, variant 7: operands scaled by exact powers of two per (state, feature),
+//     x = h1 + h2 carries 22 bits, products a2x1 + a1x2 + a1x1, the constant k'_m - K0_j folded into the spare K slot):
+//     15 MFMAs, cf riding in as the C operand of the chain.
+//   * product (2) = X^T . g with the SAME scaled f16 x2 frame operand, read back TRANSPOSED from the same LDS image
+//     (ds_read_b64_tr_b16: a 16-lane group fetches 4 frames x 16 features and receives them feature-major), and the
+//     posteriors in two f16 pieces: g1 X1 + g1 X2 + g2 X1 = 18 MFMAs (30 before).  f16 has 5 exponent bits where bf16 had
+//     8, so a rarely responsible mixture (gamma ~ 1e-30) would vanish; every mixture therefore carries its own running
+//     power-of-two scale E_m (online-softmax style): posteriors enter as exp2(D1 - E_m), a tile whose largest value would
+//     leave (2^-24, 2^15] raises E_m and rescales that mixture's sums by the exact power of two (a wave-uniform branch
+//     that is taken for the first tile and rarely afterwards); what falls below 2^-38 of the mixture's own largest
+//     posterior so far is dropped, far below f32 resolution of the sums.  The sums are S^T (feature rows x mixture
+//     columns): the mixture stays on the lane from product (1)'s accumulator through product (2) to the flush, so the
+//     scale is a per-lane register and nothing crosses lanes.  Flush: S x 2^E_m / feature scale, in float64.
+//   * the image of a 32-frame tile is 11 KiB (29 before): [2 pieces][5 k-steps] x 1 KiB in product (1)'s fragment order
+//     with the 64-byte units (4 frames) of each side rotated by (side + 2 (s & 1)) -- row reads (ds_read_b128) and
+//     transposed reads are both bank-conflict free (tools/ubench_trread.hip checks the maps with exact integers) -- plus
+//     one block of per-frame coefficients.  The producer writes 2.6 x fewer bytes, the 8 slice workgroups of a state
+//     stream 2.6 x fewer through LDS-DMA, and 8 tiles fit in flight.
+//   * unchanged: tile images built once per state by the producer; the consumer software-pipelined across tiles
+//     (posteriors(t) on the VALU beside product (1) of tile t+1, then product (2)(t) beside the reads for t+2);
+//     a frame whose scaled feature leaves the f16 range is taken out of the image (g = 0), marked in its tile's mask and
+//     added by the direct-form VALU kernel afterwards (gmm_accumulate.hip, masked mode).
 // States whose centred expansion is ill conditioned (pcl_model_conditioning) never come here.
 #include <algorithm>
 
@@ -30,19 +39,22 @@
 namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
-typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 
-#ifndef PCL_ACC16_MT
-#define PCL_ACC16_MT 1
-#endif
 #ifndef PCL_ACC16_AW
-#define PCL_ACC16_AW (PCL_ACC16_MT == 1 ? 8 : 4)
+#define PCL_ACC16_AW 8
 #endif
-constexpr int MT = PCL_ACC16_MT;       // 32-mixture tiles per consumer wave
-constexpr int AW = PCL_ACC16_AW;       // waves per consumer workgroup
+#ifndef PCL_ACC16_NSLOT
+#define PCL_ACC16_NSLOT 8
+#endif
+constexpr int AW = PCL_ACC16_AW;       // waves per consumer workgroup, one 32-mixture tile each
 constexpr float FMAXH = 6.0e4f;        // what an f16 piece may hold (gmm_score_split.hip)
 constexpr double LOG2E = 1.4426950408889634074;
+constexpr float E_INIT = -1048576.f;   // "no posterior seen yet": any real tile raises it (an integer, so E stays one)
+constexpr float G_TOP = 15.f;          // a tile whose largest log2 posterior exceeds E + G_TOP rescales (f16 max = 2^16)
+constexpr float G_SET = 12.f;          // ... to put that largest value into (2^11, 2^12]
 
 // LDS-DMA of 16 B per lane (1 KiB per wave) as an asm statement: hipcc does not count an asm memory operation, so it does
 // not drain it (s_waitcnt vmcnt(0)) in front of the next ds_read the way it does for __builtin_amdgcn_global_load_lds --
@@ -63,13 +75,18 @@ __device__ __forceinline__ unsigned int lds_addr(const void *p) {
 template <int D>
 struct Img {                           // image of one 32-frame tile: 1-KiB blocks (64 lanes x 16 B), LDS-DMA order
     static constexpr int KS = (D + 7) / 8;                 // K-steps of 16 of product (1) (spare slot at d = D)
-    static constexpr int NCT = (2 * D + 1 + 31) / 32;      // 32-column tiles of product (2)
-    static constexpr int B1 = 0;                           // [piece 2][KS]: frame-major f16 fragments (lane = side * 32 + frame)
-    static constexpr int B2 = 2 * KS;                      // [piece 3][NCT][k-step 2]: feature-major bf16 fragments
-    static constexpr int BM = B2 + 3 * NCT * 2;            // misc: cf in register order [2][16] f32 @0, gamma_f(j) [32] f64 @256
+    static constexpr int NCT = (KS + 1) / 2;               // 32-row tiles of S^T: two k-steps' 16 columns (8 x'^2 | 8 x') each
+    static constexpr int B1 = 0;                           // [piece 2][KS]: the scaled f16 x2 frame operand, see unit_of()
+    static constexpr int BM = 2 * KS;                      // misc: cf in register order [2][16] f32 @0, gamma_f(j) [32] f64 @256
     static constexpr int NB = BM + 1;
     static_assert(D % 8 != 0, "the folded constant needs a spare K slot");
 };
+// Inside the 1-KiB block of k-step s: side (0: x'^2, 1: x') x 512 B, in it eight 64-byte units of 4 frames x 16 B (8 f16
+// features of one frame), unit of frame group fg = frame >> 2 at position (fg + side + 2 (s & 1)) & 7.  A ds_read_b128 of
+// the block (lane = side * 32 + frame) covers every bank once per 16-lane group; a ds_read_b64_tr_b16 of one 32-lane half
+// touches four units {side 0, side 1} x {s even, s odd} of ONE frame group, which the rotation puts on four different
+// bank quarters.
+__host__ __device__ constexpr int unit_of(int fg, int side, int s) { return (fg + side + 2 * (s & 1)) & 7; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // tile bookkeeping: tile_off[w] = first tile of state w of this launch's state range (exclusive scan of ceil(n/32))
@@ -110,7 +127,7 @@ __global__ __launch_bounds__(256) void acc16_producer_kernel(
     const int *__restrict__ seg_hi, const long long *__restrict__ off, const ActiveFrame *__restrict__ list, const int *__restrict__ tile_off, int tile_base,
     uint4 *__restrict__ images, unsigned int *__restrict__ tile_mask, int *__restrict__ state_flag) {
     using I = Img<D>;
-    constexpr int KS = I::KS, NCT = I::NCT, XS = KS * 8 + 1;     // row stride of the staged tile (odd: conflict-free column reads)
+    constexpr int KS = I::KS, XS = KS * 8 + 1;                   // row stride of the staged tile (odd: conflict-free column reads)
     __shared__ float xs[32 * XS];
     __shared__ float cfs[32];
     __shared__ double lgs[32];
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(256) void acc16_producer_kernel(
     }
     __syncthreads();
     uint4 *img = images + (size_t)tile * (I::NB * 64);
-    // ---- (1) frame-major f16 fragments: item = (k-step s, lane = side * 32 + frame): 8 features of one frame, both pieces
+    // ---- the scaled f16 x2 frame operand: item = (k-step s, lane = side * 32 + frame): 8 features of one frame, both pieces
     const float *fs = fscale + (size_t)j * 2 * (KS * 8);
     unsigned int ovf = 0u;
     for (int it = tid; it < KS * 64; it += 256) {
@@ -172,46 +189,18 @@ __global__ __launch_bounds__(256) void acc16_producer_kernel(
                 if (__builtin_fabsf(val) > FMAXH) ovf |= 1u << f;
                 val = __builtin_fminf(__builtin_fmaxf(val, -FMAXH), FMAXH);
             } else if (d == D) {
-                val = side ? 0.f : 1.f;                          // x1: [1 | 0]  (a1: [k1 | 0], a2: [k2 | 1]: the sum is k1 + k2)
+                val = side ? 0.f : 1.f;                          // x1: [1 | 0]  (a1: [k1 | 0], a2: [k2 | 1]: the sum is k1 + k2); product (2): S0
             }
             const _Float16 a = (_Float16)val;
             const _Float16 b = (d == D) ? (_Float16)0.f : (_Float16)(val - (float)a);
             h1[x] = __builtin_bit_cast(unsigned short, a);
             h2[x] = __builtin_bit_cast(unsigned short, b);
         }
-        img[(I::B1 + 0 * KS + s) * 64 + ln] = make_uint4(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16), h1[4] | ((unsigned)h1[5] << 16), h1[6] | ((unsigned)h1[7] << 16));
-        img[(I::B1 + 1 * KS + s) * 64 + ln] = make_uint4(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16), h2[4] | ((unsigned)h2[5] << 16), h2[6] | ((unsigned)h2[7] << 16));
+        const int at = side * 32 + unit_of(f >> 2, side, s) * 4 + (f & 3);       // 16-byte position inside the block
+        img[(I::B1 + 0 * KS + s) * 64 + at] = make_uint4(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16), h1[4] | ((unsigned)h1[5] << 16), h1[6] | ((unsigned)h1[7] << 16));
+        img[(I::B1 + 1 * KS + s) * 64 + at] = make_uint4(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16), h2[4] | ((unsigned)h2[5] << 16), h2[6] | ((unsigned)h2[7] << 16));
     }
     if (ovf) atomicOr(&s_mask, ovf);
-    // ---- (2) feature-major bf16 fragments: item = (column tile ct, k-step sp, lane = h * 32 + c): 8 frames of one column,
-    //      element x <-> frame 16 sp + 8 (x >> 2) + 4 h + (x & 3) (the order product (1)'s accumulator registers come in)
-    for (int it = tid; it < NCT * 2 * 64; it += 256) {
-        const int ct = it / 128, sp = (it >> 6) & 1, ln = it & 63, h = ln >> 5, c = ln & 31;
-        const int c2 = ct * 32 + c, d = c2 >> 1, side = c2 & 1;
-        unsigned short p[3][8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const int f = 16 * sp + 8 * (x >> 2) + 4 * h + (x & 3);
-            float val = 0.f;
-            if (c2 < 2 * D) {
-                const float xc = xs[f * XS + d];
-                val = side ? xc : xc * xc;
-            } else if (c2 == 2 * D) {
-                val = 1.f;                                       // S0
-            }
-            float r = val;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const __bf16 b = (__bf16)r;
-                p[q][x] = __builtin_bit_cast(unsigned short, b);
-                r -= (float)b;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            img[(I::B2 + (q * NCT + ct) * 2 + sp) * 64 + ln] =
-                make_uint4(p[q][0] | ((unsigned)p[q][1] << 16), p[q][2] | ((unsigned)p[q][3] << 16), p[q][4] | ((unsigned)p[q][5] << 16), p[q][6] | ((unsigned)p[q][7] << 16));
-    }
     __syncthreads();
     // ---- misc block: cf in the register order of product (1)'s accumulator (lane half h, register r <-> frame
     //      (r & 3) + 8 (r >> 2) + 4 h), frames taken out of the image get -inf; gamma_f(j) for alpha_acc
@@ -241,23 +230,23 @@ __global__ __launch_bounds__(256) void acc16_producer_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// consumer: AW waves x MT m-tiles = AW MT x 32 mixtures of one state per workgroup; the slices of a state sit on block
-// indices with equal residue mod 8 (one XCD's L2).  MT = 2 at one wave per SIMD: every fragment read from LDS feeds two
-// MFMAs, product (1) runs two independent chains and product (2) six.
+// consumer: AW waves x 32 mixtures of one state per workgroup; the slices of a state sit on block indices with equal
+// residue mod 8 (one XCD's L2).
 // FRESH: the statistics are all zero (first pass after pcl_stats_zero) and every (state, mixture) belongs to exactly one wave:
 // the flush stores instead of read-modify-writing 7.7 GB of float64.
 template <int D, bool FRESH>
-__global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kernel(
-    const uint4 *__restrict__ images, const uint4 *__restrict__ pm16f, const float *__restrict__ centers,
+__global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kernel(
+    const uint4 *__restrict__ images, const uint4 *__restrict__ pm16f, const float *__restrict__ centers, const float *__restrict__ fscale,
     const double *__restrict__ means64, int M, int Mpad, int n_mtiles, int n_states, const int *__restrict__ work_states,
     const int *__restrict__ tile_off, int tile_base, double bias, double *__restrict__ st_acc, double *__restrict__ st_alpha,
     double *__restrict__ st_mean, double *__restrict__ st_cov) {
     using I = Img<D>;
     constexpr int KS = I::KS, NCT = I::NCT, NB = I::NB;
-    constexpr int NSLOT = 5;                                     // tile t in slot t % 5: t .. t + 2 being read, t + 3 and t + 4 landing
+    constexpr int NSLOT = PCL_ACC16_NSLOT;                       // tile t in slot t % NSLOT: t .. t + 2 being read, the rest landing
+    constexpr int AHEAD = NSLOT - 1;                             // tile t + AHEAD is issued at the top of tile t (its slot held tile t - 1)
     __shared__ __attribute__((aligned(16))) uint4 slot[NSLOT][NB * 64];
 
-    const int nslice = (n_mtiles + AW * MT - 1) / (AW * MT);
+    const int nslice = (n_mtiles + AW - 1) / AW;
     const int b = blockIdx.x;
     const int w = (b & 7) + 8 * (b / (8 * nslice));              // block b runs on XCD b % 8: all slices of a state on one XCD
     const int slice = (b >> 3) % nslice;
@@ -266,27 +255,24 @@ __global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kerne
     if (t0 == t1) return;
     const int j = work_states[w];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
-    const int mt0 = (slice * AW + wave) * MT;                    // this wave's m-tiles: mt0 .. mt0 + MT - 1
-    const bool live = mt0 < n_mtiles;                            // (a tile past the end repeats the last one and is not flushed)
+    const int mt = slice * AW + wave;                            // this wave's m-tile
+    const bool live = mt < n_mtiles;                             // (a wave past the end only helps with the DMA)
 
-    // parameters of this wave's m-tiles: the scoring layout of variant 7 as it is (B operand of product (1))
-    h8v pf[MT][2][KS];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int mt = min(mt0 + i, n_mtiles - 1);
+    // parameters of this wave's m-tile: the scoring layout of variant 7 as it is (B operand of product (1))
+    h8v pf[2][KS];
+    {
         const uint4 *pq = pm16f + ((size_t)j * n_mtiles + (live ? mt : 0)) * (2 * KS * 64) + lane;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) pf[i][p][s] = __builtin_bit_cast(h8v, pq[(p * KS + s) * 64]);
+            for (int s = 0; s < KS; ++s) pf[p][s] = __builtin_bit_cast(h8v, pq[(p * KS + s) * 64]);
     }
-    f16v S[MT][NCT];
+    f16v ST[NCT];                                                // S^T: rows = feature columns (registers), column = mixture (lane)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) S[i][ct][r] = 0.f;
+        for (int r = 0; r < 16; ++r) ST[ct][r] = 0.f;
+    float E = E_INIT;                                            // this lane's mixture: sums are in units of 2^E
     double galpha = 0.0;
 
     auto dma = [&](int t) {                                      // tile t -> slot t % NSLOT; the NB blocks are dealt to the waves
@@ -294,109 +280,85 @@ __global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kerne
         const unsigned int dst = __builtin_amdgcn_readfirstlane(lds_addr(&slot[t % NSLOT][0]));
         for (int p = wave; p < NB; p += AW) glds16(src + p * 64 + lane, dst + (unsigned int)p * 1024u);
     };
+    // product (1) row reads: lane = side * 32 + frame (side = half, frame = col); the unit rotation depends on s & 1
+    const int row_even = half * 32 + unit_of(col >> 2, half, 0) * 4 + (col & 3);
+    const int row_odd = half * 32 + unit_of(col >> 2, half, 1) * 4 + (col & 3);
     // (the frame fragments travel from one iteration to the next as plain 128-bit integers: carried as half vectors the
     //  compiler splits them into 16-bit halves at the loop edge and re-packs them with v_perm_b32, 80 VALU ops per tile)
     auto load1 = [&](int t, uint4 (&a1)[KS], uint4 (&a2)[KS]) {
-#ifdef PCL_ACC16_DIAG_NOLDS
-        const uint4 fake = make_uint4(t, lane, t ^ lane, 0x3c003c00u);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { a1[s] = fake; a2[s] = fake; }
-        return;
-#endif
         const uint4 *x1 = &slot[t % NSLOT][I::B1 * 64];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a2[s] = x1[(1 * KS + s) * 64 + lane];
+        for (int s = 0; s < KS; ++s) a2[s] = x1[(1 * KS + s) * 64 + ((s & 1) ? row_odd : row_even)];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a1[s] = x1[(0 * KS + s) * 64 + lane];
+        for (int s = 0; s < KS; ++s) a1[s] = x1[(0 * KS + s) * 64 + ((s & 1) ? row_odd : row_even)];
     };
-    // The chains start from the frames' coefficients cf (ln gamma - ln b in log2 units, -inf for a frame that is not in the
-    // image): the posterior's exponent comes out of the matrix pipe complete, no VALU add per value; d comes in holding cf
-    // (load_cf writes the very registers the chain accumulates in) and goes out as D1.  Small cross terms first.
-    auto mfma1 = [&](const uint4 (&a1)[KS], const uint4 (&a2)[KS], f16v (&d)[MT]) {
-#ifdef PCL_ACC16_DIAG_NOP1
-        d[0][0] += (float)a1[0].x + (float)a2[KS - 1].w;
-        return;
-#endif
+    // The chain starts from the frames' coefficients cf (ln gamma - ln b in log2 units, -inf for a frame that is not in the
+    // image): the posterior's exponent comes out of the matrix pipe complete; d comes in holding cf and goes out as D1.
+    auto mfma1 = [&](const uint4 (&a1)[KS], const uint4 (&a2)[KS], f16v &d) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a2[s]), pf[0][s], d, 0, 0, 0);   // x2 a1
 #pragma unroll
-            for (int i = 0; i < MT; ++i) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a2[s]), pf[i][0][s], d[i], 0, 0, 0);   // x2 a1
+        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[1][s], d, 0, 0, 0);   // x1 a2
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[i][1][s], d[i], 0, 0, 0);   // x1 a2
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) d[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[i][0][s], d[i], 0, 0, 0);   // x1 a1
+        for (int s = 0; s < KS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a1[s]), pf[0][s], d, 0, 0, 0);   // x1 a1
     };
-    auto load2 = [&](int t, int sp, bf8v (&bq)[3][NCT]) {
-#ifdef PCL_ACC16_DIAG_NOLDS
-        const uint4 fake2 = make_uint4(t, lane, sp, 0x3f803f80u);
+    // product (2) transposed reads (A = X^T): the 16-lane group (lane >> 4) & 1 of a half takes k-step s = 2 ct + group; in
+    // it lane 4 q + p supplies the address of frame row q, 8-byte chunk p (p >> 1 = side, p & 1 = which half of the 16 B) and
+    // lane i receives column i (i < 8: x'^2 feature 8 s + i, i >= 8: x' feature 8 s + i - 8) of 4 frames.  The fragment of
+    // k-step sp needs frames 16 sp + 4 h + {0..3} (elements 0..3) and + 8 (elements 4..7): two reads.  (KS odd: the last
+    // group of the last column tile reads the block behind its piece -- in bounds, and its rows of S^T are never looked at.)
+    const int tg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+    int tr_off[4];                                               // byte offset inside a piece for (sp, rd) -> k = 2 sp + rd, column tile 0
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+    for (int k = 0; k < 4; ++k)
+        tr_off[k] = tg * 1024 + (tp >> 1) * 512 + unit_of(2 * k + half, tp >> 1, tg) * 64 + tq * 16 + 8 * (tp & 1);
+    auto load2 = [&](int t, int sp, uint4 (&x)[2][NCT]) {
+        const unsigned char *base = reinterpret_cast<const unsigned char *>(&slot[t % NSLOT][I::B1 * 64]);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) bq[p][ct] = __builtin_bit_cast(bf8v, fake2);
-        return;
-#endif
-        const uint4 *x2 = &slot[t % NSLOT][I::B2 * 64];
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) bq[p][ct] = __builtin_bit_cast(bf8v, x2[((p * NCT + ct) * 2 + sp) * 64 + lane]);
+            for (int ct = 0; ct < NCT; ++ct) {
+                const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v *)(base + tr_off[2 * sp] + p * KS * 1024 + ct * 2048));
+                const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v *)(base + tr_off[2 * sp + 1] + p * KS * 1024 + ct * 2048));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                x[p][ct] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
     };
-    auto mfma2 = [&](const bf8v (&g1)[MT], const bf8v (&g2)[MT], const bf8v (&bq)[3][NCT]) {
-        // the MT x NCT accumulators are independent, issued round robin; small cross terms first
+    auto mfma2 = [&](const uint4 &g1, const uint4 &g2, const uint4 (&x)[2][NCT]) {
+        // the NCT accumulators are independent, issued round robin; small cross terms first
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < NCT; ++ct) ST[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, x[1][ct]), __builtin_bit_cast(h8v, g1), ST[ct], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[i], bq[2][ct], S[i][ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct) ST[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, x[0][ct]), __builtin_bit_cast(h8v, g2), ST[ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[i], bq[1][ct], S[i][ct], 0, 0, 0);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2[i], bq[0][ct], S[i][ct], 0, 0, 0);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[i], bq[1][ct], S[i][ct], 0, 0, 0);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) S[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1[i], bq[0][ct], S[i][ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct) ST[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, x[0][ct]), __builtin_bit_cast(h8v, g1), ST[ct], 0, 0, 0);
     };
 
     // Software pipeline, per wave, one basic block per tile t (the waves of a workgroup meet at ONE barrier per tile):
     //   region X   product (1) of tile t + 1  ||  VALU: D1 of tile t -> posteriors  ||  reads: product (2) fragments of tile t
     //   region Y   product (2) of tile t      ||  reads: cf and product (1) fragments of tile t + 2
-    // LDS-DMA: tile t + 4 is issued at the top of tile t and waited for (counted vmcnt, leaving the newest tile in flight)
-    // at the end of tile t + 1, two barriers before its first read: issued -> landed takes microseconds when every CU streams.
+    // LDS-DMA: tile t + AHEAD is issued at the top of tile t; at the end of tile t a wave waits (counted vmcnt) until its blocks
+    // of tile t + 3 -- first read in tile t + 1 -- have landed and leaves the newer tiles (up to AHEAD - 3 of them) in flight.
     constexpr int MYB_HI = (NB + AW - 1) / AW, MYB_LO = NB / AW;  // blocks per tile this wave issues: waves < NB % AW one more
     const bool more_blocks = wave < NB % AW;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < AHEAD; ++k)
         if (t0 + k < t1) dma(t0 + k);
     // this wave's blocks have landed -- and, as a BUILTIN the compiler's wait-count pass sees, its own parameter loads too:
     // otherwise it re-waits for them (vmcnt(0)) at their first use inside the loop, every iteration, and drains the DMA
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();                                             // everyone's have
     // Two accumulator sets take turns (the tile loop is unrolled by two): while the posteriors of tile t are read out of one,
-    // the chains of tile t + 1 run in the other, which was loaded with that tile's cf a phase earlier -- no register copies.
-    f16v dA[MT], dB[MT];
+    // the chain of tile t + 1 runs in the other, which was loaded with that tile's cf a phase earlier -- no register copies.
+    f16v dA, dB;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dA[i][r] = dB[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) dA[r] = dB[r] = 0.f;
     uint4 a1[KS], a2[KS];
-    auto load_cf = [&](int t, f16v (&c)[MT]) {                   // cf of tile t in the register order of D1 (lane half h, register r)
+    auto load_cf = [&](int t, f16v &c) {                         // cf of tile t in the register order of D1 (lane half h, register r)
         const float4 *cfp = reinterpret_cast<const float4 *>(&slot[t % NSLOT][I::BM * 64]) + half * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = cfp[q];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) { c[i][4 * q] = v.x; c[i][4 * q + 1] = v.y; c[i][4 * q + 2] = v.z; c[i][4 * q + 3] = v.w; }
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
         }
     };
     if (live) {
@@ -406,89 +368,73 @@ __global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kerne
         load_cf(t0 + 1, dB);                                     // (past the last tile: whatever the slot holds, nobody reads the product)
         load1(t0 + 1, a1, a2);
     }
-#ifdef PCL_ACC16_STAMPS          // diagnostic build: where a wave's time goes (s_memtime at points where no LDS read is pending)
-    unsigned long long st_busy = 0, st_vm = 0, st_bar = 0, st_prev = __builtin_amdgcn_s_memtime();
-    unsigned int st_n = 0;
-#endif
-    auto tile_step = [&](int t, f16v (&d1)[MT], f16v (&dn)[MT]) __attribute__((always_inline)) {
-#ifdef PCL_ACC16_DIAG_NODMA
-        const bool ahead = false;
-#else
-        const bool ahead = t + 4 < t1;
-#endif
-        if (ahead) dma(t + 4);                                   // its slot held tile t - 1: everyone left it at the last barrier
+    auto tile_step = [&](int t, f16v &d1, f16v &dn) __attribute__((always_inline)) {
+        const bool ahead = t + AHEAD < t1;
+        if (ahead) dma(t + AHEAD);                               // its slot held tile t - 1: everyone left it at the last barrier
         const uint4 *cur = &slot[t % NSLOT][0];
         if (slice == 0 && wave == 0 && lane < 32) galpha += reinterpret_cast<const double *>(cur + I::BM * 64)[32 + lane];   // byte 256: gamma_f(j)
         if (live) {
-            bf8v bq0[3][NCT], bq1[3][NCT];
-            bf8v g1a[MT], g1b[MT], g2a[MT], g2b[MT];
-            // ---- region X
+            // ---- this mixture's scale: the largest log2 posterior of the tile (both lane halves hold frames of the SAME mixture)
+            float mx = __builtin_fmaxf(__builtin_fmaxf(d1[0], d1[1]), d1[2]);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                // posteriors gamma_t(j,m) (Clustering.py:660-661) of tile t in two bf16 pieces = the A fragments of product (2)
-                typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
-                unsigned int u1[8], u2[8];
-#ifdef PCL_ACC16_DIAG_NOV
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    u1[r] = __float_as_uint(d1[i][2 * r]);
-                    u2[r] = __float_as_uint(d1[i][2 * r + 1]);
-                }
-#else
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float ga = __builtin_amdgcn_exp2f(d1[i][2 * r]), gb = __builtin_amdgcn_exp2f(d1[i][2 * r + 1]);
-                    const bf2v c = bf2v{(__bf16)ga, (__bf16)gb};                   // v_cvt_pk_bf16_f32
-                    u1[r] = __builtin_bit_cast(unsigned int, c);
-                    const bf2v e = bf2v{(__bf16)(ga - __uint_as_float(u1[r] << 16)), (__bf16)(gb - __uint_as_float(u1[r] & 0xffff0000u))};
-                    u2[r] = __builtin_bit_cast(unsigned int, e);
-                }
-#endif
-                g1a[i] = __builtin_bit_cast(bf8v, make_uint4(u1[0], u1[1], u1[2], u1[3]));
-                g1b[i] = __builtin_bit_cast(bf8v, make_uint4(u1[4], u1[5], u1[6], u1[7]));
-                g2a[i] = __builtin_bit_cast(bf8v, make_uint4(u2[0], u2[1], u2[2], u2[3]));
-                g2b[i] = __builtin_bit_cast(bf8v, make_uint4(u2[4], u2[5], u2[6], u2[7]));
+            for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, d1[r]), d1[r + 1]);
+            mx = __builtin_fmaxf(mx, d1[15]);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = __builtin_fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
+            const float rel = mx - E;                            // (-inf when every frame of the tile is padding / masked: no trigger)
+            if (__builtin_amdgcn_ballot_w64(rel > G_TOP) != 0ull) {      // rare, wave-uniform: the first tile, and a tile 8x above anything before it
+                const float delta = rel > G_TOP ? __builtin_ceilf(rel) - G_SET : 0.f;
+                const float f = __builtin_amdgcn_exp2f(-delta);  // exact power of two (0 when nothing real was summed yet)
+                E += delta;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ST[ct][r] *= f;
+            }
+            uint4 x0[2][NCT], x1[2][NCT];
+            // ---- region X: posteriors gamma_t(j,m) 2^-E (Clustering.py:660-661) of tile t in two f16 pieces = the B fragments of product (2)
+            unsigned int u1[8], u2[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float ga = __builtin_amdgcn_exp2f(d1[2 * r] - E), gb = __builtin_amdgcn_exp2f(d1[2 * r + 1] - E);
+                u1[r] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(ga, gb));
+                const float ra = ga - (float)__builtin_bit_cast(_Float16, (unsigned short)(u1[r] & 0xffffu));
+                const float rb = gb - (float)__builtin_bit_cast(_Float16, (unsigned short)(u1[r] >> 16));
+                u2[r] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+            }
+            const uint4 g1a = make_uint4(u1[0], u1[1], u1[2], u1[3]), g1b = make_uint4(u1[4], u1[5], u1[6], u1[7]);
+            const uint4 g2a = make_uint4(u2[0], u2[1], u2[2], u2[3]), g2b = make_uint4(u2[4], u2[5], u2[6], u2[7]);
             mfma1(a1, a2, dn);                                   // product (1) of tile t + 1, from its frames' coefficients
-            load2(t, 0, bq0);                                    // (asked for at the top of the tile and pinned there with a sched_barrier,
-            load2(t, 1, bq1);                                    //  the 18 reads make the first MFMA wait for all of them: 43.7 vs 41.9 ms)
+            load2(t, 0, x0);
+            load2(t, 1, x1);
             // ---- region Y
-#ifndef PCL_ACC16_DIAG_NOP2      // (timing diagnostics: wrong results)
-            mfma2(g1a, g2a, bq0);                                // product (2) of tile t: S[mixture][feature] += g^T . Xe
-            mfma2(g1b, g2b, bq1);
-#else
-            S[0][0][0] += (float)g1a[0][0] + (float)g2b[MT - 1][1] + (float)bq0[0][0][0] + (float)bq1[2][NCT - 1][3];
-#endif
+            mfma2(g1a, g2a, x0);                                 // product (2) of tile t: S^T[feature][mixture] += Xe^T . g
+            mfma2(g1b, g2b, x1);
             load_cf(t + 2, d1);                                  // (the posteriors of tile t have been read out of d1)
             load1(t + 2, a1, a2);
-#ifdef PCL_ACC16_IGLP
-            __builtin_amdgcn_iglp_opt(PCL_ACC16_IGLP);
-#endif
-#ifndef PCL_ACC16_NOSGB           // pin the fragment reads between the MFMAs (left alone the scheduler issues product (2)'s 6 NCT reads in
-            if (MT == 1) {               // one burst right in front of its first MFMA): a third of them behind every third of product (1)'s
-                                         // chain, the next tile's 4 + 2 KS reads spread through product (2).  41.9 vs 42.4 ms
-                constexpr int NX3 = KS, RX3 = 2 * NCT, NY = 10 * NCT, RY = 4 + 2 * KS, PER = NY / RY > 0 ? NY / RY : 1;
+#ifndef PCL_ACC16_NOSGB           // spread the fragment reads between the MFMAs instead of one burst in front of the first MFMA that needs them
+            {
+                constexpr int RX = 8 * NCT, RY = 4 + 2 * KS, NY = 6 * NCT, PERX = (RX + 2) / 3, PERY = (RY + NY - 1) / NY;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, NX3, 0);     // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, RX3, 0);     // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, KS, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, PERX, 0);    // DS read
                 }
 #pragma unroll
-                for (int i = 0; i < RY; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int i = 0; i < NY; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, PERY, 0);
                 }
-                if (NY - PER * RY > 0) __builtin_amdgcn_sched_group_barrier(0x008, NY - PER * RY > 0 ? NY - PER * RY : 1, 0);
             }
 #endif
         }
-#ifdef PCL_ACC16_STAMPS
-        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
-#endif
-        // this wave's blocks of tile t + 3 (issued two tiles ago) have landed; those of tile t + 4 stay in flight
-        static_assert(MYB_HI <= 8 && MYB_LO >= 1, "counted waits below");
+        // this wave's blocks of tile t + 3 have landed; those of the newer tiles stay in flight
+        static_assert(MYB_HI * (AHEAD - 3) <= 8 && AHEAD >= 3, "counted waits below");
         {
-            const int keep = !ahead ? 0 : (more_blocks ? MYB_HI : MYB_LO);       // wave-uniform
+            const int newest = min(t + AHEAD, t1 - 1);                           // the last tile issued so far
+            const int keep = max(0, newest - (t + 3)) * (more_blocks ? MYB_HI : MYB_LO);       // wave-uniform
             switch (keep) {
                 case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -501,59 +447,55 @@ __global__ __launch_bounds__(AW * 64, MT == 1 ? 2 : 1) void acc16_consumer_kerne
                 default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
             }
         }
-#ifdef PCL_ACC16_STAMPS
-        const unsigned long long st_b = __builtin_amdgcn_s_memtime();
-#endif
         __builtin_amdgcn_s_barrier();                            // (raw: __syncthreads would drain the DMA in flight) tile t + 3 is there for everyone; slot t % NSLOT is free
-#ifdef PCL_ACC16_STAMPS
-        const unsigned long long st_c = __builtin_amdgcn_s_memtime();
-        st_busy += st_a - st_prev; st_vm += st_b - st_a; st_bar += st_c - st_b; st_prev = st_c; ++st_n;
-#endif
     };
     for (int t = t0; t < t1; t += 2) {
         tile_step(t, dA, dB);
         if (t + 1 < t1) tile_step(t + 1, dB, dA);
     }
-#ifdef PCL_ACC16_STAMPS
-    if ((blockIdx.x == 40 || blockIdx.x == 1000) && lane == 0 && st_n)
-        printf("block %d wave %d (live %d) tiles %u: work %llu  dma-wait %llu  barrier %llu  (s_memtime ticks per tile)\n", blockIdx.x, wave, (int)live, st_n,
-               st_busy / st_n, st_vm / st_n, st_bar / st_n);
-#endif
 
-    // ---- flush: lane = feature column, register = mixture row; cov = S2 - 2 d S1 + d^2 S0, mean = S1 + (c + bias) S0
-    const float *cen = centers + (size_t)j * D;
+    // ---- flush: lane = mixture, register = feature row of S^T.  Row c of column tile ct <-> k-step s = 2 ct + (c >> 4), i = c & 15:
+    //      x'^2 of feature 8 s + i (i < 8) or x' of feature 8 s + i - 8; c = (r & 3) + 8 (r >> 2) + 4 h, so a lane holds S2 of
+    //      feature d in register r (r & 4 == 0) and S1 of the same d in register r + 4.  S0 is row (s = KS - 1, i = D & 7) of the last
+    //      tile.  cov = S2 - 2 dl S1 + dl^2 S0, mean = S1 + (c + bias) S0, all times 2^E / the feature's power-of-two scale.
+    if (!live) return;
+    const int m = mt * 32 + col;
+    constexpr int C0 = ((KS - 1) & 1) * 16 + (D & 7), CT0 = (KS - 1) >> 1;          // where S0 lives: row C0 of tile CT0
+    constexpr int R0 = (C0 & 3) + 4 * (C0 >> 3), H0 = (C0 >> 2) & 1;
+    float s0f = ST[CT0][R0];
+    {   // v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its second: afterwards the
+        // first result holds the LOWER half's values in both halves, the second result the UPPER half's
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0f), __float_as_uint(s0f), false, false);
+        s0f = __uint_as_float(H0 ? sw[1] : sw[0]);
+    }
+    const int Ei = (int)E;
+    const double S0 = ldexp((double)s0f, Ei);
+    if (m < M) {
+        const float *cen = centers + (size_t)j * D;
+        const float *fs = fscale + (size_t)j * 2 * (KS * 8);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int mt = mt0 + i;
-        if (mt >= n_mtiles) continue;
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float s0 = __shfl(S[i][(2 * D) >> 5][r], (lane & 32) + ((2 * D) & 31), 64);   // column 2D = the constant feature
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const float s1 = __shfl_xor(S[i][ct][r], 1, 64);                           // odd neighbour: x' column of the same d
-                const int cidx = ct * 32 + col;
-                if (m < M && !(cidx & 1) && cidx < 2 * D) {
-                    const int d = cidx >> 1;
-                    const size_t o = ((size_t)j * Mpad + m) * D + d;
-                    const double c = (double)cen[d], dl = means64[o] - c;
-                    const double S0 = (double)s0, S1 = (double)s1, S2 = (double)S[i][ct][r];
-                    const double vm = S1 + (c + bias) * S0;                        // Clustering.py:669-672
-                    const double vc = S2 - 2.0 * dl * S1 + dl * dl * S0;           // Clustering.py:674-678
-                    if (FRESH) {
-                        st_mean[o] = vm;
-                        st_cov[o] = vc;
-                    } else {
-                        st_mean[o] += vm;
-                        st_cov[o] += vc;
-                    }
-                }
-                if (m < M && cidx == 2 * D) {                                      // Clustering.py:665
-                    if (FRESH) st_acc[(size_t)j * Mpad + m] = (double)S[i][ct][r];
-                    else st_acc[(size_t)j * Mpad + m] += (double)S[i][ct][r];
+            for (int r = 0; r < 16; ++r) {
+                if (r & 4) continue;                             // the S1 partner of register r - 4
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * half, s = 2 * ct + (c >> 4), d = 8 * s + (c & 7);
+                if (s >= KS || d >= D) continue;
+                const size_t o = ((size_t)j * Mpad + m) * D + d;
+                const double cc = (double)cen[d], dl = means64[o] - cc;
+                const double S2 = ldexp((double)ST[ct][r], Ei) / (double)fs[d], S1 = ldexp((double)ST[ct][r + 4], Ei) / (double)fs[KS * 8 + d];
+                const double vm = S1 + (cc + bias) * S0;                           // Clustering.py:669-672
+                const double vc = S2 - 2.0 * dl * S1 + dl * dl * S0;               // Clustering.py:674-678
+                if (FRESH) {
+                    st_mean[o] = vm;
+                    st_cov[o] = vc;
+                } else {
+                    st_mean[o] += vm;
+                    st_cov[o] += vc;
                 }
             }
+        if (half == 0) {                                                           // Clustering.py:665 (both halves hold the same S0)
+            if (FRESH) st_acc[(size_t)j * Mpad + m] = S0;
+            else st_acc[(size_t)j * Mpad + m] += S0;
         }
     }
     if (slice == 0 && wave == 0) {
@@ -600,12 +542,12 @@ int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
 // ... and the consumer of the same group
 int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int buf, bool fresh, hipStream_t stream) {
     if (ns == 0) return PCL_OK;
-    const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW * MT - 1) / (AW * MT);
+    const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW;
     const int nblocks = ((ns + 7) / 8) * 8 * nslice;
     const int *ws = b->d_work_states + first;
 #define CONSUME16F(DD, FR)                                                                                                    \
     hipLaunchKernelGGL((acc16_consumer_kernel<DD, FR>), dim3(nblocks), dim3(AW * 64), 0, stream,                              \
-                       reinterpret_cast<const uint4 *>(b->acc16_images[buf]), reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->centers32, \
+                       reinterpret_cast<const uint4 *>(b->acc16_images[buf]), reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->centers32, ctx->fscale, \
                        ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, ws, b->acc16_tile_off[buf], 0, 100.0, ctx->st_acc, ctx->st_alpha,      \
                        ctx->st_mean, ctx->st_cov)
 #define CONSUME16(DD)                     \

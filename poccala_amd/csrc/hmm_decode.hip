@@ -14,8 +14,9 @@
 // and the gaps D1..D5 that had to be filled because the source cannot run (finished <=> best state is the last emitting
 // one; tokens keyed by tree node; all first-character nodes start; a finished word re-seeds every first-character node
 // with a uniform language model and one history entry per frame; frame semantics "all step, then all hand over") are
-// spelled out next to the CPU restatement the parity tests hold this kernel to, bit for bit (include/poccala_hip.h names it).  PARITY UNPINNED
-// against the reference itself -- nothing executable exists there.
+// spelled out next to the CPU restatement the parity tests hold this kernel to, bit for bit (include/poccala_hip.h names it).
+// The restatement's recursion, pruning, frame loop and in-word hand-over are pinned by golden G14 (those pieces of Decoder.py run
+// with a stand-in for its missing import); D1..D5 are the builder's completion of what the source cannot do.
 //
 // Mapping.  The emissions are the all-state matrix of a scoring batch (rows entry, 0..J-1, exit: pcl_batch_score), time
 // major, so a frame's J values are contiguous; the frame's row and the unit matrices (183 x 25 doubles) are staged in
@@ -773,6 +774,7 @@ int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, con
     if (n_nodes <= 0 || n_roots <= 0 || !node_units || !node_nunits || !child_ptr || !node_word || !roots)
         PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: bad arguments (n_nodes=%d, n_roots=%d)", n_nodes, n_roots);
     const int e = ctx->S - 2;
+    if (child_ptr[0] != 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: child_ptr[0] = %d, must be 0", child_ptr[0]);
     for (int i = 0; i < n_nodes; ++i) {
         const int nu = node_nunits[i];
         if (ctx->n_units >= 0xffff) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: %d units (the decoder packs unit ids into 16 bits)", ctx->n_units);
@@ -789,8 +791,11 @@ int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, con
         if (has_parent[child_idx[k]]) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: node %d has two parents (not a tree)", child_idx[k]);
         has_parent[child_idx[k]] = 1;
     }
-    for (int r = 0; r < n_roots; ++r)
-        if (roots[r] < 0 || roots[r] >= n_nodes || has_parent[roots[r]]) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: root %d is not a parentless node", roots[r]);
+    for (int r = 0; r < n_roots; ++r) {
+        if (roots[r] < 0 || roots[r] >= n_nodes || has_parent[roots[r]] == 1) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: root %d is not a parentless node", roots[r]);
+        if (has_parent[roots[r]] == 2) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_lexicon_upload: root %d is listed twice", roots[r]);
+        has_parent[roots[r]] = 2;                    // (seen as a root)
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pcl_lexicon_release(ctx);
     TRY(dev_alloc(ctx, &ctx->lex_units, (size_t)2 * n_nodes));
@@ -809,7 +814,6 @@ int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, con
     HIPCHK(ctx, hipMemcpy(ctx->d_unit_logtrans, ctx->unit_logtrans.data(), ctx->unit_logtrans.size() * 8, hipMemcpyHostToDevice));
     ctx->lex_nodes = n_nodes;
     ctx->lex_nroots = n_roots;
-    ctx->lex_units_gen = ctx->n_units;
     return PCL_OK;
 }
 

@@ -98,8 +98,26 @@ __global__ void trans_mstep_kernel(const double *__restrict__ acc_ksai, const do
 
 }  // namespace
 
+// The decoder's device copy of ln A (hmm_decode.hip) follows every change of the unit transitions: a transition M-step or a new
+// inventory of the same shape.  Waits for a decoder that may still be reading the old values on the second stream.
+static int lexicon_refresh_logtrans(pcl_ctx *ctx) {
+    if (!ctx->lex_nodes || !ctx->d_unit_logtrans) return PCL_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_unit_logtrans, ctx->unit_logtrans.data(), ctx->unit_logtrans.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+static void units_free(pcl_ctx *ctx) {
+    dev_free(ctx->d_unit_trans);
+    dev_free(ctx->hmm_ksai);
+    ctx->hmm_gamma = nullptr;                        // inside the hmm_ksai allocation
+    ctx->unit_trans.clear();
+    ctx->unit_logtrans.clear();
+}
+
 void pcl_units_release(pcl_ctx *ctx) {
-    pcl_lexicon_release(ctx);                        // the tree names units of this inventory: upload it again after new units
+    pcl_lexicon_release(ctx);                        // the tree names units of this inventory: upload it again after a DIFFERENT inventory
     dev_free(ctx->d_unit_trans);
     dev_free(ctx->hmm_ksai);
     ctx->hmm_gamma = nullptr;                        // inside the hmm_ksai allocation
@@ -147,7 +165,7 @@ static int units_pull(pcl_ctx *ctx) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->unit_trans.data(), ctx->d_unit_trans, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n; ++i) ctx->unit_logtrans[i] = log(ctx->unit_trans[i]);
-    return PCL_OK;
+    return lexicon_refresh_logtrans(ctx);            // a resident pronunciation tree decodes with the NEW transitions
 }
 
 int pcl_launch_trans_mstep(pcl_ctx *ctx) {
@@ -222,7 +240,10 @@ int pcl_units_upload(pcl_ctx *ctx, int n_units, int S, const double *trans, cons
     if (!ctx) return PCL_ERR_INVALID;
     if (n_units <= 0 || S < 3 || S > 8 || !trans) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_units_upload: bad arguments (n_units=%d, S=%d; 3 <= S <= 8)", n_units, S);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    pcl_units_release(ctx);
+    // an inventory of the same shape keeps a resident pronunciation tree (its unit ids stay valid): only the transitions change
+    const bool keep_tree = ctx->lex_nodes && n_units == ctx->n_units && S == ctx->S;
+    if (keep_tree) units_free(ctx);
+    else pcl_units_release(ctx);
     const size_t n = (size_t)n_units * S * S;
     ctx->unit_trans.assign(trans, trans + n);
     ctx->unit_logtrans.resize(n);
@@ -239,7 +260,7 @@ int pcl_units_upload(pcl_ctx *ctx, int n_units, int S, const double *trans, cons
     ctx->hmm_gamma = ctx->hmm_ksai + (size_t)n_units * (S - 2) * S;
     TRY(hmm_acc_reset(ctx));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
+    return lexicon_refresh_logtrans(ctx);
 }
 
 int pcl_units_download(pcl_ctx *ctx, double *trans) {

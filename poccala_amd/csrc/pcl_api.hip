@@ -107,7 +107,7 @@ void *pcl_pool_alloc(int device, size_t bytes) {
             return nullptr;
         }
     }
-    g_pool_live[p] = PoolBlock{cls, device};
+    g_pool_live[p] = PoolBlock{cls, device};                        // (overwrites a stale entry, should a block ever have left the pool by a raw hipFree)
     return p;
 }
 

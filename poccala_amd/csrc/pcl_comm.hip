@@ -221,12 +221,9 @@ int merge_hmm_acc(pcl_ctx *ctx) {
 
 int ensure_payload32(pcl_ctx *ctx, size_t n) {
     if (ctx->payload32_len >= n) return PCL_OK;
-    if (ctx->payload32) (void)hipFree(ctx->payload32);
-    ctx->payload32 = nullptr;
+    dev_free(ctx->payload32);                        // back to the pool it came from (a raw hipFree left a stale pool entry)
     ctx->payload32_len = 0;
-    float *p = nullptr;
-    TRY(dev_alloc(ctx, &p, n));
-    ctx->payload32 = p;
+    TRY(dev_alloc(ctx, &ctx->payload32, n));
     ctx->payload32_len = n;
     return PCL_OK;
 }
@@ -234,8 +231,7 @@ int ensure_payload32(pcl_ctx *ctx, size_t n) {
 }  // namespace
 
 void pcl_comm_release(pcl_ctx *ctx) {
-    if (ctx->payload32) (void)hipFree(ctx->payload32);
-    ctx->payload32 = nullptr;
+    dev_free(ctx->payload32);
     ctx->payload32_len = 0;
 }
 
@@ -342,7 +338,7 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
             rc = reduce_scatter_parts<double>(ctx, bases, per, 4, J);
         } else {
             TRY(ensure_payload32(ctx, ctx->stats_len));
-            float *f = (float *)ctx->payload32;
+            float *f = ctx->payload32;
             hipLaunchKernelGGL(to_f32_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->stats, f, ctx->stats_len);
             float *bases[4] = {f, f + (size_t)J * mp, f + (size_t)J * mp + J, f + (size_t)J * mp + J + (size_t)J * mpd};
             hipLaunchKernelGGL(mean_to_f32_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_mean, ctx->st_acc, ctx->centers32, ctx->Mpad,
@@ -375,7 +371,7 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
         } else {
             const size_t tot = (size_t)J * (2 * mpd + mp);
             TRY(ensure_payload32(ctx, tot));
-            float *f = (float *)ctx->payload32;
+            float *f = ctx->payload32;
             float *bases[3] = {f, f + (size_t)J * mpd, f + 2 * (size_t)J * mpd};
             const size_t per[3] = {mpd, mpd, mp};
             double *src[3] = {ctx->mean64, ctx->var64, ctx->w64};

@@ -112,14 +112,14 @@ struct pcl_ctx {
     // pronunciation tree for the decoder (hmm_decode.hip)
     int *lex_units = nullptr, *lex_nunits = nullptr, *lex_child_ptr = nullptr, *lex_child_idx = nullptr, *lex_word = nullptr, *lex_roots = nullptr;
     double *d_unit_logtrans = nullptr;
-    int lex_nodes = 0, lex_nroots = 0, lex_units_gen = 0;
+    int lex_nodes = 0, lex_nroots = 0;
     // multi-GPU (pcl_comm.hip): RCCL communicator, or the host-callback rehearsal transport
     void *comm = nullptr;
     int rank = 0, nranks = 1;
     int transport = 0;                               // 0 none, 1 RCCL, 2 host callback (several ranks on ONE device)
     pcl_allgather_fn host_allgather = nullptr;
     void *host_user = nullptr;
-    void *payload32 = nullptr;                       // f32 staging of the statistics / parameters (payload = PCL_F32)
+    float *payload32 = nullptr;                      // f32 staging of the statistics / parameters (payload = PCL_F32)
     size_t payload32_len = 0;
     std::map<std::string, KernelTimer> timers;
     bool timing = false;         // pcl_timing_enable / env PCL_TIMERS: record HIP events around every launch

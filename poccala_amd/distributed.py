@@ -78,9 +78,20 @@ _DCODE = {v: k for k, v in _DTYPES.items()}
 _MAX_FRAME = 1 << 30
 
 
-def _token():
+def _loopback(addr):
+    return addr in ('localhost', '::1') or addr.startswith('127.')
+
+
+def _token(addr='127.0.0.1'):
+    """The HMAC key of the control plane.  POCCALA_CTRL_TOKEN when the launcher set one (bench.py's self-spawn makes a random
+    one per job).  Without it -- a foreign launcher such as torch.distributed.run -- the only thing the ranks share is the run
+    id and port, which anyone can guess: that fallback is accepted on a loopback address only (one node, the hub is not
+    reachable from outside); a hub on a routable address refuses to start without an explicit token."""
     t = os.environ.get('POCCALA_CTRL_TOKEN')
-    if t is None:   # a foreign launcher (torch.distributed.run): the job's run id is all the ranks share
+    if t is None:
+        if not _loopback(addr):
+            raise RuntimeError('control plane: MASTER_ADDR=%s is not a loopback address and POCCALA_CTRL_TOKEN is not set; '
+                               'export the same random POCCALA_CTRL_TOKEN on every rank of a multi-node job' % addr)
         t = 'run:%s:%s' % (os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('MASTER_PORT', ''))
     return t.encode()
 
@@ -161,8 +172,8 @@ class Control(object):
             return
         if not 0 <= self.rank < self.world:
             raise ValueError('control plane: rank %d outside [0,%d)' % (self.rank, self.world))
-        token = _token() if token is None else token
         addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        token = _token(addr) if token is None else token
         base = int(port if port is not None else int(os.environ.get('MASTER_PORT', '29500')) + 1)
         if self.rank == 0:
             srv = None
@@ -183,7 +194,7 @@ class Control(object):
             while sum(s is not None for s in slots[1:]) < self.world - 1:
                 c, _ = srv.accept()
                 try:
-                    c.settimeout(10.0)
+                    c.settimeout(3.0)            # (the accept loop is serial: a silent stranger may hold it this long, no longer)
                     # challenge -> (rank, HMAC(challenge | rank | client nonce)) -> HMAC(client nonce | 'hub')
                     challenge = os.urandom(16)
                     c.sendall(_MAGIC + challenge)

@@ -199,6 +199,8 @@ class Engine(object):
         """The flat pronunciation tree of Lexicon.PronunciationLexicon.compile (units = ids of the loaded inventory)."""
         nu = as_c(tree['node_units'], np.int32)
         nn = as_c(tree['node_nunits'], np.int32)
+        if nu.shape != (len(nn), 2):                  # the device layout is [n_nodes][2] (PronunciationLexicon.compile(max_units=2))
+            raise ValueError('tree node_units must be (n_nodes, 2), got %r' % (nu.shape,))
         cp = as_c(tree['child_ptr'], np.int32)
         ci = as_c(tree['child_idx'], np.int32) if len(tree['child_idx']) else np.zeros(1, dtype=np.int32)
         nw = as_c(tree['node_word'], np.int32)

@@ -131,13 +131,89 @@ def test_decode_batch_dropin_and_errors(eng, lex):
     with pytest.raises(PoccalaHipError):
         b.decode()
     b.close()
-    # a new unit inventory drops the tree
+    # an inventory of the same shape keeps the tree (new transitions reach the decoder), a different one drops it
     eng.load_units(trans)
+    b = eng.all_state_batch([50], [0])
+    b.score(PCL_F32)
+    assert len(b.decode()) == 1
+    b.close()
+    eng.load_units(trans[:-1])
     b = eng.all_state_batch([50], [0])
     b.score(PCL_F32)
     with pytest.raises(PoccalaHipError):
         b.decode()
     b.close()
+
+
+def test_decode_follows_a_transition_mstep(eng, lex):
+    """the decoder's device copy of ln A must follow pcl_mstep_transitions (and a re-upload of the units): train the
+    transitions on a label-built batch in the SAME context, then decode -- bit for bit the restatement run with the NEW
+    matrices, and different from the decode before the M-step."""
+    from poccala_amd import PCL_F64, synth
+    lx, units, tree = lex
+    mean, var, w, trans = model_for(units, 3, 13, 51)
+    frames, lens, begin = synth.make_frames(3, 70, 13, seed=52, ragged=True)
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+
+    def decode_all():
+        b = eng.all_state_batch(lens, begin)
+        b.score(PCL_F64)
+        out, B = b.decode(candidate=4), b.get('B')
+        b.close()
+        return out, B
+    before, B = decode_all()
+    labels = synth.make_labels(3, 4, len(units), seed=53)
+    lb = eng.label_batch(labels, lens, begin)
+    lb.score(PCL_F64)
+    lb.forward_backward(fix_pi=False)
+    eng.hmm_acc_zero()
+    lb.accumulate_hmm()
+    eng.mstep_transitions()
+    lb.close()
+    new_trans = eng.units_download()
+    assert not np.allclose(new_trans, trans)
+    after, B2 = decode_all()
+    assert all(np.array_equal(x, y) for x, y in zip(B, B2))      # same emissions: only the transitions moved
+    eng.load_units(new_trans)                                     # the same matrices with NumPy's logarithm (the library's own
+    exact, _ = decode_all()                                       # refresh uses libm's: equal up to the last bit of ln A)
+    changed = False
+    for u in range(3):
+        fin, hist = do.decode(tree, list(new_trans), B2[u][1:-1], candidate=4, max_tokens=4096)
+        for got, tight in ((after[u], False), (exact[u], True)):
+            assert [(n, h) for n, _, h in got['final']] == [(n, h) for n, _, h in fin]
+            assert got['history'] == [(int(p), int(n)) for p, n in hist]
+            if tight:
+                assert [s for _, s, _ in got['final']] == [float(s) for _, s, _ in fin]
+            else:
+                np.testing.assert_allclose([s for _, s, _ in got['final']], [float(s) for _, s, _ in fin], rtol=1e-13)
+        changed |= [s for _, s, _ in after[u]['final']] != [s for _, s, _ in before[u]['final']]
+    assert changed
+    # the same through a re-upload of an inventory of the same shape (the tree stays)
+    eng.load_units(trans)
+    again, _ = decode_all()
+    for u in range(3):
+        assert again[u]['final'] == before[u]['final'] and again[u]['history'] == before[u]['history']
+
+
+def test_lexicon_upload_rejects_malformed_trees(eng, lex):
+    from poccala_amd import PoccalaHipError
+    lx, units, tree = lex
+    mean, var, w, trans = model_for(units, 2, 13, 61)
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    bad = dict(tree); bad['child_ptr'] = tree['child_ptr'].copy(); bad['child_ptr'][0] = -1
+    with pytest.raises(PoccalaHipError):
+        eng.load_lexicon(bad)
+    bad = dict(tree); bad['roots'] = np.concatenate([tree['roots'], tree['roots'][:1]])
+    with pytest.raises(PoccalaHipError):
+        eng.load_lexicon(bad)
+    bad = dict(tree); bad['node_units'] = np.concatenate([tree['node_units'], tree['node_units'][:, :1]], axis=1)
+    with pytest.raises(ValueError):
+        eng.load_lexicon(bad)
+    eng.load_lexicon(tree)
 
 
 def test_decode_stream_equals_chunk_by_chunk(eng, lex):

@@ -549,7 +549,7 @@ def test_c5_all_state_scoring(eng):
         for j in (0, 1, 274, 547, 548):
             np.testing.assert_allclose(B[u][1 + j], po.gmm_point(x, mean[j], var[j], w[j]), atol=F32_LOGLIK_ATOL)
         assert np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1]))
-    # the A16 recursion (Decoder.Token.viterbi, parity unpinned) over one word HMM = plain Viterbi scores on those rows
+    # the A16 recursion (Decoder.Token.viterbi, pinned by golden G14) over one word HMM = plain Viterbi scores on those rows
     b.close()
 
 

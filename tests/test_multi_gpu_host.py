@@ -165,3 +165,17 @@ def test_control_plane_frames_are_not_pickle():
             assert back.dtype == obj.dtype and np.array_equal(back, obj)
         else:
             assert back == obj
+
+
+def test_control_plane_refuses_a_guessable_key_off_loopback(monkeypatch):
+    """without POCCALA_CTRL_TOKEN the HMAC key falls back to the run id and port, which anyone can guess; that is
+    accepted on a loopback address only."""
+    from poccala_amd import distributed as dist
+    monkeypatch.delenv('POCCALA_CTRL_TOKEN', raising=False)
+    assert dist._token('127.0.0.1') and dist._token('localhost')
+    with pytest.raises(RuntimeError):
+        dist._token('10.1.2.3')
+    with pytest.raises(RuntimeError):
+        dist.Control(rank=1, world=2, addr='10.1.2.3', port=1, timeout=0.1)
+    monkeypatch.setenv('POCCALA_CTRL_TOKEN', 'secret')
+    assert dist._token('10.1.2.3') == b'secret'
