@@ -521,7 +521,7 @@ void launch_acc_f32(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int 
                     const int *state_flag = nullptr) {
     switch (ctx->D) {
 #define CASE32(DD) case DD: launch_acc_t<DD, float, 2>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count, tile_off, tile_mask, state_flag); break;
-        CASE32(13) CASE32(26) CASE32(39) CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40)
+        CASE32(13) CASE32(26) CASE32(39) CASE32(47)
 #undef CASE32
 #define CASE32W(DD) case DD: launch_acc_t<DD, float, 1>(ctx, b, ctx->frames32, ctx->params32, ctx->mean32, first, count, tile_off, tile_mask, state_flag); break;
         CASE32W(48) CASE32W(64)
@@ -530,7 +530,7 @@ void launch_acc_f32(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int 
     }
 }
 
-bool device_dim_supported(int D) { return D == 13 || D == 26 || D == 39 || D == 8 || D == 16 || D == 24 || D == 32 || D == 40 || D == 48 || D == 64; }
+bool device_dim_supported(int D) { return D == 13 || D == 26 || D == 39 || D == 47 || D == 48 || D == 64; }
 
 }  // namespace
 
@@ -593,7 +593,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     }
     // MFMA mode: well-conditioned states first (MFMA kernel), then the ill-conditioned ones (direct-form VALU kernel)
     const int D = ctx->D;
-    const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && (D == 39 || D == 26 || D == 13);
+    const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && (D == 47 || D == 39 || D == 26 || D == 13);
     b->acc_ws.clear(); b->acc_lo.clear(); b->acc_hi.clear();
     int n_good = 0;
     for (int pass = 0; pass < 2; ++pass)
@@ -717,7 +717,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD, PCL_ACC_T16 != 0>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
                        ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, b->d_work_states, b->d_seg_lo, b->d_seg_hi,   \
                        b->acc_off, b->acc_list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
-        if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
+        if (D == 47) LAUNCH_MFMA(47); else if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
 #undef LAUNCH_MFMA
     }
     if (precision == PCL_F32) {
@@ -727,7 +727,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     } else {
         switch (D) {
 #define CASE64(DD) case DD: launch_acc_t<DD, double, 1>(ctx, b, ctx->frames64, ctx->params64, ctx->mean64, 0, (int)ns); break;
-            CASE64(13) CASE64(26) CASE64(39) CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
+            CASE64(13) CASE64(26) CASE64(39) CASE64(47) CASE64(48) CASE64(64)
 #undef CASE64
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 accumulate kernel for padded D=%d", D);
         }

@@ -44,10 +44,10 @@ typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 #ifndef PCL_ACC16_AW
-#define PCL_ACC16_AW 8
+#define PCL_ACC16_AW 4
 #endif
 #ifndef PCL_ACC16_NSLOT
-#define PCL_ACC16_NSLOT 8
+#define PCL_ACC16_NSLOT 6
 #endif
 constexpr int AW = PCL_ACC16_AW;       // waves per consumer workgroup, one 32-mixture tile each
 constexpr float FMAXH = 6.0e4f;        // what an f16 piece may hold (gmm_score_split.hip)
@@ -254,7 +254,9 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
     const int t0 = tile_off[w] - tile_base, t1 = tile_off[w + 1] - tile_base;
     if (t0 == t1) return;
     const int j = work_states[w];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and the compiler must know: everything per-wave below
+                                                                         // (DMA block loop, counted waits) is otherwise compiled as EXEC-masked vector control flow
     const int mt = slice * AW + wave;                            // this wave's m-tile
     const bool live = mt < n_mtiles;                             // (a wave past the end only helps with the DMA)
 
@@ -278,7 +280,11 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
     auto dma = [&](int t) {                                      // tile t -> slot t % NSLOT; the NB blocks are dealt to the waves
         const uint4 *src = images + (size_t)t * (NB * 64);
         const unsigned int dst = __builtin_amdgcn_readfirstlane(lds_addr(&slot[t % NSLOT][0]));
-        for (int p = wave; p < NB; p += AW) glds16(src + p * 64 + lane, dst + (unsigned int)p * 1024u);
+#pragma unroll
+        for (int k = 0; k < (NB + AW - 1) / AW; ++k) {
+            const int p = wave + k * AW;
+            if (p < NB) glds16(src + p * 64 + lane, dst + (unsigned int)p * 1024u);
+        }
     };
     // product (1) row reads: lane = side * 32 + frame (side = half, frame = col); the unit rotation depends on s & 1
     const int row_even = half * 32 + unit_of(col >> 2, half, 0) * 4 + (col & 3);
@@ -361,12 +367,25 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
             c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
         }
     };
+    // largest log2 posterior of a tile for this lane's mixture (both lane halves hold frames of the SAME mixture).  It is taken
+    // at the END of the step that ran the tile's product (1) -- beside product (2) of the tile before -- so that the next step
+    // opens with one subtract and a wave-uniform branch instead of a dependent chain of ten instructions with nothing to overlap.
+    auto tile_max = [&](const f16v &d) -> float {
+        float m3 = __builtin_fmaxf(__builtin_fmaxf(d[0], d[1]), d[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) m3 = __builtin_fmaxf(__builtin_fmaxf(m3, d[r]), d[r + 1]);
+        m3 = __builtin_fmaxf(m3, d[15]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m3), __float_as_uint(m3), false, false);
+        return __builtin_fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    float mx = -INFINITY;
     if (live) {
         load1(t0, a1, a2);
         load_cf(t0, dA);
         mfma1(a1, a2, dA);
         load_cf(t0 + 1, dB);                                     // (past the last tile: whatever the slot holds, nobody reads the product)
         load1(t0 + 1, a1, a2);
+        mx = tile_max(dA);
     }
     auto tile_step = [&](int t, f16v &d1, f16v &dn) __attribute__((always_inline)) {
         const bool ahead = t + AHEAD < t1;
@@ -374,15 +393,7 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
         const uint4 *cur = &slot[t % NSLOT][0];
         if (slice == 0 && wave == 0 && lane < 32) galpha += reinterpret_cast<const double *>(cur + I::BM * 64)[32 + lane];   // byte 256: gamma_f(j)
         if (live) {
-            // ---- this mixture's scale: the largest log2 posterior of the tile (both lane halves hold frames of the SAME mixture)
-            float mx = __builtin_fmaxf(__builtin_fmaxf(d1[0], d1[1]), d1[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, d1[r]), d1[r + 1]);
-            mx = __builtin_fmaxf(mx, d1[15]);
-            {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = __builtin_fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
+            // ---- this mixture's scale: the largest log2 posterior of the tile (mx, taken at the end of the previous step)
             const float rel = mx - E;                            // (-inf when every frame of the tile is padding / masked: no trigger)
             if (__builtin_amdgcn_ballot_w64(rel > G_TOP) != 0ull) {      // rare, wave-uniform: the first tile, and a tile 8x above anything before it
                 const float delta = rel > G_TOP ? __builtin_ceilf(rel) - G_SET : 0.f;
@@ -414,6 +425,7 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
             mfma2(g1b, g2b, x1);
             load_cf(t + 2, d1);                                  // (the posteriors of tile t have been read out of d1)
             load1(t + 2, a1, a2);
+            mx = tile_max(dn);                                   // for the next step (past the last tile: never used)
 #ifndef PCL_ACC16_NOSGB           // spread the fragment reads between the MFMAs instead of one burst in front of the first MFMA that needs them
             {
                 constexpr int RX = 8 * NCT, RY = 4 + 2 * KS, NY = 6 * NCT, PERX = (RX + 2) / 3, PERY = (RY + NY - 1) / NY;
@@ -431,20 +443,15 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
 #endif
         }
         // this wave's blocks of tile t + 3 have landed; those of the newer tiles stay in flight
-        static_assert(MYB_HI * (AHEAD - 3) <= 8 && AHEAD >= 3, "counted waits below");
+        static_assert(MYB_HI * (AHEAD - 3) <= 16 && AHEAD >= 3, "counted waits below");
         {
             const int newest = min(t + AHEAD, t1 - 1);                           // the last tile issued so far
             const int keep = max(0, newest - (t + 3)) * (more_blocks ? MYB_HI : MYB_LO);       // wave-uniform
             switch (keep) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+#define W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15)
+#undef W
+                default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
             }
         }
         __builtin_amdgcn_s_barrier();                            // (raw: __syncthreads would drain the DMA in flight) tile t + 3 is there for everyone; slot t % NSLOT is free
@@ -510,6 +517,7 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
 
 size_t pcl_acc16_image_bytes(int D) {
     switch (D) {
+        case 47: return (size_t)Img<47>::NB * 1024;
         case 39: return (size_t)Img<39>::NB * 1024;
         case 26: return (size_t)Img<26>::NB * 1024;
         case 13: return (size_t)Img<13>::NB * 1024;
@@ -529,6 +537,7 @@ int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
                        ctx->kzero, ns, ws, lo, hi, b->acc_off, b->acc_list, b->acc16_tile_off[buf], 0, reinterpret_cast<uint4 *>(b->acc16_images[buf]),  \
                        b->acc16_tile_mask[buf], b->acc16_state_flag[buf])
     switch (ctx->D) {
+        case 47: PRODUCE16(47); break;
         case 39: PRODUCE16(39); break;
         case 26: PRODUCE16(26); break;
         case 13: PRODUCE16(13); break;
@@ -556,6 +565,7 @@ int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
         else CONSUME16F(DD, false);       \
     } while (0)
     switch (ctx->D) {
+        case 47: CONSUME16(47); break;
         case 39: CONSUME16(39); break;
         case 26: CONSUME16(26); break;
         case 13: CONSUME16(13); break;

@@ -237,7 +237,7 @@ int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, i
                                            ctx->params32, ctx->Mpad, tiles, b->d_segs, b->Bt, flags)
 #define CASEF(DD) case DD: if (R == 1) LAUNCHF(DD, 1); else LAUNCHF(DD, 2); break;
     switch (ctx->D) {
-        CASEF(13) CASEF(26) CASEF(39)
+        CASEF(13) CASEF(26) CASEF(39) CASEF(47)
         default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no fix-up scoring kernel for D=%d", ctx->D);
     }
 #undef CASEF
@@ -255,16 +255,16 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile 
     if (precision == PCL_F32) {
         switch (D) {
 #define CASE32(DD) case DD: launch_score_t<DD, r32(DD), PCL_CH32, float>(ctx, b, ctx->frames32, ctx->params32, tiles, n_tiles); break;
-            CASE32(13) CASE32(26) CASE32(39)
-            CASE32(8) CASE32(16) CASE32(24) CASE32(32) CASE32(40) CASE32(48) CASE32(64)
+            CASE32(13) CASE32(26) CASE32(39) CASE32(47)
+            CASE32(48) CASE32(64)
 #undef CASE32
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 scoring kernel for padded D=%d", D);
         }
     } else {
         switch (D) {
 #define CASE64(DD) case DD: launch_score_t<DD, r64(DD), 32, double>(ctx, b, ctx->frames64, ctx->params64, tiles, n_tiles); break;
-            CASE64(13) CASE64(26) CASE64(39)
-            CASE64(8) CASE64(16) CASE64(24) CASE64(32) CASE64(40) CASE64(48) CASE64(64)
+            CASE64(13) CASE64(26) CASE64(39) CASE64(47)
+            CASE64(48) CASE64(64)
 #undef CASE64
             default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f64 scoring kernel for padded D=%d", D);
         }

@@ -198,12 +198,13 @@ void launch_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
 
 int pcl_score_mfma_tile_frames() { return WG / 64 * PCL_MFMA_NT * 32; }
 
-bool pcl_score_mfma_supported(int D) { return D == 39 || D == 13 || D == 26; }
+bool pcl_score_mfma_supported(int D) { return D == 39 || D == 13 || D == 26 || D == 47; }
 
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
     if (n_tiles == 0) return PCL_OK;
     pcl_timer_begin(ctx, "score");
     switch (ctx->D) {
+        case 47: launch_t<47>(ctx, b, tiles, n_tiles); break;
         case 39: launch_t<39>(ctx, b, tiles, n_tiles); break;
         case 26: launch_t<26>(ctx, b, tiles, n_tiles); break;
         case 13: launch_t<13>(ctx, b, tiles, n_tiles); break;

@@ -281,9 +281,15 @@ int pcl_kernel_time(pcl_ctx *ctx, const char *which, float *total_ms, int *launc
 }
 
 // ================================================================ model
+// Device feature dimension.  Up to 47 it is one of 13 / 26 / 39 / 47 -- the sizes with a spare K slot in their last k-step of
+// 8, which the matrix-pipe kernels need for the folded constants -- so that EVERY model of up to 47 features is scored and
+// accumulated on the matrix pipe (the padding features are zero in the frames and carry zero coefficients; round 2 padded
+// e.g. D = 20 to 24 and silently dropped it to the 4-5x slower VALU kernels).  Above: 48 / 64 on the VALU kernels.
 static int device_dim(int D) {
-    if (D == 13 || D == 26 || D == 39) return D;
-    const int opts[] = {8, 16, 24, 32, 40, 48, 64};
+    const int pipe[] = {13, 26, 39, 47};
+    for (int o : pipe)
+        if (D <= o) return o;
+    const int opts[] = {48, 64};
     for (int o : opts)
         if (D <= o) return o;
     return -1;

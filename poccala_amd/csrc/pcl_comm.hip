@@ -18,18 +18,25 @@
 //
 // Transport: RCCL (pcl_comm_init).  pcl_comm_init_host is a rehearsal transport for several ranks on ONE device --
 // RCCL refuses that ("Duplicate GPU detected") -- where every collective goes through a caller-supplied all-gather
-// of host bytes; it runs the same orchestration code and is limited to small problems.
+// of host bytes, in chunks of 64 MiB per rank (the C4-shape exchange, 3.9 GB of statistics, goes through in
+// 64-MiB pieces); it runs the same orchestration code at the speed of the callback (a TCP hub in bench.py: seconds, not ms).
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "pcl_internal.h"
 
 namespace {
 
-constexpr size_t HOST_TRANSPORT_MAX_BYTES = 256u << 20;
+// bytes per rank and call of the host callback (PCL_HOST_CHUNK_KB: the tests use 1 KiB so that chunk edges fall inside states)
+static size_t host_chunk_bytes() {
+    const char *e = getenv("PCL_HOST_CHUNK_KB");
+    return e && atol(e) > 0 ? (size_t)atol(e) << 10 : (size_t)64 << 20;
+}
 
 __global__ void to_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
@@ -72,36 +79,42 @@ int nccl_fail(pcl_ctx *ctx, const char *what, ncclResult_t r) {
     return PCL_ERR_COMM;
 }
 
-// ---- host-callback transport: all-gather of every rank's bytes, reduced / sliced here
-int host_gather(pcl_ctx *ctx, const void *dev, size_t bytes, std::vector<char> &all) {
-    if (bytes * (size_t)ctx->nranks > HOST_TRANSPORT_MAX_BYTES)
-        PCL_FAIL(ctx, PCL_ERR_INVALID, "host rehearsal transport: %zu bytes x %d ranks is beyond its %zu-byte limit (use RCCL: one GPU per rank)",
-                 bytes, ctx->nranks, HOST_TRANSPORT_MAX_BYTES);
-    std::vector<char> mine(bytes);
-    HIPCHK(ctx, hipMemcpyAsync(mine.data(), dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    all.resize(bytes * (size_t)ctx->nranks);
-    if (ctx->host_allgather(ctx->host_user, mine.data(), bytes, all.data()) != 0) PCL_FAIL(ctx, PCL_ERR_COMM, "host rehearsal transport: the all-gather callback failed");
+// ---- host-callback transport: all-gather of every rank's bytes, reduced / sliced here, chunk by chunk
+// visit(first element, count, all): `all` holds the ranks' copies of elements [first, first + count) back to back
+template <typename T, typename F>
+int host_gather_chunks(pcl_ctx *ctx, const T *dev, size_t n, F visit) {
+    const size_t per = std::max<size_t>(host_chunk_bytes() / sizeof(T), 1);
+    std::vector<T> mine, all;
+    for (size_t first = 0; first < n; first += per) {
+        const size_t cnt = std::min(per, n - first);
+        mine.resize(cnt);
+        all.resize(cnt * (size_t)ctx->nranks);
+        HIPCHK(ctx, hipMemcpyAsync(mine.data(), dev + first, cnt * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->host_allgather(ctx->host_user, mine.data(), cnt * sizeof(T), all.data()) != 0)
+            PCL_FAIL(ctx, PCL_ERR_COMM, "host rehearsal transport: the all-gather callback failed");
+        TRY(visit(first, cnt, all.data()));
+    }
     return PCL_OK;
 }
 
 template <typename T>
 int host_allreduce(pcl_ctx *ctx, T *dev, size_t n, bool is_max) {
-    std::vector<char> all;
-    TRY(host_gather(ctx, dev, n * sizeof(T), all));
-    std::vector<T> out(n);
-    const T *a = reinterpret_cast<const T *>(all.data());
-    for (size_t i = 0; i < n; ++i) {
-        T v = a[i];
-        for (int r = 1; r < ctx->nranks; ++r) {
-            const T w = a[(size_t)r * n + i];
-            v = is_max ? (w > v ? w : v) : v + w;          // ranks in order: the same sum on every rank
+    std::vector<T> out;
+    return host_gather_chunks<T>(ctx, dev, n, [&](size_t first, size_t cnt, const T *a) -> int {
+        out.resize(cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+            T v = a[i];
+            for (int r = 1; r < ctx->nranks; ++r) {
+                const T w = a[(size_t)r * cnt + i];
+                v = is_max ? (w > v ? w : v) : v + w;          // ranks in order: the same sum on every rank
+            }
+            out[i] = v;
         }
-        out[i] = v;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(dev, out.data(), n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
+        HIPCHK(ctx, hipMemcpyAsync(dev + first, out.data(), cnt * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return PCL_OK;
+    });
 }
 
 // sum all-reduce / max all-reduce of a device array, on whichever transport is up
@@ -123,20 +136,24 @@ template <typename T>
 int reduce_scatter_parts(pcl_ctx *ctx, T *const *bases, const size_t *per_state, int nparts, int J) {
     const int n = ctx->nranks, me = ctx->rank;
     if (ctx->transport == 2) {
+        std::vector<T> out;
         for (int p = 0; p < nparts; ++p) {
             const size_t tot = per_state[p] * (size_t)J;
-            std::vector<char> all;
-            TRY(host_gather(ctx, bases[p], tot * sizeof(T), all));
-            const T *a = reinterpret_cast<const T *>(all.data());
             const size_t lo = per_state[p] * (size_t)range_lo(J, n, me), hi = per_state[p] * (size_t)range_lo(J, n, me + 1);
-            std::vector<T> out(hi - lo);
-            for (size_t i = lo; i < hi; ++i) {
-                T v = a[i];
-                for (int r = 1; r < n; ++r) v += a[(size_t)r * tot + i];
-                out[i - lo] = v;
-            }
-            if (hi > lo) HIPCHK(ctx, hipMemcpyAsync(bases[p] + lo, out.data(), (hi - lo) * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            T *base = bases[p];
+            TRY(host_gather_chunks<T>(ctx, base, tot, [&](size_t first, size_t cnt, const T *a) -> int {
+                const size_t a0 = std::max(first, lo), a1 = std::min(first + cnt, hi);      // what this rank owns of the chunk
+                if (a1 <= a0) return PCL_OK;
+                out.resize(a1 - a0);
+                for (size_t i = a0; i < a1; ++i) {
+                    T v = a[i - first];
+                    for (int r = 1; r < n; ++r) v += a[(size_t)r * cnt + (i - first)];
+                    out[i - a0] = v;
+                }
+                HIPCHK(ctx, hipMemcpyAsync(base + a0, out.data(), (a1 - a0) * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                return PCL_OK;
+            }));
         }
         return PCL_OK;
     }
@@ -166,18 +183,21 @@ template <typename T>
 int all_gather_parts(pcl_ctx *ctx, T *const *bases, const size_t *per_state, int nparts, int J) {
     const int n = ctx->nranks, me = ctx->rank;
     if (ctx->transport == 2) {
+        std::vector<T> out;
         for (int p = 0; p < nparts; ++p) {
             const size_t tot = per_state[p] * (size_t)J;
-            std::vector<char> all;
-            TRY(host_gather(ctx, bases[p], tot * sizeof(T), all));
-            const T *a = reinterpret_cast<const T *>(all.data());
-            std::vector<T> out(tot);
-            for (int r = 0; r < n; ++r) {
-                const size_t lo = per_state[p] * (size_t)range_lo(J, n, r), hi = per_state[p] * (size_t)range_lo(J, n, r + 1);
-                if (hi > lo) memcpy(out.data() + lo, a + (size_t)r * tot + lo, (hi - lo) * sizeof(T));
-            }
-            HIPCHK(ctx, hipMemcpyAsync(bases[p], out.data(), tot * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            T *base = bases[p];
+            TRY(host_gather_chunks<T>(ctx, base, tot, [&](size_t first, size_t cnt, const T *a) -> int {
+                out.resize(cnt);
+                for (int r = 0; r < n; ++r) {                      // every element from the rank that owns its state
+                    const size_t lo = per_state[p] * (size_t)range_lo(J, n, r), hi = per_state[p] * (size_t)range_lo(J, n, r + 1);
+                    const size_t a0 = std::max(first, lo), a1 = std::min(first + cnt, hi);
+                    if (a1 > a0) memcpy(out.data() + (a0 - first), a + (size_t)r * cnt + (a0 - first), (a1 - a0) * sizeof(T));
+                }
+                HIPCHK(ctx, hipMemcpyAsync(base + first, out.data(), cnt * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                return PCL_OK;
+            }));
         }
         (void)me;
         return PCL_OK;

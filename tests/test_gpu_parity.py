@@ -913,8 +913,19 @@ def test_score_fuzz_default_variant(eng, seed):
     """Random J, M (not a multiple of 32), D in {13, 26, 39}, per-dimension scales over +-2 decades, a random offset,
     random zero weights, a few far outliers: every finite score within 5e-6 relative + 2e-4 + the analytical f32 evaluation
     bound (f32_evaluation_bound) of the float64 oracle."""
+    _score_fuzz(eng, seed, [13, 26, 39])
+
+
+@pytest.mark.parametrize('seed', range(100, 108))
+def test_score_fuzz_any_dimension(eng, seed):
+    """The same with feature dimensions that are NOT 13 / 26 / 39: the library pads them to the next matrix-pipe size (13, 26,
+    39, 47; zero features, zero coefficients) instead of dropping to the VALU kernels as round 2 did for e.g. D = 20 -> 24."""
+    _score_fuzz(eng, seed, [5, 8, 14, 20, 27, 33, 40, 45, 47])
+
+
+def _score_fuzz(eng, seed, dims):
     rng = np.random.default_rng(1000 + seed)
-    D = int(rng.choice([13, 26, 39]))
+    D = int(rng.choice(dims))
     J = int(rng.integers(1, 6))
     M = int(rng.integers(1, 150))
     T = int(rng.integers(1, 400))
@@ -933,17 +944,27 @@ def test_score_fuzz_default_variant(eng, seed):
         x[rng.integers(0, T), rng.integers(0, D)] *= 10.0 ** rng.uniform(1, 4)      # outliers
     got, ref = score_all_states(eng, mean, var, w, x)
     # both sides receive the same f32 frames; the allowance is the analytical bound of an f32 evaluation of offset data
-    assert_f32_class(got, ref, f32_evaluation_bound(mean, var, w, x), what='fuzz %d:' % seed)
+    assert_f32_class(got, ref, f32_evaluation_bound(mean, var, w, x), what='fuzz %d (D=%d):' % (seed, D))
 
 
 @pytest.mark.parametrize('seed', range(4))
 def test_estep_fuzz_default_variant(eng, seed):
     """E-step statistics of random small problems (peaked posteriors: frames sampled from the label's states, so
     many (frame, mixture) posteriors are tiny and some mixtures are almost never responsible) against the oracle."""
+    _estep_fuzz(eng, seed, [13, 26, 39])
+
+
+@pytest.mark.parametrize('seed', range(100, 105))
+def test_estep_fuzz_any_dimension(eng, seed):
+    """E-step statistics with feature dimensions padded to a matrix-pipe size (20 -> 26, 33 -> 39, 40 / 45 -> 47, 8 -> 13)."""
+    _estep_fuzz(eng, seed, [8, 20, 33, 40, 45, 47])
+
+
+def _estep_fuzz(eng, seed, dims):
     from poccala_amd import PCL_F32, synth
     from poccala_amd.engine import make_sentence_batch
     rng = np.random.default_rng(500 + seed)
-    D = int(rng.choice([13, 26, 39]))
+    D = int(rng.choice(dims))
     units, M, U, L, PER = int(rng.integers(2, 6)), int(rng.integers(2, 70)), int(rng.integers(2, 7)), int(rng.integers(1, 4)), int(rng.integers(2, 6))
     mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
     mean = mean * 2.0                                            # well separated mixtures: peaked mixture posteriors

@@ -381,8 +381,10 @@ def _free_port():
     return p
 
 
-def _exchange_worker(rank, world, port, payload, uneven, q):
+def _exchange_worker(rank, world, port, payload, uneven, q, chunk_kb=None):
     try:
+        if chunk_kb:
+            os.environ['PCL_HOST_CHUNK_KB'] = str(chunk_kb)      # the transport's chunk edges fall inside states
         from poccala_amd import Engine, PCL_F32, PCL_F64, synth
         from poccala_amd.distributed import Control, shard_range
         units = 5 if uneven else 4                      # J = 15 states over 2 ranks: 7 + 8 (the rooted-reduce path)
@@ -422,19 +424,20 @@ def _exchange_worker(rank, world, port, payload, uneven, q):
         q.put((rank, 'error', traceback.format_exc()))
 
 
-@pytest.mark.parametrize('payload,uneven', [('f64', False), ('f64', True), ('f32', False)])
-def test_em_exchange_world2_on_one_device_equals_single_rank(payload, uneven):
+@pytest.mark.parametrize('payload,uneven,chunk_kb', [('f64', False, None), ('f64', True, None), ('f32', False, None), ('f64', True, 1), ('f32', False, 1)])
+def test_em_exchange_world2_on_one_device_equals_single_rank(payload, uneven, chunk_kb):
     """two GPU processes (both on device 0, host rehearsal transport in place of RCCL, which
     refuses duplicate devices) shard the utterances, reduce-scatter the statistics by state range, re-estimate the
     states they own and all-gather the model: every rank must end with the model a single rank computes from all
     utterances (f64 payload: 1e-12; f32 payload: the f32 rounding of it), and with the same next-iteration
-    log-likelihoods for its utterances."""
+    log-likelihoods for its utterances.  chunk_kb = 1: the transport moves the arrays in 1-KiB pieces (in production 64 MiB:
+    the C4-shape statistics, 3.9 GB, do not fit one callback), so chunk edges cut through states and owner ranges."""
     ctx = mp.get_context('spawn')
     res = {}
     for world in (1, 2):
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, payload, uneven, q)) for r in range(world)]
+        procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, payload, uneven, q, chunk_kb)) for r in range(world)]
         for p in procs:
             p.start()
         got = [q.get(timeout=300) for _ in range(world)]
