@@ -714,10 +714,11 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
                  roofline_estep=dict(kernel='acc16_consumer_kernel<39> (+ acc16_producer_kernel<39>, compaction)', ms=acc_ms, bound='mfma',
                                      flop_per_launch=acc_flop, algorithmic_tflops=acc_flop / (acc_ms * 1e-3) / 1e12 if acc_ms else None,
                                      surviving_pair_fraction=survive,
-                                     executed_mfma_tflops=(survive * pairs * cfg['M'] / 1024.0 * 45 * 32768 / (acc_ms * 1e-3) / 1e12) if acc_ms else None,
-                                     peak=BF16_MFMA_PEAK_TFLOPS, frac_executed=(survive * pairs * cfg['M'] / 1024.0 * 45 * 32768 / (acc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS) if acc_ms else None,
-                                     note='algorithmic = M (7D + 8) flop per (frame, state) pair over ALL pairs (SURVEY 8d); executed = 45 MFMAs of '
-                                          '32x32x16 (15 f16 for the recomputed exponent, 30 bf16 for the two weighted moments) per 32 frames x 32 mixtures of '
+                                     executed_mfma_tflops=(survive * pairs * cfg['M'] / 1024.0 * 33 * 32768 / (acc_ms * 1e-3) / 1e12) if acc_ms else None,
+                                     peak=BF16_MFMA_PEAK_TFLOPS, frac_executed=(survive * pairs * cfg['M'] / 1024.0 * 33 * 32768 / (acc_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS) if acc_ms else None,
+                                     note='algorithmic = M (7D + 8) flop per (frame, state) pair over ALL pairs (SURVEY 8d); executed = 33 MFMAs of '
+                                          '32x32x16 f16 (15 for the recomputed exponent, 18 for the two weighted moments: posteriors and features in two f16 '
+                                          'pieces each, per-mixture running power-of-two scale; round 2: 45 with bf16 x3 moments) per 32 frames x 32 mixtures of '
                                           'the SURVIVING pairs.  Bench features are random N(0,1): flat posteriors, ~78 % of the pairs survive the exact '
                                           'underflow compaction; aligned speech is peaked: extra.estep_peaked'))
     if ctl.world == 1 and P == PCL_F32 and not args.utts:

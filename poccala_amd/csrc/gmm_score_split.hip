@@ -158,112 +158,76 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
 #else
 #define SSTAMP(k)
 #endif
-    // One frame tile c of one m-tile: the three passes as ONE chain of 3 KS8 MFMAs into acc (small terms first), and the
-    // log-sum-exp of a finished accumulator.  The two are issued as a PAIR on different accumulators -- the chain of (mt, c)
-    // beside the log-sum-exp of the half-step before, (mt, 1 - c) or (mt - 1, 1) -- so that every wave's instruction stream
-    // is a steady mix of matrix and vector work.  Round 1-2 ran [30 MFMAs][32 exp + 30 add] per m-tile: the three waves of a
-    // SIMD, arbitrated round robin through identical programs, fall into step, all in the MFMA phase and then all in the
-    // vector phase with the matrix pipe empty (65 % busy, SQ_WAIT_INST_ANY 53 %).  The price: a parameter fragment is read
-    // from LDS once per frame tile instead of once per pair (30 instead of 15 ds_read_b128 per m-tile and wave).
-    auto chain = [&](int mt, int c, f16v &acc) {
+    auto process = [&](int mt) {
         const uint4 *ab = &abuf[(mt / MTS) & 1][(mt % MTS) * (CH * 64)];
-        // all fragment reads in program order first: the group barriers in mix() then deal them out one pass (KS8 reads) ahead
-        // of the MFMAs that consume them, so that no MFMA waits for a read issued right in front of it
-        h8v fr[3 * KS8];
+        f16v acc[NT];
 #pragma unroll
-        for (int s = 0; s < KS8; ++s) fr[s] = *reinterpret_cast<const h8v *>(&ab[(1 * KS8 + s) * 64 + lane]);          // a2 (x1)
+        for (int c = 0; c < NT; ++c)
 #pragma unroll
-        for (int s = 0; s < KS8; ++s) fr[KS8 + s] = *reinterpret_cast<const h8v *>(&ab[(0 * KS8 + s) * 64 + lane]);    // a1 (x2, x1)
-        const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc = zero;
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        auto pass = [&](int pa, int pb) {
 #pragma unroll
-        for (int s = 0; s < KS8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s], xb[c][0][s], acc, 0, 0, 0);          // a2 x1
+            for (int s = 0; s < KS8; ++s) {
+                const h8v a = *reinterpret_cast<const h8v *>(&ab[(pa * KS8 + s) * 64 + lane]);
 #pragma unroll
-        for (int s = 0; s < KS8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[KS8 + s], xb[c][1][s], acc, 0, 0, 0);    // a1 x2
-#pragma unroll
-        for (int s = 0; s < KS8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[KS8 + s], xb[c][0][s], acc, 0, 0, 0);    // a1 x1
-    };
-    // fast part of the log-sum-exp: no branch, so that it shares a basic block with the chain it is paired with
-    auto lse_sum = [&](const f16v &acc) -> float {
-        float e0 = __builtin_amdgcn_exp2f(acc[0]), e1 = __builtin_amdgcn_exp2f(acc[1]), e2 = __builtin_amdgcn_exp2f(acc[2]), e3 = __builtin_amdgcn_exp2f(acc[3]);
-        // four running sums (plain v_add_f32: this file is built with -fno-slp-vectorize, the packed adds the compiler would
-        // form cost far more than their issue slot beside MFMAs); beside a chain of MFMAs the latency of the adds is hidden
-#pragma unroll
-        for (int r = 4; r < 16; r += 4) {
-            e0 += __builtin_amdgcn_exp2f(acc[r]);
-            e1 += __builtin_amdgcn_exp2f(acc[r + 1]);
-            e2 += __builtin_amdgcn_exp2f(acc[r + 2]);
-            e3 += __builtin_amdgcn_exp2f(acc[r + 3]);
-        }
-        return (e0 + e1) + (e2 + e3);
-    };
-    // slow part: the first m-tile (the reference is set) or a sum that left f32 (the reference is raised), wave-uniform
-    auto lse_finish = [&](bool first, int c, f16v &acc, float part) {
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[c][pb][s], acc[c], 0, 0, 0);
+            }
+        };
+#ifdef PCL_SPLIT_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        pass(1, 0);
+        pass(0, 1);
+        pass(0, 0);
+        SSTAMP(1)
+#ifdef PCL_SPLIT_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef PCL_DIAG_NOLSE
-        sm[c] += part;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) sm[c] += acc[c][0] + acc[c][15];
         return;
 #endif
-        const float snew = sm[c] + part;
-        if (first || __any(!(snew < 3.0e38f))) {
-            float gm = acc[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[r]);
-            const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));
-            float s = sm[c];
-            if (first && !(gp > -5.0e4f)) ref_ovf = true;        // log zero everywhere, or out of the f16 constants' reach
-            if ((first || gp > 0.f) && gp > -5.0e4f) {
-                // the reference the pipe subtracts is the f16-rounded one: shift by what it actually moves
-                const _Float16 r1 = (_Float16)__builtin_fminf(__builtin_fmaxf(-(ref[c] + gp), -FMAXH), FMAXH);
-                const float nref = -(float)r1, dl = nref - ref[c];
-                ref_ovf |= __builtin_fabsf(nref) > 5.0e4f;
-                s = first ? 0.f : s * __builtin_amdgcn_exp2f(-dl);
+        for (int c = 0; c < NT; ++c) {
+            float es[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] -= dl;
-                ref[c] = nref;
-                if (half) xb[c][0][SC][JC] = r1;
+            for (int r = 0; r < 16; ++r) es[r] = __builtin_amdgcn_exp2f(acc[c][r]);
+            // plain v_add_f32 tree: under -O3 the compiler SLP-packs such adds into v_pk_add_f32, which costs far more than
+            // its issue slot beside MFMAs (in-kernel stamps: log-sum-exp phase 1830 -> 1230 cycles per m-tile), so this
+            // file is built with -fno-slp-vectorize (Makefile).  (Pinning the adds with inline asm instead returned wrong
+            // sums: the hazard recogniser does not cover a transcendental result consumed inside an asm block.)
+#pragma unroll
+            for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                for (int r = 0; r < w; ++r) es[r] += es[r + w];
+            const float snew = sm[c] + es[0];
+            if (mt == 0 || __any(!(snew < 3.0e38f))) {
+                float gm = acc[c][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
+                const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));
+                float s = sm[c];
+                if (mt == 0 && !(gp > -5.0e4f)) ref_ovf = true;      // log zero everywhere, or out of the f16 constants' reach
+                if ((mt == 0 || gp > 0.f) && gp > -5.0e4f) {
+                    // the reference the pipe subtracts is the f16-rounded one: shift by what it actually moves
+                    const _Float16 r1 = (_Float16)__builtin_fminf(__builtin_fmaxf(-(ref[c] + gp), -FMAXH), FMAXH);
+                    const float nref = -(float)r1, dl = nref - ref[c];
+                    ref_ovf |= __builtin_fabsf(nref) > 5.0e4f;
+                    s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-dl);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][r] -= dl;
+                    ref[c] = nref;
+                    if (half) xb[c][0][SC][JC] = r1;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[c][r]);
+                sm[c] = s;
+            } else {
+                sm[c] = snew;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s += __builtin_amdgcn_exp2f(acc[r]);
-            sm[c] = s;
-        } else {
-            sm[c] = snew;
         }
-    };
-    // the schedule of a half-step: the first pass's fragments, then per MFMA one read of the NEXT pass (while there is one) and
-    // two of the partner's vector instructions (16 exp + 16 add over 3 KS8 MFMAs)
-    auto mix = [&]() {
-#ifndef PCL_SPLIT16_NOSGB
-        __builtin_amdgcn_sched_group_barrier(0x100, KS8, 0);       // DS read: pass a2
-#pragma unroll
-        for (int i = 0; i < 3 * KS8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
-            if (i < KS8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read: pass a1
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    // VALU
-        }
-#endif
-    };
-    static_assert(NT == 2, "the half-step pipeline pairs the two frame tiles of a wave");
-    f16v accA, accB;                                             // frame tile 0 / 1
-    auto process = [&](int mt) {
-        if (mt == 0) {                                           // nothing to pair the first chain with
-            chain(0, 0, accA);
-            chain(0, 1, accB);
-            const float p0 = lse_sum(accA);
-            mix();
-            lse_finish(true, 0, accA, p0);
-            SSTAMP(1)
-        } else {
-            chain(mt, 0, accA);                                  // || log-sum-exp of (mt - 1, 1)
-            const float p1 = lse_sum(accB);
-            mix();
-            lse_finish(mt == 1, 1, accB, p1);
-            SSTAMP(1)
-            chain(mt, 1, accB);                                  // || log-sum-exp of (mt, 0)
-            const float p0 = lse_sum(accA);
-            mix();
-            lse_finish(false, 0, accA, p0);
-            SSTAMP(2)
-        }
+        SSTAMP(2)
     };
     const int n_stages = (n_mtiles + MTS - 1) / MTS;
     dma(0, 0);
@@ -282,7 +246,6 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
             for (int mt = st * MTS; mt < mend; ++mt) process(mt);
         }
     }
-    if (wave_active) lse_finish(n_mtiles == 1, 1, accB, lse_sum(accB));      // the last half-step's log-sum-exp
 #ifdef PCL_SPLIT_STAMPS
     if (blockIdx.x == 800 && lane == 0)
         printf("wave %d: per m-tile: dma-wait %llu  barrier %llu  dma-issue+lds+mfma %llu  lse %llu (memtime ticks)\n", wave,
