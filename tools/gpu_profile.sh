@@ -6,19 +6,24 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
-rm -rf $OUT; mkdir -p $OUT
+mkdir -p $OUT
 ARGS="--steps 3 --warmup 1 --cpu-baseline 0 --extra 0"
 run() { # tag counters... (empty = trace pass), program args...
   tag=$1; shift; ctr=$1; shift
   if [ -z "$ctr" ]; then timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- python3 "$@" > $OUT/$tag.log 2>&1 || echo "$tag failed" >> $OUT/failures.log
   else timeout 420 rocprofv3 --pmc $ctr --output-format csv -d $OUT/$tag -- python3 "$@" > $OUT/$tag.log 2>&1 || echo "$tag ($ctr) failed" >> $OUT/failures.log; fi
 }
+PARTS=${PARTS:-bench acc dec}
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+if has bench; then
 run bench_trace "" $R/bench.py $ARGS
 run bench_fetch "FETCH_SIZE" $R/bench.py $ARGS
 run bench_write "WRITE_SIZE" $R/bench.py $ARGS
 run bench_clk "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" $R/bench.py $ARGS
 run bench_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $R/bench.py $ARGS
 run bench_sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" $R/bench.py $ARGS
+fi
+if has acc; then
 run acc_trace "" $R/tools/acc_bench.py
 run acc_fetch "FETCH_SIZE" $R/tools/acc_bench.py
 run acc_write "WRITE_SIZE" $R/tools/acc_bench.py
@@ -27,12 +32,15 @@ run acc_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $R/tool
 run acc_sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" $R/tools/acc_bench.py
 run acc_lds "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" $R/tools/acc_bench.py
 run acc_tcc "TCC_HIT_sum TCC_MISS_sum" $R/tools/acc_bench.py
+fi
 DEC="$R/tools/c5_decode_bench.py 417 4096 20000 3 8192"
+if has dec; then
 run dec_trace "" $DEC
 run dec_fetch "FETCH_SIZE" $DEC
 run dec_write "WRITE_SIZE" $DEC
 run dec_clk "GRBM_GUI_ACTIVE" $DEC
 run dec_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $DEC
+fi
 RND=${RND:-r03}
 python3 $R/tools/make_profile_summary.py $OUT $RND
 find $OUT -name "*.csv" -size +1M -delete
