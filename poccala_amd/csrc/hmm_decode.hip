@@ -39,7 +39,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "pcl_internal.h"
+#include "hmm_decode_args.h"
 
 namespace {
 
@@ -52,32 +52,7 @@ constexpr int NS = 8;               // lanes per token = states of its HMM at mo
 constexpr int TG = DW / NS;         // tokens stepped per pass of the workgroup
 constexpr int SEG_LDS = 4096;       // donor segments whose offsets are searched in LDS (more: searched in HBM)
 constexpr int NONE = 0x7fffffff;
-[[maybe_unused]] constexpr int N_STAMP = 8;
-
-// Token state is kept as separate arrays (coalesced passes), two buffers of each: a frame ends with a stable compaction
-// from one into the other.  upair = the node's units, u0 | u1 << 16 (u1 = 0xffff: a one-unit node).
-struct DecArgs {
-    const UttDesc *utts;
-    const double *Bt;
-    const double *unit_logtrans;    // [n_units][S][S]
-    const int *node_units, *node_nunits, *child_ptr, *child_idx, *node_word, *roots;
-    int n_nodes, n_roots, n_units, S, cap, candidate, min_distinct, Tmax;
-    double beam, lpi1, lpi2;        // ln(1/N) for one- and two-unit nodes, from the caller's np.log
-    double *score, *p;              // [U][2][cap], [U][2][cap][NS]
-    int *node, *hist, *upair;       // [U][2][cap]
-    int *flag, *dst;                // [U][cap]: bit 0 finished, bit 1 pruned (this frame); where a token's p sits in the other p buffer
-    int *seg_ofs, *seg_cptr, *seg_hist;   // [U][cap + 2]: the frame's donors as segments of the flattened (donor, child) list
-    double *seg_score;
-    int *slot;                      // [U][n_nodes]: live token of a node, or -1
-    int *out_n, *out_node, *out_hist, *hist_n, *hist_prev, *hist_node, *trace, *overflow;
-    double *out_score;
-    long long *stamps;              // PCL_DEC_STAMPS: [N_STAMP] clock ticks per phase, utterance 0
-};
-
-__device__ __forceinline__ unsigned long long okey(double s) {       // order-preserving bits
-    const unsigned long long b = (unsigned long long)__double_as_longlong(s);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
+constexpr int N_STAMP = PCL_DEC_N_STAMP;
 
 // What a lane (state j = sub of its token) needs of ln A of the embedded HMM (AcousticModel.py:979-989), fixed per thread:
 // predecessor i reaches j through entry rc[i] of its unit's (S,S) matrix, or not at all.
@@ -175,12 +150,6 @@ __device__ __forceinline__ void step_range(const LaneCtx &c, const double *lt, c
         po0[0] = po1[0];
         po0[1] = po1[1];
     }
-}
-
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 // TLDS: the unit matrices and the frame's emission row are staged in LDS (dynamic: (n_units S S + N) doubles).
@@ -313,8 +282,8 @@ __global__ __launch_bounds__(DW) PCL_DEC_WAVES_ATTR void hmm_decode_kernel(DecAr
                 }
             }
         }
-        nd_cnt = wave_sum(nd_cnt);
-        ch_cnt = wave_sum(ch_cnt);
+        nd_cnt = pcl_wave_sum(nd_cnt);
+        ch_cnt = pcl_wave_sum(ch_cnt);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(bw, o, 64);
@@ -489,7 +458,7 @@ __global__ __launch_bounds__(DW) PCL_DEC_WAVES_ATTR void hmm_decode_kernel(DecAr
             const int i = w0 + kk * 64 + lane;
             keys[kk] = NOKEY;
             if (kk * 64 < C && i < n && !(flag[i] & 1)) {
-                const unsigned long long key = okey(sc[i]);
+                const unsigned long long key = pcl_okey(sc[i]);
                 keys[kk] = key;
                 ++cnt;
                 kmn = min(kmn, key);
@@ -497,7 +466,7 @@ __global__ __launch_bounds__(DW) PCL_DEC_WAVES_ATTR void hmm_decode_kernel(DecAr
                 atomicOr(&hist256[(unsigned int)((key * 0x9E3779B97F4A7C15ull) >> 56)], 1u);
             }
         }
-        cnt = wave_sum(cnt);
+        cnt = pcl_wave_sum(cnt);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             kmn = min(kmn, (unsigned long long)__shfl_xor((long long)kmn, o, 64));
@@ -614,7 +583,7 @@ __global__ __launch_bounds__(DW) PCL_DEC_WAVES_ATTR void hmm_decode_kernel(DecAr
             int eq = 0;
 #pragma unroll
             for (int kk = 0; kk < KMAX; ++kk) eq += keys[kk] == sel;
-            eq = wave_sum(eq);
+            eq = pcl_wave_sum(eq);
             __syncthreads();
             if (lane == 0) wsum[0][wave] = eq;
             __syncthreads();
@@ -646,7 +615,7 @@ __global__ __launch_bounds__(DW) PCL_DEC_WAVES_ATTR void hmm_decode_kernel(DecAr
                 }
             }
         }
-        keep_cnt = wave_sum(keep_cnt);
+        keep_cnt = pcl_wave_sum(keep_cnt);
         if (lane == 0) wsum[1][wave] = keep_cnt;
         __syncthreads();
         int krun = 0, n_keep = 0;
@@ -752,6 +721,7 @@ void pcl_lexicon_release(pcl_ctx *ctx) {
     dev_free(ctx->lex_child_idx);
     dev_free(ctx->lex_word);
     dev_free(ctx->lex_roots);
+    dev_free(ctx->lex_info);
     dev_free(ctx->d_unit_logtrans);
     ctx->lex_nodes = ctx->lex_nroots = 0;
 }
@@ -804,6 +774,15 @@ int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, con
     TRY(dev_alloc(ctx, &ctx->lex_child_idx, (size_t)std::max(nc, 1)));
     TRY(dev_alloc(ctx, &ctx->lex_word, (size_t)n_nodes));
     TRY(dev_alloc(ctx, &ctx->lex_roots, (size_t)n_roots));
+    TRY(dev_alloc(ctx, &ctx->lex_info, (size_t)n_nodes));
+    {   // (first child, children, words end here, unit pair) of a node in one 16-byte record
+        std::vector<int4> info(n_nodes);
+        for (int i = 0; i < n_nodes; ++i) {
+            const int u0 = node_units[2 * i], u1 = node_nunits[i] == 2 ? node_units[2 * i + 1] : 0xffff;
+            info[i] = make_int4(child_ptr[i], child_ptr[i + 1] - child_ptr[i], node_word[i] ? 1 : 0, u0 | (u1 << 16));
+        }
+        HIPCHK(ctx, hipMemcpy(ctx->lex_info, info.data(), (size_t)n_nodes * sizeof(int4), hipMemcpyHostToDevice));
+    }
     TRY(dev_alloc(ctx, &ctx->d_unit_logtrans, ctx->unit_logtrans.size()));
     HIPCHK(ctx, hipMemcpy(ctx->lex_units, node_units, (size_t)2 * n_nodes * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->lex_nunits, node_nunits, (size_t)n_nodes * 4, hipMemcpyHostToDevice));
@@ -854,12 +833,16 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     } swap_back{ctx, main_stream};
     if (ctx->dp_async) ctx->stream = ctx->stream_dp;
     const int cap = max_tokens, U = b->U, Tm = b->Tmax;
+    // left-to-right units (every model the reference builds): one lane per token, hmm_decode_lr.hip; PCL_DEC_GENERAL=1 keeps
+    // the general kernel (the parity tests run both against the restatement)
+    const char *force_general = getenv("PCL_DEC_GENERAL");
+    const bool use_lr = !(force_general && atoi(force_general)) && pcl_decode_lr_applicable(ctx, J + 2, cap);
     if (b->dec_cap != cap || b->dec_cand != candidate || b->dec_nodes != ctx->lex_nodes) {
         pcl_batch_decode_release(b);
         // doubles per utterance: score 2 cap | p 2 cap NS | seg_score cap + 2;  ints: node, hist, upair 2 cap each | flag, dst cap each |
-        // seg_ofs, seg_cptr, seg_hist cap + 2 each
+        // seg_ofs, seg_cptr, seg_hist cap + 2 each (general kernel); the left-to-right kernel lays meta 8 cap | src 2 cap over the same words
         TRY(dev_alloc(ctx, &b->dec_f64, (size_t)U * (2 * (size_t)cap * (1 + NS) + cap + 2)));
-        TRY(dev_alloc(ctx, &b->dec_work, (size_t)U * (8 * (size_t)cap + 3 * ((size_t)cap + 2))));
+        TRY(dev_alloc(ctx, &b->dec_work, (size_t)U * (10 * (size_t)cap + 3 * ((size_t)cap + 2))));
         TRY(dev_alloc(ctx, &b->dec_slot, (size_t)U * ctx->lex_nodes));
         // ints: out_n U | out_node U*cand | out_hist U*cand | hist_n U | hist_prev U*Tm | hist_node U*Tm | trace U*Tm | overflow U
         TRY(dev_alloc(ctx, &b->dec_int, (size_t)U * (3 + 2 * candidate + 3 * Tm)));
@@ -875,7 +858,7 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     a.Bt = b->Bt;
     a.unit_logtrans = ctx->d_unit_logtrans;
     a.node_units = ctx->lex_units; a.node_nunits = ctx->lex_nunits; a.child_ptr = ctx->lex_child_ptr; a.child_idx = ctx->lex_child_idx;
-    a.node_word = ctx->lex_word; a.roots = ctx->lex_roots;
+    a.node_word = ctx->lex_word; a.roots = ctx->lex_roots; a.node_info = ctx->lex_info;
     a.n_nodes = ctx->lex_nodes; a.n_roots = ctx->lex_nroots; a.n_units = ctx->n_units; a.S = ctx->S; a.cap = cap; a.candidate = candidate;
     a.min_distinct = min_distinct; a.Tmax = Tm;
     a.beam = beam; a.lpi1 = logpi_one_unit; a.lpi2 = logpi_two_units;
@@ -885,11 +868,17 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
         a.p = q; q += (size_t)U * 2 * cap * NS;
         a.seg_score = q;
         int *w = b->dec_work;
+        a.meta = (int4 *)w;                          // (left-to-right kernel: 8 cap ints per utterance)
         a.node = w; w += (size_t)U * 2 * cap;
         a.hist = w; w += (size_t)U * 2 * cap;
         a.upair = w; w += (size_t)U * 2 * cap;
         a.flag = w; w += (size_t)U * cap;
         a.dst = w; w += (size_t)U * cap;
+        if (use_lr) {                                // meta [U][2][cap] int4 | src [U][2][cap] | the seg_* arrays
+            a.dst = b->dec_work + (size_t)U * 8 * cap;
+            a.flag = nullptr;
+            w = a.dst + (size_t)U * 2 * cap;
+        }
         a.seg_ofs = w; w += (size_t)U * (cap + 2);
         a.seg_cptr = w; w += (size_t)U * (cap + 2);
         a.seg_hist = w;
@@ -912,6 +901,13 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     HIPCHK(ctx, hipMemsetAsync(d_stamps, 0, N_STAMP * sizeof(long long), ctx->stream));
     a.stamps = d_stamps;
 #endif
+    if (use_lr) {
+        pcl_timer_begin(ctx, "decode");
+        const int rc = pcl_decode_lr_launch(ctx, a, U, J + 2);
+        pcl_timer_end(ctx, "decode");
+        if (rc != PCL_OK) return rc;
+        HIPCHK(ctx, hipGetLastError());
+    } else {
     // the unit matrices and one emission row in LDS when they fit beside the kernel's static 18 KB
     const size_t table_bytes = ((size_t)ctx->n_units * ctx->S * ctx->S + (size_t)(J + 2)) * sizeof(double);
     const bool tlds = table_bytes <= 44u * 1024u;
@@ -929,12 +925,13 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
 #undef PCL_DEC_LAUNCH
     pcl_timer_end(ctx, "decode");
     HIPCHK(ctx, hipGetLastError());
+    }
 #ifdef PCL_DEC_STAMPS
     {
         long long h[N_STAMP];
         HIPCHK(ctx, hipMemcpyAsync(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "decode stamps (utterance 0, 100 MHz ticks): step %lld donors %lld pairs %lld first %lld prune %lld compact %lld\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+        fprintf(stderr, "decode stamps (utterance 0, 100 MHz ticks): step %lld donors %lld pairs %lld first|keys %lld prune %lld compact %lld select %lld\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
         dev_free(d_stamps);
     }
 #endif

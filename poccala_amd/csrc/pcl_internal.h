@@ -111,6 +111,7 @@ struct pcl_ctx {
     double *hmm_ksai = nullptr, *hmm_gamma = nullptr;   // per-unit accumulators, LOG domain: [n_units][S-2][S], [n_units][S-2]
     // pronunciation tree for the decoder (hmm_decode.hip)
     int *lex_units = nullptr, *lex_nunits = nullptr, *lex_child_ptr = nullptr, *lex_child_idx = nullptr, *lex_word = nullptr, *lex_roots = nullptr;
+    int4 *lex_info = nullptr;                        // per node (first child, children, words end here, unit pair)
     double *d_unit_logtrans = nullptr;
     int lex_nodes = 0, lex_nroots = 0;
     // multi-GPU (pcl_comm.hip): RCCL communicator, or the host-callback rehearsal transport

@@ -83,6 +83,87 @@ def test_decode_matches_cpu_restatement_bit_for_bit(eng, lex, dense, beam, cap):
     assert all(isinstance(wl, list) and wl for wl in words)
 
 
+@pytest.mark.parametrize('beam,cap', [(0.85, 4096), (0.6, 300)])
+def test_both_decode_kernels_agree_on_left_to_right_units(eng, lex, monkeypatch, beam, cap):
+    """Left-to-right unit matrices with uneven self-loop weights: the lane-per-token kernel (hmm_decode_lr.hip, the default for
+    such units) and the general kernel (PCL_DEC_GENERAL=1: 8 lanes per token, any matrices) both equal the restatement bit for
+    bit -- the terms the general kernel adds with ln A = -inf change no bit (Decoder.py:278-283)."""
+    from poccala_amd import PCL_F64, synth
+    lx, units, tree = lex
+    mean, var, w, _ = model_for(units, 3, 13, 71)
+    rng = np.random.default_rng(72)
+    trans = []
+    for _ in units:
+        a = np.zeros((S, S))
+        a[0, 1] = 1.0
+        for r in range(1, S - 1):
+            x = rng.uniform(0.05, 0.95)
+            a[r, r], a[r, r + 1] = x, 1.0 - x
+        trans.append(a)
+    trans = np.stack(trans)
+    frames, lens, begin = synth.make_frames(3, 80, 13, seed=73, ragged=True)
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F64)
+    B = b.get('B')
+    fast = b.decode(beam=beam, candidate=6, max_tokens=cap)
+    monkeypatch.setenv('PCL_DEC_GENERAL', '1')
+    general = b.decode(beam=beam, candidate=6, max_tokens=cap)
+    monkeypatch.delenv('PCL_DEC_GENERAL')
+    b.close()
+    for u in range(3):
+        trace, info = [], {}
+        fin, hist = do.decode(tree, list(trans), B[u][1:-1], beam=beam, candidate=6, max_tokens=cap, trace=trace, info=info)
+        for g in (fast[u], general[u]):
+            assert np.array_equal(g['n_tokens'], np.array(trace))
+            assert g['history'] == [(int(p), int(n)) for p, n in hist]
+            assert [(n, h) for n, _, h in g['final']] == [(n, h) for n, _, h in fin]
+            assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]
+            assert g['overflow'] == bool(info.get('overflow'))
+
+
+def test_decode_many_tokens_finish_in_one_frame(eng):
+    """Every state scores alike and every unit hurries forward (self-loop 0.1), so all tokens made in one frame finish in one
+    frame: thousands of donors at once, more per wavefront than the lane-per-token kernel keeps in LDS (its donor lists
+    spill to HBM above 128 per wave), word-end donors and first-character re-seeding in the same frames, the capacity hit
+    -- bit for bit the restatement (Decoder.py:91-143)."""
+    from poccala_amd import PCL_F64, synth
+    n_units = 183
+    tree, lx = synth.make_pronunciation_tree(3000, n_units, seed=81)
+    mean, var, w, _ = synth.make_model(n_units, 2, 13, seed=82)
+    mean[:], var[:], w[:] = mean[0], var[0], w[0]                 # one GMM for every state
+    a = np.zeros((S, S))
+    a[0, 1] = 1.0
+    for r in range(1, S - 1):
+        a[r, r], a[r, r + 1] = 0.1, 0.9
+    trans = np.stack([a] * n_units)
+    frames, lens, begin = synth.make_frames(2, 22, 13, seed=83)
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F64)
+    B = b.get('B')
+    got = b.decode(beam=1.0, candidate=4, max_tokens=8192)
+    b.close()
+    swing = 0
+    for u in range(2):
+        trace, info = [], {}
+        fin, hist = do.decode(tree, list(trans), B[u][1:-1], beam=1.0, candidate=4, max_tokens=8192, trace=trace, info=info)
+        g = got[u]
+        assert np.array_equal(g['n_tokens'], np.array(trace)), (g['n_tokens'], trace)
+        assert g['history'] == [(int(p), int(n)) for p, n in hist]
+        assert [(n, h) for n, _, h in g['final']] == [(n, h) for n, _, h in fin]
+        assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]
+        assert g['overflow'] == bool(info.get('overflow'))
+        swing = max(swing, int(np.abs(np.diff(np.array(trace))).max()))
+    assert swing > 2000                                           # (the frames this test is about did occur)
+
+
 def test_decode_properties(eng, lex):
     """A one-frame utterance returns exactly the first-step scores of the first-character nodes (ln pi + the best of entry
     row 0 and the node's emissions); the same call twice gives the same bits (no atomics, no timing dependence); and a

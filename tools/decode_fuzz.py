@@ -36,6 +36,13 @@ for case in range(cases):
         trans = []
         for _ in units:
             a = np.zeros((5, 5)); a[0, 1:3] = [0.7, 0.3]; a[1:-1, 1:] = rng.dirichlet(np.ones(4), size=3); trans.append(a)
+    elif rng.random() < 0.6:                                   # left-to-right units with random self-loop weights (the lane-per-token kernel)
+        trans = []
+        for _ in units:
+            a = np.zeros((5, 5)); a[0, 1] = 1.0
+            for r_ in (1, 2, 3):
+                x_ = rng.uniform(0.05, 0.95); a[r_, r_] = x_; a[r_, r_ + 1] = 1.0 - x_
+            trans.append(a)
     trans = np.stack(trans)
     U = int(rng.integers(1, 5))
     lens = rng.integers(1, 70, size=U).astype(np.int32)

@@ -112,14 +112,14 @@ out = ['# rocprofv3 summaries, %s: python3 tools/c5_decode_bench.py 417 4096 200
        '', '## --kernel-trace --stats (%s_decode_kernel_stats.csv)' % RND]
 kt, lines = kernel_stats('dec_trace', '%s_decode_kernel_stats.csv' % RND)
 out += lines + ['', '## --pmc passes (<= 4 counters per pass), per-dispatch averages (all launches: full shard and chunks)']
-lines, val = counters(['dec_fetch', 'dec_write', 'dec_clk', 'dec_sq1'], ['hmm_decode_kernel'])
+lines, val = counters(['dec_fetch', 'dec_write', 'dec_clk', 'dec_sq1'], ['hmm_decode_']) if True else None
 out += lines
 try:
-    v = val['hmm_decode_kernel']
-    ms = pick(kt, 'hmm_decode_kernel')
+    v = val['hmm_decode_']
+    ms = pick(kt, 'hmm_decode_')
     cyc = v['GRBM_GUI_ACTIVE'] / 8
     wc = v['SQ_WAVE_CYCLES']
-    out += ['', '## derived (hmm_decode_kernel, averages over the launches above)',
+    out += ['', '## derived (hmm_decode_lr_kernel / hmm_decode_kernel, averages over the launches above)',
             'FETCH_SIZE %.2f GB raw + WRITE_SIZE %.2f GB per launch of %.1f ms average -> %.2f TB/s raw (the token arrays are read with 8- and 4-byte lanes: no x 2)'
             % (v['FETCH_SIZE'] * 1024 / 1e9, v['WRITE_SIZE'] * 1024 / 1e9, ms, (v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 / ms / 1e9),
             'clock held %.2f GHz; wave time: SQ_WAIT_ANY %.0f %%, SQ_WAIT_INST_ANY %.0f %% of SQ_WAVE_CYCLES' % (cyc / ms / 1e6, 100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc)]
