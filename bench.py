@@ -691,6 +691,39 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     per_rank = ctl.allgather(dict(rank=ctl.rank, estep_local_ms=t_local * 1e3, estep_ms=t_rank * 1e3, exchange_ms=(t_rank - t_local) * 1e3,
                                   reduce_scatter_ms=kt['reduce_scatter'], mstep_owned_ms=kt['mstep_owned'], all_gather_ms=kt['all_gather'],
                                   derive_ms=kt['derive'], accumulate_ms=kt['accumulate'], hmm_acc_ms=kt['hmm_acc']))
+    # the same E-step from the same model with the exchange PIPELINED behind the accumulate pass (pcl_batch_accumulate_exchange: state
+    # chunks leave for reduce-scatter -> M-step -> all-gather -> derive as soon as the pass is done with them)
+    pipe = None
+    try:
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        batch.refresh_transitions()
+        eng.stats_zero()
+        batch.score(P); batch.forward_backward(fix_pi=False); batch.accumulate(P); batch.accumulate_hmm()     # (clocks, buffers)
+        eng.sync()
+        for k in ('accumulate', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive'):
+            eng.kernel_time(k)
+        eng.stats_zero()
+        eng.sync()
+        barrier()
+        t1 = time.perf_counter()
+        batch.score(P)
+        batch.forward_backward(fix_pi=False)
+        batch.accumulate_hmm()
+        batch.accumulate_exchange(P, 1e-3, payload, True, n_chunks=8)
+        eng.sync()
+        t_prank = time.perf_counter() - t1
+        barrier()
+        t_pipe = time.perf_counter() - t1
+        kp = {k: eng.kernel_time(k)[0] for k in ('accumulate', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive')}
+        pipe = dict(estep_ms=t_pipe * 1e3, frames_per_s=total_frames / t_pipe, n_chunks=8,
+                    per_rank=ctl.allgather(dict(rank=ctl.rank, estep_ms=t_prank * 1e3, accumulate_ms=kp['accumulate'], reduce_scatter_ms=kp['reduce_scatter'],
+                                                mstep_owned_ms=kp['mstep_owned'], all_gather_ms=kp['all_gather'], derive_ms=kp['derive'])),
+                    what='score -> forward-backward -> per-unit merge -> accumulate with the exchange pipelined: the kernel times are sums over the 8 '
+                         'chunks and overlap the accumulate pass (accumulate_ms is stretched by what runs beside it); estep_ms against extra.estep_ms '
+                         'is what the pipelining buys')
+    except Exception as e:                     # noqa: never the headline's problem
+        pipe = dict(error=repr(e))
     t1 = time.perf_counter()
     batch.get('logp'); batch.get('gamma'); eng.hmm_acc_download()
     t_d2h = time.perf_counter() - t1
@@ -708,6 +741,7 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
                                what='reduce-scatter of the GMM statistics by state range -> GMM.update_param on the owned J/N states -> '
                                     'all-gather of (mean, var, weight) -> layouts re-derived; per-unit transition accumulators merged by max + sum '
                                     'all-reduces, transition M-step on every rank; one rank: the M-step alone'),
+                 estep_pipelined=pipe,
                  frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
                  pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),
                  setup_s=t_setup,

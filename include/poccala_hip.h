@@ -297,6 +297,15 @@ int pcl_stats_allreduce(pcl_ctx *ctx);
  * parameters rounded to f32 in flight; every rank continues from the same rounded model).  With one rank and no
  * communicator this is pcl_mstep (+ pcl_mstep_transitions).  Synchronous at return. */
 int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_transitions);
+/* The LAST accumulate pass of an E-step and the exchange as one call, pipelined: the states are cut into n_chunks equal
+ * chunks, and as soon as the accumulate pass (which walks the states in ascending order, a group at a time) is done with a
+ * chunk, the chunk goes through reduce-scatter (inside a chunk rank r owns the r-th slice) -> GMM.update_param -> all-gather ->
+ * its layouts re-derived, on a stream of its own, beside the accumulation of the later states.  Replaces, like pcl_em_exchange,
+ * the reference's file merge + per-unit M-step (LHMM.py:256-290, Clustering.py:314-367,682-693; AcousticModel.py:918-935);
+ * same sums and M-step arithmetic, so the gathered model equals pcl_batch_accumulate + pcl_em_exchange (bit for bit on
+ * the rehearsal transport; RCCL's ring order may differ in the last bit).  One rank: M-step + derive of finished chunks beside
+ * the rest of the pass.  Synchronous at return. */
+int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covariance, int payload, int update_transitions, int n_chunks);
 int pcl_comm_destroy(pcl_ctx *ctx);
 
 #ifdef __cplusplus

@@ -689,6 +689,8 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         HIPCHK(ctx, hipEventRecord(b->acc16_ev_start, ctx->stream));            // the active-frame lists are complete
         if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ps, b->acc16_ev_start, 0));
         const int G = (int)gfirst.size();
+        bool ascending = true;
+        for (int k = 1; k < n_good; ++k) ascending = ascending && b->acc_ws[k - 1] < b->acc_ws[k];
         auto produce = [&](int g) -> int {
             const int buf = g & 1;
             if (overlap && g >= 2) HIPCHK(ctx, hipStreamWaitEvent(ps, b->acc16_ev_cons[buf], 0));      // the buffer set is free again
@@ -709,6 +711,10 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
             if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));
             if (!overlap && g + 1 < G) { rc = produce(g + 1); if (rc != PCL_OK) return rc; }
+            // a pipelined exchange is open (pcl_batch_accumulate_exchange): every state below the next group's first one has its
+            // final statistics behind what is queued now -- its chunks may leave (states come in ascending order; states of the
+            // direct-form kernel, if any, are accumulated at the end, so nothing is final before that)
+            if (ctx->pipe_active && ascending && n_bad == 0) TRY(pcl_pipe_progress(ctx, g + 1 < G ? b->acc_ws[gfirst[g + 1]] : ctx->J));
         }
     } else if (mfma && n_good > 0) {
         const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW, ns = n_good;

@@ -11,6 +11,8 @@
 //               var = max(cov_acc / acc, c_covariance)
 //           so that an EM iteration (E-step -> RCCL all-reduce -> M-step -> next E-step) never leaves the GPU.
 // Both are HBM-bound streaming passes over J*M*D elements (C4: 240 M elements, a few ms).
+#include <algorithm>
+
 #include "pcl_internal.h"
 
 namespace {
@@ -35,12 +37,12 @@ constexpr int PRE_T = 512;
 __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
                                                              const double *__restrict__ w64, int M, int Mpad, int D, int Dhost, int KS8,
                                                              int flags, float *__restrict__ centers, float *__restrict__ fscale,
-                                                             double *__restrict__ kzero) {
+                                                             double *__restrict__ kzero, int j0) {
     __shared__ double part[64 * 40];
     __shared__ float cen[64];
     __shared__ unsigned long long fbits[2][64];
     __shared__ int kbits;
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int j = j0 + blockIdx.x, tid = threadIdx.x;            // (j0: a state range re-derived on its own, pcl_launch_derive_range)
     const double *mu = mean64 + (size_t)j * Mpad * D, *vr = var64 + (size_t)j * Mpad * D;
     // ---- (A)
     const int R = min(PRE_T / D, 40), d = tid % D, r = tid / D;
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
                                                      uint4 *__restrict__ pm16f,
                                                      const double *__restrict__ kzero,
-                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what) {
+                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what, int j0) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
-    const int j = blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
+    const int j = j0 + blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
     double *mu = sh, *vr = sh + 32 * D, *k2s = vr + 32 * D, *kqs = k2s + 32;
     float *cen = reinterpret_cast<float *>(kqs + 32);
     float *fa = cen + D, *fb = fa + 32 * D;       // the f32 coefficients of the expansion: a = -log2e/(2 var), b = log2e (mu - c)/var
@@ -285,13 +287,12 @@ __global__ void mstep_kernel(const double *__restrict__ st_acc, const double *__
                              const double *__restrict__ st_mean, const double *__restrict__ st_cov, int J, int M, int Mpad,
                              int D, int Dhost, double bias, double floor_var, int j_lo, int j_hi,
                              double *__restrict__ mean64, double *__restrict__ var64, double *__restrict__ w64) {
-    const long long total = (long long)J * Mpad * D;
-    for (long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+    const long long first = (long long)j_lo * Mpad * D, total = (long long)j_hi * Mpad * D;   // a rank re-estimates the states it owns
+    for (long long gid = first + blockIdx.x * (long long)blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
         const int d = (int)(gid % D);
         const long long jm = gid / D;
         const int m = (int)(jm % Mpad), j = (int)(jm / Mpad);
         if (m >= M || d >= Dhost) continue;
-        if (j < j_lo || j >= j_hi) continue;                     // multi-GPU: a rank re-estimates the states it owns
         const double a = st_acc[jm], al = st_alpha[j];
         // A state no frame reached (alpha_acc = 0) keeps its model; a mixture of a seen state whose occupancy is exactly
         // 0 -- every gamma_t(j,m) flushed to zero in the f32 accumulate, or pruned at 2^-150 -- gets weight 0 (= acc /
@@ -342,23 +343,44 @@ static int eager_layouts(const pcl_ctx *ctx) {
     return what;
 }
 
-static int launch_derive_kernel(pcl_ctx *ctx, int what) {
+static int launch_derive_kernel(pcl_ctx *ctx, int what, int j_lo, int j_hi) {
     const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)(ctx->D + 2 * 32 * ctx->D) * sizeof(float);
-    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)(ctx->J * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
+    if (j_hi <= j_lo) return PCL_OK;
+    hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((j_hi - j_lo) * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16f),
-                       ctx->kzero, ctx->fscale, ctx->d_cond, what);
+                       ctx->kzero, ctx->fscale, ctx->d_cond, what, j_lo);
     HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+// The eager layouts of the states [j_lo, j_hi) from the master copy, on ctx->stream, nothing waited for: the pipelined
+// exchange (pcl_comm.hip) re-derives a state range as soon as its new parameters are there; pcl_derive_finish closes.
+int pcl_launch_derive_range(pcl_ctx *ctx, int j_lo, int j_hi) {
+    if (j_hi <= j_lo) return PCL_OK;
+    const int KS8f = (ctx->D + 7) / 8;
+    hipLaunchKernelGGL(state_prepass_kernel, dim3(j_hi - j_lo), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
+                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, j_lo);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_cond + j_lo, 0, (size_t)(j_hi - j_lo) * sizeof(float), ctx->stream));
+    return launch_derive_kernel(ctx, eager_layouts(ctx), j_lo, j_hi);
+}
+
+int pcl_derive_finish(pcl_ctx *ctx) {
+    ctx->layouts_valid = eager_layouts(ctx);
+    ctx->cond.resize(ctx->J);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cond.data(), ctx->d_cond, (size_t)ctx->J * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ++ctx->model_gen;
     return PCL_OK;
 }
 
 int pcl_launch_derive(pcl_ctx *ctx) {
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(ctx->J), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
-                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero);
+                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, 0);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     const int what = eager_layouts(ctx);
-    const int rc = launch_derive_kernel(ctx, what);
+    const int rc = launch_derive_kernel(ctx, what, 0, ctx->J);
     if (rc != PCL_OK) return rc;
     ctx->layouts_valid = what;
     // the per-state conditioning decides which kernel scores a state: bring it to the host (J floats)
@@ -373,7 +395,7 @@ int pcl_launch_derive(pcl_ctx *ctx) {
 int pcl_ensure_layouts(pcl_ctx *ctx, int need) {
     const int missing = need & ~ctx->layouts_valid;
     if (!missing) return PCL_OK;
-    const int rc = launch_derive_kernel(ctx, missing);
+    const int rc = launch_derive_kernel(ctx, missing, 0, ctx->J);
     if (rc != PCL_OK) return rc;
     ctx->layouts_valid |= missing;
     return PCL_OK;
@@ -381,7 +403,9 @@ int pcl_ensure_layouts(pcl_ctx *ctx, int need) {
 
 // GMM.update_param for the states [j_lo, j_hi) only (the master copy; the caller re-derives the layouts)
 int pcl_launch_mstep_range(pcl_ctx *ctx, double floor_var, int j_lo, int j_hi) {
-    hipLaunchKernelGGL(mstep_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_acc, ctx->st_alpha, ctx->st_mean,
+    if (j_hi <= j_lo) return PCL_OK;
+    const long long work = (long long)(j_hi - j_lo) * ctx->Mpad * ctx->D;
+    hipLaunchKernelGGL(mstep_kernel, dim3((unsigned)std::min<long long>(4096, (work + 255) / 256)), dim3(256), 0, ctx->stream, ctx->st_acc, ctx->st_alpha, ctx->st_mean,
                        ctx->st_cov, ctx->J, ctx->M, ctx->Mpad, ctx->D, ctx->Dhost, 100.0, floor_var, j_lo, j_hi, ctx->mean64,
                        ctx->var64, ctx->w64);
     HIPCHK(ctx, hipGetLastError());

@@ -998,6 +998,24 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     return rc;
 }
 
+int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covariance, int payload, int update_transitions, int n_chunks) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: no model uploaded");
+    if (payload != PCL_F64 && payload != PCL_F32) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate_exchange: payload %d", payload);
+    if (n_chunks < 1) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate_exchange: n_chunks %d", n_chunks);
+    if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: pcl_comm_init was not called");
+    if (update_transitions && !ctx->hmm_ksai) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: update_transitions without pcl_units_upload");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TRY(pcl_pipe_begin(ctx, c_covariance, payload, n_chunks));
+    int rc = pcl_batch_accumulate(b, precision);                 // releases chunks as its state groups finish
+    const int rf = pcl_pipe_finish(ctx, update_transitions);     // (always: closes the pipe)
+    if (rc == PCL_OK) rc = rf;
+    if (rc != PCL_OK) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
 int pcl_mstep(pcl_ctx *ctx, double c_covariance) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_mstep: no model uploaded");

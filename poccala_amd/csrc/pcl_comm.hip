@@ -49,9 +49,9 @@ __global__ void to_f64_kernel(const float *__restrict__ src, double *__restrict_
 // rounding into 6e-6 absolute on the re-estimated mean.  On the wire travels  sum g (o - c_j) = mean_acc - (bias + c_j) acc
 // (c_j = the state's expansion centre), which is of the size of the features' spread; the owner adds the term back in f64.
 __global__ void mean_to_f32_kernel(const double *__restrict__ st_mean, const double *__restrict__ st_acc, const float *__restrict__ centers,
-                                   int Mpad, int D, double bias, float *__restrict__ dst, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t jm = i / D;
+                                   int Mpad, int D, double bias, float *__restrict__ dst, size_t first, size_t n) {
+    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = first + k, jm = i / D;
         const int d = (int)(i - jm * D);
         const size_t j = jm / Mpad;
         dst[i] = (float)(st_mean[i] - (bias + (double)centers[j * D + d]) * st_acc[jm]);
@@ -248,9 +248,77 @@ int ensure_payload32(pcl_ctx *ctx, size_t n) {
     return PCL_OK;
 }
 
+
+// The statistics of the states [j0, j0 + len): in-place reduce-scatter (inside the range rank r owns the r-th slice, returned in
+// *lo / *hi); payload PCL_F32 stages them as f32 (mean_acc relative to the old centre, see mean_to_f32_kernel) and puts the owned
+// slice back as f64.
+int exchange_reduce_scatter(pcl_ctx *ctx, int payload, int j0, int len, int *lo_out, int *hi_out) {
+    const int n = ctx->nranks, me = ctx->rank, J = ctx->J;
+    const size_t mp = (size_t)ctx->Mpad, mpd = mp * ctx->D;
+    const int j_lo = j0 + range_lo(len, n, me), j_hi = j0 + range_lo(len, n, me + 1);
+    *lo_out = j_lo;
+    *hi_out = j_hi;
+    const size_t per[4] = {mp, 1, mpd, mpd};
+    int rc = PCL_OK;
+    if (payload == PCL_F64) {
+        double *bases[4] = {ctx->st_acc + per[0] * j0, ctx->st_alpha + per[1] * j0, ctx->st_mean + per[2] * j0, ctx->st_cov + per[3] * j0};
+        return reduce_scatter_parts<double>(ctx, bases, per, 4, len);
+    }
+    TRY(ensure_payload32(ctx, ctx->stats_len));
+    float *f = ctx->payload32;
+    float *full[4] = {f, f + (size_t)J * mp, f + (size_t)J * mp + J, f + (size_t)J * mp + J + (size_t)J * mpd};
+    double *src[4] = {ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov};
+    float *bases[4];
+    for (int p = 0; p < 4; ++p) {
+        bases[p] = full[p] + per[p] * j0;
+        const size_t cnt = per[p] * (size_t)len;
+        if (p == 2) hipLaunchKernelGGL(mean_to_f32_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->st_mean, ctx->st_acc, ctx->centers32, ctx->Mpad,
+                                       ctx->D, 100.0, full[2], per[2] * (size_t)j0, cnt);
+        else hipLaunchKernelGGL(to_f32_kernel, dim3(2048), dim3(256), 0, ctx->stream, src[p] + per[p] * j0, bases[p], cnt);
+    }
+    rc = reduce_scatter_parts<float>(ctx, bases, per, 4, len);
+    for (int p = 0; p < 4 && rc == PCL_OK; ++p) {                  // the owned slices back to f64, where the M-step reads them
+        const size_t lo = per[p] * (size_t)j_lo, cnt = per[p] * (size_t)(j_hi - j_lo);
+        if (!cnt) continue;
+        if (p == 2) hipLaunchKernelGGL(mean_from_f32_kernel, dim3(1024), dim3(256), 0, ctx->stream, full[2], ctx->st_acc, ctx->centers32,
+                                       ctx->Mpad, ctx->D, 100.0, ctx->st_mean, lo, cnt);      // after p == 0 put the summed acc back
+        else hipLaunchKernelGGL(to_f64_kernel, dim3(1024), dim3(256), 0, ctx->stream, full[p] + lo, src[p] + lo, cnt);
+    }
+    return rc;
+}
+
+// The new (mean, var, weight) of the states [j0, j0 + len): in-place all-gather from the ranks that own the slices.
+int exchange_all_gather(pcl_ctx *ctx, int payload, int j0, int len) {
+    const int n = ctx->nranks, me = ctx->rank, J = ctx->J;
+    const size_t mp = (size_t)ctx->Mpad, mpd = mp * ctx->D;
+    const int j_lo = j0 + range_lo(len, n, me), j_hi = j0 + range_lo(len, n, me + 1);
+    const size_t per[3] = {mpd, mpd, mp};
+    double *src[3] = {ctx->mean64, ctx->var64, ctx->w64};
+    if (payload == PCL_F64) {
+        double *bases[3] = {src[0] + per[0] * j0, src[1] + per[1] * j0, src[2] + per[2] * j0};
+        return all_gather_parts<double>(ctx, bases, per, 3, len);
+    }
+    const size_t tot = (size_t)J * (2 * mpd + mp);
+    TRY(ensure_payload32(ctx, std::max(tot, ctx->stats_len)));
+    float *f = ctx->payload32;
+    float *full[3] = {f, f + (size_t)J * mpd, f + 2 * (size_t)J * mpd};
+    float *bases[3];
+    for (int p = 0; p < 3; ++p) {
+        bases[p] = full[p] + per[p] * j0;
+        const size_t lo = per[p] * (size_t)j_lo, cnt = per[p] * (size_t)(j_hi - j_lo);
+        if (cnt) hipLaunchKernelGGL(to_f32_kernel, dim3(1024), dim3(256), 0, ctx->stream, src[p] + lo, full[p] + lo, cnt);
+    }
+    int rc = all_gather_parts<float>(ctx, bases, per, 3, len);
+    // every rank, the owner included, continues from the f32-rounded parameters: one model on all GPUs
+    for (int p = 0; p < 3 && rc == PCL_OK; ++p)
+        hipLaunchKernelGGL(to_f64_kernel, dim3(2048), dim3(256), 0, ctx->stream, bases[p], src[p] + per[p] * j0, per[p] * (size_t)len);
+    return rc;
+}
+
 }  // namespace
 
 void pcl_comm_release(pcl_ctx *ctx) {
+    pcl_pipe_release(ctx);
     dev_free(ctx->payload32);
     ctx->payload32_len = 0;
 }
@@ -344,36 +412,14 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
     if (payload != PCL_F64 && payload != PCL_F32) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_em_exchange: payload %d", payload);
     if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: pcl_comm_init was not called");
     if (update_transitions && !ctx->hmm_ksai) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: update_transitions without pcl_units_upload");
+    if (ctx->pipe_active) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: a pipelined exchange is in progress");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int J = ctx->J, n = ctx->nranks, me = ctx->rank;
-    const size_t mp = (size_t)ctx->Mpad, mpd = mp * ctx->D;
+    const int J = ctx->J;
     const bool solo = ctx->transport == 0;                       // one GPU: the M-step alone
-    const int j_lo = solo ? 0 : range_lo(J, n, me), j_hi = solo ? J : range_lo(J, n, me + 1);
-    int rc = PCL_OK;
+    int j_lo = 0, j_hi = J, rc = PCL_OK;
     if (!solo) {
         pcl_timer_begin(ctx, "reduce_scatter");
-        if (payload == PCL_F64) {
-            double *bases[4] = {ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov};
-            const size_t per[4] = {mp, 1, mpd, mpd};
-            rc = reduce_scatter_parts<double>(ctx, bases, per, 4, J);
-        } else {
-            TRY(ensure_payload32(ctx, ctx->stats_len));
-            float *f = ctx->payload32;
-            hipLaunchKernelGGL(to_f32_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->stats, f, ctx->stats_len);
-            float *bases[4] = {f, f + (size_t)J * mp, f + (size_t)J * mp + J, f + (size_t)J * mp + J + (size_t)J * mpd};
-            hipLaunchKernelGGL(mean_to_f32_kernel, dim3(4096), dim3(256), 0, ctx->stream, ctx->st_mean, ctx->st_acc, ctx->centers32, ctx->Mpad,
-                               ctx->D, 100.0, bases[2], (size_t)J * mpd);
-            const size_t per[4] = {mp, 1, mpd, mpd};
-            rc = reduce_scatter_parts<float>(ctx, bases, per, 4, J);
-            double *dst[4] = {ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov};
-            for (int p = 0; p < 4 && rc == PCL_OK; ++p) {      // the owned slices back to f64, where the M-step reads them
-                const size_t lo = per[p] * (size_t)j_lo, cnt = per[p] * (size_t)(j_hi - j_lo);
-                if (!cnt) continue;
-                if (p == 2) hipLaunchKernelGGL(mean_from_f32_kernel, dim3(1024), dim3(256), 0, ctx->stream, bases[2], ctx->st_acc, ctx->centers32,
-                                               ctx->Mpad, ctx->D, 100.0, ctx->st_mean, lo, cnt);      // after p == 0 put the summed acc back
-                else hipLaunchKernelGGL(to_f64_kernel, dim3(1024), dim3(256), 0, ctx->stream, bases[p] + lo, dst[p] + lo, cnt);
-            }
-        }
+        rc = exchange_reduce_scatter(ctx, payload, 0, J, &j_lo, &j_hi);
         pcl_timer_end(ctx, "reduce_scatter");
         if (rc != PCL_OK) return rc;
     }
@@ -384,26 +430,7 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
     if (rc != PCL_OK) return rc;
     if (!solo) {
         pcl_timer_begin(ctx, "all_gather");
-        if (payload == PCL_F64) {
-            double *bases[3] = {ctx->mean64, ctx->var64, ctx->w64};
-            const size_t per[3] = {mpd, mpd, mp};
-            rc = all_gather_parts<double>(ctx, bases, per, 3, J);
-        } else {
-            const size_t tot = (size_t)J * (2 * mpd + mp);
-            TRY(ensure_payload32(ctx, tot));
-            float *f = ctx->payload32;
-            float *bases[3] = {f, f + (size_t)J * mpd, f + 2 * (size_t)J * mpd};
-            const size_t per[3] = {mpd, mpd, mp};
-            double *src[3] = {ctx->mean64, ctx->var64, ctx->w64};
-            for (int p = 0; p < 3; ++p) {
-                const size_t lo = per[p] * (size_t)j_lo, cnt = per[p] * (size_t)(j_hi - j_lo);
-                if (cnt) hipLaunchKernelGGL(to_f32_kernel, dim3(1024), dim3(256), 0, ctx->stream, src[p] + lo, bases[p] + lo, cnt);
-            }
-            rc = all_gather_parts<float>(ctx, bases, per, 3, J);
-            // every rank, the owner included, continues from the f32-rounded parameters: one model on all GPUs
-            for (int p = 0; p < 3 && rc == PCL_OK; ++p)
-                hipLaunchKernelGGL(to_f64_kernel, dim3(4096), dim3(256), 0, ctx->stream, bases[p], src[p], per[p] * (size_t)J);
-        }
+        rc = exchange_all_gather(ctx, payload, 0, J);
         pcl_timer_end(ctx, "all_gather");
         if (rc != PCL_OK) return rc;
         TRY(merge_hmm_acc(ctx));
@@ -417,6 +444,113 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PCL_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- the exchange behind the accumulate pass, chunk by chunk
+// The accumulate pass walks the states in ascending order, a group at a time (gmm_accumulate.hip).  With a pipelined exchange
+// open, the states are cut into K equal chunks, and as soon as the pass has queued the last kernel that touches a chunk, the
+// chunk goes -- on its own stream, behind an event -- through reduce-scatter (inside the chunk rank r owns the r-th slice)
+// -> GMM.update_param on the owned slice -> all-gather -> the chunk's layouts re-derived, while the matrix pipes work on the
+// later groups.  One rank: M-step + derive of finished chunks beside the rest of the pass.  Same sums, same M-step arithmetic
+// as pcl_em_exchange; only WHO re-estimates a state differs (the r-th slice of every chunk instead of one range).
+namespace {
+struct StreamSwap {                                                // the launchers and their timers use ctx->stream
+    pcl_ctx *c;
+    hipStream_t keep;
+    StreamSwap(pcl_ctx *ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { ctx->stream = s; }
+    ~StreamSwap() { c->stream = keep; }
+};
+
+int pipe_issue_chunk(pcl_ctx *ctx, int c) {
+    const int J = ctx->J, K = ctx->pipe_K, a = range_lo(J, K, c), b = range_lo(J, K, c + 1);
+    if (b <= a) return PCL_OK;
+    const bool solo = ctx->transport == 0;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_comm, ctx->pipe_ev[c], 0));
+    StreamSwap sw(ctx, ctx->stream_comm);
+    int lo = a, hi = b, rc = PCL_OK;
+    if (!solo) {
+        pcl_timer_begin(ctx, "reduce_scatter");
+        rc = exchange_reduce_scatter(ctx, ctx->pipe_payload, a, b - a, &lo, &hi);
+        pcl_timer_end(ctx, "reduce_scatter");
+        if (rc != PCL_OK) return rc;
+    }
+    pcl_timer_begin(ctx, "mstep_owned");
+    rc = pcl_launch_mstep_range(ctx, ctx->pipe_c_cov, lo, hi);
+    pcl_timer_end(ctx, "mstep_owned");
+    if (rc != PCL_OK) return rc;
+    if (!solo) {
+        pcl_timer_begin(ctx, "all_gather");
+        rc = exchange_all_gather(ctx, ctx->pipe_payload, a, b - a);
+        pcl_timer_end(ctx, "all_gather");
+        if (rc != PCL_OK) return rc;
+    }
+    pcl_timer_begin(ctx, "derive");
+    rc = pcl_launch_derive_range(ctx, a, b);
+    pcl_timer_end(ctx, "derive");
+    return rc;
+}
+}  // namespace
+
+int pcl_pipe_begin(pcl_ctx *ctx, double c_covariance, int payload, int n_chunks) {
+    if (ctx->pipe_active) PCL_FAIL(ctx, PCL_ERR_STATE, "pipelined exchange: already open");
+    if (!ctx->stream_comm) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream_comm, hipStreamNonBlocking));
+    const int K = std::max(1, std::min(n_chunks, std::min(ctx->J, 64)));
+    while ((int)ctx->pipe_ev.size() < K) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_ev.push_back(e);
+    }
+    if (payload == PCL_F32 && ctx->transport != 0)
+        TRY(ensure_payload32(ctx, std::max(ctx->stats_len, (size_t)ctx->J * (2 * (size_t)ctx->Mpad * ctx->D + ctx->Mpad))));
+    ctx->pipe_K = K;
+    ctx->pipe_next = 0;
+    ctx->pipe_payload = payload;
+    ctx->pipe_c_cov = c_covariance;
+    ctx->pipe_active = true;
+    return PCL_OK;
+}
+
+// every state below `final_below` has its final statistics once what is queued on ctx->stream by now has run
+int pcl_pipe_progress(pcl_ctx *ctx, int final_below) {
+    if (!ctx->pipe_active) return PCL_OK;
+    while (ctx->pipe_next < ctx->pipe_K && range_lo(ctx->J, ctx->pipe_K, ctx->pipe_next + 1) <= final_below) {
+        const int c = ctx->pipe_next++;
+        HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[c], ctx->stream));
+        TRY(pipe_issue_chunk(ctx, c));
+    }
+    return PCL_OK;
+}
+
+int pcl_pipe_finish(pcl_ctx *ctx, int update_transitions) {
+    if (!ctx->pipe_active) PCL_FAIL(ctx, PCL_ERR_STATE, "pipelined exchange: not open");
+    int rc = pcl_pipe_progress(ctx, ctx->J);                       // whatever the pass did not release itself
+    ctx->pipe_active = false;
+    if (rc != PCL_OK) return rc;
+    if (!ctx->pipe_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pipe_done, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->pipe_done, ctx->stream_comm));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_done, 0));
+    if (ctx->transport != 0) TRY(merge_hmm_acc(ctx));
+    if (update_transitions) TRY(pcl_launch_trans_mstep(ctx));
+    TRY(pcl_derive_finish(ctx));
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+void pcl_pipe_release(pcl_ctx *ctx) {
+    for (hipEvent_t e : ctx->pipe_ev) hipEventDestroy(e);
+    ctx->pipe_ev.clear();
+    if (ctx->pipe_done) hipEventDestroy(ctx->pipe_done);
+    ctx->pipe_done = nullptr;
+    if (ctx->stream_comm) {
+        hipStreamSynchronize(ctx->stream_comm);
+        hipStreamDestroy(ctx->stream_comm);
+    }
+    ctx->stream_comm = nullptr;
+    ctx->pipe_active = false;
+}
+
+extern "C" {
 
 int pcl_comm_destroy(pcl_ctx *ctx) {
     if (!ctx) return PCL_ERR_INVALID;

@@ -122,6 +122,14 @@ struct pcl_ctx {
     void *host_user = nullptr;
     float *payload32 = nullptr;                      // f32 staging of the statistics / parameters (payload = PCL_F32)
     size_t payload32_len = 0;
+    // pipelined exchange (pcl_comm.hip): state chunks go through reduce-scatter -> M-step -> all-gather -> derive on stream_comm
+    // as soon as the accumulate pass has queued the last kernel that touches them
+    hipStream_t stream_comm = nullptr;
+    std::vector<hipEvent_t> pipe_ev;
+    hipEvent_t pipe_done = nullptr;
+    bool pipe_active = false;
+    int pipe_K = 0, pipe_next = 0, pipe_payload = 0;
+    double pipe_c_cov = 0.0;
     std::map<std::string, KernelTimer> timers;
     bool timing = false;         // pcl_timing_enable / env PCL_TIMERS: record HIP events around every launch
 };
@@ -277,6 +285,12 @@ int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, i
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_derive(pcl_ctx *ctx);
+int pcl_launch_derive_range(pcl_ctx *ctx, int j_lo, int j_hi);   // no wait, no generation bump: pcl_derive_finish closes
+int pcl_derive_finish(pcl_ctx *ctx);
+int pcl_pipe_begin(pcl_ctx *ctx, double c_covariance, int payload, int n_chunks);
+int pcl_pipe_progress(pcl_ctx *ctx, int final_below);
+int pcl_pipe_finish(pcl_ctx *ctx, int update_transitions);
+void pcl_pipe_release(pcl_ctx *ctx);
 int pcl_ensure_layouts(pcl_ctx *ctx, int need);
 enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_COND = 32, PCL_LAYOUT_PM16F = 128 };
 inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) { return !ctx->cond.empty() && ctx->cond[j] > ctx->cond_max; }

@@ -433,6 +433,13 @@ class Batch(object):
     def accumulate(self, precision=PCL_F32):
         self._check(self._lib.pcl_batch_accumulate(self._b, int(precision)))
 
+    def accumulate_exchange(self, precision=PCL_F32, c_covariance=1e-3, payload=PCL_F64, update_transitions=False, n_chunks=8):
+        """The last accumulate pass of an E-step and the exchange in one pipelined call (pcl_batch_accumulate_exchange): state
+        chunks leave for reduce-scatter -> M-step -> all-gather -> derive as soon as the pass is done with them."""
+        self._check(self._lib.pcl_batch_accumulate_exchange(self._b, int(precision), float(c_covariance), int(payload),
+                                                             1 if update_transitions else 0, int(n_chunks)))
+        self.eng._model_key = None
+
     def accumulate_hmm(self):
         """Per-unit ksai_acc / gamma_acc of every label position (LHMM.update_acc + add_acc); label-built batches only."""
         self._check(self._lib.pcl_batch_accumulate_hmm(self._b))

@@ -461,6 +461,85 @@ def test_em_exchange_world2_on_one_device_equals_single_rank(payload, uneven, ch
     np.testing.assert_allclose(lp2, single[6], rtol=1e-10 if payload == 'f64' else 1e-6)
 
 
+def _pipe_worker(rank, world, port, payload, pipelined, q):
+    try:
+        os.environ['PCL_ACC_IMAGE_MB'] = '1'               # many state groups: chunks leave while later groups accumulate
+        from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+        from poccala_amd.distributed import Control, shard_range
+        units = 4                                            # J = 12 states, 5 chunks of 2-3 states, slices of 1-2 states per rank
+        mean, var, w, trans = synth.make_model(units, 64, 13, seed=91)
+        frames, lens, begin = synth.make_frames(40, 100, 13, seed=92, ragged=True)
+        labels = synth.make_labels(40, 3, units, seed=93)
+        eng = Engine(0)
+        eng.enable_timing(True)
+        ctl = Control(rank, world, addr='127.0.0.1', port=port, token=b't')
+        if world > 1:
+            eng.comm_init_host(rank, world, ctl.allgather_bytes)
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        lo, hi = shard_range(40, rank, world)
+        f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
+        eng.load_frames(frames[f0:f1])
+        b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi] - f0)
+        pay = PCL_F32 if payload == 'f32' else PCL_F64
+        out = []
+        for it in range(2):                                  # two EM iterations: the second scores with the layouts the pipe derived
+            b.refresh_transitions()
+            b.score(PCL_F32)
+            b.forward_backward()
+            eng.stats_zero()
+            b.accumulate_hmm()
+            if pipelined:
+                b.accumulate_exchange(PCL_F32, 1e-3, pay, True, n_chunks=5)
+            else:
+                b.accumulate(PCL_F32)
+                eng.em_exchange(1e-3, pay, True)
+            out.append(eng.model_download() + (eng.units_download(), b.get('logp').copy()))
+        groups = eng.kernel_time('acc_consume')[1]          # state groups of the two accumulate passes
+        b.close()
+        ctl.barrier()
+        ctl.close()
+        eng.close()
+        q.put((rank, out, groups))
+    except Exception as e:      # noqa
+        import traceback
+        q.put((rank, 'error', traceback.format_exc()))
+
+
+@pytest.mark.parametrize('payload,world', [('f64', 1), ('f64', 2), ('f32', 2)])
+def test_pipelined_exchange_equals_unpipelined(payload, world):
+    """pcl_batch_accumulate_exchange releases state chunks to reduce-scatter -> M-step -> all-gather ->
+    derive while the accumulate pass works on later state groups (rank r owns the r-th slice of every chunk).  Same sums,
+    same M-step arithmetic (LHMM.py:256-290, Clustering.py:314-367,682-693): the model, the transitions and the next
+    iteration's log-likelihoods equal pcl_batch_accumulate + pcl_em_exchange bit for bit, on one rank and on two (host
+    rehearsal transport: RCCL refuses two ranks on one device), through two EM iterations."""
+    ctx = mp.get_context('spawn')
+    res = {}
+    for pipelined in (False, True):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, payload, pipelined, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        for g in got:
+            assert g[1] != 'error', g[2]
+        res[pipelined] = sorted(got, key=lambda g: g[0])
+    for r in range(world):
+        assert res[True][r][2] >= 6                          # >= 3 state groups per pass: chunks left while later groups accumulated
+        for it in range(2):
+            for a, b_ in zip(res[False][r][1][it], res[True][r][1][it]):
+                assert np.array_equal(a, b_), (r, it)
+    if world == 2:                                           # one model on both ranks
+        for k in range(4):
+            assert np.array_equal(res[True][0][1][1][k], res[True][1][1][1][k])
+    # the model did move (the exchange is not a no-op)
+    assert not np.array_equal(res[True][0][1][0][0], res[True][0][1][1][0])
+
+
 def test_rccl_world1_em_exchange_and_allreduce(eng):
     """RCCL itself (ncclCommInitRank, reduce-scatter, all-gather, all-reduce) at the one world size a one-GPU box
     allows: the exchange must leave what pcl_mstep leaves."""
