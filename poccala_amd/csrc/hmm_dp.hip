@@ -429,6 +429,25 @@ __device__ __forceinline__ double wave_lse(double v) {
     return m + log(wave_sum(exp_neg(v - m)));
 }
 
+#ifndef PCL_FB_AHEAD
+#define PCL_FB_AHEAD 4
+#endif
+constexpr int FB_AHEAD = PCL_FB_AHEAD;      // frames of emissions in flight ahead of the recursion (hmm_fb2_kernel)
+
+// the value of the lane before / after this one: a DPP wave shift, one VALU move per half (lane 0 / 63 keep their own)
+__device__ __forceinline__ double lane_before(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);          // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_after(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);          // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
                                                      const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                                      const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
@@ -447,44 +466,79 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
     const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
     const bool act = i < N;
     const double *B = Bt + d.b_off;
-    double *A_ = alpha + d.b_off, *Bv = beta + d.b_off, *G = lgam + d.b_off;
+    double *A_ = alpha + d.b_off, *Bv = beta + d.b_off;
     int pidx[2] = {0, 0}, sidx[2] = {0, 0}, nsucc = 0;
     double pval[2] = {-INFINITY, -INFINITY}, sval[2] = {-INFINITY, -INFINITY};
+    // A sentence HMM is left to right (AcousticModel.embedded, AcousticModel.py:979-989): a state is reached from the state before
+    // it and from itself, and reaches itself and the state after it.  Then the neighbour's value comes through a DPP wave shift
+    // -- a VALU move -- instead of two ds_bpermute round trips on every step of the chain; any other sparsity keeps the bpermute.
+    bool near = true;
+    bool pself[2] = {true, true}, sself[2] = {true, true};          // operand k is the lane's own value (else the neighbour's)
     if (act) {
         const int pc0 = col_ptr[d.ptr_off + i] + d.nnz_off, pc1 = col_ptr[d.ptr_off + i + 1] + d.nnz_off;
         const int sr0 = row_ptr[d.ptr_off + i] + d.nnz_off, sr1 = row_ptr[d.ptr_off + i + 1] + d.nnz_off;
         nsucc = sr1 - sr0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (k < pc1 - pc0) { pidx[k] = row_idx[pc0 + k]; pval[k] = csc_val[pc0 + k]; }
-            if (k < sr1 - sr0) { sidx[k] = col_idx[sr0 + k]; sval[k] = csr_val[sr0 + k]; }
+            if (k < pc1 - pc0) {
+                pidx[k] = row_idx[pc0 + k];
+                pval[k] = csc_val[pc0 + k];
+                pself[k] = pidx[k] == i;
+                near = near && (pidx[k] == i || pidx[k] == i - 1);
+            }
+            if (k < sr1 - sr0) {
+                sidx[k] = col_idx[sr0 + k];
+                sval[k] = csr_val[sr0 + k];
+                sself[k] = sidx[k] == i;
+                near = near && (sidx[k] == i || sidx[k] == i + 1);
+            }
         }
     }
+    const bool shift = __all(near) != 0;                            // (both waves hold the same states: the same answer)
     if (w == 0) lpi[i] = act ? logpi_in[d.vec_off + i] : -INFINITY;
-    for (long long e = threadIdx.x; e < (long long)N * N; e += 128) ksai[d.mat_off + e] = -INFINITY;   // LHMM.py:404: ln 0 entries
     __syncthreads();
     double q = -INFINITY;
     int npass = 0;
     for (;;) {
         if (w == 0) {
             // ---------------------------------------------------------------- forward (LHMM.py:335-351)
-            double bnext = act ? B[i] : 0.0, a = -INFINITY;
+            double a = -INFINITY;
             if (act) {
-                a = lpi[i] + bnext;
+                a = lpi[i] + B[i];
                 A_[i] = a;
             }
             a0s[i] = a;
-            bnext = (act && T > 1) ? B[(long long)N + i] : 0.0;
-            for (int t = 1; t < T; ++t) {
-                // the running vector stays in registers: a lane fetches its two predecessors' values with a cross-lane read
-                // (ds_bpermute) -- no LDS write, fence and read per step of the chain
-                const double p0 = __shfl(a, pidx[0], 64), p1 = __shfl(a, pidx[1], 64);
-                const double bcur = bnext;
-                if (act && t + 1 < T) bnext = B[(long long)(t + 1) * N + i];     // in flight during this step
-                if (act) {
-                    a = lse2_tab(p0 + pval[0], p1 + pval[1], sp) + bcur;
-                    A_[(long long)t * N + i] = a;
+            // the emissions of FB_AHEAD frames are in flight while FB_AHEAD steps of the chain run: a step is ~300 cycles, an L2 round
+            // trip 2-3 times that (one frame ahead, every step waited for its b_j(o_t): ~1000 cycles per step)
+            double bq[FB_AHEAD], bn[FB_AHEAD];
+#pragma unroll
+            for (int k = 0; k < FB_AHEAD; ++k) bq[k] = (act && 1 + k < T) ? B[(long long)(1 + k) * N + i] : 0.0;
+            for (int tb = 1; tb < T; tb += FB_AHEAD) {
+#pragma unroll
+                for (int k = 0; k < FB_AHEAD; ++k) bn[k] = (act && tb + FB_AHEAD + k < T) ? B[(long long)(tb + FB_AHEAD + k) * N + i] : 0.0;
+#pragma unroll
+                for (int k = 0; k < FB_AHEAD; ++k) {
+                    const int t = tb + k;
+                    if (t < T) {
+                        // the running vector stays in registers: a lane fetches its two predecessors' values with a DPP wave shift
+                        // (left-to-right HMMs) or a cross-lane read (ds_bpermute) -- no LDS write, fence and read per step of the chain
+                        double p0, p1;
+                        if (shift) {
+                            const double pb = lane_before(a);
+                            p0 = pself[0] ? a : pb;
+                            p1 = pself[1] ? a : pb;
+                        } else {
+                            p0 = __shfl(a, pidx[0], 64);
+                            p1 = __shfl(a, pidx[1], 64);
+                        }
+                        if (act) {
+                            a = lse2_tab(p0 + pval[0], p1 + pval[1], sp) + bq[k];
+                            A_[(long long)t * N + i] = a;
+                        }
+                    }
                 }
+#pragma unroll
+                for (int k = 0; k < FB_AHEAD; ++k) bq[k] = bn[k];
             }
             const double qn = wave_lse(act ? a : -INFINITY);                     // Q (LHMM.py:412-422, datasize == 1 on this path)
             if (i == 0) s_q = qn;
@@ -492,16 +546,34 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
             // ---------------------------------------------------------------- backward (LHMM.py:353-366); beta_{T-1} = 0 (quirk Q8)
             if (act) Bv[(long long)(T - 1) * N + i] = 0.0;
             double wv = act ? B[(long long)(T - 1) * N + i] + 0.0 : -INFINITY;                // w_j = b_j(o_{t+1}) + beta_{t+1}(j)
-            double b_t = (act && T > 1) ? B[(long long)(T - 2) * N + i] : 0.0, bcur = 0.0;
-            for (int t = T - 2; t >= 0; --t) {
-                const double n0 = __shfl(wv, sidx[0], 64), n1 = __shfl(wv, sidx[1], 64);
-                const double bt = b_t;
-                if (act && t > 0) b_t = B[(long long)(t - 1) * N + i];
-                if (act) {
-                    bcur = lse2_tab(sval[0] + n0, sval[1] + n1, sp);
-                    Bv[(long long)t * N + i] = bcur;
+            double bcur = 0.0, bq[FB_AHEAD], bn[FB_AHEAD];                                    // (emissions FB_AHEAD frames ahead, as above)
+#pragma unroll
+            for (int k = 0; k < FB_AHEAD; ++k) bq[k] = (act && T - 2 - k >= 0) ? B[(long long)(T - 2 - k) * N + i] : 0.0;
+            for (int tb = T - 2; tb >= 0; tb -= FB_AHEAD) {
+#pragma unroll
+                for (int k = 0; k < FB_AHEAD; ++k) bn[k] = (act && tb - FB_AHEAD - k >= 0) ? B[(long long)(tb - FB_AHEAD - k) * N + i] : 0.0;
+#pragma unroll
+                for (int k = 0; k < FB_AHEAD; ++k) {
+                    const int t = tb - k;
+                    if (t >= 0) {
+                        double n0, n1;
+                        if (shift) {
+                            const double na = lane_after(wv);
+                            n0 = sself[0] ? wv : na;
+                            n1 = sself[1] ? wv : na;
+                        } else {
+                            n0 = __shfl(wv, sidx[0], 64);
+                            n1 = __shfl(wv, sidx[1], 64);
+                        }
+                        if (act) {
+                            bcur = lse2_tab(sval[0] + n0, sval[1] + n1, sp);
+                            Bv[(long long)t * N + i] = bcur;
+                        }
+                        wv = act ? bq[k] + bcur : -INFINITY;
+                    }
                 }
-                wv = act ? bt + bcur : -INFINITY;
+#pragma unroll
+                for (int k = 0; k < FB_AHEAD; ++k) bq[k] = bn[k];
             }
             b0s[i] = (T > 1) ? bcur : 0.0;
         }
@@ -529,75 +601,7 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
             }
         }
         if (final_pass) {
-            // ---------------------------------------------------------------- xi / gamma / posteriors, parallel over t
-            double gm = -INFINITY, gs = 0.0, xm[2] = {-INFINITY, -INFINITY}, xs[2] = {0.0, 0.0};
-            // (the loads of frame t + 2 are issued before frame t is worked on: each iteration is otherwise a chain of an L2 round
-            //  trip, two wave reductions and three exponentials)
-            auto fetch = [&](int t, double &at, double &bt, double (&nx)[2]) {
-                at = -INFINITY;
-                bt = 0.0;
-                nx[0] = nx[1] = 0.0;
-                if (act && t < T) {
-                    at = A_[(long long)t * N + i];
-                    bt = Bv[(long long)t * N + i];
-                    if (t < T - 1) {
-#pragma unroll
-                        for (int k = 0; k < 2; ++k)
-                            if (k < nsucc) {
-                                const long long o = (long long)(t + 1) * N + sidx[k];
-                                nx[k] = B[o] + Bv[o];
-                            }
-                    }
-                }
-            };
-            double at_n, bt_n, nx_n[2];
-            fetch(w, at_n, bt_n, nx_n);
-            for (int t = w; t < T; t += 2) {
-                const double at = at_n, bt = bt_n, nx[2] = {nx_n[0], nx_n[1]};
-                fetch(t + 2, at_n, bt_n, nx_n);
-                const double l = at + bt;
-                // sum_value[t] = LSE_i l[i,t] (LHMM.py:488).  Every one of them is ln P(O) up to rounding, so the log-sum-exp is
-                // taken with THAT as its shift -- no maximum over the wave, and the logarithm of a sum within 1e-4 of 1 is three
-                // terms of its series; anything else (an impossible utterance: -inf) takes the general path
-                double norm;
-                const double ssum = wave_sum(act ? exp_neg(l - qnew) : 0.0), u1 = ssum - 1.0;
-                if (qnew > -INFINITY && fabs(u1) < 1.0e-4) norm = qnew + u1 * (1.0 - u1 * (0.5 - u1 * (1.0 / 3.0)));
-                else norm = wave_lse(act ? l : -INFINITY);
-                if (act) G[(long long)t * N + i] = l - norm;                     // l[:,t] - sum_value[t] (:486-500)
-                if (act && t < T - 1) {
-                    online_lse(l, gm, gs);                                       // gamma_i over t < T-1 (:442-445)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (k < nsucc)                                           // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
-                            online_lse(at + (sval[k] + nx[k]), xm[k], xs[k]);
-                }
-            }
-            // merge the two waves' partial log-sum-exps: (m, s) pairs through LDS
-            __shared__ double ms[3][2][2][64];
-            ms[0][w][0][i] = gm; ms[0][w][1][i] = gs;
-            ms[1][w][0][i] = xm[0]; ms[1][w][1][i] = xs[0];
-            ms[2][w][0][i] = xm[1]; ms[2][w][1][i] = xs[1];
-            __syncthreads();
-            if (w == 0 && act) {
-                double outv[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double m0 = ms[c][0][0][i], s0 = ms[c][0][1][i], m1 = ms[c][1][0][i], s1 = ms[c][1][1][i];
-                    const double M = fmax(m0, m1);
-                    double v = -INFINITY;
-                    if (M > -INFINITY) {
-                        double tsum = 0.0;
-                        if (m0 > -INFINITY) tsum += s0 * exp(m0 - M);
-                        if (m1 > -INFINITY) tsum += s1 * exp(m1 - M);
-                        v = M + log(tsum);
-                    }
-                    outv[c] = v;
-                }
-                gamma_out[d.vec_off + i] = outv[0];
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (k < nsucc) ksai[d.mat_off + (long long)i * N + sidx[k]] = outv[1 + k];
-            }
+            // xi / gamma / the per-frame posteriors are parallel over t: hmm_post_kernel, eight waves per utterance, right behind
             if (threadIdx.x == 0) {
                 logp[blockIdx.x] = qnew;
                 npass_out[blockIdx.x] = npass;
@@ -694,6 +698,112 @@ __global__ void hmm_viterbi_kernel(const UttDesc *__restrict__ utts, const doubl
     }
 }
 
+// The last pass's xi, gamma and per-frame posteriors (LHMM.py:394-405,431-445,486-500) from the alpha / beta the recursion
+// kernel left in HBM: nothing here is a chain over t, so eight waves share an utterance's frames (wave w: t = w, w + 8, ...);
+// each lane keeps an online (max, sum) pair per stored transition of its state, and the waves' pairs are merged in wave order
+// (deterministic, independent of the batch).  Round 2 ran this on the recursion kernel's two waves: 0.23 of the 0.52 ms the
+// forward-backward of 128 utterances took.
+constexpr int POST_W = 8;
+__global__ __launch_bounds__(64 * POST_W) void hmm_post_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                                             const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                             const double *__restrict__ csr_val, const double *__restrict__ alpha,
+                                                             const double *__restrict__ beta, double *__restrict__ lgam,
+                                                             double *__restrict__ ksai, double *__restrict__ gamma_out,
+                                                             const double *__restrict__ logp) {
+    __shared__ double ms[3][POST_W][2][64];
+    const UttDesc d = utts[blockIdx.x];
+    const int N = d.N, T = d.T;
+    const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
+    const bool act = i < N;
+    const double *B = Bt + d.b_off, *A_ = alpha + d.b_off, *Bv = beta + d.b_off;
+    double *G = lgam + d.b_off;
+    for (long long e = threadIdx.x; e < (long long)N * N; e += 64 * POST_W) ksai[d.mat_off + e] = -INFINITY;   // LHMM.py:404: ln 0 entries
+    int sidx[2] = {0, 0}, nsucc = 0;
+    double sval[2] = {-INFINITY, -INFINITY};
+    if (act) {
+        const int sr0 = row_ptr[d.ptr_off + i] + d.nnz_off, sr1 = row_ptr[d.ptr_off + i + 1] + d.nnz_off;
+        nsucc = sr1 - sr0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < sr1 - sr0) {
+                sidx[k] = col_idx[sr0 + k];
+                sval[k] = csr_val[sr0 + k];
+            }
+    }
+    const double qnew = logp[blockIdx.x];
+    double gm = -INFINITY, gs = 0.0, xm[2] = {-INFINITY, -INFINITY}, xs[2] = {0.0, 0.0};
+    // (the loads of the wave's next frame are issued before this one is worked on: each iteration is otherwise a chain of an L2
+    //  round trip, two wave reductions and three exponentials)
+    auto fetch = [&](int t, double &at, double &bt, double (&nx)[2]) {
+        at = -INFINITY;
+        bt = 0.0;
+        nx[0] = nx[1] = 0.0;
+        if (act && t < T) {
+            at = A_[(long long)t * N + i];
+            bt = Bv[(long long)t * N + i];
+            if (t < T - 1) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (k < nsucc) {
+                        const long long o = (long long)(t + 1) * N + sidx[k];
+                        nx[k] = B[o] + Bv[o];
+                    }
+            }
+        }
+    };
+    double at_n, bt_n, nx_n[2];
+    fetch(w, at_n, bt_n, nx_n);
+    for (int t = w; t < T; t += POST_W) {
+        const double at = at_n, bt = bt_n, nx[2] = {nx_n[0], nx_n[1]};
+        fetch(t + POST_W, at_n, bt_n, nx_n);
+        const double l = at + bt;
+        // sum_value[t] = LSE_i l[i,t] (LHMM.py:488).  Every one of them is ln P(O) up to rounding, so the log-sum-exp is
+        // taken with THAT as its shift -- no maximum over the wave, and the logarithm of a sum within 1e-4 of 1 is three
+        // terms of its series; anything else (an impossible utterance: -inf) takes the general path
+        double norm;
+        const double ssum = wave_sum(act ? exp_neg(l - qnew) : 0.0), u1 = ssum - 1.0;
+        if (qnew > -INFINITY && fabs(u1) < 1.0e-4) norm = qnew + u1 * (1.0 - u1 * (0.5 - u1 * (1.0 / 3.0)));
+        else norm = wave_lse(act ? l : -INFINITY);
+        if (act) G[(long long)t * N + i] = l - norm;                     // l[:,t] - sum_value[t] (:486-500)
+        if (act && t < T - 1) {
+            online_lse(l, gm, gs);                                       // gamma_i over t < T-1 (:442-445)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (k < nsucc)                                           // xi_ij (+)= alpha_t(i) + ln a_ij + b_j(o_{t+1}) + beta_{t+1}(j)   (LHMM.py:394-405)
+                    online_lse(at + (sval[k] + nx[k]), xm[k], xs[k]);
+        }
+    }
+    // merge the waves' partial log-sum-exps: (m, s) pairs through LDS, in wave order
+    ms[0][w][0][i] = gm; ms[0][w][1][i] = gs;
+    ms[1][w][0][i] = xm[0]; ms[1][w][1][i] = xs[0];
+    ms[2][w][0][i] = xm[1]; ms[2][w][1][i] = xs[1];
+    __syncthreads();
+    if (w == 0 && act) {
+        double outv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double M = -INFINITY;
+#pragma unroll
+            for (int v = 0; v < POST_W; ++v) M = fmax(M, ms[c][v][0][i]);
+            double r = -INFINITY;
+            if (M > -INFINITY) {
+                double tsum = 0.0;
+#pragma unroll
+                for (int v = 0; v < POST_W; ++v) {
+                    const double mv = ms[c][v][0][i];
+                    if (mv > -INFINITY) tsum += ms[c][v][1][i] * exp(mv - M);
+                }
+                r = M + log(tsum);
+            }
+            outv[c] = r;
+        }
+        gamma_out[d.vec_off + i] = outv[0];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < nsucc) ksai[d.mat_off + (long long)i * N + sidx[k]] = outv[1 + k];
+    }
+}
+
 // dense ragged (N,N) xi -> values of the stored transitions in CSR (row-major) order
 __global__ void ksai_gather_kernel(const UttDesc *__restrict__ utts, const int *__restrict__ row_ptr,
                                    const int *__restrict__ col_idx, const double *__restrict__ ksai, double *__restrict__ dst) {
@@ -728,12 +838,14 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     }
     pcl_timer_begin(ctx, "fb");
     static const bool one_wave = getenv("PCL_FB_ONE_WAVE") && atoi(getenv("PCL_FB_ONE_WAVE")) != 0;      // A/B: the round-1 kernel
-    if (b->max_indeg <= 2 && b->max_outdeg <= 2 && NP == 64 && !one_wave)
+    if (b->max_indeg <= 2 && b->max_outdeg <= 2 && NP == 64 && !one_wave) {
         hipLaunchKernelGGL(hmm_fb2_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->ksai,
                            b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold,
                            reinterpret_cast<const double2 *>(ctx->d_softplus));
-    else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
+        hipLaunchKernelGGL(hmm_post_kernel, dim3(b->U), dim3(64 * POST_W), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx, b->csr_val,
+                           b->alpha, b->beta, b->lgam, b->ksai, b->gamma_out, b->logp);
+    } else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
         hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
                            b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
