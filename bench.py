@@ -952,15 +952,15 @@ def other_configs(args, device):
         e.load_frames(frames)
         bs = [e.label_batch(labels[c['U'] * k:c['U'] * (k + 1)], lens[c['U'] * k:c['U'] * (k + 1)], begin[c['U'] * k:c['U'] * (k + 1)]) for k in range(nb)]
         e.kernel_time('viterbi')
-        steps = max(args.steps, 10)
-        el, sc_ms, sc_n, fb_ms, fb_n = timed_steps(e, bs, PCL_F32, align, args.warmup, steps, lambda: None)
+        steps = max(args.steps, 10) if align else max(10 * args.steps, 100)      # (a C2 step is half a millisecond: enough of them to time)
+        el, sc_ms, sc_n, fb_ms, fb_n = timed_steps(e, bs, PCL_F32, align, args.warmup if align else max(args.warmup, 20), steps, lambda: None)
         vit_ms, vit_n = e.kernel_time('viterbi')
         nfr = int(lens[:c['U']].sum())
         out[name] = dict(task='score + Viterbi forced alignment' if align else 'score + forward-backward',
                          shape='%d utterances x %d frames, M=%d, %d units, L=%d' % (c['U'], c['T'], c['M'], c['units'], c['L']),
                          value=nfr * steps / el, unit='frames/s', ms_per_step=el / steps * 1e3, steps=steps,
                          score_kernel_ms=sc_ms / max(sc_n, 1),
-                         dp_kernel='hmm_viterbi_kernel' if align else 'hmm_fb2_kernel',
+                         dp_kernel='hmm_viterbi_kernel' if align else 'hmm_fb2_kernel + hmm_post_kernel',
                          dp_kernel_ms=vit_ms / max(vit_n, 1) if align else fb_ms / max(fb_n, 1))
         for bt in bs:
             bt.close()

@@ -273,3 +273,19 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile 
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }
+
+
+// ---------------------------------------------------------------- emission rows that repeat another row of their utterance
+namespace {
+__global__ void dup_rows_kernel(const DupRow *__restrict__ dups, int n, double *__restrict__ Bt) {
+    const DupRow r = dups[blockIdx.x];
+    for (int t = threadIdx.x; t < r.T; t += blockDim.x) Bt[r.dst + (long long)t * r.N] = Bt[r.src + (long long)t * r.N];
+}
+}  // namespace
+
+int pcl_launch_dup_rows(pcl_ctx *ctx, pcl_batch *b) {
+    if (b->dups.empty()) return PCL_OK;
+    hipLaunchKernelGGL(dup_rows_kernel, dim3((unsigned)b->dups.size()), dim3(256), 0, ctx->stream, b->d_dups, (int)b->dups.size(), b->Bt);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}

@@ -52,7 +52,7 @@ constexpr int NS = 8;               // lanes per token = states of its HMM at mo
 constexpr int TG = DW / NS;         // tokens stepped per pass of the workgroup
 constexpr int SEG_LDS = 4096;       // donor segments whose offsets are searched in LDS (more: searched in HBM)
 constexpr int NONE = 0x7fffffff;
-constexpr int N_STAMP = PCL_DEC_N_STAMP;
+[[maybe_unused]] constexpr int N_STAMP = PCL_DEC_N_STAMP;
 
 // What a lane (state j = sub of its token) needs of ln A of the embedded HMM (AcousticModel.py:979-989), fixed per thread:
 // predecessor i reaches j through entry rc[i] of its unit's (S,S) matrix, or not at all.

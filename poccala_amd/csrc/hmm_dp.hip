@@ -457,6 +457,10 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                                                      double *__restrict__ gamma_out, double *__restrict__ pi_out, double *__restrict__ logp,
                                                      double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
                                                      double threshold, const double2 *__restrict__ softplus) {
+#ifndef PCL_FB_NOPRIO
+    // a latency-bound chain of few instructions, usually beside the scoring kernel's waves on the same SIMD: issue first
+    __builtin_amdgcn_s_setprio(3);
+#endif
     __shared__ double a0s[64], b0s[64], lpi[64];
     __shared__ double2 sp[SP_N];
     for (int k = threadIdx.x; k < SP_N; k += 128) sp[k] = softplus[k];
@@ -703,7 +707,10 @@ __global__ void hmm_viterbi_kernel(const UttDesc *__restrict__ utts, const doubl
 // each lane keeps an online (max, sum) pair per stored transition of its state, and the waves' pairs are merged in wave order
 // (deterministic, independent of the batch).  Round 2 ran this on the recursion kernel's two waves: 0.23 of the 0.52 ms the
 // forward-backward of 128 utterances took.
-constexpr int POST_W = 8;
+#ifndef PCL_POST_W
+#define PCL_POST_W 8
+#endif
+constexpr int POST_W = PCL_POST_W;
 __global__ __launch_bounds__(64 * POST_W) void hmm_post_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
                                                              const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                                              const double *__restrict__ csr_val, const double *__restrict__ alpha,

@@ -529,6 +529,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
+    dev_free(b->d_dups);
     dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
     return PCL_OK;
@@ -649,33 +650,65 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     for (int j = 0; j < ctx->J; ++j) start[j + 1] = start[j] + count[j];
     b->n_segs = start[ctx->J];
     b->segs.assign(b->n_segs, ScoreSeg());
-    std::vector<int> fill(start.begin(), start.end() - 1);
+    // A label that names a unit twice has the same (frames, state) pair on two rows: the reference scores it once per label
+    // position (AcousticModel.py:897-902).  Here the FIRST row of a state in an utterance is scored (a state's segments list
+    // those first: scoring tiles cover [lo, hip)), the others are copies of its emission row (dup_rows_kernel); the accumulate
+    // pass walks all of a state's segments, each row has its own posteriors.
+    std::vector<int> fill(start.begin(), start.end() - 1), nprim(ctx->J, 0);
     std::vector<long long> vtot(ctx->J, 0);
+    std::vector<int> first_row(ctx->J, -1), touched;
+    std::vector<char> is_dup((size_t)b->sumN, 0);
+    b->dups.clear();
     for (int u = 0; u < b->U; ++u) {
         const UttDesc &d = b->utt[u];
+        touched.clear();
         for (int n = 0; n < d.N; ++n) {
             const int st = row_state[d.vec_off + n];
             if (st < 0) continue;
-            ScoreSeg &s = b->segs[fill[st]++];
-            s.frame0 = d.frame0;
-            s.out0 = d.b_off + n;
-            s.len = d.T;
-            s.out_stride = d.N;
-            if (vtot[st] + d.T > 0x7fffffffLL) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: state %d has too many frames", st);
-            s.vstart = (int)vtot[st];
-            s.pad = st;
-            vtot[st] += d.T;
+            if (first_row[st] < 0) {
+                first_row[st] = n;
+                touched.push_back(st);
+                ++nprim[st];
+            } else {
+                is_dup[d.vec_off + n] = 1;
+                b->dups.push_back(DupRow{d.b_off + first_row[st], d.b_off + n, d.T, d.N});
+            }
         }
+        for (int st : touched) first_row[st] = -1;
     }
+    for (int pass = 0; pass < 2; ++pass)                         // the scored rows of every state first, then the copies
+        for (int u = 0; u < b->U; ++u) {
+            const UttDesc &d = b->utt[u];
+            for (int n = 0; n < d.N; ++n) {
+                const int st = row_state[d.vec_off + n];
+                if (st < 0 || (int)is_dup[d.vec_off + n] != pass) continue;
+                ScoreSeg &s = b->segs[fill[st]++];
+                s.frame0 = d.frame0;
+                s.out0 = d.b_off + n;
+                s.len = d.T;
+                s.out_stride = d.N;
+                if (vtot[st] + d.T > 0x7fffffffLL) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_states: state %d has too many frames", st);
+                s.vstart = (int)vtot[st];
+                s.pad = st;
+                vtot[st] += d.T;
+            }
+        }
     b->work_states.clear();
     b->state_seg_lo.clear();
     b->state_seg_hi.clear();
+    b->state_seg_hip.clear();
     for (int j = 0; j < ctx->J; ++j)
         if (count[j]) {
             b->work_states.push_back(j);
             b->state_seg_lo.push_back(start[j]);
             b->state_seg_hi.push_back(start[j + 1]);
+            b->state_seg_hip.push_back(start[j] + nprim[j]);
         }
+    dev_free(b->d_dups);
+    if (!b->dups.empty()) {
+        TRY(dev_alloc(ctx, &b->d_dups, b->dups.size()));
+        HIPCHK(ctx, pcl_h2d(ctx, b->d_dups, b->dups.data(), b->dups.size() * sizeof(DupRow)));
+    }
     dev_free(b->d_segs);
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
@@ -757,7 +790,7 @@ static std::vector<ScoreTile> make_tiles(const pcl_batch *b, const std::vector<s
     std::vector<ScoreTile> queue[NXCD];
     std::vector<long long> load(NXCD, 0);
     for (size_t k : which) {
-        const int lo = b->state_seg_lo[k], hi = b->state_seg_hi[k];
+        const int lo = b->state_seg_lo[k], hi = b->state_seg_hip[k];      // (the scored rows; the copies sit behind them)
         const long long tot = (long long)b->segs[hi - 1].vstart + b->segs[hi - 1].len;
         int g = 0;
         for (int x = 1; x < NXCD; ++x)
@@ -835,6 +868,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     } else {
         TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));
     }
+    TRY(pcl_launch_dup_rows(ctx, b));                              // rows of a state an utterance's label names again
     b->have_B = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;

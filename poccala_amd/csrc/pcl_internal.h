@@ -22,6 +22,11 @@ struct ScoreSeg {
     int vstart;
     int pad;
 };
+// An emission row that repeats another row of its utterance (the label names the unit twice): T values at stride N.
+struct DupRow {
+    long long src, dst;
+    int T, N;
+};
 // One workgroup of the scoring kernel: frames [vstart, vstart+tile) of `state`'s concatenation.
 struct ScoreTile {
     int state;
@@ -163,6 +168,9 @@ struct pcl_batch {
     ScoreSeg *d_segs = nullptr;
     std::vector<ScoreSeg> segs;              // host copy, sorted by state
     std::vector<int> state_seg_lo, state_seg_hi;  // per state with work: segment range
+    std::vector<int> state_seg_hip;               // ... of which [lo, hip) are scored and [hip, hi) are copies of a scored row
+    std::vector<DupRow> dups;
+    DupRow *d_dups = nullptr;
     std::vector<int> work_states;
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
     std::vector<int> acc_ws, acc_lo, acc_hi; // accumulate's state order (well-conditioned first)
@@ -284,6 +292,7 @@ int pcl_score_split16_tile_frames();
 int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
+int pcl_launch_dup_rows(pcl_ctx *ctx, pcl_batch *b);
 int pcl_launch_derive(pcl_ctx *ctx);
 int pcl_launch_derive_range(pcl_ctx *ctx, int j_lo, int j_hi);   // no wait, no generation bump: pcl_derive_finish closes
 int pcl_derive_finish(pcl_ctx *ctx);

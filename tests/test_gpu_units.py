@@ -372,6 +372,46 @@ def test_save_batch_acc_twice_merges_to_the_sum(tmp_path):
                 fin_close(np.float64(g.alpha_acc), np.log(st_all['alpha_acc'][j]), rtol=1e-9, atol=1e-9)
 
 
+def test_repeated_units_are_scored_once_and_accumulated_per_row(eng):
+    """A label that names a unit several times (AcousticModel.py:897-902 scores it once per label position): the library scores
+    the first row of a state in an utterance and copies its emission row to the others -- every row must still equal the
+    oracle's, the copies bit for bit the scored row, and the statistics (each row has its own posteriors, Clustering.py:653-680)
+    the oracle's E-step."""
+    from poccala_amd import PCL_F32, PCL_F64
+    mean, var, w, trans, frames, lens, begin, _ = problem(131, units=3, M=32, U=5, T=60)
+    labels = [[0, 1, 0, 0], [2, 2, 2], [1, 0, 1, 2, 1], [0], [2, 1, 2, 1]]
+    model = oracle_model(mean, var, w, trans)
+    for prec, tol in ((PCL_F32, 5e-5), (PCL_F64, 1e-10)):
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        eng.load_frames(frames)
+        b = eng.label_batch(labels, lens, begin)
+        b.score(prec)
+        B = b.get('B')
+        b.forward_backward()
+        eng.stats_zero()
+        b.accumulate(prec)
+        st = eng.stats_download()
+        lp = b.get('logp')
+        b.close()
+        occ = 0.0
+        for u, lab in enumerate(labels):
+            x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
+            _, a, bref, pi = po.score_label(x, list(lab), model)
+            fin = np.isfinite(bref)
+            assert np.allclose(B[u][fin], bref[fin], rtol=0, atol=tol)
+            for p1 in range(len(lab)):                               # rows of a repeated unit: the same bits
+                for p2 in range(p1 + 1, len(lab)):
+                    if lab[p1] == lab[p2]:
+                        assert np.array_equal(B[u][1 + p1 * E:1 + (p1 + 1) * E], B[u][1 + p2 * E:1 + (p2 + 1) * E])
+            bw = po.baum_welch(a, pi, [bref])
+            assert abs(lp[u] - bw['logp'][0]) <= 1e-6 * abs(bw['logp'][0])
+            lg = (bw['alpha'][0] + bw['beta'][0])[1:-1]              # the emitting rows' share of the frames, copies included
+            occ += float(np.exp(lg - bw['logp'][0]).sum())
+        np.testing.assert_allclose(st['alpha_acc'].sum(), occ, rtol=1e-5)
+        np.testing.assert_allclose(st['acc'].sum(axis=1), st['alpha_acc'], rtol=1e-4 if prec == PCL_F32 else 1e-10)
+
+
 # ------------------------------------------------------------------ the E-step exchange, two GPU processes on one device
 def _free_port():
     s = socket.socket()
