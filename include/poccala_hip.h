@@ -215,7 +215,9 @@ int pcl_lexicon_upload(pcl_ctx *ctx, int n_nodes, const int32_t *node_units, con
  * utterance (hand-overs beyond it are dropped and flagged); logpi_* = np.log(1/N) for N = S+0 / 2(S-2)+2 states from the
  * caller.  The reference code is dead: the gaps D1-D5 filled here are listed in
  * oracle/decoder_oracle.py, the restatement this entry point is tested against bit for bit (recursion, pruning, frame loop and in-word
- * hand-over pinned by golden G14 from the reference's own Decoder.py; the completion rules D1-D5 unpinned). */
+ * hand-over pinned by golden G14 from the reference's own Decoder.py; the completion rules D1-D5 unpinned).
+ * Two kernels, the same bits: left-to-right 5-state units (every model the reference builds, AcousticModel.py:176-181) run one
+ * lane per token (hmm_decode_lr.hip), any other unit matrices 8 lanes per token (hmm_decode.hip; env PCL_DEC_GENERAL=1 forces it). */
 int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate, int max_tokens, double logpi_one_unit,
                      double logpi_two_units);
 /* Results (NULL pointers are skipped): n_final (U,) tokens returned per utterance; node / score / hist (U, candidate), best
