@@ -471,7 +471,7 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
     const bool act = i < N;
     const double *B = Bt + d.b_off;
     double *A_ = alpha + d.b_off, *Bv = beta + d.b_off;
-    int pidx[2] = {0, 0}, sidx[2] = {0, 0}, nsucc = 0;
+    int pidx[2] = {0, 0}, sidx[2] = {0, 0};
     double pval[2] = {-INFINITY, -INFINITY}, sval[2] = {-INFINITY, -INFINITY};
     // A sentence HMM is left to right (AcousticModel.embedded, AcousticModel.py:979-989): a state is reached from the state before
     // it and from itself, and reaches itself and the state after it.  Then the neighbour's value comes through a DPP wave shift
@@ -481,7 +481,6 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
     if (act) {
         const int pc0 = col_ptr[d.ptr_off + i] + d.nnz_off, pc1 = col_ptr[d.ptr_off + i + 1] + d.nnz_off;
         const int sr0 = row_ptr[d.ptr_off + i] + d.nnz_off, sr1 = row_ptr[d.ptr_off + i + 1] + d.nnz_off;
-        nsucc = sr1 - sr0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (k < pc1 - pc0) {

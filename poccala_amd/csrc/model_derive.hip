@@ -78,11 +78,12 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
             const int dd = sub + 8 * k;
             if (dd < D && dd < Dhost && real_m) {
                 const double v = vr[(size_t)m * D + dd], dm = mu[(size_t)m * D + dd] - (double)cen[dd];
+                const double hr = 0.5 / v;                       // ONE float64 division per element (three cost 2 ms per re-derive)
                 sumvar += v;
                 if (flags & PCL_MODEL_LOGDET) sumlog += log(v);
-                kq += dm * dm / (2.0 * v);
-                mx0[k] = fmax(mx0[k], LOG2E / (2.0 * v));
-                mx1[k] = fmax(mx1[k], fabs(LOG2E * dm / v));
+                kq += dm * dm * hr;
+                mx0[k] = fmax(mx0[k], LOG2E * hr);
+                mx1[k] = fmax(mx1[k], fabs(2.0 * LOG2E * dm * hr));
             }
         }
 #pragma unroll
@@ -161,12 +162,13 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             float a = 0.f, b = 0.f;
             if (dd < Dhost) {
                 const double v = vr[ml * D + dd], dm = mu[ml * D + dd] - (double)cen[dd];
+                const double hr = 0.5 / v;                       // (one division per element, as in the prepass: the same k'_m)
                 sumvar += v;
                 if (flags & PCL_MODEL_LOGDET) sumlog += log(v);
-                kq += dm * dm / (2.0 * v);
+                kq += dm * dm * hr;
                 if (real_m) {
-                    a = (float)(-LOG2E / (2.0 * v));
-                    b = (float)(LOG2E * dm / v);
+                    a = (float)(-LOG2E * hr);
+                    b = (float)(2.0 * LOG2E * dm * hr);
                 }
             }
             fa[ml * D + dd] = a;
@@ -206,13 +208,16 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         const int ml = e / D, d = e - ml * D, m = m0 + ml;
         if (m >= Mpad) continue;
         const bool ok = m < M && d < Dhost;
-        const double s = ok ? sqrt(LOG2E / (2.0 * vr[e])) : 0.0, c = ok ? -mu[e] * s : 0.0;
         const size_t o = ((size_t)j * Mpad + m) * row + 2 * d;
-        if (wr64) *reinterpret_cast<double2 *>(params64 + o) = make_double2(s, c);
-        if (w32) {
-            *reinterpret_cast<float2 *>(params32 + o) = make_float2((float)s, (float)c);
-            mean32[((size_t)j * Mpad + m) * D + d] = ok ? (float)mu[e] : 0.f;
+        if (wr64) {                                              // float64 parity rows (derived on first use): exact float64 arithmetic
+            const double s = ok ? sqrt(LOG2E / (2.0 * vr[e])) : 0.0, c = ok ? -mu[e] * s : 0.0;
+            *reinterpret_cast<double2 *>(params64 + o) = make_double2(s, c);
+            if (w32) *reinterpret_cast<float2 *>(params32 + o) = make_float2((float)s, (float)c);
+        } else {                                                 // s = sqrt(-a) from the f32 coefficient already there: no float64 sqrt / division
+            const float s = ok ? sqrtf(-fa[e]) : 0.f;
+            *reinterpret_cast<float2 *>(params32 + o) = make_float2(s, ok ? (float)(-mu[e] * (double)s) : 0.f);
         }
+        if (w32) mean32[((size_t)j * Mpad + m) * D + d] = ok ? (float)mu[e] : 0.f;
     }
     if (w32 || wr64)
     for (int e = tid; e < 32 * (row - 2 * D); e += 256) {
@@ -250,6 +255,10 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     if (what & PCL_LAYOUT_PM16F) {
         uint4 *pf = pm16f + ((size_t)j * nmt + mt) * (2 * KS8f * 64);
         const double k0 = kzero[j];
+        float *isc = reinterpret_cast<float *>(mu);              // (the float64 tiles are not read any more) 1 / scale, exact: powers of two
+        __syncthreads();
+        for (int t = tid; t < 2 * KS8f * 8; t += 256) isc[t] = 1.0f / fscale[(size_t)j * 2 * (KS8f * 8) + t];
+        __syncthreads();
         for (int e = tid; e < 2 * KS8f * 64; e += 256) {
             const int p = (e >> 6) / KS8f, s = (e >> 6) % KS8f, ln = e & 63, half = ln >> 5, cl = ln & 31;
             const bool real_m = (m0 + cl) < M;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                 float val = 0.f;
                 bool is_const = false;
                 if (dd < D) {
-                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) / fscale[((size_t)j * 2 + half) * (KS8f * 8) + dd];
+                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) * isc[half * (KS8f * 8) + dd];
                 } else if (dd == D) {
                     is_const = true;
                     if (half == 0) {
