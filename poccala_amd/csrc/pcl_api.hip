@@ -718,6 +718,7 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     HIPCHK(ctx, pcl_h2d(ctx, b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t)));
     HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     b->have_states = true;
+    b->virt_rows_filled = false;
     b->max_state = max_state;
     b->model_J = ctx->J;
     return PCL_OK;
@@ -754,6 +755,7 @@ int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
     TRY(pcl_launch_transpose(ctx, b, b->tmp, b->Bt, 1));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     b->have_B = true;
+    b->virt_rows_filled = false;                                   // (the caller's matrix is in the buffer now)
     b->have_fb = b->have_vit = false;
     return PCL_OK;
 }
@@ -856,7 +858,10 @@ int pcl_batch_score(pcl_batch *b, int precision) {
         TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P64));
     }
     TRY(build_tiles(b, precision));
-    TRY(pcl_launch_fill_virtual_rows(ctx, b));
+    if (!b->virt_rows_filled) {                                    // entry row ln 1, exit row ln 0 (AcousticModel.py:218-219): constants,
+        TRY(pcl_launch_fill_virtual_rows(ctx, b));                // written once per row map, not once per scoring pass
+        b->virt_rows_filled = true;
+    }
     if (precision == PCL_F32 && ctx->score_variant >= 3 && pcl_score_mfma_supported(ctx->D)) {
         if (ctx->score_variant == 7) {
             TRY(pcl_launch_score_split16(ctx, b, b->d_tiles, b->n_tiles));

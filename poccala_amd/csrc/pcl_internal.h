@@ -149,6 +149,7 @@ struct pcl_batch {
     std::vector<UttDesc> utt;  // host copy
     std::vector<int32_t> row_state;
     bool have_trans = false, have_states = false, have_B = false, have_fb = false, have_vit = false, have_post = false;
+    bool virt_rows_filled = false;   // the constant entry / exit rows of Bt are in place for the current row map
     int max_outdeg = 0, max_indeg = 0;
     long long nnz = 0;
     // device
