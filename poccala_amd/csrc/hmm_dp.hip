@@ -710,7 +710,12 @@ __global__ void hmm_viterbi_kernel(const UttDesc *__restrict__ utts, const doubl
 #define PCL_POST_W 8
 #endif
 constexpr int POST_W = PCL_POST_W;
-__global__ __launch_bounds__(64 * POST_W) void hmm_post_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+#ifdef PCL_POST_WAVES
+#define PCL_POST_ATTR __attribute__((amdgpu_waves_per_eu(PCL_POST_WAVES, PCL_POST_WAVES)))
+#else
+#define PCL_POST_ATTR
+#endif
+__global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
                                                              const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                                              const double *__restrict__ csr_val, const double *__restrict__ alpha,
                                                              const double *__restrict__ beta, double *__restrict__ lgam,
