@@ -66,13 +66,16 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
       copy stream    frames of chunk k+1 travel into the frame slot that is not being scored (Engine.stage_frames)
       main stream    every GMM state x every frame of chunk k is scored
       second stream  chunk k-1 is decoded (token passing), its results come down
-    and the host packs chunk k+1 into page-locked memory meanwhile.  Batches are kept for the last few chunk shapes (the
-    lengths of a chunk's utterances) and reused alternately; a new shape costs a batch creation, which takes its buffers from
+    and the host packs chunk k+2 into page-locked memory meanwhile.  Batches are kept for the last few chunk shapes (the
+    lengths of a chunk's utterances) and reused in rotation; a new shape costs a batch creation, which takes its buffers from
     the library's device-memory pool and copies its descriptors on the main stream -- it does not wait for the decoder
     running on the second stream."""
     engine = engine or default_engine()
     bm = beam if beam_ is None else beam_
-    pool, pinned = {}, [None]
+    # batches and the page-locked staging buffer live with the ENGINE: a second stream of the same chunk shapes (or the same
+    # stream read in several calls) starts warm; Engine.close() frees them
+    pool = engine.__dict__.setdefault('_stream_pool', {})
+    pinned = engine.__dict__.setdefault('_stream_pinned', [None])
 
     def pack(chunk):
         lens = np.array([len(d) for d in chunk], dtype=np.int32)
@@ -86,41 +89,53 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
         return lens, begin
 
     def batch_for(lens, begin, k, busy):
-        key = lens.tobytes()
-        pair = pool.pop(key, None) or [None, None]
-        pool[key] = pair                                           # (most recently used last)
+        key = (lens.tobytes(), engine.J, engine.n_nodes)
+        ring = pool.pop(key, None) or [None, None, None]
+        pool[key] = ring                                           # (most recently used last)
         for old in [q for q in pool if q != key][:max(0, len(pool) - 4)]:
-            if not any(x is busy for x in pool[old] if x is not None):      # never the batch whose decoder is still running
+            if not any(x is y for x in pool[old] if x is not None for y in busy):   # never a batch whose decoder is still running
                 for x in pool.pop(old):
                     if x is not None:
                         x.close()
-        if pair[k & 1] is None:
-            pair[k & 1] = engine.all_state_batch(lens, begin)
-        return pair[k & 1]
+        if ring[k % 3] is None:
+            ring[k % 3] = engine.all_state_batch(lens, begin)
+        return ring[k % 3]
 
+    # The host runs ONE chunk ahead of the GPU: when it waits for the decoder of chunk k-1, the scoring of chunk k+1 is already
+    # queued behind the scoring of chunk k and the decoder of chunk k behind its scoring -- the main stream never runs dry and
+    # decode(k) starts beside score(k+1) the moment score(k) is done (three batches per chunk shape in rotation: one decoding,
+    # one scoring, one being fetched).
     it = iter(chunks)
-    nxt = next(it, None)
-    if nxt is None:
+    first = next(it, None)
+    if first is None:
         return
+    inflight = []
     try:
-        layout = pack(nxt)
-        prev, k = None, 0
-        while nxt is not None:
-            engine.swap_frames()                                   # chunk k is the current frame matrix
-            b = batch_for(layout[0], layout[1], k, prev)
-            b.score(precision)
-            nxt = next(it, None)
+        layout = pack(first)
+        engine.swap_frames()                                       # chunk 0 is the current frame matrix
+        b = batch_for(layout[0], layout[1], 0, inflight)
+        b.score(precision)
+        nxt = next(it, None)
+        if nxt is not None:
+            layout = pack(nxt)                                     # host packing + H2D of chunk 1 beside the GPU work
+        k = 0
+        while b is not None:
+            b.decode_launch(bm, 8, candidate, max_tokens)          # decode(k): second stream, behind score(k)
+            inflight.append(b)
+            b = None
             if nxt is not None:
-                layout = pack(nxt)                                 # host packing + H2D of chunk k+1 beside the GPU work
-            raw = prev.decode_fetch() if prev is not None else None    # waits for the decoder of chunk k-1 only
-            b.decode_launch(bm, 8, candidate, max_tokens)
-            if raw is not None:
-                yield _report(b.decode_unpack(raw), tree)          # host work (and the consumer's) beside decode(k) / score(k+1)
-            prev = b
+                engine.swap_frames()                               # chunk k+1 is the current frame matrix
+                b = batch_for(layout[0], layout[1], k + 1, inflight)
+                b.score(precision)                                 # score(k+1): main stream, behind score(k)
+                nxt = next(it, None)
+                if nxt is not None:
+                    layout = pack(nxt)                             # chunk k+2 on its way (behind the last readers of its slot)
+            if len(inflight) > 1 or b is None:
+                done = inflight.pop(0)
+                yield _report(done.decode_unpack(done.decode_fetch()), tree)   # waits for THAT decoder only
             k += 1
-        yield _report(prev.decode_results(), tree)
+        while inflight:
+            done = inflight.pop(0)
+            yield _report(done.decode_unpack(done.decode_fetch()), tree)
     finally:
-        for pair in pool.values():
-            for b in pair:
-                if b is not None:
-                    b.close()
+        inflight[:] = []                                           # (an abandoned stream: the batches stay in the engine's pool)

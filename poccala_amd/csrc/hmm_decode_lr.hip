@@ -129,6 +129,11 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
     __shared__ unsigned long long s_key;
     __shared__ int s_sel, s_rank, s_cnt, s_cn;
     const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef PCL_DECLR_NOPRIO
+    // latency bound, few instructions, 300 frames of dependent phases: beside the scoring kernel of the next chunk (the C5 pipeline)
+    // its waves issue first -- it costs the matrix-pipe-bound scoring waves little and keeps a workgroup's barrier phases short
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const UttDesc d = a.utts[u];
     const int T = d.T, Nb = d.N, cap = a.cap;

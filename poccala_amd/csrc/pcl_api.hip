@@ -139,8 +139,9 @@ int pcl_init(int device, pcl_ctx **out) {
     pcl_ctx *ctx = new pcl_ctx();
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess ||
-        (e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess) {
+        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, getenv("PCL_DP_PRIORITY") ? atoi(getenv("PCL_DP_PRIORITY")) : -1)) != hipSuccess ||
+        (e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream_desc, hipStreamNonBlocking)) != hipSuccess) {
         g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
         delete ctx;
         return PCL_ERR_HIP;
@@ -153,7 +154,7 @@ int pcl_init(int device, pcl_ctx **out) {
     ctx->score_variant = var ? atoi(var) : 7;
     if (ctx->score_variant != 1 && ctx->score_variant != 3 && ctx->score_variant != 7) {
         g_init_error = "pcl_init: PCL_SCORE_VARIANT must be 1, 3 or 7";
-        hipStreamDestroy(ctx->stream); hipStreamDestroy(ctx->stream_dp); hipStreamDestroy(ctx->stream_aux);
+        hipStreamDestroy(ctx->stream); hipStreamDestroy(ctx->stream_dp); hipStreamDestroy(ctx->stream_aux); hipStreamDestroy(ctx->stream_desc);
         delete ctx;
         return PCL_ERR_INVALID;
     }
@@ -212,6 +213,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipStreamDestroy(ctx->stream);
     hipStreamDestroy(ctx->stream_dp);
     hipStreamDestroy(ctx->stream_aux);
+    if (ctx->stream_desc) hipStreamDestroy(ctx->stream_desc);
     delete ctx;
     return PCL_OK;
 }
@@ -707,16 +709,17 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     dev_free(b->d_dups);
     if (!b->dups.empty()) {
         TRY(dev_alloc(ctx, &b->d_dups, b->dups.size()));
-        HIPCHK(ctx, pcl_h2d(ctx, b->d_dups, b->dups.data(), b->dups.size() * sizeof(DupRow)));
+        HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_dups, b->dups.data(), b->dups.size() * sizeof(DupRow)));
     }
     dev_free(b->d_segs);
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
     b->tile_frames = 0;
     TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
-    if (b->n_segs) HIPCHK(ctx, pcl_h2d(ctx, b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg)));
-    HIPCHK(ctx, pcl_h2d(ctx, b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t)));
-    HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
+    if (b->n_segs) HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg)));
+    auto up = b->launched ? pcl_h2d : pcl_h2d_fresh;             // (batch-lifetime buffers: fresh only while nothing was launched)
+    HIPCHK(ctx, up(ctx, b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t)));
+    HIPCHK(ctx, up(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     b->have_states = true;
     b->virt_rows_filled = false;
     b->max_state = max_state;
@@ -750,6 +753,7 @@ int pcl_batch_set_emissions(pcl_batch *b, const double *B) {
     if (!B) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_set_emissions: NULL argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     TRY(ensure_tmp(b));
+    b->launched = true;
     HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     HIPCHK(ctx, hipMemcpyAsync(b->tmp, B, (size_t)b->sumNT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(pcl_launch_transpose(ctx, b, b->tmp, b->Bt, 1));
@@ -833,10 +837,10 @@ static int build_tiles(pcl_batch *b, int precision) {
     b->tile_frames = tf;
     b->tile_gen = ctx->model_gen;
     TRY(dev_alloc(ctx, &b->d_tiles, tiles.size()));
-    if (!tiles.empty()) HIPCHK(ctx, pcl_h2d(ctx, b->d_tiles, tiles.data(), tiles.size() * sizeof(ScoreTile)));
+    if (!tiles.empty()) HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_tiles, tiles.data(), tiles.size() * sizeof(ScoreTile)));
     if (!tiles_v.empty()) {
         TRY(dev_alloc(ctx, &b->d_tiles_v, tiles_v.size()));
-        HIPCHK(ctx, pcl_h2d(ctx, b->d_tiles_v, tiles_v.data(), tiles_v.size() * sizeof(ScoreTile)));
+        HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_tiles_v, tiles_v.data(), tiles_v.size() * sizeof(ScoreTile)));
     }
     return PCL_OK;
 }
@@ -858,6 +862,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
         TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P64));
     }
     TRY(build_tiles(b, precision));
+    b->launched = true;
     if (!b->virt_rows_filled) {                                    // entry row ln 1, exit row ln 0 (AcousticModel.py:218-219): constants,
         TRY(pcl_launch_fill_virtual_rows(ctx, b));                // written once per row map, not once per scoring pass
         b->virt_rows_filled = true;

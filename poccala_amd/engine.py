@@ -461,11 +461,16 @@ class Batch(object):
     def decode_fetch(self):
         """Wait for the queued token passing of THIS batch (nothing else) and bring its result arrays to the host."""
         U, c, tm = self.U, self._dec_candidate, int(self.T.max())
-        nf = np.empty(U, np.int32); node = np.empty((U, c), np.int32); score = np.empty((U, c)); hist = np.empty((U, c), np.int32)
-        hn = np.empty(U, np.int32); hp = np.empty((U, tm), np.int32); hnode = np.empty((U, tm), np.int32)
-        nt = np.empty((U, tm), np.int32); ov = np.empty(U, np.int32)
+        # page-locked result buffers, kept with the batch: a device-to-host copy into pageable memory is staged by the runtime and
+        # was seen to return only when the scoring kernel of the NEXT chunk had finished (59 ms per fetch instead of 37)
+        key = (U, c, tm)
+        if getattr(self, '_dec_host', None) is None or self._dec_host[0] != key:
+            pe = self.eng.pinned_empty
+            self._dec_host = (key, [pe((U,), np.int32), pe((U, c), np.int32), pe((U, c), np.float64), pe((U, c), np.int32), pe((U,), np.int32),
+                                    pe((U, tm), np.int32), pe((U, tm), np.int32), pe((U, tm), np.int32), pe((U,), np.int32)])
+        nf, node, score, hist, hn, hp, hnode, nt, ov = self._dec_host[1]
         self._check(self._lib.pcl_batch_decode_get(self._b, ptr(nf), ptr(node), ptr(score), ptr(hist), ptr(hn), ptr(hp), ptr(hnode), ptr(nt), ptr(ov)))
-        return nf, node, score, hist, hn, hp, hnode, nt, ov, self.T.copy()
+        return tuple(x.copy() for x in (nf, node, score, hist, hn, hp, hnode, nt, ov)) + (self.T.copy(),)
 
     @staticmethod
     def decode_unpack(raw):
