@@ -164,6 +164,36 @@ def test_decode_many_tokens_finish_in_one_frame(eng):
     assert swing > 2000                                           # (the frames this test is about did occur)
 
 
+@pytest.mark.parametrize('n_units', [350, 600])
+def test_decode_with_a_large_unit_inventory(eng, n_units):
+    """More GMM states than the lane-per-token kernel prefetches per frame (J + 2 > 1024: the emission row is staged without the
+    register prefetch) and, at 600 units, more LDS than the default 64 KB (unit table + two emission rows: the launch raises the
+    kernel's dynamic-LDS limit) -- bit for bit the restatement (Decoder.py:91-167,250-288)."""
+    from poccala_amd import PCL_F64, synth
+    tree, lx = synth.make_pronunciation_tree(300, n_units, seed=61)
+    mean, var, w, trans = synth.make_model(n_units, 2, 13, seed=62)
+    trans = np.stack(trans)
+    frames, lens, begin = synth.make_frames(2, 40, 13, seed=63, ragged=True)
+    eng.load_model(mean, var, w)
+    eng.load_units(trans)
+    eng.load_lexicon(tree)
+    eng.load_frames(frames)
+    b = eng.all_state_batch(lens, begin)
+    b.score(PCL_F64)
+    B = b.get('B')
+    got = b.decode(beam=0.85, candidate=5, max_tokens=2048)
+    b.close()
+    for u in range(2):
+        trace, info = [], {}
+        fin, hist = do.decode(tree, list(trans), B[u][1:-1], beam=0.85, candidate=5, max_tokens=2048, trace=trace, info=info)
+        g = got[u]
+        assert np.array_equal(g['n_tokens'], np.array(trace))
+        assert g['history'] == [(int(p), int(n)) for p, n in hist]
+        assert [(n, h) for n, _, h in g['final']] == [(n, h) for n, _, h in fin]
+        assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]
+        assert g['overflow'] == bool(info.get('overflow'))
+
+
 def test_decode_properties(eng, lex):
     """A one-frame utterance returns exactly the first-step scores of the first-character nodes (ln pi + the best of entry
     row 0 and the node's emissions); the same call twice gives the same bits (no atomics, no timing dependence); and a
