@@ -139,7 +139,7 @@ int pcl_init(int device, pcl_ctx **out) {
     pcl_ctx *ctx = new pcl_ctx();
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, getenv("PCL_DP_PRIORITY") ? atoi(getenv("PCL_DP_PRIORITY")) : -1)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess ||      // (priority 0 measured: no difference)
         (e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream_desc, hipStreamNonBlocking)) != hipSuccess) {
         g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
