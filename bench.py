@@ -710,13 +710,16 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
         batch.score(P)
         batch.forward_backward(fix_pi=False)
         batch.accumulate_hmm()
+        os.environ['PCL_PIPE_MODE'] = '0' if world == 1 else '1'   # one GPU has no reduce-scatter to send early: measure the full chain there
         batch.accumulate_exchange(P, 1e-3, payload, True, n_chunks=8)
+        os.environ.pop('PCL_PIPE_MODE', None)
         eng.sync()
         t_prank = time.perf_counter() - t1
         barrier()
         t_pipe = time.perf_counter() - t1
         kp = {k: eng.kernel_time(k)[0] for k in ('accumulate', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive')}
         pipe = dict(estep_ms=t_pipe * 1e3, frames_per_s=total_frames / t_pipe, n_chunks=8,
+                    mode='whole chain per chunk (PCL_PIPE_MODE=0)' if world == 1 else 'reduce-scatter per chunk, M-step / all-gather / derive at the end (default)',
                     per_rank=ctl.allgather(dict(rank=ctl.rank, estep_ms=t_prank * 1e3, accumulate_ms=kp['accumulate'], reduce_scatter_ms=kp['reduce_scatter'],
                                                 mstep_owned_ms=kp['mstep_owned'], all_gather_ms=kp['all_gather'], derive_ms=kp['derive'])),
                     what='score -> forward-backward -> per-unit merge -> accumulate with the exchange pipelined: the kernel times are sums over the 8 '

@@ -305,8 +305,9 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
  * its layouts re-derived, on a stream of its own, beside the accumulation of the later states.  Replaces, like pcl_em_exchange,
  * the reference's file merge + per-unit M-step (LHMM.py:256-290, Clustering.py:314-367,682-693; AcousticModel.py:918-935);
  * same sums and M-step arithmetic, so the gathered model equals pcl_batch_accumulate + pcl_em_exchange (bit for bit on
- * the rehearsal transport; RCCL's ring order may differ in the last bit).  One rank: M-step + derive of finished chunks beside
- * the rest of the pass.  Synchronous at return. */
+ * the rehearsal transport; RCCL's ring order may differ in the last bit).  Default (env PCL_PIPE_MODE=1): only a chunk's
+ * reduce-scatter leaves early, M-steps / all-gathers / derive run at the end; PCL_PIPE_MODE=0: the whole chain per chunk (on one
+ * rank: M-step + derive of finished chunks beside the rest of the pass).  Synchronous at return. */
 int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covariance, int payload, int update_transitions, int n_chunks);
 int pcl_comm_destroy(pcl_ctx *ctx);
 

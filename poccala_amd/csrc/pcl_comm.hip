@@ -462,10 +462,36 @@ struct StreamSwap {                                                // the launch
     ~StreamSwap() { c->stream = keep; }
 };
 
+// mode 1 (default): only the chunk's REDUCE-SCATTER leaves early -- it costs the GPU little beside the accumulate pass, and it
+// is half of the bytes on the wire; M-step, all-gather and derive follow in pcl_pipe_finish.  mode 0 (PCL_PIPE_MODE=0): the
+// chunk's whole chain leaves early (measured on one GPU: the M-step and derive kernels beside the power-limited accumulate pass
+// stretch it by more than they take alone).
+int pipe_chunk_tail(pcl_ctx *ctx, int c, int lo, int hi) {          // M-step of the owned slice -> all-gather -> (mode 0: derive)
+    const int J = ctx->J, K = ctx->pipe_K, a = range_lo(J, K, c), b = range_lo(J, K, c + 1);
+    const bool solo = ctx->transport == 0;
+    pcl_timer_begin(ctx, "mstep_owned");
+    int rc = pcl_launch_mstep_range(ctx, ctx->pipe_c_cov, lo, hi);
+    pcl_timer_end(ctx, "mstep_owned");
+    if (rc != PCL_OK) return rc;
+    if (!solo) {
+        pcl_timer_begin(ctx, "all_gather");
+        rc = exchange_all_gather(ctx, ctx->pipe_payload, a, b - a);
+        pcl_timer_end(ctx, "all_gather");
+        if (rc != PCL_OK) return rc;
+    }
+    if (ctx->pipe_mode == 0) {
+        pcl_timer_begin(ctx, "derive");
+        rc = pcl_launch_derive_range(ctx, a, b);
+        pcl_timer_end(ctx, "derive");
+    }
+    return rc;
+}
+
 int pipe_issue_chunk(pcl_ctx *ctx, int c) {
     const int J = ctx->J, K = ctx->pipe_K, a = range_lo(J, K, c), b = range_lo(J, K, c + 1);
     if (b <= a) return PCL_OK;
     const bool solo = ctx->transport == 0;
+    if (solo && ctx->pipe_mode != 0) return PCL_OK;                // one GPU, nothing to send: everything waits for pcl_pipe_finish
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_comm, ctx->pipe_ev[c], 0));
     StreamSwap sw(ctx, ctx->stream_comm);
     int lo = a, hi = b, rc = PCL_OK;
@@ -475,20 +501,8 @@ int pipe_issue_chunk(pcl_ctx *ctx, int c) {
         pcl_timer_end(ctx, "reduce_scatter");
         if (rc != PCL_OK) return rc;
     }
-    pcl_timer_begin(ctx, "mstep_owned");
-    rc = pcl_launch_mstep_range(ctx, ctx->pipe_c_cov, lo, hi);
-    pcl_timer_end(ctx, "mstep_owned");
-    if (rc != PCL_OK) return rc;
-    if (!solo) {
-        pcl_timer_begin(ctx, "all_gather");
-        rc = exchange_all_gather(ctx, ctx->pipe_payload, a, b - a);
-        pcl_timer_end(ctx, "all_gather");
-        if (rc != PCL_OK) return rc;
-    }
-    pcl_timer_begin(ctx, "derive");
-    rc = pcl_launch_derive_range(ctx, a, b);
-    pcl_timer_end(ctx, "derive");
-    return rc;
+    if (ctx->pipe_mode != 0) return PCL_OK;
+    return pipe_chunk_tail(ctx, c, lo, hi);
 }
 }  // namespace
 
@@ -504,6 +518,7 @@ int pcl_pipe_begin(pcl_ctx *ctx, double c_covariance, int payload, int n_chunks)
     if (payload == PCL_F32 && ctx->transport != 0)
         TRY(ensure_payload32(ctx, std::max(ctx->stats_len, (size_t)ctx->J * (2 * (size_t)ctx->Mpad * ctx->D + ctx->Mpad))));
     ctx->pipe_K = K;
+    ctx->pipe_mode = getenv("PCL_PIPE_MODE") ? atoi(getenv("PCL_PIPE_MODE")) : 1;
     ctx->pipe_next = 0;
     ctx->pipe_payload = payload;
     ctx->pipe_c_cov = c_covariance;
@@ -530,9 +545,25 @@ int pcl_pipe_finish(pcl_ctx *ctx, int update_transitions) {
     if (!ctx->pipe_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->pipe_done, hipEventDisableTiming));
     HIPCHK(ctx, hipEventRecord(ctx->pipe_done, ctx->stream_comm));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_done, 0));
+    if (ctx->pipe_mode != 0) {                                     // the chunks' M-steps and all-gathers, then every layout at once
+        const int J = ctx->J, K = ctx->pipe_K, n = ctx->nranks, me = ctx->rank;
+        for (int c = 0; c < K; ++c) {
+            const int a = range_lo(J, K, c), b = range_lo(J, K, c + 1);
+            if (b <= a) continue;
+            const bool solo = ctx->transport == 0;
+            TRY(pipe_chunk_tail(ctx, c, solo ? a : a + range_lo(b - a, n, me), solo ? b : a + range_lo(b - a, n, me + 1)));
+        }
+    }
     if (ctx->transport != 0) TRY(merge_hmm_acc(ctx));
     if (update_transitions) TRY(pcl_launch_trans_mstep(ctx));
-    TRY(pcl_derive_finish(ctx));
+    if (ctx->pipe_mode != 0) {
+        pcl_timer_begin(ctx, "derive");
+        const int rd = pcl_launch_derive(ctx);                     // (waits, bumps the model generation)
+        pcl_timer_end(ctx, "derive");
+        if (rd != PCL_OK) return rd;
+    } else {
+        TRY(pcl_derive_finish(ctx));
+    }
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

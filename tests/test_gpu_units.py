@@ -501,9 +501,10 @@ def test_em_exchange_world2_on_one_device_equals_single_rank(payload, uneven, ch
     np.testing.assert_allclose(lp2, single[6], rtol=1e-10 if payload == 'f64' else 1e-6)
 
 
-def _pipe_worker(rank, world, port, payload, pipelined, q):
+def _pipe_worker(rank, world, port, payload, pipelined, q, mode=1):
     try:
         os.environ['PCL_ACC_IMAGE_MB'] = '1'               # many state groups: chunks leave while later groups accumulate
+        os.environ['PCL_PIPE_MODE'] = str(mode)            # 1: the reduce-scatter leaves early; 0: the chunk's whole chain
         from poccala_amd import Engine, PCL_F32, PCL_F64, synth
         from poccala_amd.distributed import Control, shard_range
         units = 4                                            # J = 12 states, 5 chunks of 2-3 states, slices of 1-2 states per rank
@@ -546,10 +547,11 @@ def _pipe_worker(rank, world, port, payload, pipelined, q):
         q.put((rank, 'error', traceback.format_exc()))
 
 
-@pytest.mark.parametrize('payload,world', [('f64', 1), ('f64', 2), ('f32', 2)])
-def test_pipelined_exchange_equals_unpipelined(payload, world):
+@pytest.mark.parametrize('payload,world,mode', [('f64', 1, 1), ('f64', 2, 1), ('f32', 2, 1), ('f64', 1, 0), ('f64', 2, 0), ('f32', 2, 0)])
+def test_pipelined_exchange_equals_unpipelined(payload, world, mode):
     """pcl_batch_accumulate_exchange releases state chunks to reduce-scatter -> M-step -> all-gather ->
-    derive while the accumulate pass works on later state groups (rank r owns the r-th slice of every chunk).  Same sums,
+    derive while the accumulate pass works on later state groups (rank r owns the r-th slice of every chunk; mode 1, the
+    default: only the reduce-scatter leaves early, the rest follows at the end; mode 0: the chunk's whole chain).  Same sums,
     same M-step arithmetic (LHMM.py:256-290, Clustering.py:314-367,682-693): the model, the transitions and the next
     iteration's log-likelihoods equal pcl_batch_accumulate + pcl_em_exchange bit for bit, on one rank and on two (host
     rehearsal transport: RCCL refuses two ranks on one device), through two EM iterations."""
@@ -558,7 +560,7 @@ def test_pipelined_exchange_equals_unpipelined(payload, world):
     for pipelined in (False, True):
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, payload, pipelined, q)) for r in range(world)]
+        procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, payload, pipelined, q, mode)) for r in range(world)]
         for p in procs:
             p.start()
         got = [q.get(timeout=300) for _ in range(world)]
