@@ -503,11 +503,14 @@ def main():
         score_variant = 0
     score_kernel_name, score_peak, score_note = KERNELS.get(score_variant, KERNELS[1])
     pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
-    flop_per_launch = pairs * cfg['M'] * (3 * cfg['D'] + 4)
+    # a label that names a unit twice has the same (frames, state) pair on two rows: the library scores it ONCE and copies the row
+    # (the reference scores it once per label position).  The scoring kernel's rate is quoted on what it computed.
+    scored_pairs = int(sum(3 * len(set(np.asarray(lab).tolist())) * int(t) for lab, t in zip(labels, lens)))
+    flop_per_launch = scored_pairs * cfg['M'] * (3 * cfg['D'] + 4)
     score_avg_ms = score_ms / max(score_n, 1)
     achieved = flop_per_launch / (score_avg_ms * 1e-3) / 1e12 if score_n else None
     # algorithmic HBM bytes per scoring launch: frames once + parameters of the states with work once + B written once
-    alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + pairs * 8
+    alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + scored_pairs * 8
     traffic, traffic_raw = args.traffic_bytes, None
     if traffic is None and args.workload == 'C4shard' and not args.utts and P == PCL_F32 and score_variant == 7:
         traffic, traffic_raw = committed_traffic()
@@ -521,7 +524,8 @@ def main():
                     kernel=score_kernel_name,
                     kernel_avg_ms=score_avg_ms, launches=score_n,
                     flop_per_launch=flop_per_launch,
-                    executed_mfma_tflops=(pairs * cfg['M'] * 480 / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant == 7 else None,
+                    executed_mfma_tflops=(scored_pairs * cfg['M'] * 480 / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant == 7 else None,
+                    scored_pairs=scored_pairs, label_pairs=pairs,
                     frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
                     note=score_note + '  SURVEY 8(d) priced this path against the 157.3 TFLOP/s FP32 vector roof; the contraction now runs on the '
                                       'f16 matrix pipe, so that roof no longer applies (frac_of_f32_mfma_peak > 1) and peak is the f16 dense MFMA peak / 3.',
@@ -860,7 +864,8 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
                          more['begin_all'][cfg['U'] * k:cfg['U'] * (k + 1)]) for k in range(nb)]
     el3, ms3, k3, fb3, kf3 = timed_steps(e3, b3, PCL_F32, False, args.warmup, args.steps, lambda: None)
     ms3 /= max(k3, 1)
-    flop = pairs * cfg['M'] * (3 * cfg['D'] + 4)
+    scored = int(sum(3 * len(set(np.asarray(lab).tolist())) for lab in labels)) * cfg['T']      # (a repeated unit is scored once)
+    flop = scored * cfg['M'] * (3 * cfg['D'] + 4)
     out['strict_f32'] = dict(kernel='gmm_score_mfma_kernel<39,2> (v_mfma_f32_32x32x2_f32, PCL_SCORE_VARIANT=3)',
                              value=frames_per_rank * args.steps / el3, ms_per_step=el3 / args.steps * 1e3, steps=args.steps, warmup=args.warmup,
                              score_ms=ms3, fb_kernel_avg_ms=fb3 / max(kf3, 1),
