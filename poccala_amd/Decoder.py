@@ -72,10 +72,9 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
     running on the second stream."""
     engine = engine or default_engine()
     bm = beam if beam_ is None else beam_
-    # batches and the page-locked staging buffer live with the ENGINE: a second stream of the same chunk shapes (or the same
-    # stream read in several calls) starts warm; Engine.close() frees them
-    pool = engine.__dict__.setdefault('_stream_pool', {})
-    pinned = engine.__dict__.setdefault('_stream_pinned', [None])
+    # batches (three per chunk shape, the four most recent shapes) and the page-locked staging buffer live with the ENGINE: a
+    # second stream of the same chunk shapes (or the same stream read in several calls) starts warm; Engine.close() frees them
+    pool, pinned = engine._stream_pool, engine._stream_pinned
 
     def pack(chunk):
         lens = np.array([len(d) for d in chunk], dtype=np.int32)

@@ -41,6 +41,7 @@ class Engine(object):
         self.n_units = self.S = 0
         self.F = 0
         self._model_key = self._frames_key = None
+        self._stream_pool, self._stream_pinned = {}, [None]       # Decoder.decode_stream: batches per chunk shape, staging buffer
         self._batches = []   # weak refs to live batches: destroyed before the context
         self._pinned = []    # page-locked host allocations (pinned_empty)
         self._staged = None
@@ -57,6 +58,7 @@ class Engine(object):
                 if b is not None:
                     b.close()
             self._batches = []
+            self._stream_pool, self._stream_pinned = {}, [None]
             for p in self._pinned:
                 self._lib.pcl_host_free(self._ctx, p)
             self._pinned = []
