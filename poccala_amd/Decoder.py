@@ -80,9 +80,13 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
         lens = np.array([len(d) for d in chunk], dtype=np.int32)
         begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
         rows, dim = int(lens.sum()), int(np.asarray(chunk[0]).shape[1])
-        if pinned[0] is None or pinned[0].shape[0] < rows or pinned[0].shape[1] != dim:
-            pinned[0] = engine.pinned_empty((rows, dim), np.float32)
-        view = pinned[0][:rows]
+        if pinned[0] is None or pinned[0].size < rows * dim:
+            # grow-only, by doubling; the old buffer is free to go: every copy staged from it was waited for by swap_frames()
+            grown = max(rows * dim, 2 * (pinned[0].size if pinned[0] is not None else 0))
+            if pinned[0] is not None:
+                engine.pinned_free(pinned[0])
+            pinned[0] = engine.pinned_empty((grown,), np.float32)
+        view = pinned[0][:rows * dim].reshape(rows, dim)
         np.concatenate([np.asarray(d, dtype=np.float32) for d in chunk], axis=0, out=view)
         engine.stage_frames(view)
         return lens, begin

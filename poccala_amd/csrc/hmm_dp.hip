@@ -456,7 +456,8 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
                                                      double *__restrict__ beta, double *__restrict__ lgam, double *__restrict__ ksai,
                                                      double *__restrict__ gamma_out, double *__restrict__ pi_out, double *__restrict__ logp,
                                                      double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
-                                                     double threshold, const double2 *__restrict__ softplus) {
+                                                     double threshold, const double2 *__restrict__ softplus, const int *__restrict__ kmax) {
+    if (pcl_fb_linear_ok(kmax, blockIdx.x, utts[blockIdx.x].T)) return;      // done by hmm_fbl_kernel (hmm_fb_linear.hip); block-uniform
 #ifndef PCL_FB_NOPRIO
     // a latency-bound chain of few instructions, usually beside the scoring kernel's waves on the same SIMD: issue first
     __builtin_amdgcn_s_setprio(3);
@@ -720,9 +721,10 @@ __global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(con
                                                              const double *__restrict__ csr_val, const double *__restrict__ alpha,
                                                              const double *__restrict__ beta, double *__restrict__ lgam,
                                                              double *__restrict__ ksai, double *__restrict__ gamma_out,
-                                                             const double *__restrict__ logp) {
+                                                             const double *__restrict__ logp, const int *__restrict__ kmax) {
     __shared__ double ms[3][POST_W][2][64];
     const UttDesc d = utts[blockIdx.x];
+    if (pcl_fb_linear_ok(kmax, blockIdx.x, d.T)) return;                      // done by hmm_postl_kernel
     const int N = d.N, T = d.T;
     const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
     const bool act = i < N;
@@ -849,13 +851,24 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     }
     pcl_timer_begin(ctx, "fb");
     static const bool one_wave = getenv("PCL_FB_ONE_WAVE") && atoi(getenv("PCL_FB_ONE_WAVE")) != 0;      // A/B: the round-1 kernel
+    b->fb_linear = false;
     if (b->max_indeg <= 2 && b->max_outdeg <= 2 && NP == 64 && !one_wave) {
+        // left-to-right sentence HMMs (everything AcousticModel.embedded builds): the scaled linear-domain chain (hmm_fb_linear.hip);
+        // the log-domain kernels behind it take the utterances whose values do not fit its int32 exponents (usually none: their
+        // workgroups return at once), and everything when the structure is not left to right or PCL_FB_LINEAR=0
+        const bool lin = b->left_right && pcl_fb_linear_enabled();
+        if (lin) {
+            TRY(pcl_launch_fb_linear(ctx, b, fix_pi, threshold));
+            b->fb_linear = true;
+        }
+        const int *kmax = lin ? b->fb_kmax : nullptr;
         hipLaunchKernelGGL(hmm_fb2_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->ksai,
                            b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold,
-                           reinterpret_cast<const double2 *>(ctx->d_softplus));
+                           reinterpret_cast<const double2 *>(ctx->d_softplus), kmax);
+        if (lin) TRY(pcl_launch_fb_linear_post(ctx, b));
         hipLaunchKernelGGL(hmm_post_kernel, dim3(b->U), dim3(64 * POST_W), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx, b->csr_val,
-                           b->alpha, b->beta, b->lgam, b->ksai, b->gamma_out, b->logp);
+                           b->alpha, b->beta, b->lgam, b->ksai, b->gamma_out, b->logp, kmax);
     } else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
         hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,

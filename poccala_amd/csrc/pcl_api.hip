@@ -531,6 +531,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
+    dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax);
     dev_free(b->d_dups);
     dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
@@ -545,6 +546,19 @@ int pcl_batch_upload_sparse(pcl_batch *b, const std::vector<int> &row_ptr, const
                             const std::vector<int> &row_idx, const std::vector<double> &csc_val, const double *logpi) {
     pcl_ctx *ctx = b->ctx;
     b->nnz = (long long)col_idx.size();
+    // left to right: state i is entered from i - 1 and from itself only (what AcousticModel.embedded builds, AcousticModel.py:979-989)
+    b->left_right = true;
+    for (int u = 0; u < b->U && b->left_right; ++u) {
+        const UttDesc &d = b->utt[u];
+        for (int i = 0; i < d.N && b->left_right; ++i)
+            for (int k = row_ptr[d.ptr_off + i]; k < row_ptr[d.ptr_off + i + 1]; ++k) {
+                const int j = col_idx[(size_t)d.nnz_off + k];
+                if (j != i && j != i + 1) {
+                    b->left_right = false;
+                    break;
+                }
+            }
+    }
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->nz_tmp);
@@ -982,7 +996,24 @@ int pcl_batch_get(pcl_batch *b, int what, void *host) {
     if ((what == PCL_GET_PATH || what == PCL_GET_POINT) && !b->have_vit) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_get: run pcl_batch_viterbi first");
     if (mat) {
         TRY(ensure_tmp(b));
-        TRY(pcl_launch_transpose(ctx, b, mat, b->tmp, 0));
+        double *logs = nullptr;
+        if ((what == PCL_GET_ALPHA || what == PCL_GET_BETA) && b->fb_linear) {
+            // the scaled forward-backward keeps (mantissa, exponent) pairs; the logarithms the reference holds are made here, on demand
+            TRY(dev_alloc(ctx, &logs, (size_t)b->sumNT));
+            const int rc = pcl_launch_fb_to_log(ctx, b, mat, what == PCL_GET_ALPHA ? b->alpha_e : b->beta_e, logs);
+            if (rc != PCL_OK) {
+                dev_free(logs);
+                return rc;
+            }
+            mat = logs;
+        }
+        const int rt = pcl_launch_transpose(ctx, b, mat, b->tmp, 0);
+        if (logs) {
+            hipStreamSynchronize(ctx->stream);
+            pcl_free_synced_scope done;
+            dev_free(logs);
+        }
+        TRY(rt);
         HIPCHK(ctx, hipMemcpyAsync(host, b->tmp, (size_t)b->sumNT * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return PCL_OK;

@@ -165,6 +165,12 @@ struct pcl_batch {
     int *col_ptr = nullptr, *row_idx = nullptr;   // CSC (predecessors, ascending source index)
     double *csc_val = nullptr;
     double *xi_m = nullptr, *xi_s = nullptr;      // per CSR entry online-LSE state
+    // scaled linear-domain forward-backward (hmm_fb_linear.hip): packed exp(B), the int32 exponents of alpha / beta (their
+    // mantissas live in `alpha` / `beta`), per utterance the exponent maxima of the range test
+    unsigned long long *Bp = nullptr;
+    int *alpha_e = nullptr, *beta_e = nullptr, *fb_kmax = nullptr;
+    bool left_right = false;                      // every state is reached from itself / the state before it only (AcousticModel.embedded)
+    bool fb_linear = false;                       // the last forward-backward left (mantissa, exponent) pairs in alpha / beta
     unsigned short *bp = nullptr;                 // Viterbi back-pointers, time-major (t, n)
     int32_t *d_row_state = nullptr;
     // scoring work lists
@@ -210,6 +216,22 @@ struct pcl_batch {
     int n_occ = 0;
     int *occ_ptr = nullptr, *occ_utt = nullptr, *occ_row0 = nullptr;   // unit -> [occ_ptr[u], occ_ptr[u+1]) -> (utterance, first emitting row)
 };
+
+// ---------------------------------------------------------------- scaled linear-domain forward-backward (hmm_fb_linear.hip)
+// value = m 2^e, e an int32 per lane.  Zero lives in the exponent: below LE_PZ a value IS zero; a zero factor (ln 0) adds
+// LE_ZADD; sums are floored at LE_FLOOR so that nothing wraps; real exponents stay inside (-LE_LIMIT, LE_LIMIT).
+constexpr int LE_ZADD = -(1 << 29);
+constexpr int LE_FLOOR = -(1 << 30);
+constexpr int LE_PZ = -(1 << 28);
+constexpr int LE_LIMIT = 1 << 26;
+// does utterance u (T frames) fit the int32 exponents and the packed emission word?  kmax = per utterance
+// [max |k| of the emissions, of ln A, of the caller's ln pi] (k = power of two of exp(.)), written by hmm_emis_pack_kernel;
+// nullptr = the scaled kernels are not in use (every utterance is the log-domain kernels')
+__device__ __forceinline__ bool pcl_fb_linear_ok(const int *kmax, int u, int T) {
+    if (!kmax) return false;
+    const long long kb = kmax[3 * u], ka = kmax[3 * u + 1], kp = kmax[3 * u + 2];
+    return kb < 32760 && (kb + ka + 4) * (long long)(T + 2) + kp < (long long)LE_LIMIT;
+}
 
 // ---------------------------------------------------------------- error helpers
 #define PCL_FAIL(ctx, code, ...)                         \
@@ -289,6 +311,10 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile 
 int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b);
 int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold);
 int pcl_launch_viterbi(pcl_ctx *ctx, pcl_batch *b, int end_state_back);
+bool pcl_fb_linear_enabled();                                              // env PCL_FB_LINEAR=0: the log-domain kernels only
+int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold);
+int pcl_launch_fb_linear_post(pcl_ctx *ctx, pcl_batch *b);
+int pcl_launch_fb_to_log(pcl_ctx *ctx, pcl_batch *b, const double *m, const int *e, double *out);
 int pcl_launch_regroup(pcl_ctx *ctx, pcl_batch *b, const int32_t *d_row_unit, int gmm_num, int32_t *d_frame_unit, int32_t *d_frame_k);
 int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst);
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);

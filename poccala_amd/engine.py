@@ -44,6 +44,7 @@ class Engine(object):
         self._stream_pool, self._stream_pinned = {}, [None]       # Decoder.decode_stream: batches per chunk shape, staging buffer
         self._batches = []   # weak refs to live batches: destroyed before the context
         self._pinned = []    # page-locked host allocations (pinned_empty)
+        self._pinned_sizes, self._pinned_named = {}, {}
         self._staged = None
 
     # ------------------------------------------------------------------ plumbing
@@ -61,7 +62,7 @@ class Engine(object):
             self._stream_pool, self._stream_pinned = {}, [None]
             for p in self._pinned:
                 self._lib.pcl_host_free(self._ctx, p)
-            self._pinned = []
+            self._pinned, self._pinned_sizes, self._pinned_named = [], {}, {}
             self._lib.pcl_destroy(self._ctx)
             self._ctx = None
 
@@ -169,8 +170,37 @@ class Engine(object):
         p = C.c_void_p()
         self._check(self._lib.pcl_host_alloc(self._ctx, n, C.byref(p)))
         self._pinned.append(p)
+        self._pinned_sizes[p.value] = n
         buf = (C.c_char * n).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def pinned_free(self, arr_or_ptr):
+        """Release one pinned_empty() allocation before the engine closes."""
+        addr = arr_or_ptr if isinstance(arr_or_ptr, int) else arr_or_ptr.__array_interface__['data'][0]
+        for k, p in enumerate(self._pinned):
+            if p.value == addr:
+                self._lib.pcl_host_free(self._ctx, p)
+                del self._pinned[k]
+                return
+        raise ValueError('not a pinned_empty() allocation of this engine')
+
+    def pinned_bytes(self):
+        """Page-locked host bytes this engine holds (soak tests assert that a ragged stream keeps it bounded)."""
+        return int(sum(self._pinned_sizes.get(p.value, 0) for p in self._pinned))
+
+    def _pinned_views(self, name, shapes):
+        """Arrays of the given (shape, dtype) list over ONE grow-only page-locked buffer per name (kept with the engine, reused by
+        every caller of that name; grown by doubling, the old buffer freed)."""
+        need = [int(np.prod(sh)) * np.dtype(dt).itemsize for sh, dt in shapes]
+        off = np.concatenate([[0], np.cumsum([(n + 63) // 64 * 64 for n in need])])
+        total = int(off[-1]) or 64
+        cur = self._pinned_named.get(name)
+        if cur is None or cur.nbytes < total:
+            if cur is not None:
+                self.pinned_free(cur)
+            cur = self.pinned_empty((max(total, 2 * (cur.nbytes if cur is not None else 0)),), np.uint8)
+            self._pinned_named[name] = cur
+        return [cur[int(off[k]):int(off[k]) + need[k]].view(dt).reshape(sh) for k, (sh, dt) in enumerate(shapes)]
 
     def batch(self, N, T, frame_begin=None):
         return Batch(self, N, T, frame_begin)
@@ -463,14 +493,13 @@ class Batch(object):
     def decode_fetch(self):
         """Wait for the queued token passing of THIS batch (nothing else) and bring its result arrays to the host."""
         U, c, tm = self.U, self._dec_candidate, int(self.T.max())
-        # page-locked result buffers, kept with the batch: a device-to-host copy into pageable memory is staged by the runtime and
-        # was seen to return only when the scoring kernel of the NEXT chunk had finished (59 ms per fetch instead of 37)
-        key = (U, c, tm)
-        if getattr(self, '_dec_host', None) is None or self._dec_host[0] != key:
-            pe = self.eng.pinned_empty
-            self._dec_host = (key, [pe((U,), np.int32), pe((U, c), np.int32), pe((U, c), np.float64), pe((U, c), np.int32), pe((U,), np.int32),
-                                    pe((U, tm), np.int32), pe((U, tm), np.int32), pe((U, tm), np.int32), pe((U,), np.int32)])
-        nf, node, score, hist, hn, hp, hnode, nt, ov = self._dec_host[1]
+        # page-locked result buffers: a device-to-host copy into pageable memory is staged by the runtime and was seen to return only
+        # when the scoring kernel of the NEXT chunk had finished (59 ms per fetch instead of 37).  They belong to the ENGINE, one
+        # grow-only set: the call below is synchronous and the arrays are copied out before it returns, so every batch can share them
+        # (a ragged stream makes a new batch per chunk: per-batch buffers grew without bound and put 9 hipHostMalloc on every chunk)
+        shapes = [((U,), np.int32), ((U, c), np.int32), ((U, c), np.float64), ((U, c), np.int32), ((U,), np.int32),
+                  ((U, tm), np.int32), ((U, tm), np.int32), ((U, tm), np.int32), ((U,), np.int32)]
+        nf, node, score, hist, hn, hp, hnode, nt, ov = self.eng._pinned_views('decode_results', shapes)
         self._check(self._lib.pcl_batch_decode_get(self._b, ptr(nf), ptr(node), ptr(score), ptr(hist), ptr(hn), ptr(hp), ptr(hnode), ptr(nt), ptr(ov)))
         return tuple(x.copy() for x in (nf, node, score, hist, hn, hp, hnode, nt, ov)) + (self.T.copy(),)
 

@@ -16,6 +16,8 @@ def _label_job(args):
     bw = po.baum_welch(a, pi, [bref], fix_code=fix_code)
     l = bw['alpha'][0] + bw['beta'][0]
     lg = l - po.lse(l, axis=0)[None, :]
+    if want_bw == 'xi':                            # + the un-normalised ln xi (N,N) and ln gamma (N,) of the final pass (quirk Q5)
+        return bref, float(bw['logp'][0]), lg, a, pi, bw['ksai'], bw['gamma']
     return bref, float(bw['logp'][0]), lg, a, pi
 
 
@@ -28,6 +30,31 @@ def _rows_job(args):
         for s in range(0, x.shape[0], 20):                       # bounds the (T,M,D) temporary
             out[k, s:s + 20] = po.gmm_point(x[s:s + 20], m, v, w)
     return out
+
+
+def _bw_units_job(args):
+    """Baum-Welch on GIVEN emissions + LHMM.update_acc's slicing (LHMM.py:473-500) + add_acc (:149-161) merged per unit inside
+    the utterance: {unit: (ksai_acc (S-2,S), gamma_acc (S-2,))}, log domain."""
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import poccala_oracle as po
+    a, pi, b, label, s = args
+    e = s - 2
+    bw = po.baum_welch(a, pi, [b])
+    kv, gv = bw['ksai'][1:-1, :], bw['gamma'][1:-1]
+    out = {}
+    for pos, unit in enumerate(label):
+        k, g = kv[pos * e:pos * e + e, pos * e:pos * e + s], gv[pos * e:pos * e + e]
+        if unit in out:
+            out[unit] = (po.logaddexp_q4(out[unit][0], k), po.logaddexp_q4(out[unit][1], g))
+        else:
+            out[unit] = (k.copy(), g.copy())
+    return out, float(bw['logp'][0]), int(bw['n_pass'])
+
+
+def bw_unit_jobs(jobs):
+    """jobs: [(A, pi, B (N,T), label, S)] -> [({unit: (ksai_acc, gamma_acc)}, logp, n_pass)]: the HMM half of the E-step on given emissions."""
+    with mp.get_context('spawn').Pool(min(workers(), len(jobs))) as pool:
+        return pool.map(_bw_units_job, jobs, chunksize=4)
 
 
 def workers():

@@ -5,7 +5,8 @@ The small-M end-to-end tests (test_gpu_parity.py::test_estep_*) cannot reach wha
 256-mixture slice workgroups of a state, several state groups alternating between the two tile-image buffers, last-tile
 images of long active lists.  Here the device's OWN ln gamma_t(j) and ln b_j(o_t) go into the oracle's update_acc for every
 occurrence of a handful of states, so the comparison isolates the accumulate kernels: acc, alpha_acc, mean_acc, cov_acc per
-mixture, f32-class default (rtol 2e-4, atol 1e-6 of the state's largest entry) and PCL_F64 (1e-9)."""
+mixture, f32-class default (rtol 1e-4 -- the north-star bound --, atol 1e-6 of the state's largest entry) and PCL_F64 (1e-9);
+the measured worst cases go to profiles/r04_parity_report.json (tests/_parity.py)."""
 import os
 
 import numpy as np
@@ -33,6 +34,7 @@ def pick_states(alpha_acc, rng, extra=1):
 def run_case(cfg_name, prec, image_mb, peaked, n_extra=1, min_groups=0):
     from poccala_amd import Engine, PCL_F32, PCL_F64, synth
     from _oracle_pool import state_statistics
+    from _parity import hold
     P = PCL_F32 if prec == 'f32' else PCL_F64
     c = synth.CONFIGS[cfg_name]
     mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
@@ -83,8 +85,9 @@ def run_case(cfg_name, prec, image_mb, peaked, n_extra=1, min_groups=0):
                 jobs.append((x, lg[u][row].copy(), B[u][row].copy(), mean[j], var[j], w[j]))
                 owner.append(j)
     res = state_statistics(jobs)
-    rt, at = (2e-4, 1e-6) if prec == 'f32' else (1e-9, 1e-13)
+    rt, at = (1e-4, 1e-6) if prec == 'f32' else (1e-9, 1e-13)
     worst = {}
+    tag = '%s accumulate %s%s' % (cfg_name, prec, ' peaked' if peaked else '')
     for j in picks:
         ref = dict(acc=0.0, alpha_acc=0.0, mean_acc=0.0, cov_acc=0.0)
         for o, r in zip(owner, res):
@@ -94,7 +97,7 @@ def run_case(cfg_name, prec, image_mb, peaked, n_extra=1, min_groups=0):
         for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
             got, want = np.asarray(st[key][j]), np.asarray(ref[key])
             scale = float(np.abs(want).max())
-            np.testing.assert_allclose(got, want, rtol=rt, atol=at * scale, err_msg='%s of state %d (%s %s)' % (key, j, cfg_name, prec))
+            hold(tag, key, got, want, rt, at * scale)
             big = np.abs(want) > 1e-3 * scale
             if big.any():
                 worst[key] = max(worst.get(key, 0.0), float((np.abs(got - want)[big] / np.abs(want)[big]).max()))

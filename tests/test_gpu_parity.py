@@ -7,6 +7,7 @@ to 1e-9.  All DP state is float64 in both modes.
 import numpy as np
 import pytest
 
+from _parity import hold, note
 from oracle import poccala_oracle as po
 
 pytestmark = pytest.mark.gpu
@@ -284,7 +285,7 @@ def test_estep_end_to_end(eng, prec):
                 ref['cov_acc'][j] += np.exp(a['cov_acc'])
     for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
         scale = np.abs(ref[key]).max()
-        np.testing.assert_allclose(st[key], ref[key], rtol=2 * rt, atol=scale * (1e-6 if prec == 'f32' else 1e-13), err_msg=key)
+        hold('estep small %s' % prec, key, st[key], ref[key], rt, scale * (1e-6 if prec == 'f32' else 1e-13))
     b.close()
 
 
@@ -369,7 +370,7 @@ def test_em_iteration_on_device(eng, prec):
     from poccala_amd import PCL_F32, PCL_F64
     from poccala_amd.engine import make_sentence_batch
     P = PCL_F32 if prec == 'f32' else PCL_F64
-    rt = 2e-4 if prec == 'f32' else 1e-8
+    rt = F32_RTOL if prec == 'f32' else 1e-8
     mean, var, w, trans, frames, lens, begin, labels = small_problem(501, units=3, M=6, D=13, U=12, T=80, L=3)
     eng.load_model(mean, var, w)
     m0, v0, w0 = eng.model_download()
@@ -402,9 +403,9 @@ def test_em_iteration_on_device(eng, prec):
     used = sorted(set(int(u) * (S - 2) + k for lab in labels for u in lab for k in range(S - 2)))
     for j in used:
         rw, rm, rv = po.gmm_update_param(merged[j], c_covariance=1e-3)
-        np.testing.assert_allclose(nw[j], rw, rtol=rt)
-        np.testing.assert_allclose(nm[j], rm, rtol=rt, atol=rt)
-        np.testing.assert_allclose(nv[j], rv, rtol=10 * rt)
+        hold('em iteration small %s' % prec, 're-estimated weights', nw[j], rw, rt)
+        hold('em iteration small %s' % prec, 're-estimated means', nm[j], rm, rt, rt)
+        hold('em iteration small %s' % prec, 're-estimated variances', nv[j], rv, rt)
     # second E-step on the re-derived device layouts
     b.score(P)
     B2 = b.get('B')
@@ -669,7 +670,7 @@ def test_ill_conditioned_states_use_direct_form(eng):
                     refs[key][j] += np.exp(a[key])
     for key in refs:
         scale = np.abs(refs[key]).max()
-        np.testing.assert_allclose(stt[key], refs[key], rtol=2 * F32_RTOL, atol=scale * 1e-6, err_msg=key)
+        hold('estep mixed conditioning f32', key, stt[key], refs[key], F32_RTOL, scale * 1e-6)
 
     # an M-step changes the conditioning; the same batch must pick the new split up
     eng.mstep(1e-3)
@@ -999,12 +1000,12 @@ def _estep_fuzz(eng, seed, dims):
                     refs[key][jj] += np.exp(a[key])
     for key in refs:
         scale = np.abs(refs[key]).max()
-        np.testing.assert_allclose(stt[key], refs[key], rtol=2 * F32_RTOL, atol=scale * 1e-6, err_msg=key)
+        hold('estep fuzz f32', key, stt[key], refs[key], F32_RTOL, scale * 1e-6)
     # mixtures with a meaningful occupancy: their re-estimated means must agree to 1e-4 of a standard deviation scale
     occ = refs['acc'] > 1e-3
     mu_ref = refs['mean_acc'][occ] / refs['acc'][occ][:, None] - 100.0
     mu_got = stt['mean_acc'][occ] / stt['acc'][occ][:, None] - 100.0
-    np.testing.assert_allclose(mu_got, mu_ref, rtol=0, atol=2e-4)
+    hold('estep fuzz f32', 're-estimated means (occupancy > 1e-3)', mu_got, mu_ref, 0.0, 1e-4)
     b.close()
 
 
@@ -1022,10 +1023,14 @@ def _last_tile_utterances(labels, n_units, how_many):
 
 def test_c4_shard_deep_parity(eng):
     """The headline configuration at full size against the oracle, in depth: 16 random utterances + the utterances owning
-    the last tile of 8 states -- every emission row (2048-mix), log P(O) and the normalised posteriors gamma_t(j) of each.
-    The oracle runs on the host cores (about 15 s of NumPy per utterance)."""
+    the last tile of 8 states -- every emission row (2048-mix), log P(O), the normalised posteriors gamma_t(j), and the
+    un-normalised xi / gamma of the final pass relative to P(O) (quirk Q5; the north star names xi).  Then the HMM half of
+    the E-step at full size: the per-unit ksai_acc / gamma_acc of ALL 1000 units over ALL 1024 utterances against the
+    oracle's Baum-Welch + update_acc + add_acc on the device's own emissions (float64 on both sides).
+    The oracle runs on the host cores (about 15 s of NumPy per scored utterance)."""
     from poccala_amd import PCL_F32, synth
-    from _oracle_pool import label_jobs
+    from poccala_amd.engine import embedded_structure
+    from _oracle_pool import bw_unit_jobs, label_jobs
     c = synth.CONFIGS['C4shard']
     mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
     frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
@@ -1036,7 +1041,10 @@ def test_c4_shard_deep_parity(eng):
     b = eng.label_batch(labels, lens, begin)
     b.score(PCL_F32)
     b.forward_backward(fix_pi=False)
-    B, lp, lg = b.get('B'), b.get('logp'), b.get('lgamma')
+    eng.stats_zero()
+    b.accumulate_hmm()
+    B, lp, lg, ks, ga, npass = b.get('B'), b.get('logp'), b.get('lgamma'), b.get('ksai'), b.get('gamma'), b.get('npass')
+    hk, hg = eng.hmm_acc_download()
     b.close()
     tail_utts, _ = _last_tile_utterances(labels, c['units'], 8)
     pick = sorted(set(np.random.default_rng(77).choice(c['U'], 16, replace=False).tolist()) | set(tail_utts))
@@ -1044,16 +1052,33 @@ def test_c4_shard_deep_parity(eng):
     for u in pick:
         model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)])
                  for unit in set(labels[u])}
-        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, True))
-    worst_b = worst_g = 0.0
-    for u, (bref, lpref, lgref, _, _) in zip(pick, label_jobs(jobs)):
+        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, 'xi'))
+    tag = 'C4shard deep parity f32 (%d utterances end to end)' % len(pick)
+    for u, (bref, lpref, lgref, _, _, ksref, garef) in zip(pick, label_jobs(jobs)):
         fin_close(B[u], bref, rtol=0, atol=F32_LOGLIK_ATOL)
-        np.testing.assert_allclose(lp[u], lpref, rtol=F32_RTOL)
-        g, gref = np.exp(lg[u]), np.exp(lgref)
-        np.testing.assert_allclose(g, gref, rtol=F32_RTOL, atol=1e-6)          # occupancies: 1e-4 relative (north star), 1e-6 floor
-        worst_b = max(worst_b, float(np.abs(B[u][1:-1] - bref[1:-1]).max()))
-        worst_g = max(worst_g, float(np.abs(g - gref).max()))
-    print('C4 shard, %d utterances vs oracle: max |d ln b| = %.2e, max |d gamma| = %.2e' % (len(pick), worst_b, worst_g))
+        hold(tag, 'ln b_j(o_t)', B[u][1:-1], bref[1:-1], 0.0, F32_LOGLIK_ATOL)
+        hold(tag, 'ln P(O)', lp[u], lpref, F32_RTOL)
+        hold(tag, 'gamma_t(j) normalised', np.exp(lg[u]), np.exp(lgref), F32_RTOL, 1e-6)     # occupancies: 1e-4 relative (north star), 1e-6 floor
+        fk = np.isfinite(ksref)
+        assert np.array_equal(np.isfinite(ks[u]), fk)
+        hold(tag, 'xi_ij / P(O) (sum over t)', np.exp(ks[u][fk] - lp[u]), np.exp(ksref[fk] - lpref), F32_RTOL, 1e-6)
+        hold(tag, 'gamma_i / P(O) (sum over t)', np.exp(ga[u][1:-1] - lp[u]), np.exp(garef[1:-1] - lpref), F32_RTOL, 1e-6)
+    # the HMM half at full size, float64 against float64: every utterance's Baum-Welch on the device's emissions
+    jobs = []
+    for u in range(c['U']):
+        a, pi = embedded_structure(len(labels[u]), [trans[i] for i in labels[u]])
+        jobs.append((a, pi, B[u], [int(x) for x in labels[u]], S))
+    rk = np.full((c['units'], S - 2, S), -np.inf)
+    rg = np.full((c['units'], S - 2), -np.inf)
+    for u, (accs, lpref, npref) in enumerate(bw_unit_jobs(jobs)):
+        assert npref == npass[u], 'pass count of utterance %d' % u
+        np.testing.assert_allclose(lp[u], lpref, rtol=1e-12)
+        for unit, (k, g) in accs.items():
+            rk[unit] = po.logaddexp_q4(rk[unit], k)
+            rg[unit] = po.logaddexp_q4(rg[unit], g)
+    tag = 'C4shard HMM accumulators f64 (all %d utterances, %d units, device emissions)' % (c['U'], c['units'])
+    hold(tag, 'ksai_acc (log)', hk, rk, 1e-10)
+    hold(tag, 'gamma_acc (log)', hg, rg, 1e-10)
 
 
 def test_c3_deep_parity_and_flip_rate(eng):

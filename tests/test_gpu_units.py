@@ -273,9 +273,10 @@ def test_mstep_unseen_state_and_zero_occupancy_mixture(eng):
         for key in mj:
             mj[key] = np.logaddexp(mj[key], a[key])
     rw, rm, rv = po.gmm_update_param(mj, c_covariance=1e-3)
-    np.testing.assert_allclose(nw[1], rw, rtol=2e-4)
-    np.testing.assert_allclose(nm[1], rm, rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(nv[1], rv, rtol=2e-3)
+    from _parity import hold
+    hold('guarded M-step small f32', 're-estimated weights', nw[1], rw, 1e-4)
+    hold('guarded M-step small f32', 're-estimated means', nm[1], rm, 1e-4, 1e-4)
+    hold('guarded M-step small f32', 're-estimated variances', nv[1], rv, 1e-4)
     b.refresh_transitions()
     b.score(PCL_F32)
     b.forward_backward()

@@ -21,4 +21,4 @@ for fix in (False, True):
     for _ in range(20):
         b.forward_backward(fix_pi=fix)
     ms, k = eng.kernel_time('fb')
-    print('%s U=%d fix_pi=%s: %.3f ms per launch (%d passes), logP[0] = %.10f' % ('one-wave' if os.environ.get('PCL_FB_ONE_WAVE') else 'two-wave', U, fix, ms / k, b.get('npass')[0], b.get('logp')[0]))
+    print('%s U=%d fix_pi=%s: %.3f ms per launch (%d passes), logP[0] = %.10f' % ('one-wave' if os.environ.get('PCL_FB_ONE_WAVE') else ('log-domain' if os.environ.get('PCL_FB_LINEAR') == '0' else 'scaled-linear'), U, fix, ms / k, b.get('npass')[0], b.get('logp')[0]))
