@@ -42,6 +42,16 @@ CPU_FAITHFUL_ROWS = 12            # label states (of 60) the reference's per-mix
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 HBM_PEAK_GBS = 8000.0
+# what `dtype` says for the default f32-class path: the arithmetic, not a precision claim
+DTYPE_NAME = 'f32-class (f16x2 split operands, f32 accumulate; f64 dynamic programming)'
+
+
+def resolve_payload(args, world):
+    """wire format of the E-step exchange: f32 by default as soon as there is a wire (1.94 GB per exchange
+    instead of 3.9), f64 on one rank where nothing travels; --payload overrides."""
+    from poccala_amd import PCL_F32, PCL_F64
+    name = args.payload if args.payload != 'auto' else ('f32' if world > 1 else 'f64')
+    return PCL_F32 if name == 'f32' else PCL_F64
 
 
 def parse():
@@ -60,12 +70,14 @@ def parse():
     p.add_argument('--words', type=int, default=20000, help='--workload C5shard: random words added to the synthetic lexicon')
     p.add_argument('--max-tokens', type=int, default=8192, help='--workload C5shard: live tokens per utterance')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
+    p.add_argument('--sustain', type=float, default=10.0, help='seconds the headline loop is held for value_sustained')
     p.add_argument('--extra-timeout', type=int, default=600, help='seconds the untimed extras (and the shutdown) may take before rank 0 prints the line without them')
     p.add_argument('--traffic-bytes', type=float, default=None,
                    help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md '
                         'prescribes (2 x FETCH_SIZE for the wide streaming reads + WRITE_SIZE); default: the figure committed in '
                         'profiles/ (tools/gpu_profile.sh)')
-    p.add_argument('--payload', default='f64', choices=['f64', 'f32'], help='wire format of the E-step exchange measured under "extra"')
+    p.add_argument('--payload', default='auto', choices=['auto', 'f64', 'f32'],
+                   help='wire format of the E-step exchange: auto = f32 when there is more than one rank (half the bytes on xGMI), f64 on one')
     return p.parse_args()
 
 
@@ -327,7 +339,7 @@ def bench_decode(args, rank, world, local):
         print(json.dumps({
             'metric': 'frames/sec all-state GMM-score + lexicon token-passing decode, 39-d MFCC, 4096-mix', 'value': U * T * world * args.steps / elapsed,
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME, 'data': 'synthetic',
             'config': {'workload': 'C5shard: %d utterances/GPU x %d frames, D=%d, all %d GMM states x %d mixtures for every frame; token passing over a '
                                    'synthetic tree of %d words (%d nodes, %d first-character nodes), <= %d live tokens per utterance, beam 0.85 (Decoder.py:34)'
                                    % (U, T, D, units_n * 3, M, lx.size, len(tree['names']), len(tree['roots']), args.max_tokens),
@@ -395,6 +407,118 @@ def timed_steps(eng, batches, P, align, warmup, steps, barrier):
     return elapsed, score_ms, score_n, fb_ms, fb_n
 
 
+
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7          # MI355X_MICROARCH.md: 7 point-to-point links per GPU, ~153 GB/s each way
+
+
+def exchange_wire_model(cfg, n, payload_bytes):
+    """What one E-step exchange puts on the wire per rank at world size n, and what xGMI would need for it -- a PREDICTION to hold
+    the first real multi-GPU line against (no N > 1 timing exists from this box).  Statistics: J M (2D + 1) + J values,
+    reduce-scattered by state range (each rank sends and receives (n-1)/n of the block); model: J M (2D + 1) values,
+    all-gathered (each rank receives (n-1)/n).  Bounds: every link busy at once (a direct exchange: each of the n-1 peers' shards on
+    its own link) and one link at a time (a single ring)."""
+    J, M, D = cfg['units'] * 3, cfg['M'], cfg['D']
+    stats = (J * M * (2 * D + 1) + J) * payload_bytes
+    model = J * M * (2 * D + 1) * payload_bytes
+    f = (n - 1) / n if n > 1 else 0.0
+    rs, ag = stats * f, model * f
+    links = min(XGMI_LINKS, max(1, n - 1))
+    return dict(world=n, payload_bytes_per_value=payload_bytes, reduce_scatter_bytes_per_rank=rs, all_gather_bytes_per_rank=ag,
+                predicted_ms_all_links=(rs + ag) / (links * XGMI_LINK_GBS * 1e9) * 1e3 if n > 1 else 0.0,
+                predicted_ms_one_link=(rs + ag) / (XGMI_LINK_GBS * 1e9) * 1e3 if n > 1 else 0.0,
+                note='prediction from the guide\'s link figures, not a measurement; + the per-unit transition accumulators (%d doubles, two all-reduces)' % (cfg['units'] * 18))
+
+
+def sustained_loop(eng, batches, P, seconds, block=100):
+    """The headline's loop (score + forward-backward, the resident batches in alternation) for at least `seconds`: blocks of
+    `block` steps, a device sync after each; while a block is queued the shader clock the chip actually holds is probed on the
+    device (Engine.clock_probe: s_memtime against the 100 MHz s_memrealtime, 2 ms beside the scoring kernel)."""
+    nb = len(batches)
+    n = [0]
+
+    def step():
+        bt = batches[n[0] % nb]
+        n[0] += 1
+        bt.score(P)
+        bt.forward_backward(fix_pi=False)
+    blocks, clocks = [], []
+    eng.sync()
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < seconds:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step()
+        try:
+            clocks.append(eng.clock_probe(2000))
+        except Exception:                      # noqa: a probe that fails must not cost the figure
+            pass
+        eng.sync()
+        blocks.append(time.perf_counter() - t0)
+    total = time.perf_counter() - t_all
+    return n[0], total, blocks, clocks
+
+
+def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2):
+    """SURVEY 8(d)'s end-to-end protocol on the headline's work: every step's frames come up over PCIe and its results go down,
+    both beside the kernels of the neighbouring steps.  Per step: H2D of the NEXT batch's frames into the frame slot that is not
+    being scored (copy stream) | score -> Viterbi (main stream) -> forward-backward (second stream) of this batch | D2H of ln P(O),
+    ln gamma_t(j) (all of it: 152 MB), the stored ln xi, the Viterbi paths and scores into page-locked buffers (download stream).
+    Two batches / two frame slots / two result sets in rotation; the host waits for a result set only when it is about to be reused."""
+    U, T = cfg['U'], cfg['T']
+    nfr = U * T
+    pin = [eng.pinned_empty((nfr, cfg['D']), np.float32) for _ in range(2)]
+    for k in range(2):
+        pin[k][:] = frames[k * nfr:(k + 1) * nfr]
+    begin = np.arange(U, dtype=np.int64) * T
+    eng.stage_frames(pin[0])
+    eng.swap_frames()
+    batches, res = [], []
+    for k in range(2):
+        if k == 1:                             # (its chunk must be the current matrix when the batch is laid out)
+            eng.stage_frames(pin[1])
+            eng.swap_frames()
+        b = eng.label_batch(labels_all[k * U:(k + 1) * U], lens_all[k * U:(k + 1) * U], begin)
+        b.score(P); b.viterbi(); b.forward_backward(fix_pi=False)          # lazy buffers
+        batches.append(b)
+        res.append(b.result_buffers())
+    eng.sync()
+    total = warm + steps
+    eng.stage_frames(pin[0])
+    t0 = None
+    for k in range(total):
+        if k == warm:
+            eng.sync()
+            for b in batches:
+                if k >= 2:
+                    b.fetch_wait()
+            t0 = time.perf_counter()
+        bt = batches[k % 2]
+        eng.swap_frames()                      # chunk k is the current frame matrix (its copy had a whole step to arrive)
+        if k + 1 < total:
+            eng.stage_frames(pin[(k + 1) % 2])
+        if k >= 2:
+            bt.fetch_wait()                    # the host is done with this batch's previous results (a consumer would have read them)
+        bt.score(P)
+        bt.viterbi()
+        bt.forward_backward(fix_pi=False)
+        bt.fetch_async(res[k % 2])
+    for b in batches:
+        b.fetch_wait()
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    last = batches[(total - 1) % 2]
+    ok = bool(np.array_equal(res[(total - 1) % 2]['logp'], last.get('logp')) and np.array_equal(res[(total - 1) % 2]['path'], np.concatenate(last.get('path'))))
+    bytes_down = int(sum(v.nbytes for v in res[0].values()))
+    for b in batches:
+        b.close()
+    eng.load_frames(frames)                    # back to the resident matrix the other measurements index
+    return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, h2d_bytes_per_step=int(pin[0].nbytes),
+                d2h_bytes_per_step=bytes_down, results_intact=ok,
+                what='per step: frames H2D (copy stream) | score + Viterbi + forward-backward | ln P(O), ln gamma_t(j), stored ln xi, Viterbi paths '
+                     'and scores D2H into page-locked memory (download stream); wall clock over the whole pipeline, the copies overlapped '
+                     'behind the neighbouring steps\' kernels')
+
+
 def engine_with_variant(device, variant):
     """A fresh context whose scoring kernel is PCL_SCORE_VARIANT=variant (read by pcl_init)."""
     from poccala_amd import Engine
@@ -424,6 +548,10 @@ def main():
     from poccala_amd import synth
     if args.workload == 'C5shard':                # BASELINE config 5: all-state scoring + lexicon token-passing decode
         return bench_decode(args, rank, world, local)
+    if args.workload == 'C4':                     # config 4 at its stated size: 8192 utterances, one whole EM iteration
+        return bench_c4_full(args, rank, world, local)
+    if args.workload == 'C5':                     # config 5 at its stated size: the 1M-frame corpus streamed
+        return bench_c5_full(args, rank, world, local)
     P_name = args.precision
     cfg = dict(synth.CONFIGS[args.workload])
     if args.utts:
@@ -554,12 +682,36 @@ def main():
 
     info = eng.device_info()                   # (not from the watchdog thread: the main thread may be inside the runtime)
 
+    # beside the headline, from the same resident batches (outside the timed region): the same loop held for >= 10 s, and the
+    # end-to-end pipeline of SURVEY 8(d) with every step's frames and results crossing PCIe
+    sustained = pcie = None
+    if args.extra and not align and P == PCL_F32:
+        t_mark2 = time.perf_counter()
+        try:
+            ns, tot, blocks, clocks = sustained_loop(eng, batches, P, args.sustain)
+            tot = ctl.allreduce_max(tot)
+            sustained = dict(value=frames_per_rank * world * ns / tot, seconds=tot, steps=ns,
+                             ms_per_100_steps=dict(min=min(blocks) * 1e3, median=float(np.median(blocks)) * 1e3, max=max(blocks) * 1e3),
+                             shader_mhz=dict(min=min(clocks), median=float(np.median(clocks)), max=max(clocks), probes=len(clocks)) if clocks else None,
+                             clock_source='on-device probe beside the scoring kernel: s_memtime (shader cycles) / s_memrealtime (100 MHz) over 2 ms, once per '
+                                          '100 steps; the PMC figure (GRBM_GUI_ACTIVE per kernel) is in profiles/; rocm-smi sclk is the requested level, not this')
+        except Exception as e:                 # noqa: never the headline's problem
+            sustained = dict(error=repr(e))
+        tl['sustained_loop_s'] = time.perf_counter() - t_mark2
+        t_mark2 = time.perf_counter()
+        if world == 1 and not args.utts and nb >= 2:
+            try:
+                pcie = pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, max(args.steps, 20))
+            except Exception as e:             # noqa
+                pcie = dict(error=repr(e))
+        tl['pcie_inclusive_loop_s'] = time.perf_counter() - t_mark2
+
     def make_line(extra):
         out = {
             'metric': 'frames/sec GMM-score+Viterbi forced alignment, 39-d MFCC, 2048-mix' if align else 'frames/sec GMM-score+fwd-bwd, 39-d MFCC, 2048-mix',
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE_NAME if P == PCL_F32 else 'f64', 'data': 'synthetic',
             'config': {'workload': ('%s: %d utterances/GPU x %d frames, D=%d MFCC, M=%d mixtures, %d units (J=%d tied GMM states), '
                                     'L=%d units/utterance (N=%d-state sentence HMMs); GMM scoring of the %d label states of every frame '
                                     + ('+ Viterbi forced alignment (LHMM.viterbi, bit-exact given the emissions)' if align else
@@ -579,6 +731,12 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        if sustained:
+            out['value_sustained'] = sustained.get('value')
+            out['sustained'] = sustained
+        if pcie:
+            out['value_pcie_inclusive'] = pcie.get('value')
+            out['pcie_inclusive'] = pcie
         if extra:
             out['extra'] = extra
             if extra.get('roofline_estep'):
@@ -684,7 +842,8 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     t_h2d = (time.perf_counter() - t1) / len(batches)
     # full E-step: score -> forward-backward -> GMM statistics + per-unit transition accumulators -> exchange
     # (reduce-scatter by state range -> M-step on the owned states -> all-gather of the model) -> transition M-step
-    payload = PCL_F32 if args.payload == 'f32' else PCL_F64
+    payload = resolve_payload(args, world)
+    payload_name = 'f32' if payload == PCL_F32 else 'f64'
     batch.accumulate(P)                       # setup, not measured: the accumulate pass's work lists and tile-image buffers are
     batch.accumulate_hmm()                    # allocated on first use
     eng.sync()
@@ -763,13 +922,14 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     extra = dict(viterbi_frames_per_s_per_gpu=frames_per_rank / t_vit, viterbi_kernel_ms=vit_ms,
                  regroup_kernel_ms=rg_ms, regroup_call_ms=t_regroup * 1e3,
                  estep_frames_per_s=total_frames / t_estep, estep_ms=t_estep * 1e3, accumulate_ms=acc_ms, hmm_acc_ms=kt['hmm_acc'],
-                 exchange=dict(payload=args.payload, per_rank=per_rank,
+                 exchange=dict(payload=payload_name, per_rank=per_rank,
+                               wire=exchange_wire_model(cfg, world, 4 if payload == PCL_F32 else 8),
+                               wire_at_8_gpus_f32=exchange_wire_model(cfg, 8, 4),
                                what='reduce-scatter of the GMM statistics by state range -> GMM.update_param on the owned J/N states -> '
                                     'all-gather of (mean, var, weight) -> layouts re-derived; per-unit transition accumulators merged by max + sum '
                                     'all-reduces, transition M-step on every rank; one rank: the M-step alone'),
                  estep_pipelined=pipe,
                  frames_h2d_ms=t_h2d * 1e3, results_d2h_ms=t_d2h * 1e3,
-                 pcie_inclusive_frames_per_s_per_gpu=frames_per_rank / (elapsed / args.steps + t_h2d + t_d2h),
                  setup_s=t_setup,
                  roofline_estep=dict(kernel='acc16_consumer_kernel<39> (+ acc16_producer_kernel<39>, compaction)', ms=acc_ms, bound='mfma',
                                      flop_per_launch=acc_flop, algorithmic_tflops=acc_flop / (acc_ms * 1e-3) / 1e12 if acc_ms else None,
@@ -1026,6 +1186,198 @@ def other_configs(args, device):
     b.close()
     e.close()
     return out
+
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at the size BASELINE.json states (not their per-GPU shares)
+# ------------------------------------------------------------------------------------------------
+C4_BATCHES = 8            # 8 x 1024 utterances = the 8192 of config 4
+
+
+def c4_corpus_batch(k):
+    """batch k of the 8192-utterance corpus of config 4: (frames (307200, 39) f32, lens, labels); seeded by k alone, so that any
+    split over ranks sees the same corpus."""
+    from poccala_amd import synth
+    c = synth.CONFIGS['C4shard']
+    frames, lens, _ = synth.make_frames(c['U'], c['T'], c['D'], seed=1000 + k)
+    labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2000 + k)
+    return frames, lens, labels
+
+
+def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
+    """Config 4 whole: ALL 8192 utterances through one EM iteration -- per batch of 1024: score -> forward-backward -> GMM
+    statistics + per-unit transition accumulators, the 8 batches into ONE statistics block -> the exchange (reduce-scatter ->
+    GMM.update_param on the owned states -> all-gather; one rank: the M-step) -> transition M-step -> the batches take the new
+    transitions (AcousticModel.py:842-882: the Pool over the corpus, then multi_embedded_training_2).  The batches are dealt
+    round-robin to the ranks (strong scaling: --workload C4 --gpus N); on one GPU all 8 are resident.  Returns a dict."""
+    from poccala_amd import synth
+    c = synth.CONFIGS['C4shard']
+    rank, world = ctl.rank, ctl.world
+    mine = [k for k in range(C4_BATCHES) if k % world == rank]
+    t0 = time.perf_counter()
+    if model is None:
+        model = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    mean, var, w, trans = model
+    parts = [c4_corpus_batch(k) for k in mine]
+    frames = np.concatenate([p_[0] for p_ in parts], axis=0) if parts else np.zeros((1, c['D']), dtype=np.float32)
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
+    eng.load_frames(frames)
+    batches, off = [], 0
+    for fr, lens, labels in parts:
+        begin = off + np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))])
+        batches.append(eng.label_batch(labels, lens, begin))
+        off += int(lens.sum())
+    del frames, parts
+    t_setup = time.perf_counter() - t0
+
+    def iteration():
+        eng.stats_zero()
+        for bt in batches:                     # scoring of batch k+1 beside the forward-backward of batch k (second stream)
+            bt.score(P)
+            bt.forward_backward(fix_pi=False)
+        for bt in batches:
+            bt.accumulate(P)
+            bt.accumulate_hmm()
+        eng.em_exchange(1e-3, payload, True)
+        for bt in batches:
+            bt.refresh_transitions()
+    for _ in range(warm):
+        iteration()
+    eng.sync()
+    names = ('score', 'fb', 'accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive')
+    for k in names:
+        eng.kernel_time(k)
+    ctl.barrier()
+    t1 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    eng.sync()
+    ctl.barrier()
+    elapsed = ctl.allreduce_max(time.perf_counter() - t1)
+    kt = {k: eng.kernel_time(k)[0] / iters for k in names}
+    lp = np.concatenate([bt.get('logp') for bt in batches]) if batches else np.zeros(0)
+    npass = np.concatenate([bt.get('npass') for bt in batches]) if batches else np.zeros(0, dtype=np.int32)
+    st = eng.stats_download(moments=False)
+    for bt in batches:
+        bt.close()
+    nfr = C4_BATCHES * c['U'] * c['T']
+    return dict(task='full Baum-Welch EM iteration: score + forward-backward + GMM / transition statistics for every batch into one statistics block, '
+                     'exchange + M-step (GMM and transitions), batches refreshed',
+                shape='%d utterances (%d batches of %d) x %d frames, D=%d, M=%d, %d units (J=%d), L=%d' % (C4_BATCHES * c['U'], C4_BATCHES, c['U'], c['T'], c['D'], c['M'], c['units'], c['units'] * 3, c['L']),
+                value=nfr * iters / elapsed, unit='frames/s', ms_per_iteration=elapsed / iters * 1e3, iterations=iters, n_gpus=world,
+                batches_on_this_rank=len(batches), kernel_ms_per_iteration_rank0=kt, setup_s=t_setup,
+                loglik_mean_rank0=float(lp.mean()) if len(lp) else None, passes_max_rank0=int(npass.max()) if len(npass) else None,
+                states_seen_rank0=int((st['alpha_acc'] > 0).sum()),
+                what='the configuration BASELINE.json states (8192 utterances), not the per-GPU share the headline loop times; the model moves from iteration to iteration (EM)')
+
+
+def c5_corpus_chunks(n_chunks=24, per=139, ragged=False):
+    """the 1M-frame corpus of config 5 as the chunks a loader would hand over: 24 chunks x 139 utterances x 300 frames = 1,000,800
+    frames (ragged: 200..400 frames per utterance, a new chunk shape every time).  Yields lists of (T_u, 39) float32 arrays."""
+    from poccala_amd import synth
+    c = synth.CONFIGS['C5shard']
+    for k in range(n_chunks):
+        frames, lens, begin = synth.make_frames(per, c['T'], c['D'], seed=7000 + k, ragged=ragged)
+        yield [frames[begin[u]:begin[u] + lens[u]] for u in range(per)]
+
+
+def run_c5_full(eng, tree, max_tokens, ragged=False, n_chunks=24, per=139):
+    """Config 5 whole on one GPU: the 1M-frame corpus streamed through Decoder.decode_stream (H2D of chunk k+1 beside the scoring
+    of chunk k beside the token passing of chunk k-1), every one of the 549 states x 4096 mixtures scored for every frame.
+    The model, units and tree must be loaded.  Returns a dict; `value` counts the whole stream's wall clock incl. PCIe both ways."""
+    from poccala_amd import Decoder, PCL_F32
+    chunks = list(c5_corpus_chunks(n_chunks, per, ragged))
+    nfr = int(sum(len(x) for ch in chunks for x in ch))
+    eng.kernel_time('score'); eng.kernel_time('decode')
+    t0 = time.perf_counter()
+    n_utt = n_over = 0
+    tok = []
+    for res in Decoder.decode_stream(iter(chunks), tree, engine=eng, precision=PCL_F32, max_tokens=max_tokens, candidate=5):
+        n_utt += len(res)
+        n_over += sum(1 for r in res if r[2]['overflow'])
+        tok.append(float(np.mean([r[2]['n_tokens'].mean() for r in res])))
+    eng.sync()
+    el = time.perf_counter() - t0
+    sc_ms, k1 = eng.kernel_time('score')
+    de_ms, k2 = eng.kernel_time('decode')
+    return dict(task='the 1M-frame corpus streamed chunk by chunk: H2D + all-state scoring + lexicon token-passing decode + results on the host',
+                shape='%d chunks x %d utterances%s, %d frames in all' % (n_chunks, per, ' of 200..400 frames (a new chunk shape every time)' if ragged else ' x 300 frames', nfr),
+                value=nfr / el, unit='frames/s', wall_s=el, utterances=n_utt, utterances_at_the_cap=n_over, live_tokens_mean=float(np.mean(tok)),
+                score_kernel_ms_per_chunk=sc_ms / max(k1, 1), decode_kernel_ms_per_chunk=de_ms / max(k2, 1), pinned_host_bytes=eng.pinned_bytes())
+
+
+def bench_c4_full(args, rank, world, local):
+    """--workload C4: the line for config 4 at its stated size (strong scaling over --gpus)."""
+    from poccala_amd import Engine, PCL_F32, PCL_F64
+    from poccala_amd.distributed import Control
+    from poccala_amd.engine import device_count
+    ndev = device_count()
+    dev = int(os.environ.get('POCCALA_DEVICE', local))
+    shared = bool(os.environ.get('POCCALA_SHARE_DEVICE')) and 0 < ndev < world
+    if shared:
+        dev = dev % ndev
+    eng = Engine(dev)
+    eng.enable_timing(True)
+    ctl = Control(rank, world)
+    if world > 1 or os.environ.get('POCCALA_FORCE_DIST'):
+        if shared or os.environ.get('POCCALA_NO_RCCL'):
+            eng.comm_init_host(rank, world, ctl.allgather_bytes)
+        else:
+            eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
+    payload = resolve_payload(args, world)
+    r = run_c4_full(eng, ctl, PCL_F32 if args.precision == 'f32' else PCL_F64, payload, iters=max(1, args.steps), warm=max(1, args.warmup))
+    if rank == 0:
+        info = eng.device_info()
+        print(json.dumps({'metric': 'frames/sec full Baum-Welch EM iteration (E-step + exchange + M-step), 39-d MFCC, 2048-mix, 8192 utterances',
+                          'value': r['value'], 'unit': 'frames/s', 'n_gpus': world, 'steps': r['iterations'], 'warmup': max(1, args.warmup),
+                          'ms_per_step': r['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                          'dtype': DTYPE_NAME if args.precision == 'f32' else 'f64', 'data': 'synthetic',
+                          'config': {'workload': 'C4: ' + r['shape'], 'device': info['name'], 'cus': info['cus'], 'payload': 'f32' if payload == PCL_F32 else 'f64',
+                                     'transport': eng.comm_info()['transport']},
+                          'detail': r}))
+        sys.stdout.flush()
+    ctl.barrier()
+    eng._lib.pcl_comm_destroy(eng._ctx)
+    ctl.close()
+    eng.close()
+
+
+def bench_c5_full(args, rank, world, local):
+    """--workload C5: config 5 at its stated size on one GPU (with --gpus N every rank streams its own 1/N of the chunks: weak pieces
+    of a strong split -- no collective on this path)."""
+    from poccala_amd import Engine, synth
+    from poccala_amd.distributed import Control
+    c = synth.CONFIGS['C5shard']
+    eng = Engine(int(os.environ.get('POCCALA_DEVICE', local)))
+    eng.enable_timing(True)
+    ctl = Control(rank, world)
+    tree, lx = synth.make_pronunciation_tree(args.words, c['units'])
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'])
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
+    eng.load_lexicon(tree)
+    n_chunks = 24 // world if world > 1 else 24
+    run_c5_full(eng, tree, args.max_tokens, n_chunks=min(4, n_chunks))          # warm: batches, buffers, clocks
+    ctl.barrier()
+    r = run_c5_full(eng, tree, args.max_tokens, n_chunks=n_chunks)
+    rg = run_c5_full(eng, tree, args.max_tokens, ragged=True, n_chunks=n_chunks)
+    ctl.barrier()
+    wall = ctl.allreduce_max(r['wall_s'])
+    if rank == 0:
+        info = eng.device_info()
+        nfr = n_chunks * 139 * c['T'] * world
+        print(json.dumps({'metric': 'frames/sec streamed all-state GMM-score + lexicon token-passing decode, 39-d MFCC, 4096-mix, 1M-frame corpus',
+                          'value': nfr / wall, 'unit': 'frames/s', 'n_gpus': world, 'steps': 1, 'warmup': 1, 'ms_per_step': wall * 1e3,
+                          'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': DTYPE_NAME, 'data': 'synthetic',
+                          'config': {'workload': 'C5: ' + r['shape'] + '; tree of %d words / %d nodes, <= %d live tokens' % (lx.size, len(tree['names']), args.max_tokens),
+                                     'device': info['name'], 'cus': info['cus']},
+                          'detail': r, 'ragged': rg}))
+        sys.stdout.flush()
+    ctl.barrier()
+    ctl.close()
+    eng.close()
 
 
 def zero_change_route(n_utts=3):

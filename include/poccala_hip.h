@@ -229,6 +229,29 @@ int pcl_batch_decode_get(pcl_batch *b, int32_t *n_final, int32_t *node, double *
 /* Copy a result to a caller buffer (layouts in pcl_get_what). */
 int pcl_batch_get(pcl_batch *b, int what, void *host);
 
+/* Results on their way to the host WHILE the GPU goes on (the end-to-end protocol moves B / gamma / paths off the
+ * device).  pcl_batch_fetch_async queues, behind everything this batch has queued so far (scoring, forward-backward on the second
+ * stream, Viterbi), device-to-host copies of the selected results on the library's download stream and returns at once;
+ * pcl_batch_fetch_wait blocks until they have landed.  A later compute call on the SAME batch waits for the copies on the device
+ * (its buffers are being read), other batches run beside them.  Destinations should be page-locked (pcl_host_alloc): a copy
+ * into pageable memory is staged by the runtime and is not asynchronous.  NULL pointers are skipped.  Layouts:
+ *   logp   (U,) f64                                  == PCL_GET_LOGP
+ *   lgamma ragged, per utterance TIME-MAJOR (T_u, N_u) f64: the transpose of PCL_GET_LGAMMA's (N_u, T_u) -- the device layout,
+ *          so that nothing but the copy stands between the kernel and the host (the caller views it transposed);
+ *          == l - sum_value of LHMM.update_acc (LHMM.py:486-500), what Clustering.GMM.update_acc is fed
+ *   ksai_nz f64, ln xi of the stored transitions     == PCL_GET_KSAI_NZ (LHMM.__ksai, quirk Q5)
+ *   path   ragged (T_u,) int32, point (U,) f64       == PCL_GET_PATH / PCL_GET_POINT (needs pcl_batch_viterbi) */
+/* sizes of the ragged result arrays of a batch: sum N_u T_u, sum N_u, sum T_u, stored transitions (ln A > -inf).  NULLs are skipped. */
+int pcl_batch_sizes(pcl_batch *b, int64_t *sum_nt, int64_t *sum_n, int64_t *sum_t, int64_t *nnz);
+int pcl_batch_fetch_async(pcl_batch *b, double *logp, double *lgamma_tm, double *ksai_nz, int32_t *path, double *point);
+int pcl_batch_fetch_wait(pcl_batch *b);
+
+/* The clock the shader engines actually hold, measured on the device: one wavefront on the library's auxiliary stream reads the
+ * shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) `spin_us` microseconds apart, beside
+ * whatever the other streams are running.  rocm-smi's sclk is the REQUESTED level; under the matrix-pipe kernels the chip holds
+ * 1.6-1.8 GHz of its 2.4.  Synchronous (waits for the probe only). */
+int pcl_clock_probe(pcl_ctx *ctx, int spin_us, double *shader_mhz);
+
 /* ----------------------------------------------------------------- E-step statistics
  * A13: Clustering.GMM.update_acc (Clustering.py:653-680) for every (utterance, emitting row) of the
  * batch, summed into ctx-resident per-state statistics.  The reference keeps them in the log domain

@@ -42,6 +42,10 @@ PROTOTYPES = {
     'pcl_batch_forward_backward': (_i, [_vp, _i, _d]),
     'pcl_batch_viterbi': (_i, [_vp, _i]),
     'pcl_batch_get': (_i, [_vp, _i, _vp]),
+    'pcl_batch_sizes': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'pcl_batch_fetch_async': (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcl_batch_fetch_wait': (_i, [_vp]),
+    'pcl_clock_probe': (_i, [_vp, _i, C.POINTER(C.c_double)]),
     'pcl_stats_zero': (_i, [_vp]),
     'pcl_batch_accumulate': (_i, [_vp, _i]),
     'pcl_accumulate_prune': (_i, [_vp, C.c_double]),

@@ -826,7 +826,28 @@ __global__ void ksai_gather_kernel(const UttDesc *__restrict__ utts, const int *
             dst[d.nnz_off + k] = ksai[d.mat_off + (long long)i * d.N + col_idx[d.nnz_off + k]];
 }
 
+// the shader clock under load: one wave reads the shader-cycle counter and the constant 100 MHz counter, spins, reads them again
+__global__ void clock_probe_kernel(unsigned long long spin_ticks, unsigned long long *out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c0; out[1] = c1; out[2] = r0; out[3] = r1;
+}
+
 }  // namespace
+
+int pcl_launch_clock_probe(pcl_ctx *ctx, int spin_us, unsigned long long *d_out) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->stream_aux, (unsigned long long)spin_us * 100ULL, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
 
 int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst) {
     hipLaunchKernelGGL(ksai_gather_kernel, dim3(b->U), dim3(64), 0, ctx->stream, b->d_utt, b->row_ptr, b->col_idx, b->ksai, dst);

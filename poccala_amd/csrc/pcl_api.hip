@@ -141,7 +141,8 @@ int pcl_init(int device, pcl_ctx **out) {
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess ||      // (priority 0 measured: no difference)
         (e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream_desc, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&ctx->stream_desc, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream_d2h, hipStreamNonBlocking)) != hipSuccess) {
         g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
         delete ctx;
         return PCL_ERR_HIP;
@@ -214,6 +215,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipStreamDestroy(ctx->stream_dp);
     hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream_desc) hipStreamDestroy(ctx->stream_desc);
+    if (ctx->stream_d2h) hipStreamDestroy(ctx->stream_d2h);
     delete ctx;
     return PCL_OK;
 }
@@ -225,6 +227,7 @@ int pcl_sync(pcl_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream_aux));
+    if (ctx->stream_d2h) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_d2h));
     return PCL_OK;
 }
 
@@ -235,6 +238,10 @@ static int batch_join(pcl_batch *b) {
     if (b->dp_pending) {
         HIPCHK(b->ctx, hipStreamWaitEvent(b->ctx->stream, b->ev_dp, 0));
         b->dp_pending = false;
+    }
+    if (b->fetch_pending) {                                  // result copies still reading this batch's buffers (pcl_batch_fetch_async)
+        HIPCHK(b->ctx, hipStreamWaitEvent(b->ctx->stream, b->ev_fetch, 0));
+        b->fetch_pending = false;
     }
     return PCL_OK;
 }
@@ -519,6 +526,8 @@ int pcl_batch_destroy(pcl_batch *b) {
     hipStreamSynchronize(b->ctx->stream);
     hipStreamSynchronize(b->ctx->stream_aux);
     if (b->dp_pending && b->ev_dp) hipEventSynchronize(b->ev_dp);
+    if (b->ev_fetch) { hipEventSynchronize(b->ev_fetch); hipEventDestroy(b->ev_fetch); }
+    if (b->ev_fetch_src) hipEventDestroy(b->ev_fetch_src);
     pcl_free_synced_scope done;                              // the frees below skip their device-wide wait
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
@@ -904,6 +913,10 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
     if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_forward_backward: no transitions set");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_forward_backward: no emissions (score or set_emissions first)");  // LHMM.py:69
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (b->fetch_pending) {                                  // the copies of the previous results read lgam / ksai: main stream first (stream_dp follows it below)
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_fetch, 0));
+        b->fetch_pending = false;
+    }
     if (!b->alpha) {
         TRY(dev_alloc(ctx, &b->alpha, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->beta, (size_t)b->sumNT));
@@ -1038,6 +1051,74 @@ int pcl_batch_get(pcl_batch *b, int what, void *host) {
     }
     HIPCHK(ctx, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_batch_sizes(pcl_batch *b, int64_t *sum_nt, int64_t *sum_n, int64_t *sum_t, int64_t *nnz) {
+    if (!b) return PCL_ERR_INVALID;
+    if (sum_nt) *sum_nt = b->sumNT;
+    if (sum_n) *sum_n = b->sumN;
+    if (sum_t) *sum_t = b->sumT;
+    if (nnz) *nnz = b->nnz;
+    return PCL_OK;
+}
+
+int pcl_batch_fetch_async(pcl_batch *b, double *logp, double *lgamma_tm, double *ksai_nz, int32_t *path, double *point) {
+    if (!b) return PCL_ERR_INVALID;
+    pcl_ctx *ctx = b->ctx;
+    if ((logp || lgamma_tm || ksai_nz) && !b->have_fb) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_fetch_async: run pcl_batch_forward_backward first");
+    if ((path || point) && !b->have_vit) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_fetch_async: run pcl_batch_viterbi first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!b->ev_fetch) {
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_fetch, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_fetch_src, hipEventDisableTiming));
+    }
+    hipStream_t ds = ctx->stream_d2h;
+    // behind what the batch has queued: the main stream as of now (scoring, Viterbi), the second stream's forward-backward
+    HIPCHK(ctx, hipEventRecord(b->ev_fetch_src, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_fetch_src, 0));
+    if (b->dp_pending) HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_dp, 0));
+    if (ksai_nz) {
+        if (!b->nz_tmp) TRY(dev_alloc(ctx, &b->nz_tmp, (size_t)b->nnz));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ds;                                     // (the launcher uses ctx->stream)
+        const int rc = pcl_launch_ksai_gather(ctx, b, b->nz_tmp);
+        ctx->stream = main_stream;
+        if (rc != PCL_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ksai_nz, b->nz_tmp, (size_t)b->nnz * 8, hipMemcpyDeviceToHost, ds));
+    }
+    if (logp) HIPCHK(ctx, hipMemcpyAsync(logp, b->logp, (size_t)b->U * 8, hipMemcpyDeviceToHost, ds));
+    if (lgamma_tm) HIPCHK(ctx, hipMemcpyAsync(lgamma_tm, b->lgam, (size_t)b->sumNT * 8, hipMemcpyDeviceToHost, ds));
+    if (path) HIPCHK(ctx, hipMemcpyAsync(path, b->path, (size_t)b->sumT * 4, hipMemcpyDeviceToHost, ds));
+    if (point) HIPCHK(ctx, hipMemcpyAsync(point, b->point, (size_t)b->U * 8, hipMemcpyDeviceToHost, ds));
+    HIPCHK(ctx, hipEventRecord(b->ev_fetch, ds));
+    b->fetch_pending = true;
+    return PCL_OK;
+}
+
+int pcl_batch_fetch_wait(pcl_batch *b) {
+    if (!b) return PCL_ERR_INVALID;
+    if (!b->ev_fetch) PCL_FAIL(b->ctx, PCL_ERR_STATE, "pcl_batch_fetch_wait: nothing was fetched");
+    HIPCHK(b->ctx, hipEventSynchronize(b->ev_fetch));
+    b->fetch_pending = false;
+    return PCL_OK;
+}
+
+int pcl_clock_probe(pcl_ctx *ctx, int spin_us, double *shader_mhz) {
+    if (!ctx || !shader_mhz || spin_us < 1 || spin_us > 1000000) return PCL_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr, h[4] = {0, 0, 0, 0};
+    TRY(dev_alloc(ctx, &d, (size_t)4));
+    int rc = pcl_launch_clock_probe(ctx, spin_us, d);
+    if (rc == PCL_OK && hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream_aux) != hipSuccess) rc = PCL_ERR_HIP;
+    if (rc == PCL_OK && hipStreamSynchronize(ctx->stream_aux) != hipSuccess) rc = PCL_ERR_HIP;
+    {
+        pcl_free_synced_scope done;                           // (the probe is the only user of d and it has finished)
+        dev_free(d);
+    }
+    if (rc != PCL_OK) PCL_FAIL(ctx, rc, "pcl_clock_probe: HIP error");
+    const double cyc = (double)(h[1] - h[0]), ref = (double)(h[3] - h[2]);
+    *shader_mhz = ref > 0 ? cyc / ref * 100.0 : 0.0;          // s_memrealtime counts at 100 MHz
     return PCL_OK;
 }
 

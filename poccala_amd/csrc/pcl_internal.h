@@ -78,6 +78,7 @@ struct pcl_ctx {
     hipStream_t stream_dp = nullptr;   // forward-backward runs here, beside the next batch's scoring on `stream`
     hipStream_t stream_aux = nullptr;  // the accumulate pass's tile-image producer runs here, beside its consumer on `stream`
     hipStream_t stream_desc = nullptr; // descriptor uploads of batches that have nothing in flight (pcl_h2d_fresh)
+    hipStream_t stream_d2h = nullptr;  // pcl_batch_fetch_async: results travel to the host beside the next step's kernels
     bool dp_async = true;              // env PCL_DP_STREAM=0: everything on one stream
     int score_variant = 0;       // 7 = two-piece f16 split on the matrix pipe (default), 3 = f32-input MFMA (strict f32), 1 = direct form on the VALU
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
@@ -185,6 +186,8 @@ struct pcl_batch {
     std::vector<int> acc_ws, acc_lo, acc_hi; // accumulate's state order (well-conditioned first)
     hipEvent_t ev_main = nullptr, ev_dp = nullptr;   // main stream -> stream_dp hand-over, and back
     bool dp_pending = false;                 // forward-backward queued on stream_dp and not yet joined
+    hipEvent_t ev_fetch = nullptr, ev_fetch_src = nullptr;   // pcl_batch_fetch_async: copies done / the main stream at the time of the call
+    bool fetch_pending = false;              // result copies queued on stream_d2h: the next compute call on this batch waits for them
     int *d_tile_flags = nullptr;             // split-f16 scoring: per tile, 1 = a scaled feature left the f16 range (rescored)
     ScoreTile *d_tiles_v = nullptr;          // MFMA mode only: tiles of ill-conditioned states for the VALU kernel
     int n_segs = 0, n_tiles = 0, n_tiles_v = 0, tile_frames = 0, tile_gen = -1;
@@ -317,6 +320,7 @@ int pcl_launch_fb_linear_post(pcl_ctx *ctx, pcl_batch *b);
 int pcl_launch_fb_to_log(pcl_ctx *ctx, pcl_batch *b, const double *m, const int *e, double *out);
 int pcl_launch_regroup(pcl_ctx *ctx, pcl_batch *b, const int32_t *d_row_unit, int gmm_num, int32_t *d_frame_unit, int32_t *d_frame_k);
 int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst);
+int pcl_launch_clock_probe(pcl_ctx *ctx, int spin_us, unsigned long long *d_out);
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
 void pcl_accumulate_release(pcl_batch *b);
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);

@@ -1,11 +1,12 @@
 """Host side of the multi-GPU path: one process per GPU, utterances sharded across ranks.
 
 The data path needs no collective for scoring / forward-backward / Viterbi (utterances are
-independent, AcousticModel/AcousticModel.py:865-870).  The E-step has ONE exchange: the GMM
-statistics are summed by RCCL inside libpoccala_hip.so (pcl_stats_allreduce); the tiny per-unit HMM
-accumulators are un-normalised LOG values and are merged here with a
-max-then-sum all-reduce, which is the log-sum-exp the reference's file reducer computes
-(StatisticalModel/LHMM.py:272-290).  `dist` is torch.distributed (gloo for control traffic).
+independent, AcousticModel/AcousticModel.py:865-870).  The E-step has ONE exchange, inside
+libpoccala_hip.so over RCCL (pcl_em_exchange: the GMM statistics by state range, the per-unit HMM
+accumulators -- un-normalised LOG values, SURVEY quirk Q5 -- by a max-then-sum all-reduce, the
+log-sum-exp the reference's file reducer computes, StatisticalModel/LHMM.py:272-290).  This module
+is the host side: the utterance split and a small TCP control plane.  No PyTorch here (north star);
+the torch.distributed (gloo) helpers the CPU world-2 tests use live in tests/_dist_torch.py.
 """
 import numpy as np
 
@@ -15,38 +16,6 @@ def shard_range(n_items, rank, world):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
-
-
-def broadcast_unique_id(engine, dist, rank):
-    """rank 0 creates the 128-byte ncclUniqueId, everyone receives it."""
-    box = [engine.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    return box[0]
-
-
-def allreduce_logsumexp(arr, dist):
-    """Elementwise log-sum-exp of a float64 array over all ranks (util.log_sum_exp semantics: an
-    element that is -inf everywhere stays -inf)."""
-    import torch
-    a = np.ascontiguousarray(arr, dtype=np.float64)
-    top = torch.from_numpy(a.copy())
-    dist.all_reduce(top, op=dist.ReduceOp.MAX)
-    top = top.numpy()
-    safe = np.where(np.isinf(top), 0.0, top)
-    with np.errstate(all='ignore'):
-        s = torch.from_numpy(np.exp(a - safe))
-    dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    with np.errstate(all='ignore'):
-        out = safe + np.log(s.numpy())
-    return np.where(np.isinf(top), top, out)
-
-
-def allreduce_sum_host(arr, dist):
-    """Sum of a host array over ranks (control-plane sized data only; GPU statistics use RCCL)."""
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64).copy())
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.numpy()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -79,7 +48,21 @@ _MAX_FRAME = 1 << 30
 
 
 def _loopback(addr):
-    return addr in ('localhost', '::1') or addr.startswith('127.')
+    """Does MASTER_ADDR name this machine's loopback interface?  IPv4 literals are parsed (a hostname such as 127.example.com is
+    not one); a hostname counts when every address it resolves to is a loopback address -- which covers 'localhost' and, on
+    the usual single-node images, the node's own hostname (/etc/hosts maps it to 127.0.1.1).  The hub socket is AF_INET, so an
+    IPv6 literal is never accepted."""
+    import ipaddress
+    try:
+        ip = ipaddress.ip_address(addr)
+        return ip.version == 4 and ip.is_loopback
+    except ValueError:
+        pass
+    try:
+        infos = socket.getaddrinfo(addr, None, socket.AF_INET)
+    except OSError:
+        return False
+    return bool(infos) and all(ipaddress.ip_address(i[4][0]).is_loopback for i in infos)
 
 
 def _token(addr='127.0.0.1'):
@@ -90,8 +73,9 @@ def _token(addr='127.0.0.1'):
     t = os.environ.get('POCCALA_CTRL_TOKEN')
     if t is None:
         if not _loopback(addr):
-            raise RuntimeError('control plane: MASTER_ADDR=%s is not a loopback address and POCCALA_CTRL_TOKEN is not set; '
-                               'export the same random POCCALA_CTRL_TOKEN on every rank of a multi-node job' % addr)
+            raise RuntimeError('control plane: MASTER_ADDR=%s does not resolve to a loopback address and POCCALA_CTRL_TOKEN is not set; '
+                               'export the same random POCCALA_CTRL_TOKEN on every rank of a multi-node job (a single-node job whose '
+                               'MASTER_ADDR is the node\'s routable hostname needs it too, or MASTER_ADDR=127.0.0.1)' % addr)
         t = 'run:%s:%s' % (os.environ.get('TORCHELASTIC_RUN_ID', ''), os.environ.get('MASTER_PORT', ''))
     return t.encode()
 

@@ -93,6 +93,13 @@ class Engine(object):
         self._check(self._lib.pcl_kernel_time(self._ctx, which.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def clock_probe(self, spin_us=1000):
+        """The shader clock (MHz) the chip holds right now, measured on the device beside whatever is running (s_memtime against
+        the constant 100 MHz s_memrealtime over `spin_us` microseconds); rocm-smi's sclk is the requested level."""
+        mhz = C.c_double()
+        self._check(self._lib.pcl_clock_probe(self._ctx, int(spin_us), C.byref(mhz)))
+        return mhz.value
+
     # ------------------------------------------------------------------ model / frames
     def load_model(self, mean, var, weight, logdet=False):
         """mean, var (J,M,D) -- var is the DIAGONAL of the reference's (M,D,D) covariance (util.py:23);
@@ -356,9 +363,18 @@ class Engine(object):
     def stats_allreduce(self):
         self._check(self._lib.pcl_stats_allreduce(self._ctx))
 
-    def em_exchange(self, c_covariance=1e-3, payload=PCL_F64, update_transitions=False):
+    def default_payload(self):
+        """Wire format of the E-step exchange when the caller does not choose: float32 as soon as there is a wire (SURVEY section 5 /
+        8e: the 1.94 GB of statistics and the model cross xGMI as f32, half the bytes; every rank continues from the same rounded
+        model; mean_acc travels as mean_acc - (bias + c_j) acc so that the rounding is not amplified), float64 on one rank."""
+        return PCL_F32 if self.comm_info()['nranks'] > 1 else PCL_F64
+
+    def em_exchange(self, c_covariance=1e-3, payload=None, update_transitions=False):
         """reduce-scatter of the statistics by state range -> M-step on the owned states -> all-gather of the model
-        (+ merge of the per-unit HMM accumulators, + the transition update on request).  One rank: the M-step."""
+        (+ merge of the per-unit HMM accumulators, + the transition update on request).  One rank: the M-step.
+        payload: PCL_F32 / PCL_F64, None = default_payload()."""
+        if payload is None:
+            payload = self.default_payload()
         self._check(self._lib.pcl_em_exchange(self._ctx, float(c_covariance), int(payload), 1 if update_transitions else 0))
         self._model_key = None
 
@@ -465,9 +481,12 @@ class Batch(object):
     def accumulate(self, precision=PCL_F32):
         self._check(self._lib.pcl_batch_accumulate(self._b, int(precision)))
 
-    def accumulate_exchange(self, precision=PCL_F32, c_covariance=1e-3, payload=PCL_F64, update_transitions=False, n_chunks=8):
+    def accumulate_exchange(self, precision=PCL_F32, c_covariance=1e-3, payload=None, update_transitions=False, n_chunks=8):
         """The last accumulate pass of an E-step and the exchange in one pipelined call (pcl_batch_accumulate_exchange): state
-        chunks leave for reduce-scatter -> M-step -> all-gather -> derive as soon as the pass is done with them."""
+        chunks leave for reduce-scatter -> M-step -> all-gather -> derive as soon as the pass is done with them.
+        payload None = Engine.default_payload() (f32 on the wire when there is one)."""
+        if payload is None:
+            payload = self.eng.default_payload()
         self._check(self._lib.pcl_batch_accumulate_exchange(self._b, int(precision), float(c_covariance), int(payload),
                                                              1 if update_transitions else 0, int(n_chunks)))
         self.eng._model_key = None
@@ -520,6 +539,39 @@ class Batch(object):
     def refresh_transitions(self):
         """Take the engine's CURRENT unit transitions (after mstep_transitions / em_exchange); label-built batches only."""
         self._check(self._lib.pcl_batch_refresh_transitions(self._b))
+
+    # ------------------------------------------------------------------ results on their way to the host while the GPU goes on
+    def result_buffers(self, want=('logp', 'lgamma', 'ksai_nz', 'path', 'point')):
+        """Page-locked destination arrays for fetch_async (kept with the engine until it closes)."""
+        pe = self.eng.pinned_empty
+        out = {}
+        if 'logp' in want:
+            out['logp'] = pe((self.U,), np.float64)
+        if 'lgamma' in want:
+            out['lgamma'] = pe((int(self._nt_off[-1]),), np.float64)
+        if 'ksai_nz' in want:
+            nnz = np.zeros(1, dtype=np.int64)        # (label-built batches: the library built the transition lists)
+            self._check(self._lib.pcl_batch_sizes(self._b, None, None, None, ptr(nnz)))
+            out['ksai_nz'] = pe((int(nnz[0]),), np.float64)
+        if 'path' in want:
+            out['path'] = pe((int(self._t_off[-1]),), np.int32)
+        if 'point' in want:
+            out['point'] = pe((self.U,), np.float64)
+        return out
+
+    def fetch_async(self, bufs):
+        """Queue the device-to-host copies of the results named in `bufs` (result_buffers()) behind everything this batch has
+        queued; returns at once.  fetch_wait() blocks until they have landed; the next compute call on this batch waits for them
+        on the device."""
+        g = lambda k: ptr(bufs[k]) if k in bufs else None
+        self._check(self._lib.pcl_batch_fetch_async(self._b, g('logp'), g('lgamma'), g('ksai_nz'), g('path'), g('point')))
+
+    def fetch_wait(self):
+        self._check(self._lib.pcl_batch_fetch_wait(self._b))
+
+    def lgamma_views(self, flat):
+        """fetch_async's time-major ln gamma_t(j) as the reference's (N, T) matrices (transposed views, no copy)."""
+        return [flat[self._nt_off[u]:self._nt_off[u + 1]].reshape(self.T[u], self.N[u]).T for u in range(self.U)]
 
     # ------------------------------------------------------------------ outputs
     def regroup(self, row_unit, gmm_num):

@@ -420,3 +420,61 @@ def test_c5_decode_at_shard_shape(eng):
     assert [s for _, s, _ in g['final']] == [float(s) for _, s, _ in fin]
     assert g['overflow'] == bool(info.get('overflow'))
     assert np.array_equal(g['n_tokens'], one[7]['n_tokens'][:tcut])           # a prefix of the full-length run
+
+
+def test_c5_full_corpus_streamed():
+    """BASELINE config 5 at the size it states: the 1M-frame corpus (24 chunks x 139 utterances x 300 frames = 1,000,800 frames)
+    streamed through Decoder.decode_stream -- H2D of chunk k+1 beside the all-state scoring of chunk k beside the token passing of
+    chunk k-1 (the reference reads one utterance at a time inside its worker, AcousticModel.py:723-768; Decoder.py:91-167).
+    Properties over the whole stream (every utterance answered, live tokens within the cap, candidates ordered, history chains
+    acyclic and word-ending) and streamed = resident bit for bit on three chunks; then a RAGGED stream (a new chunk shape every
+    time, hence a new batch per chunk): the same equality, and the engine's page-locked memory stays bounded."""
+    from poccala_amd import Decoder, Engine, PCL_F32, synth
+    c = synth.CONFIGS['C5shard']
+    cap, per, n_chunks = 8192, 139, 24
+    tree, lx = synth.make_pronunciation_tree(20000, c['units'])
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=5)
+    eng = Engine(0)
+    try:
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        eng.load_lexicon(tree)
+
+        def corpus(ragged, n):
+            for k in range(n):
+                frames, lens, begin = synth.make_frames(per, c['T'], c['D'], seed=7000 + k, ragged=ragged)
+                yield [frames[begin[u]:begin[u] + lens[u]] for u in range(per)]
+
+        def check(res, lens):
+            assert len(res) == len(lens)
+            for (words, score, r), t in zip(res, lens):
+                nt = r['n_tokens']
+                assert len(nt) == t and nt.min() > 0 and nt.max() <= cap
+                sc = [s for _, s, _ in r['final']]
+                assert len(sc) == min(5, int(nt[-1])) and sc == sorted(sc, reverse=True) and np.isfinite(sc).all()
+                for i, (prev, node) in enumerate(r['history']):
+                    assert -1 <= prev < i and tree['node_word'][node]
+
+        for ragged, n, keep in ((False, n_chunks, (0, 13, 23)), (True, 8, (2, 7))):
+            kept, frames_done, pinned_mid = {}, 0, None
+            for k, res in enumerate(Decoder.decode_stream(corpus(ragged, n), tree, engine=eng, precision=PCL_F32, max_tokens=cap, candidate=5)):
+                lens = [len(r[2]['n_tokens']) for r in res]
+                check(res, lens)
+                frames_done += sum(lens)
+                if k in keep:
+                    kept[k] = res
+                if k == 3:
+                    pinned_mid = eng.pinned_bytes()
+            assert k == n - 1
+            if not ragged:
+                assert frames_done == n_chunks * per * c['T'] == 1000800
+            else:
+                assert eng.pinned_bytes() <= 2 * pinned_mid + (1 << 20), (pinned_mid, eng.pinned_bytes())   # grow-only by doubling: bounded
+            for k, res in kept.items():                                  # the same chunk, resident: identical results
+                chunk = list(corpus(ragged, k + 1))[k]
+                ref = Decoder.decode_batch(chunk, tree, engine=eng, precision=PCL_F32, max_tokens=cap, candidate=5)
+                for a, b in zip(res, ref):
+                    assert a[0] == b[0] and a[1] == b[1] and a[2]['final'] == b[2]['final'] and a[2]['history'] == b[2]['history']
+                    assert np.array_equal(a[2]['n_tokens'], b[2]['n_tokens']) and a[2]['overflow'] == b[2]['overflow']
+    finally:
+        eng.close()

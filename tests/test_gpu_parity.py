@@ -1144,3 +1144,92 @@ def test_c5_shard_full_size(eng):
     for u in (0, c['U'] - 1):
         ref = state_rows(frames[begin[u]:begin[u] + lens[u]].astype(np.float64), gm)
         np.testing.assert_allclose(B[u][1:-1], ref, rtol=0, atol=F32_LOGLIK_ATOL)
+
+
+# ------------------------------------------------------------------ BASELINE config 4 at the size it states: 8192 utterances
+def test_c4_full_size_one_statistics_block():
+    """configs[3] whole on one GPU: 8 batches of 1024 utterances (2,457,600 frames) through one EM iteration INTO ONE
+    statistics block (AcousticModel.py:842-882: the corpus fan-out, then the merge + update of multi_embedded_training_2).
+    Size-independent properties: sum_j gamma_t(j) = 1; the occupancies of the block equal the sum of the 8 single-batch runs
+    BIT FOR BIT (float64 sums, one read-modify-write per state and batch, in batch order); the zeroth moment is conserved
+    (sum_j alpha_acc[j] = sum of the emitting-state posteriors of every frame); the per-unit transition accumulators equal the
+    log-sum of the single-batch ones; after the M-step the model is finite, the weights of every seen state sum to 1, and the
+    second iteration's mean log-likelihood is higher than the first's (EM)."""
+    from poccala_amd import Engine, PCL_F32, synth
+    c = synth.CONFIGS['C4shard']
+    NB = 8
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    eng = Engine(0)
+    try:
+        parts = []
+        for k in range(NB):
+            fr, lens, _ = synth.make_frames(c['U'], c['T'], c['D'], seed=1000 + k)
+            parts.append((fr, lens, synth.make_labels(c['U'], c['L'], c['units'], seed=2000 + k)))
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        eng.load_frames(np.concatenate([p[0] for p in parts], axis=0))
+        batches, off = [], 0
+        for fr, lens, labels in parts:
+            begin = off + np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))])
+            batches.append(eng.label_batch(labels, lens, begin))
+            off += int(lens.sum())
+        del parts
+
+        def estep():
+            eng.stats_zero()
+            for b in batches:
+                b.score(PCL_F32)
+                b.forward_backward(fix_pi=False)
+            for b in batches:
+                b.accumulate(PCL_F32)
+                b.accumulate_hmm()
+        estep()
+        whole = eng.stats_download(moments=False)
+        hk, hg = eng.hmm_acc_download()
+        lp1 = np.concatenate([b.get('logp') for b in batches])
+        assert np.isfinite(lp1).all() and len(lp1) == NB * c['U']
+        # posteriors: normalised per frame; zeroth moment conserved over the whole corpus
+        total_gamma = 0.0
+        for k, b in enumerate(batches):
+            lg = b.get('lgamma')
+            for u in range(0, c['U'], 97):
+                np.testing.assert_allclose(po.lse(lg[u], axis=0), 0.0, atol=1e-9)
+            total_gamma += float(sum(np.exp(l[1:-1]).sum() for l in lg))
+            del lg
+        np.testing.assert_allclose(whole['alpha_acc'].sum(), total_gamma, rtol=1e-9)
+        np.testing.assert_allclose(whole['acc'].sum(axis=1), whole['alpha_acc'], rtol=1e-4)
+        # the block = the 8 single-batch runs summed in batch order, bit for bit
+        run_acc, run_al = np.zeros_like(whole['acc']), np.zeros_like(whole['alpha_acc'])
+        rk, rg = np.full_like(hk, -np.inf), np.full_like(hg, -np.inf)
+        for b in batches:
+            eng.stats_zero()
+            b.accumulate(PCL_F32)
+            b.accumulate_hmm()
+            one = eng.stats_download(moments=False)
+            run_acc += one['acc']
+            run_al += one['alpha_acc']
+            k1, g1 = eng.hmm_acc_download()
+            rk, rg = po.logaddexp_q4(rk, k1), po.logaddexp_q4(rg, g1)
+        assert np.array_equal(run_al, whole['alpha_acc']), 'alpha_acc of the 8-batch block != the sum of the single-batch runs'
+        assert np.array_equal(run_acc, whole['acc']), 'acc of the 8-batch block != the sum of the single-batch runs'
+        fin_close(hk, rk, rtol=1e-12)
+        fin_close(hg, rg, rtol=1e-12)
+        note('C4 full size (8192 utterances, one statistics block)', 'frames', int(NB * c['U'] * c['T']))
+        note('C4 full size (8192 utterances, one statistics block)', 'block_equals_sum_of_single_batch_runs', 'bit for bit (acc, alpha_acc); transition accumulators 1e-12')
+        # the M-step on the whole corpus' statistics, then a second iteration
+        estep()
+        eng.em_exchange(c_covariance=1e-3, update_transitions=True)
+        nm, nv, nw = eng.model_download()
+        assert np.isfinite(nm).all() and np.isfinite(nv).all() and (nv > 0).all() and np.isfinite(nw).all()
+        seen = whole['alpha_acc'] > 0
+        np.testing.assert_allclose(nw[seen].sum(axis=1), 1.0, rtol=1e-6)
+        for b in batches:
+            b.refresh_transitions()
+        estep()
+        lp2 = np.concatenate([b.get('logp') for b in batches])
+        assert lp2.mean() > lp1.mean(), (lp1.mean(), lp2.mean())
+        note('C4 full size (8192 utterances, one statistics block)', 'mean_loglik_iteration_1_2', [float(lp1.mean()), float(lp2.mean())])
+        for b in batches:
+            b.close()
+    finally:
+        eng.close()

@@ -717,3 +717,118 @@ def test_accumulate_prune_is_off_by_default_and_bounded(eng):
     assert np.abs(cut['alpha_acc'] - exact['alpha_acc']).max() <= n_cut * 2.0 ** -40
     # (the f32 sums also regroup: leaving frames out moves the others to different 32-frame tiles -> f32 rounding noise)
     np.testing.assert_allclose(cut['acc'], exact['acc'], rtol=2e-6, atol=n_cut * 2.0 ** -40 + 1e-9)
+
+
+# ------------------------------------------------------------------ the exchange at the world sizes the target has (4 and 8)
+class _ThreadGather(object):
+    """all-gather of host bytes between n rank THREADS of this process (the rehearsal transport's callback): a GPU box allows
+    at most 6 processes on its card, so 8 ranks are 8 contexts on device 0 driven by 8 threads -- the library's calls release
+    the GIL and the callback re-enters Python on the calling thread."""
+
+    def __init__(self, n):
+        import threading
+        self.n, self.slots, self.bar = n, [None] * n, threading.Barrier(n)
+
+    def fn(self, rank):
+        def gather(data):
+            self.slots[rank] = data
+            self.bar.wait(timeout=120)
+            out = list(self.slots)
+            self.bar.wait(timeout=120)
+            return out
+        return gather
+
+
+def _run_ranks(world, body):
+    """run body(rank, gather_fn or None) on `world` threads; returns the results in rank order (exceptions re-raised)."""
+    import threading
+    tg = _ThreadGather(world)
+    out, err = [None] * world, []
+
+    def run(r):
+        try:
+            out[r] = body(r, tg.fn(r) if world > 1 else None)
+        except Exception:          # noqa
+            import traceback
+            err.append(traceback.format_exc())
+            tg.bar.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not err, err[0]
+    return out
+
+
+@pytest.mark.parametrize('world', [4, 8])
+@pytest.mark.parametrize('payload', ['f64', 'f32'])
+def test_exchange_world_4_and_8_equals_single_rank(world, payload):
+    """the N-rank statistics / model equal the 1-rank ones (f64 payload 1e-12, f32 payload rtol 1e-5), at the world
+    sizes of the target node.  21 utterances (not divisible by 4 or 8) and J = 15 states (not divisible either: rooted reduces /
+    broadcasts per owner); per rank: E-step on its utterances, then (a) pcl_stats_allreduce -> every rank holds the global
+    statistics, (b) pcl_em_exchange -> every rank holds the model a single rank re-estimates from all utterances, (c) the
+    pipelined pcl_batch_accumulate_exchange = (b) bit for bit.  Replaces LHMM.py:256-290 / Clustering.py:314-367."""
+    from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+    from poccala_amd.distributed import shard_range
+    units, U = 5, 21
+    mean, var, w, trans = synth.make_model(units, 8, 13, seed=131)
+    frames, lens, begin = synth.make_frames(U, 60, 13, seed=132, ragged=True)
+    labels = synth.make_labels(U, 3, units, seed=133)
+    pay = PCL_F32 if payload == 'f32' else PCL_F64
+
+    def body_for(n):
+        def body(rank, gather):
+            eng = Engine(0)
+            try:
+                if gather is not None:
+                    eng.comm_init_host(rank, n, gather)
+                eng.load_model(mean, var, w)
+                eng.load_units(np.stack(trans))
+                lo, hi = shard_range(U, rank, n)
+                f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
+                eng.load_frames(frames[f0:f1])
+                b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi] - f0)
+                res = {}
+                # (a) the plain all-reduce: global statistics on every rank
+                b.score(PCL_F64); b.forward_backward(); eng.stats_zero(); b.accumulate(PCL_F64); b.accumulate_hmm()
+                if gather is not None:
+                    eng.stats_allreduce()
+                res['stats'] = eng.stats_download()
+                res['hmm'] = eng.hmm_acc_download()
+                # (b) reduce-scatter -> owned M-step -> all-gather
+                eng.stats_zero(); b.accumulate(PCL_F64); b.accumulate_hmm()
+                eng.em_exchange(1e-3, pay, True)
+                res['model'] = eng.model_download() + (eng.units_download(),)
+                b.refresh_transitions(); b.score(PCL_F64); b.forward_backward()
+                res['lp'] = b.get('logp')
+                # (c) the same from the same start, pipelined
+                eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); b.refresh_transitions()
+                b.score(PCL_F64); b.forward_backward(); eng.stats_zero(); b.accumulate_hmm()
+                b.accumulate_exchange(PCL_F64, 1e-3, pay, True, n_chunks=4)
+                res['model_pipe'] = eng.model_download() + (eng.units_download(),)
+                res['info'] = eng.comm_info()
+                b.close()
+                return res
+            finally:
+                eng.close()
+        return body
+    single = _run_ranks(1, body_for(1))[0]
+    ranks = _run_ranks(world, body_for(world))
+    tol = dict(rtol=1e-12, atol=1e-12) if payload == 'f64' else dict(rtol=1e-5, atol=1e-6)
+    for r, g in enumerate(ranks):
+        assert g['info']['transport'] == 'host-rehearsal' and g['info']['nranks'] == world and g['info']['rank'] == r
+        for k in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):                 # (a) is float64 on the wire whatever the payload
+            np.testing.assert_allclose(g['stats'][k], single['stats'][k], rtol=1e-12, atol=1e-12, err_msg='all-reduced %s on rank %d' % (k, r))
+        for a, b_ in zip(g['hmm'], single['hmm']):
+            fin = np.isfinite(b_)
+            assert np.array_equal(np.isfinite(a), fin)
+            np.testing.assert_allclose(a[fin], b_[fin], rtol=1e-12)
+        for k in range(3):
+            np.testing.assert_allclose(g['model'][k], single['model'][k], err_msg='model part %d on rank %d' % (k, r), **tol)
+        np.testing.assert_allclose(g['model'][3], single['model'][3], rtol=1e-12, atol=1e-300)
+        for k in range(4):                                                   # every rank holds ONE model; the pipelined call gives the same bits
+            assert np.array_equal(g['model'][k], ranks[0]['model'][k])
+            assert np.array_equal(g['model_pipe'][k], g['model'][k]), (r, k)
+    lp = np.concatenate([g['lp'] for g in ranks])
+    np.testing.assert_allclose(lp, single['lp'], rtol=1e-10 if payload == 'f64' else 1e-5)

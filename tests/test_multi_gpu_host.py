@@ -37,7 +37,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from oracle import poccala_oracle as po
     from poccala_amd import synth
-    from poccala_amd.distributed import allreduce_logsumexp, allreduce_sum_host, shard_range
+    from _dist_torch import allreduce_logsumexp, allreduce_sum_host
+    from poccala_amd.distributed import shard_range
     units, M, D, U, T, L = 3, 4, 5, 6, 30, 2
     mean, var, w, trans = synth.make_model(units, M, D, seed=5)
     frames, lens, begin = synth.make_frames(U, T, D, seed=6)
