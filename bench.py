@@ -70,7 +70,7 @@ def parse():
     p.add_argument('--words', type=int, default=20000, help='--workload C5shard: random words added to the synthetic lexicon')
     p.add_argument('--max-tokens', type=int, default=8192, help='--workload C5shard: live tokens per utterance')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
-    p.add_argument('--sustain', type=float, default=10.0, help='seconds the headline loop is held for value_sustained')
+    p.add_argument('--sustain', type=float, default=10.0, help='seconds the headline loop is held for value_sustained (0 = skip it and the PCIe-inclusive loop)')
     p.add_argument('--extra-timeout', type=int, default=600, help='seconds the untimed extras (and the shutdown) may take before rank 0 prints the line without them')
     p.add_argument('--traffic-bytes', type=float, default=None,
                    help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md '
@@ -466,6 +466,7 @@ def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2
     Two batches / two frame slots / two result sets in rotation; the host waits for a result set only when it is about to be reused."""
     U, T = cfg['U'], cfg['T']
     nfr = U * T
+    legs = set(os.environ.get('POCCALA_PCIE_LEGS', 'h2d,d2h,vit').split(','))     # diagnosis: drop a leg to see what it costs
     pin = [eng.pinned_empty((nfr, cfg['D']), np.float32) for _ in range(2)]
     for k in range(2):
         pin[k][:] = frames[k * nfr:(k + 1) * nfr]
@@ -493,15 +494,18 @@ def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2
                     b.fetch_wait()
             t0 = time.perf_counter()
         bt = batches[k % 2]
-        eng.swap_frames()                      # chunk k is the current frame matrix (its copy had a whole step to arrive)
-        if k + 1 < total:
-            eng.stage_frames(pin[(k + 1) % 2])
-        if k >= 2:
+        if 'h2d' in legs or k < 2:
+            eng.swap_frames()                  # chunk k is the current frame matrix (its copy had a whole step to arrive)
+            if k + 1 < total and ('h2d' in legs or k < 1):
+                eng.stage_frames(pin[(k + 1) % 2])
+        if k >= 2 and 'd2h' in legs:
             bt.fetch_wait()                    # the host is done with this batch's previous results (a consumer would have read them)
         bt.score(P)
-        bt.viterbi()
+        if 'vit' in legs:
+            bt.viterbi()
         bt.forward_backward(fix_pi=False)
-        bt.fetch_async(res[k % 2])
+        if 'd2h' in legs or k < 2:
+            bt.fetch_async(res[k % 2] if 'vit' in legs else {q: v for q, v in res[k % 2].items() if q not in ('path', 'point')})
     for b in batches:
         b.fetch_wait()
     eng.sync()
@@ -512,7 +516,7 @@ def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2
     for b in batches:
         b.close()
     eng.load_frames(frames)                    # back to the resident matrix the other measurements index
-    return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, h2d_bytes_per_step=int(pin[0].nbytes),
+    return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, legs=sorted(legs), h2d_bytes_per_step=int(pin[0].nbytes),
                 d2h_bytes_per_step=bytes_down, results_intact=ok,
                 what='per step: frames H2D (copy stream) | score + Viterbi + forward-backward | ln P(O), ln gamma_t(j), stored ln xi, Viterbi paths '
                      'and scores D2H into page-locked memory (download stream); wall clock over the whole pipeline, the copies overlapped '
@@ -685,7 +689,7 @@ def main():
     # beside the headline, from the same resident batches (outside the timed region): the same loop held for >= 10 s, and the
     # end-to-end pipeline of SURVEY 8(d) with every step's frames and results crossing PCIe
     sustained = pcie = None
-    if args.extra and not align and P == PCL_F32:
+    if args.sustain > 0 and not align and P == PCL_F32:
         t_mark2 = time.perf_counter()
         try:
             ns, tot, blocks, clocks = sustained_loop(eng, batches, P, args.sustain)
@@ -1257,6 +1261,9 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
     ctl.barrier()
     elapsed = ctl.allreduce_max(time.perf_counter() - t1)
     kt = {k: eng.kernel_time(k)[0] / iters for k in names}
+    for bt in batches:                         # (untimed: the log-likelihoods under the model the timed iterations left)
+        bt.score(P)
+        bt.forward_backward(fix_pi=False)
     lp = np.concatenate([bt.get('logp') for bt in batches]) if batches else np.zeros(0)
     npass = np.concatenate([bt.get('npass') for bt in batches]) if batches else np.zeros(0, dtype=np.int32)
     st = eng.stats_download(moments=False)

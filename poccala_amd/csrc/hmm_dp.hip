@@ -448,16 +448,14 @@ __device__ __forceinline__ double lane_after(double v) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
-                                                     const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
-                                                     const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
-                                                     const int *__restrict__ row_idx, const double *__restrict__ csc_val,
-                                                     const double *__restrict__ logpi_in, double *__restrict__ alpha,
-                                                     double *__restrict__ beta, double *__restrict__ lgam, double *__restrict__ ksai,
-                                                     double *__restrict__ gamma_out, double *__restrict__ pi_out, double *__restrict__ logp,
-                                                     double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
-                                                     double threshold, const double2 *__restrict__ softplus, const int *__restrict__ kmax) {
-    if (pcl_fb_linear_ok(kmax, blockIdx.x, utts[blockIdx.x].T)) return;      // done by hmm_fbl_kernel (hmm_fb_linear.hip); block-uniform
+__device__ __forceinline__ void hmm_fb2_body(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                             const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                             const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
+                                             const int *__restrict__ row_idx, const double *__restrict__ csc_val,
+                                             const double *__restrict__ logpi_in, double *__restrict__ alpha,
+                                             double *__restrict__ beta, double *__restrict__ pi_out, double *__restrict__ logp,
+                                             double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
+                                             double threshold, const double2 *__restrict__ softplus) {
 #ifndef PCL_FB_NOPRIO
     // a latency-bound chain of few instructions, usually beside the scoring kernel's waves on the same SIMD: issue first
     __builtin_amdgcn_s_setprio(3);
@@ -618,6 +616,18 @@ __global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict_
     }
 }
 
+__global__ __launch_bounds__(128) void hmm_fb2_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                                     const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                     const double *__restrict__ csr_val, const int *__restrict__ col_ptr,
+                                                     const int *__restrict__ row_idx, const double *__restrict__ csc_val,
+                                                     const double *__restrict__ logpi_in, double *__restrict__ alpha,
+                                                     double *__restrict__ beta, double *__restrict__ pi_out, double *__restrict__ logp,
+                                                     double *__restrict__ qtrace, int32_t *__restrict__ npass_out, int fix_pi,
+                                                     double threshold, const double2 *__restrict__ softplus) {
+    hmm_fb2_body(utts, Bt, row_ptr, col_idx, csr_val, col_ptr, row_idx, csc_val, logpi_in, alpha, beta, pi_out, logp, qtrace, npass_out, fix_pi,
+                 threshold, softplus);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Viterbi (LHMM.py:546-609).  Bit-exact in float64: adds in the reference's order
 // (p_i + ln A_ij) -> max with first-index tie-break -> + prob[j,t].
@@ -716,15 +726,14 @@ constexpr int POST_W = PCL_POST_W;
 #else
 #define PCL_POST_ATTR
 #endif
-__global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
-                                                             const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
-                                                             const double *__restrict__ csr_val, const double *__restrict__ alpha,
-                                                             const double *__restrict__ beta, double *__restrict__ lgam,
-                                                             double *__restrict__ ksai, double *__restrict__ gamma_out,
-                                                             const double *__restrict__ logp, const int *__restrict__ kmax) {
+__device__ __forceinline__ void hmm_post_body(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                              const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                              const double *__restrict__ csr_val, const double *__restrict__ alpha,
+                                              const double *__restrict__ beta, double *__restrict__ lgam,
+                                              double *__restrict__ ksai, double *__restrict__ gamma_out,
+                                              const double *__restrict__ logp) {
     __shared__ double ms[3][POST_W][2][64];
     const UttDesc d = utts[blockIdx.x];
-    if (pcl_fb_linear_ok(kmax, blockIdx.x, d.T)) return;                      // done by hmm_postl_kernel
     const int N = d.N, T = d.T;
     const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
     const bool act = i < N;
@@ -817,6 +826,19 @@ __global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(con
     }
 }
 
+__global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+                                                             const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                             const double *__restrict__ csr_val, const double *__restrict__ alpha,
+                                                             const double *__restrict__ beta, double *__restrict__ lgam,
+                                                             double *__restrict__ ksai, double *__restrict__ gamma_out,
+                                                             const double *__restrict__ logp) {
+    hmm_post_body(utts, Bt, row_ptr, col_idx, csr_val, alpha, beta, lgam, ksai, gamma_out, logp);
+}
+
+// The scaled linear-domain forward-backward for left-to-right sentence HMMs (its kernels hand the utterances outside their
+// exponent range to the two bodies above)
+#include "hmm_fb_linear.inc"
+
 // dense ragged (N,N) xi -> values of the stored transitions in CSR (row-major) order
 __global__ void ksai_gather_kernel(const UttDesc *__restrict__ utts, const int *__restrict__ row_ptr,
                                    const int *__restrict__ col_idx, const double *__restrict__ ksai, double *__restrict__ dst) {
@@ -842,6 +864,41 @@ __global__ void clock_probe_kernel(unsigned long long spin_ticks, unsigned long 
 }
 
 }  // namespace
+
+// ---- launchers of the scaled linear-domain forward-backward (hmm_fb_linear.inc)
+bool pcl_fb_linear_enabled() {
+    const char *v = getenv("PCL_FB_LINEAR");            // read per call: the tests switch between the two paths inside one process
+    return !(v && atoi(v) == 0);
+}
+
+int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold) {
+    if (!b->Bp) {
+        TRY(dev_alloc(ctx, &b->Bp, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->alpha_e, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->beta_e, (size_t)b->sumNT));
+        TRY(dev_alloc(ctx, &b->fb_kmax, (size_t)3 * b->U));
+    }
+    hipLaunchKernelGGL(hmm_emis_pack_kernel, dim3(b->U), dim3(1024), 0, ctx->stream, b->d_utt, b->Bt, b->Bp, b->fb_kmax, b->row_ptr, b->csr_val,
+                       b->logpi);
+    hipLaunchKernelGGL(hmm_fbl_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx, b->csr_val,
+                       b->logpi, b->alpha, b->alpha_e, b->beta, b->beta_e, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, b->Bt, b->col_ptr,
+                       b->row_idx, b->csc_val, reinterpret_cast<const double2 *>(ctx->d_softplus));
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_fb_linear_post(pcl_ctx *ctx, pcl_batch *b) {
+    hipLaunchKernelGGL(hmm_postl_kernel, dim3(b->U), dim3(64 * POSTL_W), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx,
+                       b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->gamma_out, b->logp, b->Bt);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_fb_to_log(pcl_ctx *ctx, pcl_batch *b, const double *m, const int *e, double *out) {
+    hipLaunchKernelGGL(hmm_to_log_kernel, dim3(8, b->U), dim3(256), 0, ctx->stream, b->d_utt, b->fb_kmax, m, e, out);
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
 
 int pcl_launch_clock_probe(pcl_ctx *ctx, int spin_us, unsigned long long *d_out) {
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->stream_aux, (unsigned long long)spin_us * 100ULL, d_out);
@@ -874,22 +931,20 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
     static const bool one_wave = getenv("PCL_FB_ONE_WAVE") && atoi(getenv("PCL_FB_ONE_WAVE")) != 0;      // A/B: the round-1 kernel
     b->fb_linear = false;
     if (b->max_indeg <= 2 && b->max_outdeg <= 2 && NP == 64 && !one_wave) {
-        // left-to-right sentence HMMs (everything AcousticModel.embedded builds): the scaled linear-domain chain (hmm_fb_linear.hip);
-        // the log-domain kernels behind it take the utterances whose values do not fit its int32 exponents (usually none: their
-        // workgroups return at once), and everything when the structure is not left to right or PCL_FB_LINEAR=0
-        const bool lin = b->left_right && pcl_fb_linear_enabled();
-        if (lin) {
+        // left-to-right sentence HMMs (everything AcousticModel.embedded builds): the scaled linear-domain chain (hmm_fb_linear.inc),
+        // whose kernels run the log-domain bodies for the utterances that do not fit its int32 exponents (usually none); any other
+        // structure, or PCL_FB_LINEAR=0: the log-domain kernels
+        if (b->left_right && pcl_fb_linear_enabled()) {
             TRY(pcl_launch_fb_linear(ctx, b, fix_pi, threshold));
+            TRY(pcl_launch_fb_linear_post(ctx, b));
             b->fb_linear = true;
+        } else {
+            hipLaunchKernelGGL(hmm_fb2_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
+                               b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->pi_out, b->logp, b->qtrace, b->npass,
+                               fix_pi, threshold, reinterpret_cast<const double2 *>(ctx->d_softplus));
+            hipLaunchKernelGGL(hmm_post_kernel, dim3(b->U), dim3(64 * POST_W), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx, b->csr_val,
+                               b->alpha, b->beta, b->lgam, b->ksai, b->gamma_out, b->logp);
         }
-        const int *kmax = lin ? b->fb_kmax : nullptr;
-        hipLaunchKernelGGL(hmm_fb2_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
-                           b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->ksai,
-                           b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold,
-                           reinterpret_cast<const double2 *>(ctx->d_softplus), kmax);
-        if (lin) TRY(pcl_launch_fb_linear_post(ctx, b));
-        hipLaunchKernelGGL(hmm_post_kernel, dim3(b->U), dim3(64 * POST_W), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx, b->csr_val,
-                           b->alpha, b->beta, b->lgam, b->ksai, b->gamma_out, b->logp, kmax);
     } else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
         hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
