@@ -458,13 +458,15 @@ def sustained_loop(eng, batches, P, seconds, block=100):
     return n[0], total, blocks, clocks
 
 
-def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2):
+def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=3):
     """SURVEY 8(d)'s end-to-end protocol on the headline's work: every step's frames come up over PCIe and its results go down,
     both beside the kernels of the neighbouring steps.  Per step: H2D of the NEXT batch's frames into the frame slot that is not
     being scored (copy stream) | score -> Viterbi (main stream) -> forward-backward (second stream) of this batch | D2H of ln P(O),
     ln gamma_t(j) (all of it: 152 MB), the stored ln xi, the Viterbi paths and scores into page-locked buffers (download stream).
-    Two batches / two frame slots / two result sets in rotation; the host waits for a result set only when it is about to be reused."""
-    U, T = cfg['U'], cfg['T']
+    THREE batches and result sets in rotation (two frame slots): the forward-backward of step k runs beside the scoring of step
+    k+1 and its results leave during step k+2, so a batch's buffers are free again only two steps later; with two batches the
+    scoring of step k+2 waited for that download (17.3 instead of 15.7 ms per step)."""
+    U, T, NB = cfg['U'], cfg['T'], 3
     nfr = U * T
     legs = set(os.environ.get('POCCALA_PCIE_LEGS', 'h2d,d2h,vit').split(','))     # diagnosis: drop a leg to see what it costs
     pin = [eng.pinned_empty((nfr, cfg['D']), np.float32) for _ in range(2)]
@@ -474,11 +476,8 @@ def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2
     eng.stage_frames(pin[0])
     eng.swap_frames()
     batches, res = [], []
-    for k in range(2):
-        if k == 1:                             # (its chunk must be the current matrix when the batch is laid out)
-            eng.stage_frames(pin[1])
-            eng.swap_frames()
-        b = eng.label_batch(labels_all[k * U:(k + 1) * U], lens_all[k * U:(k + 1) * U], begin)
+    for k in range(NB):
+        b = eng.label_batch(labels_all[(k % 2) * U:(k % 2 + 1) * U], lens_all[(k % 2) * U:(k % 2 + 1) * U], begin)
         b.score(P); b.viterbi(); b.forward_backward(fix_pi=False)          # lazy buffers
         batches.append(b)
         res.append(b.result_buffers())
@@ -489,38 +488,44 @@ def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=2
     for k in range(total):
         if k == warm:
             eng.sync()
-            for b in batches:
-                if k >= 2:
-                    b.fetch_wait()
             t0 = time.perf_counter()
-        bt = batches[k % 2]
-        if 'h2d' in legs or k < 2:
-            eng.swap_frames()                  # chunk k is the current frame matrix (its copy had a whole step to arrive)
-            if k + 1 < total and ('h2d' in legs or k < 1):
-                eng.stage_frames(pin[(k + 1) % 2])
-        if k >= 2 and 'd2h' in legs:
+            eng.kernel_time('score'); eng.kernel_time('fb')
+        bt = batches[k % NB]
+        eng.swap_frames()                      # chunk k is the current frame matrix (its copy had a whole step to arrive)
+        if k + 1 < total and 'h2d' in legs:
+            eng.stage_frames(pin[(k + 1) % 2])
+        elif k + 1 < total:
+            eng.stage_frames(pin[(k + 1) % 2][:1])                              # (diagnosis: a one-row chunk keeps the protocol, moves nothing)
+        if k >= NB and 'd2h' in legs:
             bt.fetch_wait()                    # the host is done with this batch's previous results (a consumer would have read them)
         bt.score(P)
         if 'vit' in legs:
             bt.viterbi()
         bt.forward_backward(fix_pi=False)
-        if 'd2h' in legs or k < 2:
-            bt.fetch_async(res[k % 2] if 'vit' in legs else {q: v for q, v in res[k % 2].items() if q not in ('path', 'point')})
-    for b in batches:
-        b.fetch_wait()
+        if 'd2h' in legs:
+            bt.fetch_async(res[k % NB] if 'vit' in legs else {q: v for q, v in res[k % NB].items() if q not in ('path', 'point')})
+    if 'd2h' in legs:
+        for b in batches:
+            b.fetch_wait()
     eng.sync()
     elapsed = time.perf_counter() - t0
-    last = batches[(total - 1) % 2]
-    ok = bool(np.array_equal(res[(total - 1) % 2]['logp'], last.get('logp')) and np.array_equal(res[(total - 1) % 2]['path'], np.concatenate(last.get('path'))))
+    sc_ms, sc_n = eng.kernel_time('score')
+    fb_ms, fb_n = eng.kernel_time('fb')
+    last = batches[(total - 1) % NB]
+    ok = None
+    if 'd2h' in legs:
+        ok = bool(np.array_equal(res[(total - 1) % NB]['logp'], last.get('logp')))
+        if 'vit' in legs:
+            ok = ok and bool(np.array_equal(res[(total - 1) % NB]['path'], np.concatenate(last.get('path'))))
     bytes_down = int(sum(v.nbytes for v in res[0].values()))
     for b in batches:
         b.close()
     eng.load_frames(frames)                    # back to the resident matrix the other measurements index
     return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, legs=sorted(legs), h2d_bytes_per_step=int(pin[0].nbytes),
-                d2h_bytes_per_step=bytes_down, results_intact=ok,
+                d2h_bytes_per_step=bytes_down, results_intact=ok, score_kernel_ms=sc_ms / max(sc_n, 1), fb_span_ms=fb_ms / max(fb_n, 1),
                 what='per step: frames H2D (copy stream) | score + Viterbi + forward-backward | ln P(O), ln gamma_t(j), stored ln xi, Viterbi paths '
                      'and scores D2H into page-locked memory (download stream); wall clock over the whole pipeline, the copies overlapped '
-                     'behind the neighbouring steps\' kernels')
+                     'behind the neighbouring steps\' kernels; three batches / result sets in rotation')
 
 
 def engine_with_variant(device, variant):
@@ -1261,6 +1266,27 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
     ctl.barrier()
     elapsed = ctl.allreduce_max(time.perf_counter() - t1)
     kt = {k: eng.kernel_time(k)[0] / iters for k in names}
+    # where an iteration's wall clock goes: one more iteration with a device sync between its phases (untimed)
+    phases = {}
+    def lap(name, t0):
+        eng.sync()
+        phases[name] = (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+    tp = time.perf_counter()
+    eng.stats_zero()
+    for bt in batches:
+        bt.score(P)
+        bt.forward_backward(fix_pi=False)
+    tp = lap('score_and_forward_backward_ms', tp)
+    for bt in batches:
+        bt.accumulate(P)
+        bt.accumulate_hmm()
+    tp = lap('accumulate_ms', tp)
+    eng.em_exchange(1e-3, payload, True)
+    tp = lap('exchange_and_mstep_ms', tp)
+    for bt in batches:
+        bt.refresh_transitions()
+    tp = lap('refresh_transitions_ms', tp)
     for bt in batches:                         # (untimed: the log-likelihoods under the model the timed iterations left)
         bt.score(P)
         bt.forward_backward(fix_pi=False)
@@ -1274,7 +1300,7 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
                      'exchange + M-step (GMM and transitions), batches refreshed',
                 shape='%d utterances (%d batches of %d) x %d frames, D=%d, M=%d, %d units (J=%d), L=%d' % (C4_BATCHES * c['U'], C4_BATCHES, c['U'], c['T'], c['D'], c['M'], c['units'], c['units'] * 3, c['L']),
                 value=nfr * iters / elapsed, unit='frames/s', ms_per_iteration=elapsed / iters * 1e3, iterations=iters, n_gpus=world,
-                batches_on_this_rank=len(batches), kernel_ms_per_iteration_rank0=kt, setup_s=t_setup,
+                batches_on_this_rank=len(batches), kernel_ms_per_iteration_rank0=kt, phase_ms_rank0=phases, setup_s=t_setup,
                 loglik_mean_rank0=float(lp.mean()) if len(lp) else None, passes_max_rank0=int(npass.max()) if len(npass) else None,
                 states_seen_rank0=int((st['alpha_acc'] > 0).sum()),
                 what='the configuration BASELINE.json states (8192 utterances), not the per-GPU share the headline loop times; the model moves from iteration to iteration (EM)')
