@@ -31,6 +31,14 @@ class AcousticModel(DataInitialization):
         self.__address = parameters_path or os.environ.get('parameters_file_path', '.')
         self.__loaded_units = []
         self.processes = processes or 1
+        # the two workers at batched speed (multi_embedded_training_1 / multi_process_data below): what the calls queued
+        self.__queued = {'train': [], 'align': []}
+        self.__queued_frames = 0
+        self.__data_files = 0
+        self.flush_frames = 1 << 19            # flush by itself once this many frames are queued (bounds the host copy)
+        self.worker_precision = None           # None: f32-class E-step, float64 alignment (bit-exact paths)
+        self.worker_units = None               # {unit: LHMM}: unit models held in memory instead of re-read from the parameter tree
+        self.worker_engine = None
 
     loaded_units = property(lambda self: self.__loaded_units)
     statenum = property(lambda self: self.__state_num)
@@ -273,6 +281,94 @@ class AcousticModel(DataInitialization):
         d = np.asarray(data_list[0]).shape[1]
         return ({unit: [np.concatenate(parts, axis=0) if parts else np.zeros((0, d)) for parts in slots]
                  for unit, slots in out.items()}, dropped)
+
+    # ------------------------------------------------------------------ the reference's two workers, at batched speed
+    # The reference fans its corpus out over a Pool, one call per utterance (AcousticModel.py:861-870, :709-712): every call
+    # builds one LHMM per label position, scores, embeds, runs Baum-Welch / Viterbi and writes files.  Called like that, one
+    # utterance at a time, a GPU sees 300 frames per launch (extra.zero_change_route: ~5 k frames/s).  The two methods below keep
+    # the reference's signatures and file outputs but DEFER the work: a call queues (label, data); flush_workers() -- called by
+    # the caller after its loop, and by itself every `flush_frames` frames -- runs everything queued as one batch through
+    # estep_batch / segment_batch and writes what the per-utterance workers would have written, merged per unit:
+    #   multi_embedded_training_1 -> <unit>/HMM/{ksai-acc,gamma-acc}/*.npy, <unit>/GMM_k/{acc,alpha-acc,mean-acc,covariance-acc}/*.npy
+    #                                (one file set per unit and flush instead of one per utterance x label position; the merge of
+    #                                 multi_embedded_training_2 -- LHMM.init_acc / GMM.init_acc, a log-sum-exp over the files --
+    #                                 gives the same sums)
+    #   multi_process_data        -> <unit>/data/*.pkl, one pickle per contiguous run of the unit (AcousticModel.__save_data)
+    # No Pool, no Controller: only these two entry points.
+    def _worker_units(self, units, init):
+        if self.worker_units is not None:
+            return {u: self.worker_units[u] for u in units}
+        out = {}
+        for u in units:                          # init_unit + init_parameter ONCE per unit and flush (the reference: per label position)
+            hmm = self.init_unit(unit=u, new_log=init)
+            self.init_parameter(unit=u, hmm=hmm)
+            out[u] = hmm
+        return out
+
+    def multi_embedded_training_1(self, label, data, init, *args):
+        """AcousticModel.multi_embedded_training_1(label, data, init, show_q, load_num, file_count, fix_code)
+        (AcousticModel.py:884-916), deferred: see flush_workers."""
+        fix_code = int(args[3]) if len(args) > 3 else 0
+        self.__queued['train'].append((list(label), np.asarray(data), bool(init), fix_code))
+        self.__queued_frames += len(data)
+        if self.__queued_frames >= self.flush_frames:
+            self.flush_workers()
+
+    def multi_process_data(self, label, data, init, *args):
+        """AcousticModel.multi_process_data(label, data, init, load_num, file_count, fix_code) (AcousticModel.py:723-768):
+        init -> the utterance is cut into equal chunks per label unit at once (__eq_segment mode 'e', host work); otherwise the
+        forced alignment is deferred: see flush_workers."""
+        if init:
+            self.eq_segment(np.asarray(data), list(label), mode='e', save=self.save_data)
+            return
+        self.__queued['align'].append((list(label), np.asarray(data), False, 0))
+        self.__queued_frames += len(data)
+        if self.__queued_frames >= self.flush_frames:
+            self.flush_workers()
+
+    def save_data(self, unit, unit_data):
+        """AcousticModel.__save_data (AcousticModel.py:331-351): one pickle per block under <unit>/data/ (the reference names the
+        file by pid and second, so two blocks of one second overwrite each other; a running number is appended here)."""
+        import pickle
+        import time
+        path = self.unit_path(unit) + '/data'
+        os.makedirs(path, exist_ok=True)
+        self.__data_files += 1
+        with open('%s/%s_data_%s_%s_%06d.pkl' % (path, unit, os.getpid(), int(time.time()), self.__data_files), 'wb') as f:
+            pickle.dump(unit_data, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def flush_workers(self):
+        """Run everything multi_embedded_training_1 / multi_process_data queued, as batches.  Returns
+        {'train': (utterances, frames, logp array), 'align': (utterances, frames, dropped utterance indices)}."""
+        out = {}
+        queued, self.__queued = self.__queued, {'train': [], 'align': []}
+        self.__queued_frames = 0
+        eng = self.worker_engine
+        if queued['train']:
+            lp_all, n_utt, n_fr = [], 0, 0
+            for fix_code in sorted({q[3] for q in queued['train']}):          # (one E-step per fix_code: it decides what is accumulated)
+                part = [q for q in queued['train'] if q[3] == fix_code]
+                labels, datas = [q[0] for q in part], [q[1] for q in part]
+                units = self._worker_units(sorted({u for lab in labels for u in lab}), part[0][2])
+                stats, hmm_acc, logp = self.estep_batch(labels, datas, units, fix_code=fix_code,
+                                                        precision=PCL_F32 if self.worker_precision is None else self.worker_precision, engine=eng)
+                self.save_batch_acc(stats, hmm_acc, units)
+                lp_all.append(logp)
+                n_utt += len(part)
+                n_fr += int(sum(len(d) for d in datas))
+            out['train'] = (n_utt, n_fr, np.concatenate(lp_all))
+        if queued['align']:
+            labels, datas = [q[0] for q in queued['align']], [q[1] for q in queued['align']]
+            units = self._worker_units(sorted({u for lab in labels for u in lab}), False)
+            blocks, dropped = self.segment_batch(labels, datas, units, precision=PCL_F64 if self.worker_precision is None else self.worker_precision,
+                                                 engine=eng)
+            for unit, runs in blocks.items():                                   # AcousticModel.py:758-764
+                for run in runs:
+                    self.save_data(unit, run)
+            for u in dropped:
+                self.log.note('viterbi切分失败', cls='w')                         # AcousticModel.py:755 (the utterance is discarded)
+            out['align'] = (len(labels), int(sum(len(d) for d in datas)), dropped)
+        return out
 
     def save_batch_acc(self, stats, hmm_acc, unit_hmms):
         """Write the result of `estep_batch` as reference-format accumulator files (log domain, float64,

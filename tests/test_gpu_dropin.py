@@ -351,3 +351,62 @@ def test_per_gmm_calls_do_not_disturb_a_batched_estep_in_flight(golden):
     twice = eng.stats_download()
     np.testing.assert_allclose(twice['acc'], 2 * before['acc'], rtol=1e-12)
     b.close()
+
+
+@pytest.mark.parametrize('case', ['G6_small_fix0', 'G6_small_fix1', 'G6_small_fix4', 'G6_n62_fix0'])
+@pytest.mark.parametrize('prec', ['f64', 'f32'])
+def test_worker_flow_through_the_deferred_shim(golden, tmp_path, case, prec):
+    """The reference's two workers called with THEIR signatures (multi_embedded_training_1(label, data, init, show_q, load_num,
+    file_count, fix_code), AcousticModel.py:884-916; multi_process_data(label, data, init, load_num, file_count, fix_code),
+    :723-768) on the drop-in's deferred-batch shim: the calls queue, flush_workers() runs one batched E-step / alignment and
+    writes the reference's files.  What multi_embedded_training_2's merge (init_acc: a log-sum-exp over the accumulator files)
+    then reads must equal the golden per-position accumulators of the reference merged per unit; the data pickles must be the
+    reference's runs (discriminate) of the golden Viterbi path.  The utterance is queued TWICE: every accumulator doubles."""
+    import pickle
+    from poccala_amd import PCL_F32, PCL_F64
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    g = golden(case)
+    fix = int(g['fix_code'])
+    x = g['x']
+    label, hmm_list = build_units(g)
+    am = AcousticModel(RecLog(), 'XIF_tone', state_num=S, mix_level=int(g['w_0_0'].shape[0]), dct_num=x.shape[1], delta_1=False, delta_2=False,
+                       parameters_path=str(tmp_path))
+    for pos, u in enumerate(label):                           # the parameter tree the workers read their unit models from
+        am.save_parameter(u, hmm_list[pos])
+    am.worker_precision = PCL_F64 if prec == 'f64' else PCL_F32
+    # ---- E-step worker
+    for n in range(2):
+        am.multi_embedded_training_1(label, x, False, False, n + 1, 2, fix)
+    out = am.flush_workers()
+    assert out['train'][0] == 2 and out['train'][1] == 2 * len(x)
+    rt, at = (1e-8, 1e-10) if prec == 'f64' else (1e-4, 1e-4)
+    ln2 = np.log(2.0)
+    for u in sorted(set(label)):
+        pos_u = [p for p, v in enumerate(label) if v == u]
+        hmm = am.init_unit(u)
+        am.init_parameter(u, hmm)
+        hmm.init_acc(am.unit_path(u))
+        if not fix & 4:
+            rk = np.logaddexp.reduce([g['ksai_acc_%d' % p] for p in pos_u], axis=0) + ln2
+            rg = np.logaddexp.reduce([g['gamma_acc_%d' % p] for p in pos_u], axis=0) + ln2
+            fin_close(hmm.ksai_acc, rk, rtol=1e-10)
+            fin_close(hmm.gamma_acc, rg, rtol=1e-10)
+        if not fix & 2:
+            for k in range(S - 2):
+                gm = hmm.profunction[1 + k]
+                gm.init_acc(am.unit_path(u))
+                for name, got in (('acc', gm.acc), ('alpha_acc', np.float64(gm.alpha_acc)), ('mean_acc', gm.mean_acc),
+                                  ('cov_acc', np.array(gm._GMM__covariance_acc))):
+                    want = np.logaddexp.reduce([g['%s_%d_%d' % (name, p, k)] for p in pos_u], axis=0) + ln2
+                    fin_close(got, want, rtol=rt, atol=at)
+    # ---- alignment worker
+    am.multi_process_data(label, x, False, 1, 1, 2)
+    out = am.flush_workers()
+    assert out['align'][0] == 1 and out['align'][2] == []
+    for u in sorted(set(label)):
+        d = am.unit_path(u) + '/data'
+        blocks = [pickle.load(open(os.path.join(d, f), 'rb')) for f in sorted(os.listdir(d))]
+        want = [x[g['disc_%s_%d' % (u, ri)]] for ri in range(int(g['disc_%s_n' % u]))]
+        assert len(blocks) == len(want)
+        for b_, w_ in zip(blocks, want):
+            assert np.array_equal(b_, w_)
