@@ -1193,9 +1193,35 @@ def other_configs(args, device):
                                   'G14 from the reference itself; first-word seeding, word-to-word hand-over, node-keyed tokens, the finished test on the '
                                   'last emitting state and the frame order (rules D1-D5) are the builder\'s completion, not the reference\'s')
     b.close()
+    # config 5 at its stated size: the 1M-frame corpus streamed through the same engine (model, units and tree are loaded)
+    try:
+        run_c5_full(e, tree, args.max_tokens, n_chunks=3)                       # warm: batches per chunk shape, staging buffers, clocks
+        out['C5'] = run_c5_full(e, tree, args.max_tokens)
+        out['C5_ragged'] = run_c5_full(e, tree, args.max_tokens, ragged=True)
+    except Exception as ex:                    # noqa: never the headline's problem
+        out['C5'] = dict(error=repr(ex))
     e.close()
+    # config 4 at its stated size: 8192 utterances through one whole EM iteration on this GPU
+    try:
+        from poccala_amd import PCL_F64
+        e = Engine(device)
+        e.enable_timing(True)
+        out['C4'] = run_c4_full(e, _Solo(), PCL_F32, PCL_F64, iters=1, warm=1)
+        e.close()
+    except Exception as ex:                    # noqa
+        out['C4'] = dict(error=repr(ex))
     return out
 
+
+class _Solo(object):
+    """the control plane of a one-rank job (what run_c4_full needs of poccala_amd.distributed.Control)."""
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def allreduce_max(self, x):
+        return x
 
 
 # ------------------------------------------------------------------------------------------------

@@ -402,6 +402,10 @@ def test_worker_flow_through_the_deferred_shim(golden, tmp_path, case, prec):
     # ---- alignment worker
     am.multi_process_data(label, x, False, 1, 1, 2)
     out = am.flush_workers()
+    if len(set(g['vit_path_conv'].astype(str))) < len(set(label)):          # the path misses a label unit: the reference discards the utterance (:754-757)
+        assert out['align'][0] == 1 and out['align'][2] == [0]
+        assert not any(os.path.isdir(am.unit_path(u) + '/data') for u in set(label))
+        return
     assert out['align'][0] == 1 and out['align'][2] == []
     for u in sorted(set(label)):
         d = am.unit_path(u) + '/data'
