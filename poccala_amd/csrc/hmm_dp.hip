@@ -876,9 +876,9 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
         TRY(dev_alloc(ctx, &b->Bp, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->alpha_e, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->beta_e, (size_t)b->sumNT));
-        TRY(dev_alloc(ctx, &b->fb_kmax, (size_t)3 * b->U));
+        TRY(dev_alloc(ctx, &b->fb_kmax, (size_t)PCL_FB_KREC * b->U));
     }
-    hipLaunchKernelGGL(hmm_emis_pack_kernel, dim3(b->U), dim3(1024), 0, ctx->stream, b->d_utt, b->Bt, b->Bp, b->fb_kmax, b->row_ptr, b->csr_val,
+    hipLaunchKernelGGL(hmm_emis_pack_kernel, dim3(PACK_BLOCKS, b->U), dim3(256), 0, ctx->stream, b->d_utt, b->Bt, b->Bp, b->fb_kmax, b->row_ptr, b->csr_val,
                        b->logpi);
     hipLaunchKernelGGL(hmm_fbl_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx, b->csr_val,
                        b->logpi, b->alpha, b->alpha_e, b->beta, b->beta_e, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, b->Bt, b->col_ptr,

@@ -227,13 +227,18 @@ constexpr int LE_ZADD = -(1 << 29);
 constexpr int LE_FLOOR = -(1 << 30);
 constexpr int LE_PZ = -(1 << 28);
 constexpr int LE_LIMIT = 1 << 26;
-// does utterance u (T frames) fit the int32 exponents and the packed emission word?  kmax = per utterance
-// [max |k| of the emissions, of ln A, of the caller's ln pi] (k = power of two of exp(.)), written by hmm_emis_pack_kernel;
-// nullptr = the scaled kernels are not in use (every utterance is the log-domain kernels')
+// does utterance u (T frames) fit the int32 exponents and the packed emission word?  kmax = per utterance a record of
+// PCL_FB_KREC ints written by hmm_emis_pack_kernel: max |k| (k = power of two of exp(.)) of the emissions, one per packing
+// workgroup [0..7], of ln A [8], of the caller's ln pi [9]; nullptr = the scaled kernels are not in use
+constexpr int PCL_FB_KREC = 10;
 __device__ __forceinline__ bool pcl_fb_linear_ok(const int *kmax, int u, int T) {
     if (!kmax) return false;
-    const long long kb = kmax[3 * u], ka = kmax[3 * u + 1], kp = kmax[3 * u + 2];
-    return kb < 32760 && (kb + ka + 4) * (long long)(T + 2) + kp < (long long)LE_LIMIT;
+    const int *r = kmax + (size_t)PCL_FB_KREC * u;
+    int kb = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) kb = max(kb, r[k]);
+    const long long ka = r[8], kp = r[9];
+    return kb < 32760 && ((long long)kb + ka + 4) * (long long)(T + 2) + kp < (long long)LE_LIMIT;
 }
 
 // ---------------------------------------------------------------- error helpers
