@@ -805,7 +805,7 @@ def committed_traffic():
         now = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
     except OSError:
         now = None
-    for name in ('r03_bench_summary.txt', 'r02_bench_summary.txt'):
+    for name in ('r04_bench_summary.txt', 'r03_bench_summary.txt', 'r02_bench_summary.txt'):
         try:
             fetch = write = sha = None
             for line in open(os.path.join(ROOT, 'profiles', name)):

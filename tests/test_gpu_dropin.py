@@ -389,8 +389,9 @@ def test_worker_flow_through_the_deferred_shim(golden, tmp_path, case, prec):
         if not fix & 4:
             rk = np.logaddexp.reduce([g['ksai_acc_%d' % p] for p in pos_u], axis=0) + ln2
             rg = np.logaddexp.reduce([g['gamma_acc_%d' % p] for p in pos_u], axis=0) + ln2
-            fin_close(hmm.ksai_acc, rk, rtol=1e-10)
-            fin_close(hmm.gamma_acc, rg, rtol=1e-10)
+            # (log-domain, un-normalised: under f32-class scoring ln P(O) itself moves by ~1e-6; 1e-4 absolute = 1e-4 relative on xi / gamma)
+            fin_close(hmm.ksai_acc, rk, rtol=1e-10 if prec == 'f64' else 0.0, atol=0.0 if prec == 'f64' else 1e-4)
+            fin_close(hmm.gamma_acc, rg, rtol=1e-10 if prec == 'f64' else 0.0, atol=0.0 if prec == 'f64' else 1e-4)
         if not fix & 2:
             for k in range(S - 2):
                 gm = hmm.profunction[1 + k]

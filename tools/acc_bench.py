@@ -14,9 +14,10 @@ eng.load_model(mean, var, w); eng.load_frames(frames)
 b, n = make_sentence_batch(eng, labels, lens, begin, trans)
 b.score(PCL_F32); b.forward_backward(fix_pi=False)
 eng.stats_zero(); b.accumulate(PCL_F32); eng.sync(); eng.kernel_time('accumulate')
-for _ in range(3):
+PASSES = int(os.environ.get('ACC_PASSES', '4')) - 1            # (+ the warm-up pass above: ACC_PASSES passes in the trace)
+for _ in range(PASSES):
     eng.stats_zero(); b.accumulate(PCL_F32)
 ms, k = eng.kernel_time('accumulate')
 st = eng.stats_download()
 print('%s: accumulate %.2f ms/pass   sum acc = %.6f (frames x states occupancy), alpha_acc sum = %.6f' % (
-    os.path.basename(os.environ.get('POCCALA_HIP_LIB', 'default')), ms / k, st['acc'].sum() / 4, st['alpha_acc'].sum() / 4))
+    os.path.basename(os.environ.get('POCCALA_HIP_LIB', 'default')), ms / k, st['acc'].sum(), st['alpha_acc'].sum()))

@@ -45,7 +45,7 @@ def pick(kt, name):
 
 
 # ---------------------------------------------------------------- bench.py (score + forward-backward)
-out = ['# rocprofv3 summaries, %s: python3 bench.py --steps 3 --warmup 1 --cpu-baseline 0 --extra 0 (one MI355X, C4 shard)' % RND,
+out = ['# rocprofv3 summaries, %s: python3 bench.py --steps 20 --warmup 2 --cpu-baseline 0 --extra 0 --sustain 0 (one MI355X, C4 shard)' % RND,
        '# produced by tools/gpu_profile.sh + tools/make_profile_summary.py; one --kernel-trace --stats pass and separate --pmc passes',
        '', '## --kernel-trace --stats (%s_bench_kernel_stats.csv)' % RND]
 import hashlib
@@ -53,7 +53,7 @@ _src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 out.insert(2, 'kernel_source_sha16 gmm_score_split.hip %s' % hashlib.sha256(open(_src, 'rb').read()).hexdigest()[:16])   # bench.py withholds `traffic` when the source has moved on
 kt, lines = kernel_stats('bench_trace', '%s_bench_kernel_stats.csv' % RND)
 out += lines + ['', '## --pmc passes (<= 4 counters per pass, no trace domains), per-dispatch averages']
-lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fb'])
+lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fbl_kernel', 'hmm_postl_kernel', 'hmm_emis_pack_kernel'])
 out += lines
 try:
     v = val['gmm_score_split16_kernel']
@@ -79,7 +79,8 @@ except (KeyError, IndexError) as e:
 open(os.path.join(P, '%s_bench_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
 
 # ---------------------------------------------------------------- accumulate pass (tools/acc_bench.py)
-out = ['# rocprofv3 summaries, %s: python3 tools/acc_bench.py (one MI355X, C4 shard, flat posteriors: 4 accumulate passes, 7 state groups each)' % RND,
+ACC_PASSES = int(os.environ.get('ACC_PASSES', '4'))
+out = ['# rocprofv3 summaries, %s: python3 tools/acc_bench.py (one MI355X, C4 shard, flat posteriors: %d accumulate passes)' % (RND, ACC_PASSES),
        '', '## --kernel-trace --stats (%s_accumulate_kernel_stats.csv)' % RND]
 kt, lines = kernel_stats('acc_trace', '%s_accumulate_kernel_stats.csv' % RND)
 out += lines + ['', '## --pmc passes (<= 4 counters per pass), per-dispatch averages']
@@ -93,8 +94,8 @@ try:
     cyc = v['GRBM_GUI_ACTIVE'] / 8
     mf = v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024
     wc = v['SQ_WAVE_CYCLES']
-    out += ['', '## derived (acc16_consumer_kernel<39>, per dispatch = one state group; %d dispatches in 4 passes)' % n,
-            'consumer %.2f ms/dispatch, producer %.2f ms/dispatch; per pass: %d groups' % (ms, pick(kt, 'acc16_producer_kernel'), n // 4),
+    out += ['', '## derived (acc16_consumer_kernel<39>, per dispatch = one state group; %d dispatches in %d passes)' % (n, ACC_PASSES),
+            'consumer %.2f ms/dispatch, producer %.2f ms/dispatch; per pass: %d groups' % (ms, pick(kt, 'acc16_producer_kernel'), n // ACC_PASSES),
             'GRBM_GUI_ACTIVE %.4g (sum of 8 XCDs) -> clock held %.2f GHz; SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs = %.3g cycles -> matrix pipe %.0f %% busy'
             % (v['GRBM_GUI_ACTIVE'], cyc / ms / 1e6, mf, 100 * mf / cyc),
             'wave time: SQ_WAIT_ANY %.0f %% (s_waitcnt / barrier), SQ_WAIT_INST_ANY %.0f %% (issue stalls: pipe, dependencies), SQ_ACTIVE_INST_ANY %.0f %% of SQ_WAVE_CYCLES'
@@ -105,6 +106,29 @@ try:
 except (KeyError, IndexError, ZeroDivisionError) as e:
     out.append('(derived block incomplete: %r)' % (e,))
 open(os.path.join(P, '%s_accumulate_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
+
+# ---------------------------------------------------------------- forward-backward alone (tools/fb_bench.py: 62-state sentence HMMs x 300 frames)
+out = ['# rocprofv3 summaries, %s: python3 tools/fb_bench.py U (one MI355X; U sentence HMMs of 62 states x 300 frames, random emissions, nothing beside them;' % RND,
+       '# 60 + 20 launches with a free pi (3 passes) and as many with a locked one: the scaled linear-domain route of csrc/hmm_fb_linear.inc)']
+for U in (128, 1024):
+    kt, lines = kernel_stats('fb%d_trace' % U, '%s_fb%d_kernel_stats.csv' % (RND, U))
+    out += ['', '## U = %d: --kernel-trace --stats' % U] + [l for l in lines if 'hmm_' in l]
+    lines, val = counters(['fb%d_mem' % U, 'fb%d_clk' % U, 'fb%d_sq1' % U, 'fb%d_sq2' % U], ['hmm_fbl_kernel', 'hmm_postl_kernel', 'hmm_emis_pack_kernel'])
+    out += ['## U = %d: --pmc passes, per-dispatch averages' % U] + lines
+    try:
+        steps = 299 * 3.5                       # chain steps per launch, averaged over the free-pi (4 walks: beta + 3 alpha) and locked-pi (2 walks) halves
+        for name in ('hmm_emis_pack_kernel', 'hmm_fbl_kernel', 'hmm_postl_kernel'):
+            v = val[name]
+            ms = pick(kt, name)
+            cyc = v['GRBM_GUI_ACTIVE'] / 8
+            wc = v['SQ_WAVE_CYCLES']
+            gb = (v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 / 1e9
+            out.append('derived %-22s %.3f ms/launch, clock %.2f GHz, FETCH+WRITE %.3f GB raw = %.2f TB/s; wave time: waiting (s_waitcnt / barrier) %.0f %%, issue stalls %.0f %%, issuing %.0f %%; %.3g VALU + %.3g SALU instructions per wave-launch'
+                       % (name, ms, cyc / ms / 1e6, gb, gb / ms, 100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, 100 * v['SQ_ACTIVE_INST_ANY'] / wc,
+                          v['SQ_INSTS_VALU'] / (U * (2 if 'fbl' in name else 8)), v['SQ_INSTS_SALU'] / (U * (2 if 'fbl' in name else 8))))
+    except (KeyError, IndexError, ZeroDivisionError) as e:
+        out.append('(derived block incomplete: %r)' % (e,))
+open(os.path.join(P, '%s_fb_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
 
 # ---------------------------------------------------------------- C5 shard: all-state scoring + token passing (tools/c5_decode_bench.py)
 out = ['# rocprofv3 summaries, %s: python3 tools/c5_decode_bench.py 417 4096 20000 3 8192 (one MI355X: BASELINE config 5 per-GPU shard, 417 x 300 frames,' % RND,
