@@ -119,14 +119,21 @@ struct Fast<double> {
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 };
 
+// MASTER = true (the masked fix-up of the matrix-pipe pass): a lane makes its mixture's row [s_d c_d ... k2] and its mean from the
+// float64 master copy with derive_kernel's arithmetic, so params32 / mean32 need not exist for it (see gmm_score.hip, MasterModel).
+struct AccMaster {
+    const double *mean64, *var64, *w64;
+    int M, Dhost, flags;
+};
+
 // grid = (mixture slices, states with work).  A lane owns mixture `m` of state `j`.
-template <int D, typename real, int MINW>
+template <int D, typename real, int MINW, bool MASTER = false>
 __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     const real *__restrict__ frames, const real *__restrict__ params, const real *__restrict__ means, int Mpad,
     const int *__restrict__ work_states, const int *__restrict__ seg_lo, const int *__restrict__ seg_hi,
     const long long *__restrict__ off, const ActiveFrame *__restrict__ list, double bias, double *__restrict__ st_acc,
     double *__restrict__ st_alpha, double *__restrict__ st_mean, double *__restrict__ st_cov,
-    const int *__restrict__ tile_off, const unsigned int *__restrict__ tile_mask, const int *__restrict__ state_flag) {
+    const int *__restrict__ tile_off, const unsigned int *__restrict__ tile_mask, const int *__restrict__ state_flag, AccMaster mm) {
     // tile_mask != NULL (fix-up of the f16 producer / consumer path, gmm_accumulate_f16.hip): only the frames whose bit is set
     // in their 32-frame tile's mask are accumulated -- the ones that path took out because a scaled feature left the f16
     // range -- and alpha_acc is left alone (the consumer summed gamma_t(j) of every frame).
@@ -143,23 +150,49 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     if (beg == end) return;
     const int m = blockIdx.x * WG + threadIdx.x;
     const bool live = m < Mpad;
-    const real *p = params + ((size_t)j * Mpad + (live ? m : 0)) * ROW;
+    const real *p = MASTER ? nullptr : params + ((size_t)j * Mpad + (live ? m : 0)) * ROW;
+    const size_t jm_ld = (size_t)j * Mpad + (live ? m : 0);
 
     // f32: the 2D scoring parameters stay in VGPRs for the whole pass.  f64 (parity mode) re-reads them
     // (L1-resident, 632 B per lane): with them resident the kernel needs > 256 VGPRs per lane and hipcc's
     // AGPR spill code for 64-bit values returned doubles with damaged low words (2^-20 relative errors).
     constexpr bool PREG = sizeof(real) == 4;
     real s[PREG ? D : 1], c[PREG ? D : 1], S1[D], S2[D];
+    static_assert(!MASTER || PREG, "the on-the-fly rows are the f32 fix-up's");
+    real k2;
+    if (MASTER) {
+        constexpr double L2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
+        const bool real_m = live && m < mm.M;
+        double tail = 0.0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (PREG) {
-            s[d] = p[2 * d];
-            c[d] = p[2 * d + 1];
+        for (int d = 0; d < D; ++d) {
+            real sv = 0, cv = 0;
+            if (real_m && d < mm.Dhost) {
+                const double v = mm.var64[jm_ld * D + d], mu = mm.mean64[jm_ld * D + d];
+                const float a = (float)(-L2E * (0.5 / v));
+                const float sf = sqrtf(-a);
+                sv = (real)sf;
+                cv = (real)(float)(-mu * (double)sf);
+                tail += (mm.flags & PCL_MODEL_LOGDET) ? log(v) : v;
+            }
+            s[PREG ? d : 0] = sv;
+            c[PREG ? d : 0] = cv;
+            S1[d] = 0;
+            S2[d] = 0;
         }
-        S1[d] = 0;
-        S2[d] = 0;
+        k2 = real_m ? (real)(float)(L2E * (log(mm.w64[jm_ld]) - 0.5 * mm.Dhost * LOG_2PI - 0.5 * tail)) : (real)-INFINITY;
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (PREG) {
+                s[d] = p[2 * d];
+                c[d] = p[2 * d + 1];
+            }
+            S1[d] = 0;
+            S2[d] = 0;
+        }
+        k2 = p[2 * D];
     }
-    const real k2 = p[2 * D];
     real S0 = 0;
     double galpha = 0.0;  // slice 0 only: sum_t gamma_t(j)
     constexpr double LOG2E = 1.4426950408889634074;
@@ -206,13 +239,14 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
         const size_t jm = (size_t)j * Mpad + m;
         const double a0 = (double)S0;
         st_acc[jm] += a0;                                                   // Clustering.py:665
-        const real *mu = means + jm * D;
+        const real *mu = MASTER ? nullptr : means + jm * D;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const double sd = (double)(PREG ? s[d] : p[2 * d]);
             if (sd > 0.0) {
                 // sum g (o + bias) = sum g (o - mu) + (mu + bias) sum g    (Clustering.py:669-672)
-                st_mean[jm * D + d] += (double)S1[d] / sd + ((double)mu[d] + bias) * a0;
+                const double mud = MASTER ? (double)(float)mm.mean64[jm * D + d] : (double)mu[d];      // (mean32 holds the f32 rounding)
+                st_mean[jm * D + d] += (double)S1[d] / sd + (mud + bias) * a0;
                 st_cov[jm * D + d] += (double)S2[d] / (sd * sd);            // Clustering.py:674-678
             }
         }
@@ -511,9 +545,16 @@ void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *pa
                   const int *tile_off = nullptr, const unsigned int *tile_mask = nullptr, const int *state_flag = nullptr) {
     if (count == 0) return;
     dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)count);
+    if (tile_mask && sizeof(real) == 4) {                              // the masked fix-up: rows from the master copy
+        const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags};
+        hipLaunchKernelGGL((gmm_accumulate_kernel<D, float, MINW, true>), grid, dim3(WG), 0, ctx->stream, (const float *)frames, (const float *)nullptr,
+                           (const float *)nullptr, ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0,
+                           ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag, mm);
+        return;
+    }
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
                        ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
-                       ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag);
+                       ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag, AccMaster{});
 }
 
 // f32, states [first, first + count) of the accumulate order (optionally only the frames a tile mask marks)
@@ -728,6 +769,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     }
     if (precision == PCL_F32) {
         const int first = mfma ? n_good : 0, count = mfma ? n_bad : (int)ns;
+        if (count > 0) TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P32));   // whole states on the direct-form kernel: its layouts, derived on first use
         if (device_dim_supported(D)) launch_acc_f32(ctx, b, first, count);
         else PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no f32 accumulate kernel for padded D=%d", D);
     } else {

@@ -60,12 +60,21 @@ struct Fast<double> {
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
 };
 
-template <int D, int R, int CH, typename real>
+// The float64 master copy of a state's parameters, for the FIX-UP launches (MASTER = true): the rows [s_d c_d ... k2] the kernel
+// reads are made on the fly from (mean, var, weight) with derive_kernel's arithmetic (model_derive.hip) while they are staged in
+// LDS, so the 3 GB of direct-form layouts (params32, mean32) need not exist unless a whole state is scored by this kernel: they
+// fed the fix-up paths only, and a flagged tile pays D square roots per mixture against 2 D x 256 FMAs.
+struct MasterModel {
+    const double *mean64, *var64, *w64;
+    int M, Dhost, flags;
+};
+
+template <int D, int R, int CH, typename real, bool MASTER = false>
 __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict__ frames,
                                                           const real *__restrict__ params, int Mpad,
                                                           const ScoreTile *__restrict__ tiles,
                                                           const ScoreSeg *__restrict__ segs,
-                                                          double *__restrict__ out, const int *__restrict__ flags) {
+                                                          double *__restrict__ out, const int *__restrict__ flags, MasterModel mm) {
     constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
     __shared__ __attribute__((aligned(16))) real lds[CH * ROW];
 
@@ -108,7 +117,36 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
     for (int c0 = 0; c0 < Mpad; c0 += CH) {
         const int n = min(CH, Mpad - c0);
         __syncthreads();
-        {
+        if (MASTER) {
+            constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
+            const size_t jm0 = (size_t)tile.state * Mpad + c0;
+            for (int i = threadIdx.x; i < n * D; i += WG) {
+                const int ml = i / D, d = i - ml * D;
+                const bool ok = (c0 + ml) < mm.M && d < mm.Dhost;
+                real sv = 0, cv = 0;
+                if (ok) {
+                    const double v = mm.var64[(jm0 + ml) * D + d], mu = mm.mean64[(jm0 + ml) * D + d];
+                    const float a = (float)(-LOG2E * (0.5 / v));             // (derive_kernel: s = sqrt(-a) from the f32 coefficient)
+                    const float sf = sqrtf(-a);
+                    sv = (real)sf;
+                    cv = (real)(float)(-mu * (double)sf);
+                }
+                lds[ml * ROW + 2 * d] = sv;
+                lds[ml * ROW + 2 * d + 1] = cv;
+            }
+            for (int ml = threadIdx.x; ml < n; ml += WG) {
+                double k2 = -INFINITY;
+                if (c0 + ml < mm.M) {
+                    double tail = 0.0;                                       // util.py:29 (quirk Q1): sum(var); the log-determinant only on request
+                    for (int d = 0; d < mm.Dhost; ++d) {
+                        const double v = mm.var64[(jm0 + ml) * D + d];
+                        tail += (mm.flags & PCL_MODEL_LOGDET) ? log(v) : v;
+                    }
+                    k2 = LOG2E * (log(mm.w64[jm0 + ml]) - 0.5 * mm.Dhost * LOG_2PI - 0.5 * tail);
+                }
+                lds[ml * ROW + 2 * D] = (real)(float)k2;
+            }
+        } else {
             constexpr int VEC = 16 / sizeof(real);
             const real *src = pbase + (size_t)c0 * ROW;
             for (int i = threadIdx.x * VEC; i < n * ROW; i += WG * VEC) {
@@ -199,7 +237,7 @@ __global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *
 template <int D, int R, int CH, typename real>
 void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const ScoreTile *tiles, int n_tiles) {
     hipLaunchKernelGGL((gmm_score_kernel<D, R, CH, real>), dim3(n_tiles), dim3(WG), 0, ctx->stream, frames, params,
-                       ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr);
+                       ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, MasterModel{});
 }
 
 // frames per lane for each (D, precision); the tile is WG * R frames.  x[R][D] must stay in VGPRs
@@ -233,8 +271,9 @@ int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, i
     const int tf = pcl_score_split16_tile_frames(), R = tf / WG;      // frames per lane so that a workgroup covers the same tile
     if (tf % WG || (R != 1 && R != 2)) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: fix-up tile size mismatch");
     pcl_timer_begin(ctx, "score_fixup");
-#define LAUNCHF(DD, RR) hipLaunchKernelGGL((gmm_score_kernel<DD, RR, PCL_CH32, float>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
-                                           ctx->params32, ctx->Mpad, tiles, b->d_segs, b->Bt, flags)
+    const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags};      // (no params32 needed: see MasterModel)
+#define LAUNCHF(DD, RR) hipLaunchKernelGGL((gmm_score_kernel<DD, RR, PCL_CH32, float, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
+                                           (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, flags, mm)
 #define CASEF(DD) case DD: if (R == 1) LAUNCHF(DD, 1); else LAUNCHF(DD, 2); break;
     switch (ctx->D) {
         CASEF(13) CASEF(26) CASEF(39) CASEF(47)
@@ -251,6 +290,7 @@ int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile 
     if (n_tiles == 0) return PCL_OK;
     const int D = ctx->D;
     const char *tname = (tiles == b->d_tiles_v) ? "score_direct" : "score";   // the ill-conditioned remainder is timed apart
+    if (precision == PCL_F32) TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P32));     // (derived on first use: whole states on this kernel are the exception)
     pcl_timer_begin(ctx, tname);
     if (precision == PCL_F32) {
         switch (D) {

@@ -877,6 +877,7 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
         TRY(dev_alloc(ctx, &b->alpha_e, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->beta_e, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->fb_kmax, (size_t)PCL_FB_KREC * b->U));
+        TRY(dev_alloc(ctx, &b->fb_dump, (size_t)64));                  // where the posterior kernel's lanes beyond N "store"
     }
     hipLaunchKernelGGL(hmm_emis_pack_kernel, dim3(PACK_BLOCKS, b->U), dim3(256), 0, ctx->stream, b->d_utt, b->Bt, b->Bp, b->fb_kmax, b->row_ptr, b->csr_val,
                        b->logpi);
@@ -889,7 +890,7 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
 
 int pcl_launch_fb_linear_post(pcl_ctx *ctx, pcl_batch *b) {
     hipLaunchKernelGGL(hmm_postl_kernel, dim3(b->U), dim3(64 * POSTL_W), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx,
-                       b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->gamma_out, b->logp, b->Bt);
+                       b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->gamma_out, b->logp, b->Bt, b->fb_dump);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

@@ -345,14 +345,31 @@ int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64
 }
 
 // layouts every launch of the active scoring variant reads; the others (f64 parity mode) are derived on first use
+// The direct-form f32 rows (params32, mean32: 3 GB at C4, a third of what a re-derive wrote) are read only when WHOLE states are
+// scored / accumulated by the direct-form kernels: variant 1, a feature dimension without a matrix-pipe instance, or states whose
+// conditioning leaves the centred expansion's range -- they are derived on first use (pcl_ensure_layouts); the fix-up launches of
+// the matrix-pipe path make their rows from the master copy (gmm_score.hip MasterModel).  PCL_EAGER_P32=1: as before (A/B).
 static int eager_layouts(const pcl_ctx *ctx) {
-    int what = PCL_LAYOUT_P32 | PCL_LAYOUT_COND;              // direct-form f32 kernels: fix-up, ill-conditioned states, variant 1
+    int what = PCL_LAYOUT_COND;
+    static const bool eager32 = getenv("PCL_EAGER_P32") && atoi(getenv("PCL_EAGER_P32")) != 0;
+    if (ctx->score_variant == 1 || !pcl_score_mfma_supported(ctx->D) || eager32) what |= PCL_LAYOUT_P32;
     if (ctx->score_variant == 3) what |= PCL_LAYOUT_PM32;
     if (ctx->score_variant == 7) what |= PCL_LAYOUT_PM16F;
     return what;
 }
 
+static int alloc_for(pcl_ctx *ctx, int what) {                 // the buffers of the lazily derived layouts
+    const size_t np = (size_t)ctx->J * ctx->Mpad * ctx->row, nm = (size_t)ctx->J * ctx->Mpad * ctx->D;
+    if ((what & PCL_LAYOUT_P32) && !ctx->params32) {
+        TRY(dev_alloc(ctx, &ctx->params32, np));
+        TRY(dev_alloc(ctx, &ctx->mean32, nm));
+    }
+    if ((what & PCL_LAYOUT_P64) && !ctx->params64) TRY(dev_alloc(ctx, &ctx->params64, np));
+    return PCL_OK;
+}
+
 static int launch_derive_kernel(pcl_ctx *ctx, int what, int j_lo, int j_hi) {
+    TRY(alloc_for(ctx, what));
     const size_t shm = (size_t)(2 * 32 * ctx->D + 64) * sizeof(double) + (size_t)(ctx->D + 2 * 32 * ctx->D) * sizeof(float);
     if (j_hi <= j_lo) return PCL_OK;
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((j_hi - j_lo) * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,

@@ -329,9 +329,7 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
                 v64[((size_t)j * Mpad + m) * Dd + d] = vr;
             }
         }
-    TRY(dev_alloc(ctx, &ctx->params32, np));
-    TRY(dev_alloc(ctx, &ctx->params64, np));
-    TRY(dev_alloc(ctx, &ctx->mean32, nm));
+    (void)np;                                                     // (params32 / params64 / mean32: allocated when first derived, model_derive.hip)
     TRY(dev_alloc(ctx, &ctx->mean64, nm));
     TRY(dev_alloc(ctx, &ctx->var64, nm));
     TRY(dev_alloc(ctx, &ctx->w64, nw));
@@ -540,7 +538,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
-    dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax);
+    dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax); dev_free(b->fb_dump);
     dev_free(b->d_dups);
     dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;

@@ -170,6 +170,7 @@ struct pcl_batch {
     // mantissas live in `alpha` / `beta`), per utterance the exponent maxima of the range test
     unsigned long long *Bp = nullptr;
     int *alpha_e = nullptr, *beta_e = nullptr, *fb_kmax = nullptr;
+    double *fb_dump = nullptr;
     bool left_right = false;                      // every state is reached from itself / the state before it only (AcousticModel.embedded)
     bool fb_linear = false;                       // the last forward-backward left (mantissa, exponent) pairs in alpha / beta
     unsigned short *bp = nullptr;                 // Viterbi back-pointers, time-major (t, n)
