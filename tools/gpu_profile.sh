@@ -37,7 +37,8 @@ fi
 if has fb; then
 for U in 128 1024; do
 run fb${U}_trace "" $R/tools/fb_bench.py $U
-run fb${U}_mem "FETCH_SIZE WRITE_SIZE" $R/tools/fb_bench.py $U
+run fb${U}_fetch "FETCH_SIZE" $R/tools/fb_bench.py $U
+run fb${U}_write "WRITE_SIZE" $R/tools/fb_bench.py $U
 run fb${U}_clk "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" $R/tools/fb_bench.py $U
 run fb${U}_sq1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" $R/tools/fb_bench.py $U
 run fb${U}_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" $R/tools/fb_bench.py $U

@@ -113,7 +113,7 @@ out = ['# rocprofv3 summaries, %s: python3 tools/fb_bench.py U (one MI355X; U se
 for U in (128, 1024):
     kt, lines = kernel_stats('fb%d_trace' % U, '%s_fb%d_kernel_stats.csv' % (RND, U))
     out += ['', '## U = %d: --kernel-trace --stats' % U] + [l for l in lines if 'hmm_' in l]
-    lines, val = counters(['fb%d_mem' % U, 'fb%d_clk' % U, 'fb%d_sq1' % U, 'fb%d_sq2' % U], ['hmm_fbl_kernel', 'hmm_postl_kernel', 'hmm_emis_pack_kernel'])
+    lines, val = counters(['fb%d_fetch' % U, 'fb%d_write' % U, 'fb%d_clk' % U, 'fb%d_sq1' % U, 'fb%d_sq2' % U], ['hmm_fbl_kernel', 'hmm_postl_kernel', 'hmm_emis_pack_kernel'])
     out += ['## U = %d: --pmc passes, per-dispatch averages' % U] + lines
     try:
         steps = 299 * 3.5                       # chain steps per launch, averaged over the free-pi (4 walks: beta + 3 alpha) and locked-pi (2 walks) halves
