@@ -403,10 +403,11 @@ int pcl_frames_upload(pcl_ctx *ctx, int64_t F, int D, const void *frames, int dt
 int pcl_frames_stage(pcl_ctx *ctx, int64_t F, int D, const float *frames) {
     if (!ctx) return PCL_ERR_INVALID;
     if (F <= 0 || D <= 0 || !frames) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_stage: bad shape F=%lld D=%d", (long long)F, D);
-    if (device_dim(D) != D) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_stage: feature dimension %d needs host padding; use pcl_frames_upload", D);
+    const int Dd = device_dim(D);
+    if (Dd < 0) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_frames_stage: feature dimension %d > 64 is not supported", D);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int back = ctx->frames_front == 0 ? 1 : 0;
-    const size_t n = (size_t)F * D;
+    const size_t n = (size_t)F * Dd;
     if (n > ctx->frames_slot_cap[back]) {                          // (grows only: a steady stream of equal chunks allocates twice)
         dev_free(ctx->frames_slot[back]);
         ctx->frames_slot_cap[back] = 0;
@@ -415,7 +416,15 @@ int pcl_frames_stage(pcl_ctx *ctx, int64_t F, int D, const float *frames) {
     }
     if (!ctx->ev_stage) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming));
     if (ctx->have_slot_free) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_slot_free, 0));   // its last readers
-    HIPCHK(ctx, hipMemcpyAsync(ctx->frames_slot[back], frames, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream_aux));
+    if (Dd == D) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->frames_slot[back], frames, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream_aux));
+    } else {
+        // a dimension without a kernel instance of its own (D = 8, 20, 40, ...): rows are padded to the device dimension on the way
+        // in -- the pad columns zeroed, the rows copied with a pitch -- as pcl_frames_upload pads on the host
+        HIPCHK(ctx, hipMemsetAsync(ctx->frames_slot[back], 0, n * sizeof(float), ctx->stream_aux));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->frames_slot[back], (size_t)Dd * sizeof(float), frames, (size_t)D * sizeof(float), (size_t)D * sizeof(float),
+                                     (size_t)F, hipMemcpyHostToDevice, ctx->stream_aux));
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev_stage, ctx->stream_aux));
     ctx->staged_slot = back;
     ctx->staged_F = F;
@@ -436,7 +445,8 @@ int pcl_frames_swap(pcl_ctx *ctx) {
     ctx->frames_front = ctx->staged_slot;
     ctx->frames32 = ctx->frames_slot[ctx->frames_front];
     ctx->F = ctx->staged_F;
-    ctx->FD = ctx->FDhost = ctx->staged_D;
+    ctx->FDhost = ctx->staged_D;
+    ctx->FD = device_dim(ctx->staged_D);
     ctx->staged_slot = -1;
     return PCL_OK;
 }
@@ -1131,17 +1141,24 @@ int pcl_stats_zero(pcl_ctx *ctx) {
     return PCL_OK;
 }
 
+// what pcl_batch_accumulate needs of the batch and the context (checked before anything is queued; pcl_batch_accumulate_exchange checks
+// it BEFORE it opens the pipe: a pass that cannot run must not be followed by an exchange of incomplete statistics)
+static int accumulate_precheck(pcl_batch *b, int precision, const char *who) {
+    pcl_ctx *ctx = b->ctx;
+    if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "%s: precision %d", who, precision);
+    if (!b->have_post) PCL_FAIL(ctx, PCL_ERR_STATE, "%s: run pcl_batch_forward_backward (or set_posteriors) first", who);
+    if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "%s: no emissions", who);
+    if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "%s: pcl_batch_set_states was not called", who);
+    if (ctx->F == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "%s: no frames uploaded", who);
+    if (ctx->FDhost != ctx->Dhost) PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
+    return batch_revalidate(b, who);
+}
+
 int pcl_batch_accumulate(pcl_batch *b, int precision) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
     TRY(batch_join(b));
-    if (precision != PCL_F32 && precision != PCL_F64) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate: precision %d", precision);
-    if (!b->have_post) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: run pcl_batch_forward_backward (or set_posteriors) first");
-    if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no emissions");
-    if (!b->have_states) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: pcl_batch_set_states was not called");
-    if (ctx->F == 0) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate: no frames uploaded");
-    if (ctx->FDhost != ctx->Dhost) PCL_FAIL(ctx, PCL_ERR_INVALID, "data dimension %d does not match model dimension %d", ctx->FDhost, ctx->Dhost);
-    TRY(batch_revalidate(b, "pcl_batch_accumulate"));
+    TRY(accumulate_precheck(b, precision, "pcl_batch_accumulate"));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (precision == PCL_F64) {
         TRY(ensure_frames64(ctx));
@@ -1161,8 +1178,11 @@ int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covarian
     if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: pcl_comm_init was not called");
     if (update_transitions && !ctx->hmm_ksai) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: update_transitions without pcl_units_upload");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    TRY(accumulate_precheck(b, precision, "pcl_batch_accumulate_exchange"));   // nothing is exchanged for a pass that cannot run
     TRY(pcl_pipe_begin(ctx, c_covariance, payload, n_chunks));
     int rc = pcl_batch_accumulate(b, precision);                 // releases chunks as its state groups finish
+    // (a failure from here on is a HIP / allocation error in the middle of the pass: the pipe is closed -- the collectives stay
+    //  matched across the ranks -- and the error is returned; the caller must treat the model as undefined)
     const int rf = pcl_pipe_finish(ctx, update_transitions);     // (always: closes the pipe)
     if (rc == PCL_OK) rc = rf;
     if (rc != PCL_OK) return rc;

@@ -327,17 +327,20 @@ def test_lexicon_upload_rejects_malformed_trees(eng, lex):
     eng.load_lexicon(tree)
 
 
-def test_decode_stream_equals_chunk_by_chunk(eng, lex):
+@pytest.mark.parametrize('D', [13, 20])
+def test_decode_stream_equals_chunk_by_chunk(eng, lex, D):
     """The streaming pipeline (frames of chunk k+1 on the copy stream, scoring of chunk k on the main stream, token passing
     of chunk k-1 on the second stream, batches reused per chunk shape) returns, chunk by chunk, exactly what decode_batch
-    returns for that chunk alone -- including a chunk of a different shape in the middle and a one-utterance tail."""
+    returns for that chunk alone -- including a chunk of a different shape in the middle and a one-utterance tail.  D = 20 has no
+    kernel instance of its own: the staged rows are padded to 26 on their way into the frame slot, as the resident
+    upload pads them on the host."""
     from poccala_amd import Decoder, PCL_F32, synth
     lx, units, tree0 = lex
-    mean, var, w, trans = model_for(units, 3, 13, 41)
+    mean, var, w, trans = model_for(units, 3, D, 41)
     tree = Decoder.load_inventory(eng, units, mean, var, w, trans, lx)
     rng = np.random.default_rng(42)
     shapes = [[40, 40, 40], [40, 40, 40], [25, 60], [40, 40, 40], [40, 40, 40], [33]]
-    chunks = [[rng.standard_normal((t, 13)).astype(np.float32) for t in sh] for sh in shapes]
+    chunks = [[rng.standard_normal((t, D)).astype(np.float32) for t in sh] for sh in shapes]
     ref = [Decoder.decode_batch(ch, tree, engine=eng, precision=PCL_F32, candidate=4, max_tokens=600) for ch in chunks]
     got = list(Decoder.decode_stream(iter(chunks), tree, engine=eng, precision=PCL_F32, candidate=4, max_tokens=600))
     assert len(got) == len(ref)

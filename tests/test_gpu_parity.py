@@ -587,8 +587,26 @@ def test_cabi_error_codes(eng):
         b.set_emissions([np.zeros((3, 19))])
     b.set_states([np.array([-1, 1, -2], dtype=np.int32)])
     b.score()
+    # the pipelined accumulate + exchange refuses BEFORE it opens the pipe when the pass cannot run (no posteriors yet): the model and
+    # its generation stay untouched (it used to run the M-step on incomplete statistics and then return the error)
+    before = eng.model_download()
+    with pytest.raises(PoccalaHipError, match='forward_backward'):
+        b.accumulate_exchange()
+    for x, y in zip(before, eng.model_download()):
+        assert np.array_equal(x, y)
+    with pytest.raises(PoccalaHipError, match='fetch'):
+        b.fetch_wait()                                               # nothing was fetched
     b.forward_backward()
     assert np.isfinite(b.get('logp')[0])
+    # results on their way to the host while the GPU goes on: the asynchronous fetch equals the synchronous getters
+    b.viterbi()
+    bufs = b.result_buffers()
+    b.fetch_async(bufs)
+    b.fetch_wait()
+    assert np.array_equal(bufs['logp'], b.get('logp')) and np.array_equal(bufs['path'], np.concatenate(b.get('path')))
+    assert np.array_equal(b.lgamma_views(bufs['lgamma'])[0], b.get('lgamma')[0], equal_nan=True)
+    assert np.array_equal(bufs['ksai_nz'], np.concatenate(b.get('ksai_nz')), equal_nan=True) and bufs['point'][0] == b.get('point')[0]
+    assert 500.0 < eng.clock_probe(200) < 3000.0                     # the shader clock, measured on the device (MHz)
     b.close()
     with pytest.raises(PoccalaHipError, match='has N=0'):
         eng.batch([0], [5])
