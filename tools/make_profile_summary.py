@@ -123,8 +123,8 @@ for U in (128, 1024):
             cyc = v['GRBM_GUI_ACTIVE'] / 8
             wc = v['SQ_WAVE_CYCLES']
             gb = (v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024 / 1e9
-            out.append('derived %-22s %.3f ms/launch, clock %.2f GHz, FETCH+WRITE %.3f GB raw = %.2f TB/s; wave time: waiting (s_waitcnt / barrier) %.0f %%, issue stalls %.0f %%, issuing %.0f %%; %.3g VALU + %.3g SALU instructions per wave-launch'
-                       % (name, ms, cyc / ms / 1e6, gb, gb / ms, 100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, 100 * v['SQ_ACTIVE_INST_ANY'] / wc,
+            out.append('derived %-22s %.3f ms/launch, FETCH+WRITE %.3f GB raw = %.2f TB/s; wave time: waiting (s_waitcnt / barrier) %.0f %%, issue stalls %.0f %%, issuing %.0f %%; %.3g VALU + %.3g SALU instructions per wave-launch'
+                       % (name, ms, gb, gb / ms, 100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, 100 * v['SQ_ACTIVE_INST_ANY'] / wc,
                           v['SQ_INSTS_VALU'] / (U * (2 if 'fbl' in name else 8)), v['SQ_INSTS_SALU'] / (U * (2 if 'fbl' in name else 8))))
     except (KeyError, IndexError, ZeroDivisionError) as e:
         out.append('(derived block incomplete: %r)' % (e,))
