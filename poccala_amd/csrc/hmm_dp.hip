@@ -726,20 +726,22 @@ constexpr int POST_W = PCL_POST_W;
 #else
 #define PCL_POST_ATTR
 #endif
-__device__ __forceinline__ void hmm_post_body(const UttDesc *__restrict__ utts, const double *__restrict__ Bt,
+// NW waves share the utterance's frames (t = w, w + NW, ...); NW = 1: one wave does everything (the fall-back inside hmm_postl_kernel)
+template <int NW>
+__device__ __forceinline__ void hmm_post_body(const UttDesc *__restrict__ utts, int u, const double *__restrict__ Bt,
                                               const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
                                               const double *__restrict__ csr_val, const double *__restrict__ alpha,
                                               const double *__restrict__ beta, double *__restrict__ lgam,
                                               double *__restrict__ ksai, double *__restrict__ gamma_out,
                                               const double *__restrict__ logp) {
-    __shared__ double ms[3][POST_W][2][64];
-    const UttDesc d = utts[blockIdx.x];
+    __shared__ double ms[3][NW][2][64];
+    const UttDesc d = utts[u];
     const int N = d.N, T = d.T;
     const int w = threadIdx.x >> 6, i = threadIdx.x & 63;
     const bool act = i < N;
     const double *B = Bt + d.b_off, *A_ = alpha + d.b_off, *Bv = beta + d.b_off;
     double *G = lgam + d.b_off;
-    for (long long e = threadIdx.x; e < (long long)N * N; e += 64 * POST_W) ksai[d.mat_off + e] = -INFINITY;   // LHMM.py:404: ln 0 entries
+    for (long long e = threadIdx.x; e < (long long)N * N; e += 64 * NW) ksai[d.mat_off + e] = -INFINITY;   // LHMM.py:404: ln 0 entries
     int sidx[2] = {0, 0}, nsucc = 0;
     double sval[2] = {-INFINITY, -INFINITY};
     if (act) {
@@ -752,7 +754,7 @@ __device__ __forceinline__ void hmm_post_body(const UttDesc *__restrict__ utts, 
                 sval[k] = csr_val[sr0 + k];
             }
     }
-    const double qnew = logp[blockIdx.x];
+    const double qnew = logp[u];
     double gm = -INFINITY, gs = 0.0, xm[2] = {-INFINITY, -INFINITY}, xs[2] = {0.0, 0.0};
     // (the loads of the wave's next frame are issued before this one is worked on: each iteration is otherwise a chain of an L2
     //  round trip, two wave reductions and three exponentials)
@@ -775,9 +777,9 @@ __device__ __forceinline__ void hmm_post_body(const UttDesc *__restrict__ utts, 
     };
     double at_n, bt_n, nx_n[2];
     fetch(w, at_n, bt_n, nx_n);
-    for (int t = w; t < T; t += POST_W) {
+    for (int t = w; t < T; t += NW) {
         const double at = at_n, bt = bt_n, nx[2] = {nx_n[0], nx_n[1]};
-        fetch(t + POST_W, at_n, bt_n, nx_n);
+        fetch(t + NW, at_n, bt_n, nx_n);
         const double l = at + bt;
         // sum_value[t] = LSE_i l[i,t] (LHMM.py:488).  Every one of them is ln P(O) up to rounding, so the log-sum-exp is
         // taken with THAT as its shift -- no maximum over the wave, and the logarithm of a sum within 1e-4 of 1 is three
@@ -806,12 +808,12 @@ __device__ __forceinline__ void hmm_post_body(const UttDesc *__restrict__ utts, 
         for (int c = 0; c < 3; ++c) {
             double M = -INFINITY;
 #pragma unroll
-            for (int v = 0; v < POST_W; ++v) M = fmax(M, ms[c][v][0][i]);
+            for (int v = 0; v < NW; ++v) M = fmax(M, ms[c][v][0][i]);
             double r = -INFINITY;
             if (M > -INFINITY) {
                 double tsum = 0.0;
 #pragma unroll
-                for (int v = 0; v < POST_W; ++v) {
+                for (int v = 0; v < NW; ++v) {
                     const double mv = ms[c][v][0][i];
                     if (mv > -INFINITY) tsum += ms[c][v][1][i] * exp(mv - M);
                 }
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(con
                                                              const double *__restrict__ beta, double *__restrict__ lgam,
                                                              double *__restrict__ ksai, double *__restrict__ gamma_out,
                                                              const double *__restrict__ logp) {
-    hmm_post_body(utts, Bt, row_ptr, col_idx, csr_val, alpha, beta, lgam, ksai, gamma_out, logp);
+    hmm_post_body<POST_W>(utts, blockIdx.x, Bt, row_ptr, col_idx, csr_val, alpha, beta, lgam, ksai, gamma_out, logp);
 }
 
 // The scaled linear-domain forward-backward for left-to-right sentence HMMs (its kernels hand the utterances outside their
@@ -889,8 +891,15 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
 }
 
 int pcl_launch_fb_linear_post(pcl_ctx *ctx, pcl_batch *b) {
-    hipLaunchKernelGGL(hmm_postl_kernel, dim3(b->U), dim3(64 * POSTL_W), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx,
-                       b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->gamma_out, b->logp, b->Bt, b->fb_dump);
+    if (!b->fb_part_m) {
+        TRY(dev_alloc(ctx, &b->fb_part_m, (size_t)b->U * 3 * POSTL_W * 64));
+        TRY(dev_alloc(ctx, &b->fb_part_e, (size_t)b->U * 3 * POSTL_W * 64));
+    }
+    hipLaunchKernelGGL(hmm_postl_kernel, dim3(POSTL_W, b->U), dim3(64), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx,
+                       b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->gamma_out, b->logp, b->Bt, b->fb_dump, b->fb_part_m,
+                       b->fb_part_e);
+    hipLaunchKernelGGL(hmm_postl_merge_kernel, dim3(b->U), dim3(64), 0, ctx->stream, b->d_utt, b->fb_kmax, b->row_ptr, b->col_idx, b->fb_part_m,
+                       b->fb_part_e, b->ksai, b->gamma_out);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

@@ -138,9 +138,24 @@ int pcl_init(int device, pcl_ctx **out) {
     if (device < 0 || device >= n) PCL_FAIL(nullptr, PCL_ERR_INVALID, "pcl_init: device %d out of range [0,%d)", device, n);
     pcl_ctx *ctx = new pcl_ctx();
     ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
-        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess ||      // (priority 0 measured: no difference)
-        (e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess ||
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
+        delete ctx;
+        return PCL_ERR_HIP;
+    }
+    {
+        hipDeviceProp_t prop0;
+        if (hipGetDeviceProperties(&prop0, device) == hipSuccess) ctx->cus = prop0.multiProcessorCount;
+    }
+    // (compute units set aside for the second stream with hipExtStreamCreateWithCUMask were tried in round 4: 8 of 256 cost the scoring
+    //  kernel 20 %, 16 cost 70 %, and the posterior kernel's in-loop span did not move -- it waits for registers, not for CUs)
+    if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream_dp, hipStreamDefault, -1)) != hipSuccess) {      // (priority 0 measured: no difference)
+        g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
+        delete ctx;
+        return PCL_ERR_HIP;
+    }
+    if ((e = hipStreamCreate(&ctx->stream_aux)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream_desc, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->stream_d2h, hipStreamNonBlocking)) != hipSuccess) {
         g_init_error = std::string("pcl_init: ") + hipGetErrorString(e);
@@ -548,7 +563,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->row_ptr); dev_free(b->col_idx); dev_free(b->csr_val);
     dev_free(b->col_ptr); dev_free(b->row_idx); dev_free(b->csc_val);
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
-    dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax); dev_free(b->fb_dump);
+    dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax); dev_free(b->fb_dump); dev_free(b->fb_part_m); dev_free(b->fb_part_e);
     dev_free(b->d_dups);
     dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;

@@ -171,6 +171,8 @@ struct pcl_batch {
     unsigned long long *Bp = nullptr;
     int *alpha_e = nullptr, *beta_e = nullptr, *fb_kmax = nullptr;
     double *fb_dump = nullptr;
+    double *fb_part_m = nullptr;                  // per utterance, sum and wave: the posterior kernel's partial sums (mantissa, exponent)
+    int *fb_part_e = nullptr;
     bool left_right = false;                      // every state is reached from itself / the state before it only (AcousticModel.embedded)
     bool fb_linear = false;                       // the last forward-backward left (mantissa, exponent) pairs in alpha / beta
     unsigned short *bp = nullptr;                 // Viterbi back-pointers, time-major (t, n)
