@@ -14,9 +14,9 @@
  *   - The caller owns every host buffer (C-contiguous NumPy arrays).  The library
  *     owns all device memory (inside pcl_ctx / pcl_batch).
  *   - One pcl_ctx = one GPU.  Calls on a ctx are serialised by the caller (one process or
- *     thread per GPU).  Internally a ctx owns two HIP streams: pcl_batch_forward_backward
- *     runs on the second one, ordered after everything queued before it, so that it
- *     overlaps the scoring of ANOTHER batch queued after it; any later call on the same
+ *     thread per GPU).  Internally a ctx owns two HIP streams: pcl_batch_forward_backward and
+ *     pcl_batch_viterbi run on the second one, ordered after everything queued before them, so that they
+ *     overlap the scoring of ANOTHER batch queued after them; any later call on the same
  *     batch, pcl_sync and every download wait for it (env PCL_DP_STREAM=0: one stream).  Uploads, downloads (pcl_batch_get,
  *     pcl_*_download) and pcl_stats_allreduce are synchronous at return.  The compute
  *     calls -- pcl_batch_score / _forward_backward / _viterbi / _accumulate,

@@ -976,16 +976,37 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
 int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
-    TRY(batch_join(b));
     if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no transitions set");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no emissions (score or set_emissions first)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (b->fetch_pending) {                                  // result copies still reading this batch's path / point buffers
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_fetch, 0));
+        b->fetch_pending = false;
+    }
     if (!b->bp) {
         TRY(dev_alloc(ctx, &b->bp, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->path, (size_t)b->sumT));
         TRY(dev_alloc(ctx, &b->point, (size_t)b->U));
     }
-    TRY(pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0));
+    if (ctx->dp_async) {
+        // like the forward-backward: on the second stream, behind everything the main stream has queued (this batch's scoring), beside
+        // the NEXT batch's scoring; in order with a forward-backward of the same batch already queued there (round 4: on the main
+        // stream the 0.35 ms recursion sat between two scoring kernels -- config 3's step is score + Viterbi)
+        if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
+        if (!b->ev_main) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(b->ev_main, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream_dp;                      // the launcher and its timer use ctx->stream
+        const int rc = pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0);
+        ctx->stream = main_stream;
+        if (rc != PCL_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(b->ev_dp, ctx->stream_dp));
+        b->dp_pending = true;
+    } else {
+        TRY(batch_join(b));
+        TRY(pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0));
+    }
     b->have_vit = true;
     return PCL_OK;
 }
