@@ -172,3 +172,66 @@ def test_impossible_utterance(eng):
     log = run_fb(eng, labels, trans, Bs, False, False)
     assert np.isneginf(lin['logp'][1]) and np.isneginf(log['logp'][1])
     compare(lin, log)
+
+
+@pytest.mark.parametrize('fix_pi', [False, True])
+def test_left_to_right_hmms_of_any_size_match_the_oracle(eng, fix_pi):
+    """left-to-right HMMs that are NOT built from labels: N = 2 .. 64 states (the wave's last lane included), random self-loop /
+    advance probabilities, a state without a self-loop, a dead end, random pi with zeros, -inf emissions sprinkled in -- against
+    the oracle's baum_welch (LHMM.py:335-471, 526-544) at 1e-10, and equal to the log-domain kernels."""
+    rng = np.random.default_rng(77)
+    sizes = [(2, 9), (3, 1), (5, 40), (14, 33), (63, 120), (64, 300), (64, 2), (31, 7)]
+    As, pis, Bs = [], [], []
+    for n, t in sizes:
+        a = np.zeros((n, n))
+        for i in range(n - 1):
+            x = rng.uniform(0.1, 0.9)
+            a[i, i], a[i, i + 1] = x, 1.0 - x
+        a[n - 1, n - 1] = 1.0
+        if n > 4:
+            a[2, 2], a[2, 3] = 0.0, 1.0                     # no self-loop
+            a[n - 1, n - 1] = 0.0                           # the last state leads nowhere (as the exit state of a sentence HMM)
+        p = rng.dirichlet(np.ones(n))
+        if n > 3:
+            p[1] = 0.0
+            p /= p.sum()
+        b = -60.0 + 25.0 * rng.standard_normal((n, t))
+        b[rng.random((n, t)) < 0.03] = -np.inf
+        b[0, 0] = -50.0                                     # (at least one way in)
+        As.append(a); pis.append(p); Bs.append(b)
+    res = {}
+    for linear in (True, False):
+        old = os.environ.get('PCL_FB_LINEAR')
+        os.environ['PCL_FB_LINEAR'] = '1' if linear else '0'
+        try:
+            b = eng.batch([s[0] for s in sizes], [s[1] for s in sizes])
+            with np.errstate(divide='ignore'):
+                b.set_transitions([np.log(a) for a in As], [np.log(p) for p in pis])
+            b.set_emissions(Bs)
+            b.forward_backward(fix_pi=fix_pi)
+            res[linear] = {k: b.get(k) for k in ('alpha', 'beta', 'lgamma', 'ksai', 'gamma', 'pi', 'logp', 'npass', 'qtrace')}
+            b.close()
+        finally:
+            if old is None:
+                os.environ.pop('PCL_FB_LINEAR', None)
+            else:
+                os.environ['PCL_FB_LINEAR'] = old
+    compare(res[True], res[False])
+    lin = res[True]
+    tag = 'scaled forward-backward vs oracle (left-to-right HMMs of 2..64 states)'
+    for u in range(len(sizes)):
+        with np.errstate(all='ignore'):
+            bw = po.baum_welch(As[u], pis[u], [Bs[u]], fix_code=1 if fix_pi else 0)
+        assert lin['npass'][u] == bw['n_pass'], u
+        if not np.isfinite(bw['logp'][0]):
+            assert not np.isfinite(lin['logp'][u])
+            continue
+        hold(tag, 'ln alpha', lin['alpha'][u], bw['alpha'][0], 1e-10, 1e-9)
+        hold(tag, 'ln beta', lin['beta'][u], bw['beta'][0], 1e-10, 1e-9)
+        hold(tag, 'ln P(O)', lin['logp'][u], bw['logp'][0], 1e-10)
+        if sizes[u][1] > 1:
+            fk = np.isfinite(bw['ksai'])
+            assert np.array_equal(np.isfinite(lin['ksai'][u]), fk), u
+            hold(tag, 'ln xi (sum over t)', lin['ksai'][u][fk], bw['ksai'][fk], 1e-10, 1e-9)
+            hold(tag, 'ln gamma (sum over t)', lin['gamma'][u], bw['gamma'], 1e-10, 1e-9)
+        np.testing.assert_allclose(lin['pi'][u], bw['pi'], rtol=1e-9, atol=1e-300)
