@@ -22,6 +22,8 @@ def measure(got, want, rtol, atol=0.0):
     fin = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), fin), 'finite pattern differs'
     g, w = got[fin], want[fin]
+    if np.ndim(atol):                            # an absolute term per element (cov_acc_atol)
+        atol = np.broadcast_to(np.asarray(atol, dtype=np.float64), want.shape)[fin]
     if g.size == 0:
         return dict(max_abs=0.0, max_rel=0.0, used=0.0, n=0)
     err = np.abs(g - w)
@@ -30,12 +32,31 @@ def measure(got, want, rtol, atol=0.0):
     if (tol == 0).any() and err[tol == 0].max() > 0:
         used = float('inf')
     big = np.abs(w) > (atol / rtol if rtol > 0 else np.inf)
+    atol = float(np.max(atol)) if np.ndim(atol) else atol
     return dict(max_abs=float(err.max()), max_rel=float((err[big] / np.abs(w[big])).max()) if big.any() else 0.0, used=used, n=int(g.size))
 
 
+KAPPA_COV = 1.5e-6
+
+
+def cov_acc_atol(acc, mean, var, floor):
+    """The absolute term of the bound on cov_acc[j, m, d] of the f32-class accumulate pass.  The pass forms RAW moments about the state's
+    expansion centre c_j on the matrix pipe (S2 = sum g x'^2, S1 = sum g x', S0 = sum g, x' = x - c_j) and shifts them to the mixture's
+    mean in float64: cov = S2 - 2 d S1 + d^2 S0, d = mu - c_j.  Each raw moment carries a relative error eta (operands in two f16 pieces,
+    f32 accumulation), so |d cov_acc| ~ eta acc (d^2 + var): an absolute error that no bound relative to cov_acc[j, m, d] itself describes
+    when a mixture sits far from the centre in units of its own width.  MEASURED: tools/cov_error_probe.py, 400 random E-steps
+    (profiles/r04_cov_error_model.txt): the largest (|d cov_acc| - 1e-4 |cov_acc|) / (acc (d^2 + var)) is 8.4e-7; mean_acc and acc
+    need no such term (1e-4 relative holds everywhere).  The bound used: 1e-4 relative + `floor` + 1.5e-6 acc (d^2 + var).
+    acc (..., M), mean / var (..., M, D) of the same states; returns (..., M, D)."""
+    c = mean.mean(axis=-2, keepdims=True).astype(np.float32).astype(np.float64)     # model_derive.hip: c_j = (float) mean_m mu
+    return floor + KAPPA_COV * np.asarray(acc)[..., None] * ((mean - c) ** 2 + var)
+
+
 def hold(config, quantity, got, want, rtol, atol=0.0, note=None):
-    """assert |got - want| <= atol + rtol |want| on every finite entry (same finite pattern) and record the measured worst case."""
+    """assert |got - want| <= atol + rtol |want| on every finite entry (same finite pattern) and record the measured worst case.
+    atol: a number, or an array broadcastable to the data (recorded by its maximum)."""
     m = measure(got, want, rtol, atol)
+    atol = float(np.max(atol)) if np.ndim(atol) else atol
     rec = REPORT.setdefault(config, {}).setdefault(quantity, dict(bound=dict(rtol=rtol, atol=atol), max_abs=0.0, max_rel=0.0, used=0.0, n=0))
     rec['bound'] = dict(rtol=max(rec['bound']['rtol'], rtol), atol=max(rec['bound']['atol'], atol))
     for k in ('max_abs', 'max_rel', 'used'):
