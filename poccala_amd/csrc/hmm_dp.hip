@@ -95,7 +95,8 @@ __global__ void hmm_fb_kernel(const UttDesc *__restrict__ utts, const double *__
                               double *__restrict__ beta, double *__restrict__ lgam, double *__restrict__ xi_m,
                               double *__restrict__ xi_s, double *__restrict__ ksai, double *__restrict__ gamma_out,
                               double *__restrict__ pi_out, double *__restrict__ logp, double *__restrict__ qtrace,
-                              int32_t *__restrict__ npass_out, int fix_pi, double threshold) {
+                              int32_t *__restrict__ npass_out, int fix_pi, double threshold, const int *__restrict__ kmax) {
+    if (pcl_fb_linear_ok(kmax, blockIdx.x, utts[blockIdx.x].T)) return;      // done by the scaled multi-wave kernels (hmm_fb_linear_mw.inc); block-uniform
     constexpr int KR = KREG > 0 ? KREG : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ Red red;
@@ -840,6 +841,7 @@ __global__ __launch_bounds__(64 * POST_W) PCL_POST_ATTR void hmm_post_kernel(con
 // The scaled linear-domain forward-backward for left-to-right sentence HMMs (its kernels hand the utterances outside their
 // exponent range to the two bodies above)
 #include "hmm_fb_linear.inc"
+#include "hmm_fb_linear_mw.inc"
 
 // dense ragged (N,N) xi -> values of the stored transitions in CSR (row-major) order
 __global__ void ksai_gather_kernel(const UttDesc *__restrict__ utts, const int *__restrict__ row_ptr,
@@ -879,10 +881,20 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
         TRY(dev_alloc(ctx, &b->alpha_e, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->beta_e, (size_t)b->sumNT));
         TRY(dev_alloc(ctx, &b->fb_kmax, (size_t)PCL_FB_KREC * b->U));
-        TRY(dev_alloc(ctx, &b->fb_dump, (size_t)64));                  // where the posterior kernel's lanes beyond N "store"
+        TRY(dev_alloc(ctx, &b->fb_dump, (size_t)128));                  // where the posterior kernel's lanes beyond N "store"
     }
     hipLaunchKernelGGL(hmm_emis_pack_kernel, dim3(PACK_BLOCKS, b->U), dim3(256), 0, ctx->stream, b->d_utt, b->Bt, b->Bp, b->fb_kmax, b->row_ptr, b->csr_val,
                        b->logpi);
+    const int NPc = (b->Nmax + 63) / 64 * 64;
+    if (NPc > 64) {
+#define LAUNCH_CM(W)                                                                                                                             \
+    hipLaunchKernelGGL((hmm_fblm_kernel<W>), dim3(b->U), dim3(128 * W), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx, b->csr_val, \
+                       b->logpi, b->alpha, b->alpha_e, b->beta, b->beta_e, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, b->fb_dump)
+        if (NPc == 128) LAUNCH_CM(2); else if (NPc == 192) LAUNCH_CM(3); else LAUNCH_CM(4);
+#undef LAUNCH_CM
+        HIPCHK(ctx, hipGetLastError());
+        return PCL_OK;
+    }
     hipLaunchKernelGGL(hmm_fbl_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx, b->csr_val,
                        b->logpi, b->alpha, b->alpha_e, b->beta, b->beta_e, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, b->Bt, b->col_ptr,
                        b->row_idx, b->csc_val, reinterpret_cast<const double2 *>(ctx->d_softplus));
@@ -891,9 +903,21 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
 }
 
 int pcl_launch_fb_linear_post(pcl_ctx *ctx, pcl_batch *b) {
+    const int NPp = (b->Nmax + 63) / 64 * 64;
     if (!b->fb_part_m) {
-        TRY(dev_alloc(ctx, &b->fb_part_m, (size_t)b->U * 3 * POSTL_W * 64));
-        TRY(dev_alloc(ctx, &b->fb_part_e, (size_t)b->U * 3 * POSTL_W * 64));
+        TRY(dev_alloc(ctx, &b->fb_part_m, (size_t)b->U * 3 * POSTL_W * NPp));
+        TRY(dev_alloc(ctx, &b->fb_part_e, (size_t)b->U * 3 * POSTL_W * NPp));
+    }
+    if (NPp > 64) {                                                  // more than one wave of states: hmm_fb_linear_mw.inc
+#define LAUNCH_PM(W)                                                                                                                              \
+    hipLaunchKernelGGL((hmm_postlm_kernel<W>), dim3(POSTL_W, b->U), dim3(64 * W), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx, \
+                       b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->logp, b->fb_dump, b->fb_part_m, b->fb_part_e)
+        if (NPp == 128) LAUNCH_PM(2); else if (NPp == 192) LAUNCH_PM(3); else LAUNCH_PM(4);
+#undef LAUNCH_PM
+        hipLaunchKernelGGL(hmm_postlm_merge_kernel, dim3(b->U), dim3(NPp), 0, ctx->stream, b->d_utt, b->fb_kmax, b->row_ptr, b->col_idx, b->fb_part_m,
+                           b->fb_part_e, b->ksai, b->gamma_out);
+        HIPCHK(ctx, hipGetLastError());
+        return PCL_OK;
     }
     hipLaunchKernelGGL(hmm_postl_kernel, dim3(POSTL_W, b->U), dim3(64), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx,
                        b->csr_val, b->alpha, b->alpha_e, b->beta, b->beta_e, b->lgam, b->ksai, b->gamma_out, b->logp, b->Bt, b->fb_dump, b->fb_part_m,
@@ -955,14 +979,22 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
             hipLaunchKernelGGL(hmm_post_kernel, dim3(b->U), dim3(64 * POST_W), 0, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx, b->csr_val,
                                b->alpha, b->beta, b->lgam, b->ksai, b->gamma_out, b->logp);
         }
-    } else if (b->max_indeg <= 2 && b->max_outdeg <= 2)
+    } else if (b->max_indeg <= 2 && b->max_outdeg <= 2) {
+        // more than 64 states (a label of 21 units has 65): left-to-right HMMs of up to 256 states run the scaled chain spread over
+        // several waves (hmm_fb_linear_mw.inc); the log-domain kernel behind it takes the utterances outside the exponent range
+        const bool lin = b->left_right && NP <= 256 && pcl_fb_linear_enabled();
+        if (lin) {
+            TRY(pcl_launch_fb_linear(ctx, b, fix_pi, threshold));
+            TRY(pcl_launch_fb_linear_post(ctx, b));
+            b->fb_linear = true;
+        }
         hipLaunchKernelGGL(hmm_fb_kernel<2>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
-                           b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
-    else
+                           b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, lin ? b->fb_kmax : nullptr);
+    } else
         hipLaunchKernelGGL(hmm_fb_kernel<0>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
-                           b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold);
+                           b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, (const int *)nullptr);
     pcl_timer_end(ctx, "fb");
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;

@@ -91,9 +91,11 @@ def problem(seed, U, L, units=7, Ts=None, scale=4.0, offset=-85.0):
 
 
 @pytest.mark.parametrize('fix_pi', [False, True])
-def test_linear_equals_log_domain(eng, fix_pi):
-    """ragged lengths incl. T = 1 .. 9 (every tail of the 4-frame blocks) and the canonical 62 x 300."""
-    model, trans, labels, Bs = problem(5, 12, 20, Ts=[300, 1, 2, 3, 4, 5, 6, 7, 8, 9, 299, 150])
+@pytest.mark.parametrize('L', [20, 21, 40, 63, 84])
+def test_linear_equals_log_domain(eng, fix_pi, L):
+    """ragged lengths incl. T = 1 .. 9 (every tail of the 4-frame blocks) and the canonical 62 x 300; L = 21 .. 84 units: 65 .. 254
+    states, the multi-wave chain against the log-domain multi-wave kernel."""
+    model, trans, labels, Bs = problem(5, 12, L, Ts=[300, 1, 2, 3, 4, 5, 6, 7, 8, 9, 299, 150])
     eng.load_model(*model)
     lin = run_fb(eng, labels, trans, Bs, fix_pi, True)
     log = run_fb(eng, labels, trans, Bs, fix_pi, False)
@@ -175,12 +177,17 @@ def test_impossible_utterance(eng):
 
 
 @pytest.mark.parametrize('fix_pi', [False, True])
-def test_left_to_right_hmms_of_any_size_match_the_oracle(eng, fix_pi):
+@pytest.mark.parametrize('wide', [False, True])
+def test_left_to_right_hmms_of_any_size_match_the_oracle(eng, fix_pi, wide):
     """left-to-right HMMs that are NOT built from labels: N = 2 .. 64 states (the wave's last lane included), random self-loop /
     advance probabilities, a state without a self-loop, a dead end, random pi with zeros, -inf emissions sprinkled in -- against
-    the oracle's baum_welch (LHMM.py:335-471, 526-544) at 1e-10, and equal to the log-domain kernels."""
+    the oracle's baum_welch (LHMM.py:335-471, 526-544) at 1e-10, and equal to the log-domain kernels.  wide: up to 256 states in one
+    batch with short ones (the chain spread over 2..4 wavefronts, hmm_fb_linear_mw.inc: values crossing a wave boundary through LDS,
+    whole waves without a state)."""
     rng = np.random.default_rng(77)
     sizes = [(2, 9), (3, 1), (5, 40), (14, 33), (63, 120), (64, 300), (64, 2), (31, 7)]
+    if wide:
+        sizes = [(65, 50), (122, 300), (128, 33), (129, 20), (200, 64), (256, 40), (7, 12), (64, 31), (192, 1), (193, 2)]
     As, pis, Bs = [], [], []
     for n, t in sizes:
         a = np.zeros((n, n))

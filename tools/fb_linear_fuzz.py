@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the scaled linear-domain forward-backward (csrc/hmm_fb_linear.inc) against the log-domain kernels it
-replaced (PCL_FB_LINEAR=0) on the same batches: random numbers of states (2..64) and frames (1..400), self-loop probabilities
+replaced (PCL_FB_LINEAR=0) on the same batches: random numbers of states (2..256: one to four wavefronts per chain) and frames (1..400), self-loop probabilities
 from 1e-6 to 1 - 1e-6, emissions from mild to thousands of nats apart with ln 0 sprinkled in, pi free / locked, thresholds
 that end the pass loop anywhere.  usage: fb_linear_fuzz.py [first seed] [count]"""
 import os, sys
@@ -20,7 +20,7 @@ for seed in range(first, first + count):
     scale = float(rng.choice([1.0, 8.0, 60.0, 700.0]))
     As, pis, Bs, sizes = [], [], [], []
     for _ in range(U):
-        n, t = int(rng.integers(2, 65)), int(rng.integers(1, 401))
+        n, t = int(rng.integers(2, rng.choice([65, 65, 129, 257]))), int(rng.integers(1, 401))
         a = np.zeros((n, n))
         for i in range(n - 1):
             x = float(rng.choice([rng.uniform(0.05, 0.95), 1e-6, 1 - 1e-6]))
