@@ -81,22 +81,24 @@ def note(config, key, value):
 
 
 def write():
+    """profiles/r04_parity_report.json <- the records of this session merged INTO what the file already holds (a session that runs a
+    subset of the tests refreshes its configs and leaves the others), and the same body to gpurun_out/ (what travels back from the GPU box)."""
     if not REPORT:
         return
-    body = dict(what='measured worst cases of the GPU parity tests (tests/_parity.py): every entry was asserted against its bound in the run that wrote this file',
+    main = os.path.join(ROOT, 'profiles', 'r04_parity_report.json')
+    merged = {}
+    try:
+        merged = dict(json.load(open(main)).get('configs', {}))
+    except (OSError, ValueError):
+        pass
+    merged.update(REPORT)
+    body = dict(what='measured worst cases of the GPU parity tests (tests/_parity.py): every entry was asserted against its bound in the run that wrote it',
                 contract='BASELINE.json north_star: log-likelihoods and gamma / xi occupancies within 1e-4 relative in f32, Viterbi bit-exact',
-                configs=REPORT)
+                configs=merged)
     for d in (os.path.join(ROOT, 'profiles'), os.path.join(ROOT, 'gpurun_out')):
         try:
             os.makedirs(d, exist_ok=True)
-            path = os.path.join(d, 'r04_parity_report.json')
-            old = {}
-            if os.path.exists(path) and os.environ.get('POCCALA_PARITY_MERGE'):
-                old = json.load(open(path)).get('configs', {})
-            merged = dict(old)
-            merged.update(REPORT)
-            body['configs'] = merged
-            with open(path, 'w') as f:
+            with open(os.path.join(d, 'r04_parity_report.json'), 'w') as f:
                 json.dump(body, f, indent=1, sort_keys=True)
         except OSError:
             pass
