@@ -332,6 +332,10 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
  * reduce-scatter leaves early, M-steps / all-gathers / derive run at the end; PCL_PIPE_MODE=0: the whole chain per chunk (on one
  * rank: M-step + derive of finished chunks beside the rest of the pass).  Synchronous at return. */
 int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covariance, int payload, int update_transitions, int n_chunks);
+/* Of the last pcl_batch_accumulate_exchange: its number of chunks and how many of them left for the exchange WHILE the accumulate pass was
+ * still running (0: the pass released none -- states out of ascending order or on the direct-form kernel -- and the call was the plain
+ * accumulate + exchange).  NULLs are skipped. */
+int pcl_pipe_info(pcl_ctx *ctx, int *chunks, int *released_early);
 int pcl_comm_destroy(pcl_ctx *ctx);
 
 #ifdef __cplusplus

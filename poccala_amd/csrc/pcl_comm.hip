@@ -372,6 +372,13 @@ int pcl_comm_init_host(pcl_ctx *ctx, int rank, int nranks, pcl_allgather_fn fn, 
     return PCL_OK;
 }
 
+int pcl_pipe_info(pcl_ctx *ctx, int *chunks, int *released_early) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (chunks) *chunks = ctx->pipe_K;
+    if (released_early) *released_early = ctx->pipe_early;
+    return PCL_OK;
+}
+
 int pcl_comm_info(pcl_ctx *ctx, int *rank, int *nranks, int *transport, int *rccl_nranks) {
     if (!ctx) return PCL_ERR_INVALID;
     if (rank) *rank = ctx->rank;
@@ -487,6 +494,13 @@ int pipe_chunk_tail(pcl_ctx *ctx, int c, int lo, int hi) {          // M-step of
     return rc;
 }
 
+// INVARIANT the early release rests on: every kernel of the accumulate pass (count / scan / fill, producer, consumer, the masked and
+// the direct-form fix-up) and the M-step / derive kernels index the statistics, the master copy and every layout strictly PER STATE --
+// no kernel reads a state's mean64 / centers32 / fscale / kzero / pm16f while working on another state.  A chunk [a, b) may therefore be
+// re-estimated (mode 0: and re-derived) on stream_comm while the main and auxiliary streams still accumulate states >= b.  Whoever
+// adds a kernel that looks across states (a global normaliser, a shared codebook) must close the pipe first.  pcl_pipe_info reports
+// how many chunks did leave early: 0 means the pass could not release any (states out of ascending order, or states on the direct-form
+// kernel, which are accumulated last) and the call was the plain accumulate + exchange.
 int pipe_issue_chunk(pcl_ctx *ctx, int c) {
     const int J = ctx->J, K = ctx->pipe_K, a = range_lo(J, K, c), b = range_lo(J, K, c + 1);
     if (b <= a) return PCL_OK;
@@ -520,6 +534,7 @@ int pcl_pipe_begin(pcl_ctx *ctx, double c_covariance, int payload, int n_chunks)
     ctx->pipe_K = K;
     ctx->pipe_mode = getenv("PCL_PIPE_MODE") ? atoi(getenv("PCL_PIPE_MODE")) : 1;
     ctx->pipe_next = 0;
+    ctx->pipe_early = 0;
     ctx->pipe_payload = payload;
     ctx->pipe_c_cov = c_covariance;
     ctx->pipe_active = true;
@@ -531,6 +546,7 @@ int pcl_pipe_progress(pcl_ctx *ctx, int final_below) {
     if (!ctx->pipe_active) return PCL_OK;
     while (ctx->pipe_next < ctx->pipe_K && range_lo(ctx->J, ctx->pipe_K, ctx->pipe_next + 1) <= final_below) {
         const int c = ctx->pipe_next++;
+        if (final_below < ctx->J) ++ctx->pipe_early;              // released by the accumulate pass itself, not by pcl_pipe_finish
         HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[c], ctx->stream));
         TRY(pipe_issue_chunk(ctx, c));
     }

@@ -135,6 +135,7 @@ struct pcl_ctx {
     std::vector<hipEvent_t> pipe_ev;
     hipEvent_t pipe_done = nullptr;
     bool pipe_active = false;
+    int pipe_early = 0;                                            // chunks of the last pipelined call that left while the pass was still running
     int pipe_K = 0, pipe_next = 0, pipe_payload = 0, pipe_mode = 1;   // mode 1: only the reduce-scatter leaves early; 0: the whole chain
     double pipe_c_cov = 0.0;
     std::map<std::string, KernelTimer> timers;

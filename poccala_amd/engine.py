@@ -360,6 +360,12 @@ class Engine(object):
         self._check(self._lib.pcl_comm_info(self._ctx, C.byref(r), C.byref(n), C.byref(t), C.byref(c)))
         return dict(rank=r.value, nranks=n.value, transport={0: 'none', 1: 'rccl', 2: 'host-rehearsal'}[t.value], rccl_nranks=c.value)
 
+    def pipe_info(self):
+        """(chunks, released_early) of the last accumulate_exchange: how many state chunks left for the exchange while the pass still ran."""
+        k, e = C.c_int(), C.c_int()
+        self._check(self._lib.pcl_pipe_info(self._ctx, C.byref(k), C.byref(e)))
+        return k.value, e.value
+
     def stats_allreduce(self):
         self._check(self._lib.pcl_stats_allreduce(self._ctx))
 

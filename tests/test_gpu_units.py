@@ -538,6 +538,9 @@ def _pipe_worker(rank, world, port, payload, pipelined, q, mode=1):
                 eng.em_exchange(1e-3, pay, True)
             out.append(eng.model_download() + (eng.units_download(), b.get('logp').copy()))
         groups = eng.kernel_time('acc_consume')[1]          # state groups of the two accumulate passes
+        if pipelined:
+            chunks, early = eng.pipe_info()
+            assert chunks == 5 and early >= 1, (chunks, early)   # the pass itself released chunks (no silent fall-back to 'no overlap')
         b.close()
         ctl.barrier()
         ctl.close()
