@@ -376,6 +376,9 @@ class AcousticModel(DataInitialization):
         so that the reference's multi_embedded_training_2 (AcousticModel.py:918-935) can merge them."""
         units = sorted(unit_hmms)
         e = self.__state_num - 2
+        if stats is not None:
+            with np.errstate(divide='ignore'):                          # ln 0 = -inf for a state no frame reached
+                ln = {k: np.log(stats[k]) for k in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc')}
         for ui, unit in enumerate(units):
             hmm = unit_hmms[unit]
             touched = False
@@ -387,15 +390,14 @@ class AcousticModel(DataInitialization):
                 hmm.add_acc(hmm_acc[unit][0], hmm_acc[unit][1])
                 touched = True
             if stats is not None:
-                with np.errstate(divide='ignore'):
-                    for k in range(e):
-                        j = ui * e + k
-                        g = hmm.profunction[1 + k]
-                        g.acc = np.log(stats['acc'][j])                 # ln 0 = -inf for a state no frame reached
-                        g.alpha_acc = float(np.log(stats['alpha_acc'][j]))
-                        g.mean_acc = np.log(stats['mean_acc'][j])
-                        g.covariance_acc = list(np.log(stats['cov_acc'][j]))
-                        touched = touched or stats['alpha_acc'][j] > 0
+                for k in range(e):
+                    j = ui * e + k
+                    g = hmm.profunction[1 + k]
+                    g.acc = ln['acc'][j]
+                    g.alpha_acc = float(ln['alpha_acc'][j])
+                    g.mean_acc = ln['mean_acc'][j]
+                    g.covariance_acc = ln['cov_acc'][j]
+                    touched = touched or stats['alpha_acc'][j] > 0
             if touched:
                 self.save_acc(unit, hmm)
                 hmm.reset_acc()

@@ -17,7 +17,7 @@ from ..Exceptions import DataDimensionError, NullLog
 from .._lib import PCL_F32, PCL_F64
 from ..runtime import scratch_engine
 from .DataInitialization import DataInitialization
-from .util import log_sum_exp
+from .util import log_sum_exp, save_acc_file
 
 
 def _lse2(a, b):
@@ -227,14 +227,8 @@ class Clustering(DataInitialization):
             stamp = int(time.time())
             for sub, name, val in (('acc', 'GMM_acc', self.__acc), ('alpha-acc', 'GMM_alpha_acc', self.__alpha_acc),
                                    ('mean-acc', 'GMM_mean_acc', self.__mean_acc),
-                                   ('covariance-acc', 'GMM_covariance_acc', np.array(self.__covariance_acc))):
-                os.makedirs(p + '/' + sub, exist_ok=True)
-                f = p + '/%s/%s_%d.npy' % (sub, name, stamp)
-                k = 0
-                while os.path.exists(f):        # the reference overwrites same-second files (SURVEY section 5 race)
-                    k += 1
-                    f = p + '/%s/%s_%d%03d.npy' % (sub, name, stamp, k)
-                np.save(f, val)
+                                   ('covariance-acc', 'GMM_covariance_acc', np.asarray(self.__covariance_acc))):
+                save_acc_file(p + '/' + sub, name, stamp, val)
 
         def init_acc(self, path):
             """Merge every accumulator file under the unit directory (Clustering.py:314-367)."""

@@ -15,7 +15,7 @@ import numpy as np
 from ..runtime import scratch_engine
 from .._lib import PCL_F64
 from .DataInitialization import DataInitialization
-from .util import log_sum_exp, matrix_log_sum_exp
+from .util import log_sum_exp, matrix_log_sum_exp, save_acc_file
 
 
 def _np_log(a):
@@ -279,13 +279,7 @@ class LHMM(DataInitialization):
         p = path + '/HMM'
         stamp = int(time.time())
         for sub, name, val in (('ksai-acc', 'ksai_acc', self.__ksai_acc), ('gamma-acc', 'gamma_acc', self.__gamma_acc)):
-            os.makedirs(p + '/' + sub, exist_ok=True)
-            f = p + '/%s/%s_%d.npy' % (sub, name, stamp)
-            k = 0
-            while os.path.exists(f):
-                k += 1
-                f = p + '/%s/%s_%d%03d.npy' % (sub, name, stamp, k)
-            np.save(f, val)
+            save_acc_file(p + '/' + sub, name, stamp, val)
 
     def init_acc(self, path):
         p = path + '/HMM'

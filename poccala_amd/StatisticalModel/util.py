@@ -52,3 +52,45 @@ def matrix_log_sum_exp(array_list, axis_x):
         safe = np.where(np.isinf(top), 0.0, top)
         out = safe + np.log(np.exp(stack - safe).sum(axis=0))
     return np.where(np.isinf(top), top, out)
+
+
+_NPY_HEADERS = {}
+_NEXT_NAME = {}            # names taken within the current second by this process: {stamp: {prefix: next k}}
+
+
+def save_acc_file(directory, name, stamp, val):
+    """Write one accumulator as <directory>/<name>_<stamp>[kkk].npy without overwriting a file of the same second (the
+    reference does overwrite).  Same bytes as np.save; the header is cached per (shape, dtype) and the
+    name is claimed with an exclusive create, because a worker flush writes several hundred of these small files and
+    np.save's per-file stat/format work was most of the flush."""
+    import io
+    import os
+    val = np.asarray(val, order='C')           # (np.ascontiguousarray would turn the 0-d alpha accumulator into shape (1,))
+    if val.dtype.hasobject:
+        raise TypeError('accumulators are plain numeric arrays')
+    key = (val.shape, val.dtype.str)
+    head = _NPY_HEADERS.get(key)
+    if head is None:
+        buf = io.BytesIO()
+        np.lib.format.write_array_header_1_0(buf, {'descr': val.dtype.str, 'fortran_order': False, 'shape': val.shape})
+        head = _NPY_HEADERS[key] = buf.getvalue()
+    if stamp not in _NEXT_NAME:
+        _NEXT_NAME.clear()
+        _NEXT_NAME[stamp] = {}
+    taken = _NEXT_NAME[stamp]
+    prefix = '%s/%s_%d' % (directory, name, stamp)
+    k = taken.get(prefix, 0)
+    while True:
+        f = prefix + ('%03d.npy' % k if k else '.npy')
+        try:
+            fd = open(f, 'xb')
+            break
+        except FileExistsError:                 # (another process, or an earlier run, within the same second)
+            k += 1
+        except FileNotFoundError:
+            os.makedirs(directory, exist_ok=True)
+    taken[prefix] = k + 1
+    with fd:
+        fd.write(head)
+        fd.write(val.data if val.ndim else val.tobytes())
+    return f

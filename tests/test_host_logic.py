@@ -1,5 +1,6 @@
 """Host-side logic of the product package that needs no GPU: sentence-HMM construction (A7), discriminate,
 the log-sum-exp helpers that merge per-unit accumulators, the MFCC filter/DCT matrices, sharding."""
+import os
 import numpy as np
 import pytest
 
@@ -125,3 +126,24 @@ def test_decode_result_unpacking_and_word_chain_without_gpu():
     rep = Decoder._report(res, tree)
     assert rep[0][0] == [['ni', 'ni2'], ['hao'], ['ma']] and rep[0][1] == -10.5
     assert rep[1][0] == [] and rep[1][1] == -3.25
+
+
+def test_save_acc_file_writes_np_save_bytes_and_never_overwrites(tmp_path):
+    """The worker shim's accumulator writer (util.save_acc_file): byte-for-byte what np.save writes for the reference's
+    accumulator shapes (incl. the 0-d alpha accumulator), and a second file of the same second gets a new name."""
+    import io
+    from poccala_amd.StatisticalModel.util import save_acc_file
+    d = str(tmp_path / 'u' / 'GMM_0' / 'acc')
+    names = []
+    for v in (np.float64(3.5), 2.0, np.arange(6.).reshape(2, 3), np.float32([1, 2]), np.full(4, -np.inf)):
+        f = save_acc_file(d, 'GMM_acc', 1700000000, v)
+        names.append(os.path.basename(f))
+        ref = io.BytesIO()
+        np.save(ref, v)
+        assert open(f, 'rb').read() == ref.getvalue()
+        assert np.load(f).shape == np.shape(v)
+    assert names == ['GMM_acc_1700000000.npy'] + ['GMM_acc_1700000000%03d.npy' % k for k in range(1, 5)]
+    open(d + '/GMM_acc_1700000001.npy', 'wb').close()                    # a file some other worker wrote this second
+    assert os.path.basename(save_acc_file(d, 'GMM_acc', 1700000001, np.zeros(2))) == 'GMM_acc_1700000001001.npy'
+    t = np.arange(6.).reshape(2, 3).T                                     # not C-contiguous: written in C order
+    assert np.array_equal(np.load(save_acc_file(d, 'GMM_acc', 1700000002, t)), t)
