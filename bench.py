@@ -43,6 +43,8 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP3
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
 HBM_PEAK_GBS = 8000.0
 # what `dtype` says for the default f32-class path: the arithmetic, not a precision claim
+C5_CORPUS_UTTS = 3336         # config 5: 1M frames = 3336 utterances x 300 frames
+C5_CHUNK_UTTS = 417          # utterances per stream chunk (8 chunks; profiles/r04_c5_chunk_sweep.txt: 139 -> 0.76, 417 -> 0.80, 834 -> 0.82, 1668 -> 0.76 M frames/s)
 DTYPE_NAME = 'f32-class (f16x2 split operands, f32 accumulate; f64 dynamic programming)'
 
 
@@ -69,6 +71,7 @@ def parse():
     p.add_argument('--cpu-baseline', type=int, default=1, help='0 = skip the CPU baseline leg')
     p.add_argument('--words', type=int, default=20000, help='--workload C5shard: random words added to the synthetic lexicon')
     p.add_argument('--max-tokens', type=int, default=8192, help='--workload C5shard: live tokens per utterance')
+    p.add_argument('--c5-chunk', type=int, default=C5_CHUNK_UTTS, help='--workload C5: utterances per stream chunk (the 3336-utterance corpus is cut into 3336 / this many chunks)')
     p.add_argument('--extra', type=int, default=1, help='0 = skip the untimed extra measurements')
     p.add_argument('--sustain', type=float, default=10.0, help='seconds the headline loop is held for value_sustained (0 = skip it and the PCIe-inclusive loop)')
     p.add_argument('--extra-timeout', type=int, default=600, help='seconds the untimed extras (and the shutdown) may take before rank 0 prints the line without them')
@@ -1360,8 +1363,8 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
                      'initial model (re-uploaded outside the timed region)')
 
 
-def c5_corpus_chunks(n_chunks=24, per=139, ragged=False):
-    """the 1M-frame corpus of config 5 as the chunks a loader would hand over: 24 chunks x 139 utterances x 300 frames = 1,000,800
+def c5_corpus_chunks(n_chunks=C5_CORPUS_UTTS // C5_CHUNK_UTTS, per=C5_CHUNK_UTTS, ragged=False):
+    """the 1M-frame corpus of config 5 as the chunks a loader would hand over: 8 chunks x 417 utterances x 300 frames = 1,000,800
     frames (ragged: 200..400 frames per utterance, a new chunk shape every time).  Yields lists of (T_u, 39) float32 arrays."""
     from poccala_amd import synth
     c = synth.CONFIGS['C5shard']
@@ -1370,7 +1373,7 @@ def c5_corpus_chunks(n_chunks=24, per=139, ragged=False):
         yield [frames[begin[u]:begin[u] + lens[u]] for u in range(per)]
 
 
-def run_c5_full(eng, tree, max_tokens, ragged=False, n_chunks=24, per=139):
+def run_c5_full(eng, tree, max_tokens, ragged=False, n_chunks=C5_CORPUS_UTTS // C5_CHUNK_UTTS, per=C5_CHUNK_UTTS):
     """Config 5 whole on one GPU: the 1M-frame corpus streamed through Decoder.decode_stream (H2D of chunk k+1 beside the scoring
     of chunk k beside the token passing of chunk k-1), every one of the 549 states x 4096 mixtures scored for every frame.
     The model, units and tree must be loaded.  Returns a dict; `value` counts the whole stream's wall clock incl. PCIe both ways."""
@@ -1445,16 +1448,17 @@ def bench_c5_full(args, rank, world, local):
     eng.load_model(mean, var, w)
     eng.load_units(np.stack(trans))
     eng.load_lexicon(tree)
-    n_chunks = 24 // world if world > 1 else 24
-    run_c5_full(eng, tree, args.max_tokens, n_chunks=min(4, n_chunks))          # warm: batches, buffers, clocks
+    per = args.c5_chunk
+    n_chunks = max(1, (C5_CORPUS_UTTS // per) // world)
+    run_c5_full(eng, tree, args.max_tokens, n_chunks=min(3, n_chunks), per=per)          # warm: batches, buffers, clocks
     ctl.barrier()
-    r = run_c5_full(eng, tree, args.max_tokens, n_chunks=n_chunks)
-    rg = run_c5_full(eng, tree, args.max_tokens, ragged=True, n_chunks=n_chunks)
+    r = run_c5_full(eng, tree, args.max_tokens, n_chunks=n_chunks, per=per)
+    rg = run_c5_full(eng, tree, args.max_tokens, ragged=True, n_chunks=n_chunks, per=per)
     ctl.barrier()
     wall = ctl.allreduce_max(r['wall_s'])
     if rank == 0:
         info = eng.device_info()
-        nfr = n_chunks * 139 * c['T'] * world
+        nfr = n_chunks * per * c['T'] * world
         print(json.dumps({'metric': 'frames/sec streamed all-state GMM-score + lexicon token-passing decode, 39-d MFCC, 4096-mix, 1M-frame corpus',
                           'value': nfr / wall, 'unit': 'frames/s', 'n_gpus': world, 'steps': 1, 'warmup': 1, 'ms_per_step': wall * 1e3,
                           'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': DTYPE_NAME, 'data': 'synthetic',
