@@ -1293,7 +1293,7 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
     for _ in range(warm):
         estep()                                # (lazy buffers, clocks; no M-step: the model stays the initial one)
     eng.sync()
-    names = ('score', 'score_direct', 'fb', 'accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive')
+    names = ('score', 'score_subset', 'score_direct', 'fb', 'accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive')
     elapsed = 0.0
     for it in range(iters):
         if it:
@@ -1310,12 +1310,17 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
         elapsed += ctl.allreduce_max(time.perf_counter() - t1)
     kt = {k: eng.kernel_time(k)[0] / iters for k in names}
     cond, cmax = eng.model_conditioning()
-    off_pipe = int((cond > cmax).sum())
+    n_off, off_limit = eng.model_split_info()
+    off_pipe = int((n_off > off_limit).sum()) if off_limit > 0 else int((cond > cmax).sum())
+    split_states = int(((n_off > 0) & (n_off <= off_limit)).sum())
+    for k in names:
+        eng.kernel_time(k)
     eng.sync()
     t1 = time.perf_counter()
     iteration()
     eng.sync()
     t_second = ctl.allreduce_max(time.perf_counter() - t1)
+    kt2 = {k: eng.kernel_time(k)[0] for k in names}
     rewind()
     # where an iteration's wall clock goes: one more iteration from the initial model with a device sync between its phases (untimed)
     phases = {}
@@ -1354,11 +1359,14 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
                 batches_on_this_rank=len(batches), kernel_ms_per_iteration_rank0=kt, phase_ms_rank0=phases, setup_s=t_setup,
                 loglik_mean_rank0=float(lp.mean()) if len(lp) else None, passes_max_rank0=int(npass.max()) if len(npass) else None,
                 states_seen_rank0=int((st['alpha_acc'] > 0).sum()),
-                second_iteration=dict(ms=t_second * 1e3, frames_per_s=nfr / t_second, states_off_the_matrix_pipe=off_pipe, states=int(len(cond)), cond_max=float(cmax),
+                second_iteration=dict(ms=t_second * 1e3, frames_per_s=nfr / t_second, states_off_the_matrix_pipe=off_pipe, split_states=split_states,
+                                      mixtures_off_the_matrix_pipe=float(n_off.sum()) / float(len(n_off) * c['M']), off_pipe_limit_per_state=off_limit,
+                                      states=int(len(cond)), cond_max=float(cmax), kernel_ms_rank0=kt2,
                                       what='the NEXT iteration, on the model the first M-step left: the bench features are N(0,1) noise, 2048 mixtures per state have ~6000 '
-                                           'frames to share, so the re-estimated mixtures collapse onto single frames (variances at the floor) and every state\'s '
-                                           'conditioning leaves the range of the centred f32-class expansion (cond > cond_max): scoring falls back to the direct-form '
-                                           'kernel, 5x slower -- a property of noise data, stated rather than hidden'),
+                                           'frames to share, so re-estimated mixtures start to collapse onto single frames and every state has a few whose own conditioning '
+                                           'leaves the range of the centred f32-class expansion (cond_m > cond_max).  Round 4 splits such states: those mixtures alone are '
+                                           'evaluated by the direct-form kernels and merged (score_subset), the state stays on the matrix pipe (before: the whole state '
+                                           'left it, 5x slower).  After two more iterations on noise most mixtures sit at the variance floor and whole states do leave'),
                 what='the configuration BASELINE.json states (8192 utterances), not the per-GPU share the headline loop times; every timed iteration starts from the '
                      'initial model (re-uploaded outside the timed region)')
 

@@ -287,6 +287,17 @@ int pcl_model_download(pcl_ctx *ctx, double *mean, double *var, double *weight);
  * any model.  cond: J floats (may be NULL); cond_max: 1 float (may be NULL).  Recomputed by upload and by pcl_mstep. */
 int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
 
+/* Split states (round 4).  The limit above is a property of single mixtures: one tight mixture far from the state's centre
+ * used to send its whole state (2048 mixtures) to the direct-form kernels, and after an M-step nearly every state has a few.
+ * A mixture whose own term cond_jm exceeds cond_max is now taken out of the matrix-core layouts instead (it looks like a
+ * zero-weight mixture there and does not enter the state's feature scales or cond[j]); the direct-form kernels evaluate the
+ * state's list of such mixtures and the two parts are merged -- ln(e^a + e^b) of the two partial log-sum-exps in scoring,
+ * += into the same statistics in the accumulate pass -- so the result is the reference's sum over all mixtures
+ * (Clustering.py:740-767, :653-680) whichever kernel evaluated a term.  A state leaves the matrix cores as a whole only when
+ * more than *limit of its mixtures are out (env PCL_SPLIT_MAX = share of M, default 0.5; 0 = whole states, as before).
+ * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
+int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
+
 /* ----------------------------------------------------------------- MFCC front-end (next row f4: the step before the path)
  * AudioProcessing.MFCC.mfcc (StatisticalModel/AudioProcessing.py:416-448) for U signals at once, float64:
  * pre-emphasis 0.98 (:184), framing sampletime/overlap (:201), per-FRAME window factor (:228, as the reference

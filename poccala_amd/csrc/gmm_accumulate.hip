@@ -121,9 +121,13 @@ struct Fast<double> {
 
 // MASTER = true (the masked fix-up of the matrix-pipe pass): a lane makes its mixture's row [s_d c_d ... k2] and its mean from the
 // float64 master copy with derive_kernel's arithmetic, so params32 / mean32 need not exist for it (see gmm_score.hip, MasterModel).
+// Split states (pcl_internal.h): the masked fix-up leaves the off-pipe mixtures (`bad`) out, as the matrix-pipe pass did; the SUBSET launch
+// (bad_idx != NULL) gives a lane the idx-th off-pipe mixture of its state, walks ALL the state's frames and leaves alpha_acc alone.
 struct AccMaster {
     const double *mean64, *var64, *w64;
     int M, Dhost, flags;
+    const unsigned char *bad;
+    const int *bad_idx, *nbad;
 };
 
 // grid = (mixture slices, states with work).  A lane owns mixture `m` of state `j`.
@@ -148,8 +152,14 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     const int j = work_states[w];
     const long long beg = off[seg_lo[w]], end = off[seg_hi[w]];
     if (beg == end) return;
-    const int m = blockIdx.x * WG + threadIdx.x;
-    const bool live = m < Mpad;
+    int m = blockIdx.x * WG + threadIdx.x;
+    bool live = m < Mpad;
+    const bool subset = MASTER && mm.bad_idx != nullptr;
+    if (MASTER && subset) {
+        if ((int)(blockIdx.x * WG) >= mm.nbad[j]) return;                  // (uniform: no lane of this slice has a mixture)
+        live = m < mm.nbad[j];
+        m = live ? mm.bad_idx[(size_t)j * Mpad + m] : 0;
+    }
     const real *p = MASTER ? nullptr : params + ((size_t)j * Mpad + (live ? m : 0)) * ROW;
     const size_t jm_ld = (size_t)j * Mpad + (live ? m : 0);
 
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     real k2;
     if (MASTER) {
         constexpr double L2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
-        const bool real_m = live && m < mm.M;
+        const bool real_m = live && m < mm.M && (subset || !(mm.bad && mm.bad[jm_ld]));
         double tail = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cf[threadIdx.x] = ((fmask >> threadIdx.x) & 1u) ? (real)(a.coef * LOG2E) : (real)-INFINITY;
-            if (blockIdx.x == 0 && !tile_mask) galpha += a.lg;
+            if (blockIdx.x == 0 && !tile_mask && !subset) galpha += a.lg;
         }
         __syncthreads();
         for (int f = 0; f < nf; ++f) {
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
             }
         }
     }
-    if (blockIdx.x == 0 && !tile_mask) {
+    if (blockIdx.x == 0 && !tile_mask && !subset) {
         // deterministic block sum of the per-thread partial posteriors
         double v = galpha;
 #pragma unroll
@@ -546,7 +556,7 @@ void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *pa
     if (count == 0) return;
     dim3 grid((ctx->Mpad + WG - 1) / WG, (unsigned)count);
     if (tile_mask && sizeof(real) == 4) {                              // the masked fix-up: rows from the master copy
-        const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags};
+        const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, nullptr, nullptr};
         hipLaunchKernelGGL((gmm_accumulate_kernel<D, float, MINW, true>), grid, dim3(WG), 0, ctx->stream, (const float *)frames, (const float *)nullptr,
                            (const float *)nullptr, ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0,
                            ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag, mm);
@@ -555,6 +565,26 @@ void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *pa
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
                        ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
                        ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag, AccMaster{});
+}
+
+// split states among [first, first + count) of the accumulate order (split_flag marks them): their off-pipe mixtures over all their frames
+template <int D, int MINW>
+void launch_acc_subset_t(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int *split_flag) {
+    dim3 grid((std::max(ctx->split_max, 1) + WG - 1) / WG, (unsigned)count);
+    const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
+    hipLaunchKernelGGL((gmm_accumulate_kernel<D, float, MINW, true>), grid, dim3(WG), 0, ctx->stream, ctx->frames32, (const float *)nullptr,
+                       (const float *)nullptr, ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0,
+                       ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov, (const int *)nullptr, (const unsigned int *)nullptr, split_flag + first, mm);
+}
+void launch_acc_subset(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int *split_flag) {
+    if (count == 0) return;
+    switch (ctx->D) {
+        case 13: launch_acc_subset_t<13, 2>(ctx, b, first, count, split_flag); break;
+        case 26: launch_acc_subset_t<26, 2>(ctx, b, first, count, split_flag); break;
+        case 39: launch_acc_subset_t<39, 2>(ctx, b, first, count, split_flag); break;
+        case 47: launch_acc_subset_t<47, 2>(ctx, b, first, count, split_flag); break;
+        default: break;
+    }
 }
 
 // f32, states [first, first + count) of the accumulate order (optionally only the frames a tile mask marks)
@@ -582,6 +612,7 @@ void pcl_accumulate_release(pcl_batch *b) {
     dev_free(b->d_work_states);
     dev_free(b->d_seg_lo);
     dev_free(b->d_seg_hi);
+    dev_free(b->d_split_flag);
     for (int k = 0; k < 2; ++k) {
         dev_free(b->acc16_images[k]);
         dev_free(b->acc16_tile_off[k]);
@@ -596,7 +627,7 @@ void pcl_accumulate_release(pcl_batch *b) {
     b->acc16_ev_start = nullptr;
     b->acc16_cap_tiles = b->acc16_cap_states = 0;
     b->acc_cnt = nullptr; b->acc_off = nullptr; b->acc_list = nullptr;
-    b->d_work_states = b->d_seg_lo = b->d_seg_hi = nullptr;
+    b->d_work_states = b->d_seg_lo = b->d_seg_hi = b->d_split_flag = nullptr;
     b->acc_cap_list = b->acc_cap_segs = b->acc_cap_states = 0;
 }
 
@@ -626,7 +657,9 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         dev_free(b->d_work_states);
         dev_free(b->d_seg_lo);
         dev_free(b->d_seg_hi);
-        b->d_work_states = b->d_seg_lo = b->d_seg_hi = nullptr;
+        dev_free(b->d_split_flag);
+        b->d_work_states = b->d_seg_lo = b->d_seg_hi = b->d_split_flag = nullptr;
+        TRY(dev_alloc(ctx, &b->d_split_flag, (size_t)(ns)));
         TRY(dev_alloc(ctx, &b->d_work_states, (size_t)(ns)));
         TRY(dev_alloc(ctx, &b->d_seg_lo, (size_t)(ns)));
         TRY(dev_alloc(ctx, &b->d_seg_hi, (size_t)(ns)));
@@ -636,7 +669,8 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     const int D = ctx->D;
     const bool mfma = precision == PCL_F32 && ctx->score_variant >= 3 && (D == 47 || D == 39 || D == 26 || D == 13);
     b->acc_ws.clear(); b->acc_lo.clear(); b->acc_hi.clear();
-    int n_good = 0;
+    int n_good = 0, n_split = 0;
+    b->acc_split.clear();
     for (int pass = 0; pass < 2; ++pass)
         for (size_t k = 0; k < ns; ++k) {
             const bool bad = mfma && pcl_state_uses_valu(ctx, b->work_states[k]);
@@ -644,6 +678,9 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             b->acc_ws.push_back(b->work_states[k]);
             b->acc_lo.push_back(b->state_seg_lo[k]);
             b->acc_hi.push_back(b->state_seg_hi[k]);
+            const int sp = (mfma && pass == 0 && pcl_state_is_split(ctx, b->work_states[k])) ? 1 : 0;
+            b->acc_split.push_back(sp);
+            n_split += sp;
             n_good += pass == 0;
         }
     const int n_bad = (int)ns - n_good;
@@ -652,6 +689,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     HIPCHK(ctx, hipMemcpyAsync(b->d_work_states, b->acc_ws.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(b->d_seg_lo, b->acc_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(b->d_seg_hi, b->acc_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (n_split) HIPCHK(ctx, hipMemcpyAsync(b->d_split_flag, b->acc_split.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 
     // a frame survives unless every gamma_t(j,m) <= gamma_t(j) underflows to exactly 0 in the
     // kernel's arithmetic (f32: 2^-149, f64: 2^-1074)
@@ -750,6 +788,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             pcl_timer_end(ctx, "acc_consume");
             if (rc != PCL_OK) return rc;
             launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
+            if (n_split) launch_acc_subset(ctx, b, gfirst[g], gcount[g], b->d_split_flag);                    // the mixtures the pipe left out (split states)
             if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));
             if (!overlap && g + 1 < G) { rc = produce(g + 1); if (rc != PCL_OK) return rc; }
             // a pipelined exchange is open (pcl_batch_accumulate_exchange): every state below the next group's first one has its
@@ -766,6 +805,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
                        b->acc_off, b->acc_list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
         if (D == 47) LAUNCH_MFMA(47); else if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
 #undef LAUNCH_MFMA
+        if (n_split) launch_acc_subset(ctx, b, 0, n_good, b->d_split_flag);
     }
     if (precision == PCL_F32) {
         const int first = mfma ? n_good : 0, count = mfma ? n_bad : (int)ns;

@@ -64,12 +64,17 @@ struct Fast<double> {
 // reads are made on the fly from (mean, var, weight) with derive_kernel's arithmetic (model_derive.hip) while they are staged in
 // LDS, so the 3 GB of direct-form layouts (params32, mean32) need not exist unless a whole state is scored by this kernel: they
 // fed the fix-up paths only, and a flagged tile pays D square roots per mixture against 2 D x 256 FMAs.
+// Split states (pcl_internal.h): `bad` marks the mixtures that are off the matrix pipe.  A fix-up launch (MASTER) rescoring a flagged tile
+// leaves them out like the pipe did; the SUBSET launch scores exactly them -- the state's compacted list bad_idx[0 .. nbad) -- for every
+// frame of the split states and log-adds the result to what the pipe wrote.
 struct MasterModel {
     const double *mean64, *var64, *w64;
     int M, Dhost, flags;
+    const unsigned char *bad;
+    const int *bad_idx, *nbad;
 };
 
-template <int D, int R, int CH, typename real, bool MASTER = false>
+template <int D, int R, int CH, typename real, bool MASTER = false, bool SUBSET = false>
 __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict__ frames,
                                                           const real *__restrict__ params, int Mpad,
                                                           const ScoreTile *__restrict__ tiles,
@@ -113,19 +118,24 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
         sm[r] = 0;
     }
 
+    static_assert(!SUBSET || MASTER, "the subset launch makes its rows from the master copy");
     const real *pbase = params + (size_t)tile.state * Mpad * ROW;
-    for (int c0 = 0; c0 < Mpad; c0 += CH) {
-        const int n = min(CH, Mpad - c0);
+    const int n_sub = SUBSET ? mm.nbad[tile.state] : 0;
+    const int Mloop = SUBSET ? (n_sub + GROUP - 1) / GROUP * GROUP : Mpad;       // (whole groups: the filler rows are log zero)
+    for (int c0 = 0; c0 < Mloop; c0 += CH) {
+        const int n = min(CH, Mloop - c0);
         __syncthreads();
         if (MASTER) {
             constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
             const size_t jm0 = (size_t)tile.state * Mpad + c0;
+            const size_t js0 = (size_t)tile.state * Mpad;
             for (int i = threadIdx.x; i < n * D; i += WG) {
                 const int ml = i / D, d = i - ml * D;
-                const bool ok = (c0 + ml) < mm.M && d < mm.Dhost;
+                const bool ok = SUBSET ? ((c0 + ml) < n_sub && d < mm.Dhost) : ((c0 + ml) < mm.M && d < mm.Dhost);
                 real sv = 0, cv = 0;
                 if (ok) {
-                    const double v = mm.var64[(jm0 + ml) * D + d], mu = mm.mean64[(jm0 + ml) * D + d];
+                    const size_t jm = SUBSET ? js0 + mm.bad_idx[js0 + c0 + ml] : jm0 + ml;
+                    const double v = mm.var64[jm * D + d], mu = mm.mean64[jm * D + d];
                     const float a = (float)(-LOG2E * (0.5 / v));             // (derive_kernel: s = sqrt(-a) from the f32 coefficient)
                     const float sf = sqrtf(-a);
                     sv = (real)sf;
@@ -136,13 +146,15 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
             }
             for (int ml = threadIdx.x; ml < n; ml += WG) {
                 double k2 = -INFINITY;
-                if (c0 + ml < mm.M) {
+                const bool have = SUBSET ? (c0 + ml) < n_sub : ((c0 + ml) < mm.M && !(mm.bad && mm.bad[jm0 + ml]));
+                if (have) {
+                    const size_t jm = SUBSET ? js0 + mm.bad_idx[js0 + c0 + ml] : jm0 + ml;
                     double tail = 0.0;                                       // util.py:29 (quirk Q1): sum(var); the log-determinant only on request
                     for (int d = 0; d < mm.Dhost; ++d) {
-                        const double v = mm.var64[(jm0 + ml) * D + d];
+                        const double v = mm.var64[jm * D + d];
                         tail += (mm.flags & PCL_MODEL_LOGDET) ? log(v) : v;
                     }
-                    k2 = LOG2E * (log(mm.w64[jm0 + ml]) - 0.5 * mm.Dhost * LOG_2PI - 0.5 * tail);
+                    k2 = LOG2E * (log(mm.w64[jm]) - 0.5 * mm.Dhost * LOG_2PI - 0.5 * tail);
                 }
                 lds[ml * ROW + 2 * D] = (real)(float)k2;
             }
@@ -195,7 +207,12 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
     for (int r = 0; r < R; ++r) {
         if (valid[r]) {
             // all-(-inf) components (every weight zero): sum stays 0 -> log2(0) = -inf, as util.py:63-65
-            const double res = (sm[r] > 0) ? LN2 * ((double)mx[r] + ::log2((double)sm[r])) : -INFINITY;
+            double res = (sm[r] > 0) ? LN2 * ((double)mx[r] + ::log2((double)sm[r])) : -INFINITY;
+            if (SUBSET) {                                                    // ln (e^pipe + e^these): the pipe's part is in the buffer
+                const double old = out[oidx[r]];
+                const double hi = fmax(old, res), lo = fmin(old, res);
+                res = (hi > -INFINITY) ? hi + log1p(exp(lo - hi)) : -INFINITY;
+            }
             out[oidx[r]] = res;
         }
     }
@@ -271,7 +288,7 @@ int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, i
     const int tf = pcl_score_split16_tile_frames(), R = tf / WG;      // frames per lane so that a workgroup covers the same tile
     if (tf % WG || (R != 1 && R != 2)) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: fix-up tile size mismatch");
     pcl_timer_begin(ctx, "score_fixup");
-    const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags};      // (no params32 needed: see MasterModel)
+    const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, nullptr, nullptr};      // (no params32 needed: see MasterModel)
 #define LAUNCHF(DD, RR) hipLaunchKernelGGL((gmm_score_kernel<DD, RR, PCL_CH32, float, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
                                            (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, flags, mm)
 #define CASEF(DD) case DD: if (R == 1) LAUNCHF(DD, 1); else LAUNCHF(DD, 2); break;
@@ -282,6 +299,23 @@ int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, i
 #undef CASEF
 #undef LAUNCHF
     pcl_timer_end(ctx, "score_fixup");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+// the off-pipe mixtures of the split states, direct form, log-added to the matrix pipe's result (tiles: the direct-form tile size)
+int pcl_launch_score_subset(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
+    if (n_tiles == 0) return PCL_OK;
+    pcl_timer_begin(ctx, "score_subset");
+    const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
+    switch (ctx->D) {
+#define CASES(DD) case DD: hipLaunchKernelGGL((gmm_score_kernel<DD, r32(DD), PCL_CH32, float, true, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
+                                               (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, mm); break;
+        CASES(13) CASES(26) CASES(39) CASES(47)
+#undef CASES
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no subset scoring kernel for D=%d", ctx->D);
+    }
+    pcl_timer_end(ctx, "score_subset");
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

@@ -37,7 +37,8 @@ constexpr int PRE_T = 512;
 __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
                                                              const double *__restrict__ w64, int M, int Mpad, int D, int Dhost, int KS8,
                                                              int flags, float *__restrict__ centers, float *__restrict__ fscale,
-                                                             double *__restrict__ kzero, int j0) {
+                                                             double *__restrict__ kzero, int j0, float cond_split,
+                                                             unsigned char *__restrict__ bad, int *__restrict__ bad_idx, int *__restrict__ nbad) {
     __shared__ double part[64 * 40];
     __shared__ float cen[64];
     __shared__ unsigned long long fbits[2][64];
@@ -73,17 +74,19 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         const int m = m0 + ml;
         const bool real_m = m < M;
         double sumvar = 0.0, sumlog = 0.0, kq = 0.0;
+        double t0[8], t1[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dd = sub + 8 * k;
+            t0[k] = t1[k] = 0.0;
             if (dd < D && dd < Dhost && real_m) {
                 const double v = vr[(size_t)m * D + dd], dm = mu[(size_t)m * D + dd] - (double)cen[dd];
                 const double hr = 0.5 / v;                       // ONE float64 division per element (three cost 2 ms per re-derive)
                 sumvar += v;
                 if (flags & PCL_MODEL_LOGDET) sumlog += log(v);
                 kq += dm * dm * hr;
-                mx0[k] = fmax(mx0[k], LOG2E * hr);
-                mx1[k] = fmax(mx1[k], fabs(2.0 * LOG2E * dm * hr));
+                t0[k] = LOG2E * hr;
+                t1[k] = fabs(2.0 * LOG2E * dm * hr);
             }
         }
 #pragma unroll
@@ -92,7 +95,18 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
             sumlog += __shfl_xor(sumlog, o, 64);
             kq += __shfl_xor(kq, o, 64);
         }
-        if (sub == 0 && real_m) {
+        // a mixture whose own cancelling term is beyond the expansion's range leaves the matrix-pipe layouts (pcl_internal.h, split
+        // states): it must not set the state's feature scales or K0 either, or the mixtures that stay would lose their bits to it
+        const bool off_pipe = real_m && (float)(LOG2E * kq) > cond_split;
+        if (sub == 0 && real_m) bad[(size_t)j * Mpad + m] = off_pipe ? 1 : 0;
+        if (!off_pipe) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                mx0[k] = fmax(mx0[k], t0[k]);
+                mx1[k] = fmax(mx1[k], t1[k]);
+            }
+        }
+        if (sub == 0 && real_m && !off_pipe) {
             // util.py:29 (quirk Q1): -D/2 ln 2pi - 1/2 sum(var); textbook log-determinant only on request
             const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
             const double k2 = LOG2E * (log(w64[(size_t)j * Mpad + m]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
@@ -126,6 +140,28 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
         kzero[j] = (i == (int)0x80808080 || !(f > -3.0e38f)) ? 0.0 : (double)f;      // no real mixture at all: anything
     }
+    // the state's off-pipe mixtures as an ascending list (the flags were written by this workgroup before the barriers above)
+    {
+        __shared__ int cnt[PRE_T];
+        const int per = (M + PRE_T - 1) / PRE_T, lo = min(tid * per, M), hi = min(lo + per, M);
+        int c = 0;
+        for (int m = lo; m < hi; ++m) c += bad[(size_t)j * Mpad + m];
+        cnt[tid] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int i = 0; i < PRE_T; ++i) {
+                const int v = cnt[i];
+                cnt[i] = run;
+                run += v;
+            }
+            nbad[j] = run;
+        }
+        __syncthreads();
+        int pos = cnt[tid];
+        for (int m = lo; m < hi; ++m)
+            if (bad[(size_t)j * Mpad + m]) bad_idx[(size_t)j * Mpad + pos++] = m;
+    }
 }
 
 // one workgroup per (state, 32-mixture tile): the tile's mean/var rows are staged in LDS with coalesced
@@ -137,14 +173,17 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                                                      float *__restrict__ mean32, float *__restrict__ pm32,
                                                      uint4 *__restrict__ pm16f,
                                                      const double *__restrict__ kzero,
-                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what, int j0) {
+                                                     const float *__restrict__ fscale, float *__restrict__ cond, int what, int j0,
+                                                     const unsigned char *__restrict__ bad) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int nmt = Mpad32 / 32, KS = D + 1, KS4 = (KS + 3) / 4;
     const int j = j0 + blockIdx.x / nmt, mt = blockIdx.x % nmt, m0 = mt * 32;
     double *mu = sh, *vr = sh + 32 * D, *k2s = vr + 32 * D, *kqs = k2s + 32;
     float *cen = reinterpret_cast<float *>(kqs + 32);
     float *fa = cen + D, *fb = fa + 32 * D;       // the f32 coefficients of the expansion: a = -log2e/(2 var), b = log2e (mu - c)/var
+    __shared__ unsigned char offp[32];            // mixtures of this tile that are off the matrix pipe (split states): absent from pm32 / pm16f
     const int tid = threadIdx.x;
+    if (tid < 32) offp[tid] = (m0 + tid < M) ? bad[(size_t)j * Mpad + m0 + tid] : 0;
     for (int e = tid; e < 32 * D; e += 256) {
         const int m = m0 + e / D;
         const bool ok = m < M && (e % D) < Dhost;
@@ -192,10 +231,12 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
             // conditioning of the centred expansion: the largest cancelling term of this state (non-negative floats
             // order like their bit patterns, so an integer atomicMax works)
             if (real_m && (what & PCL_LAYOUT_COND)) {
+                // (over ALL mixtures: what the state's worst mixture looks like; with split states the off-pipe ones are counted
+                // in nbad and the host decides from that, pcl_state_uses_valu)
                 atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint((float)(LOG2E * kq)));
-                // the 16x16x32 kernel keeps the constant in f16 pieces: a real k' beyond their range sends the state to
-                // the direct-form kernels as well
-                if ((what & PCL_LAYOUT_PM16F) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
+                // the 16x16x32 kernel keeps the constant in f16 pieces: a real k' (of a mixture that stays on the pipe) beyond their
+                // range sends the state to the direct-form kernels as well
+                if (!offp[ml] && (what & PCL_LAYOUT_PM16F) && k2 > -INFINITY && fabs(k2 - LOG2E * kq) > 5.0e4)
                     atomicMax(reinterpret_cast<unsigned int *>(cond + j), __float_as_uint(1.0e30f));
             }
         }
@@ -232,14 +273,14 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
     if (what & PCL_LAYOUT_PM32)
     for (int e = tid; e < KS4 * 64; e += 256) {
         const int q = e >> 6, ln = e & 63, half = ln >> 5, cl = ln & 31;
-        const bool real_m = (m0 + cl) < M;
+        const bool real_m = (m0 + cl) < M && !offp[cl];
         float v[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int s = 4 * q + x;
             float val = 0.f;
             if (s < D) {
-                val = half ? fb[cl * D + s] : fa[cl * D + s];
+                val = offp[cl] ? 0.f : (half ? fb[cl * D + s] : fa[cl * D + s]);
             } else if (s == D) {
                 // the constant pair: k' on the low half-wave, 1 in the spare slot (multiplied by 0 in plain
                 // scoring, by -ref / cf in the kernels that use the slot)
@@ -261,7 +302,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
         __syncthreads();
         for (int e = tid; e < 2 * KS8f * 64; e += 256) {
             const int p = (e >> 6) / KS8f, s = (e >> 6) % KS8f, ln = e & 63, half = ln >> 5, cl = ln & 31;
-            const bool real_m = (m0 + cl) < M;
+            const bool real_m = (m0 + cl) < M && !offp[cl];
             unsigned short h[8];
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
@@ -269,7 +310,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const double *__restrict__ 
                 float val = 0.f;
                 bool is_const = false;
                 if (dd < D) {
-                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) * isc[half * (KS8f * 8) + dd];
+                    val = offp[cl] ? 0.f : (half ? fb[cl * D + dd] : fa[cl * D + dd]) * isc[half * (KS8f * 8) + dd];
                 } else if (dd == D) {
                     is_const = true;
                     if (half == 0) {
@@ -375,7 +416,7 @@ static int launch_derive_kernel(pcl_ctx *ctx, int what, int j_lo, int j_hi) {
     hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((j_hi - j_lo) * (ctx->Mpad32 / 32))), dim3(256), shm, ctx->stream, ctx->mean64, ctx->var64,
                        ctx->w64, ctx->centers32, ctx->M, ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->row, ctx->model_flags,
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16f),
-                       ctx->kzero, ctx->fscale, ctx->d_cond, what, j_lo);
+                       ctx->kzero, ctx->fscale, ctx->d_cond, what, j_lo, ctx->d_bad);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }
@@ -386,7 +427,8 @@ int pcl_launch_derive_range(pcl_ctx *ctx, int j_lo, int j_hi) {
     if (j_hi <= j_lo) return PCL_OK;
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(j_hi - j_lo), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
-                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, j_lo);
+                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, j_lo, pcl_split_threshold(ctx), ctx->d_bad,
+                       ctx->d_bad_idx, ctx->d_nbad);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond + j_lo, 0, (size_t)(j_hi - j_lo) * sizeof(float), ctx->stream));
     return launch_derive_kernel(ctx, eager_layouts(ctx), j_lo, j_hi);
 }
@@ -395,6 +437,8 @@ int pcl_derive_finish(pcl_ctx *ctx) {
     ctx->layouts_valid = eager_layouts(ctx);
     ctx->cond.resize(ctx->J);
     HIPCHK(ctx, hipMemcpyAsync(ctx->cond.data(), ctx->d_cond, (size_t)ctx->J * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->nbad.resize(ctx->J);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->nbad.data(), ctx->d_nbad, (size_t)ctx->J * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ++ctx->model_gen;
     return PCL_OK;
@@ -403,7 +447,8 @@ int pcl_derive_finish(pcl_ctx *ctx) {
 int pcl_launch_derive(pcl_ctx *ctx) {
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(ctx->J), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
-                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, 0);
+                       ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, 0, pcl_split_threshold(ctx), ctx->d_bad,
+                       ctx->d_bad_idx, ctx->d_nbad);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     const int what = eager_layouts(ctx);
     const int rc = launch_derive_kernel(ctx, what, 0, ctx->J);
@@ -412,6 +457,8 @@ int pcl_launch_derive(pcl_ctx *ctx) {
     // the per-state conditioning decides which kernel scores a state: bring it to the host (J floats)
     ctx->cond.resize(ctx->J);
     HIPCHK(ctx, hipMemcpyAsync(ctx->cond.data(), ctx->d_cond, (size_t)ctx->J * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->nbad.resize(ctx->J);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->nbad.data(), ctx->d_nbad, (size_t)ctx->J * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ++ctx->model_gen;
     return PCL_OK;

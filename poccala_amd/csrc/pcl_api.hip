@@ -175,6 +175,7 @@ int pcl_init(int device, pcl_ctx **out) {
         return PCL_ERR_INVALID;
     }
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
+    if (const char *sm = getenv("PCL_SPLIT_MAX")) ctx->split_frac = std::min(1.0f, std::max(0.0f, (float)atof(sm)));
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
     if (const char *tm = getenv("PCL_TIMERS")) ctx->timing = atoi(tm) != 0;
     *out = ctx;
@@ -194,6 +195,10 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->fscale);
     dev_free(ctx->centers32);
     dev_free(ctx->d_cond);
+    dev_free(ctx->d_bad);
+    dev_free(ctx->d_bad_idx);
+    dev_free(ctx->d_nbad);
+    ctx->nbad.clear();
     dev_free(ctx->stats);
     ctx->st_acc = ctx->st_alpha = ctx->st_mean = ctx->st_cov = nullptr;
     ctx->J = ctx->M = ctx->Mpad = 0;
@@ -354,6 +359,10 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->fscale, (size_t)J * 2 * ((Dd + 7) / 8) * 8));
     TRY(dev_alloc(ctx, &ctx->centers32, (size_t)J * Dd));
     TRY(dev_alloc(ctx, &ctx->d_cond, (size_t)J));
+    TRY(dev_alloc(ctx, &ctx->d_bad, (size_t)J * Mpad));
+    TRY(dev_alloc(ctx, &ctx->d_bad_idx, (size_t)J * Mpad));
+    TRY(dev_alloc(ctx, &ctx->d_nbad, (size_t)J));
+    ctx->split_max = (int)(ctx->split_frac * (float)M);
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->var64, v64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->w64, w64.data(), nw * sizeof(double), hipMemcpyHostToDevice));
@@ -565,7 +574,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
     dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax); dev_free(b->fb_dump); dev_free(b->fb_part_m); dev_free(b->fb_part_e);
     dev_free(b->d_dups);
-    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
+    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tiles_s); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
     return PCL_OK;
 }
@@ -760,6 +769,8 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     dev_free(b->d_segs);
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
+    dev_free(b->d_tiles_s);
+    b->n_tiles_s = 0;
     b->tile_frames = 0;
     TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
     if (b->n_segs) HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg)));
@@ -874,8 +885,20 @@ static int build_tiles(pcl_batch *b, int precision) {
     for (size_t k = 0; k < b->work_states.size(); ++k) (mfma && pcl_state_uses_valu(ctx, b->work_states[k]) ? bad : good).push_back(k);
     const std::vector<ScoreTile> tiles = make_tiles(b, good, tf);
     const std::vector<ScoreTile> tiles_v = bad.empty() ? std::vector<ScoreTile>() : make_tiles(b, bad, pcl_score_tile_frames(ctx->D, PCL_F32));
+    // split states: on the matrix pipe (in `good`) AND, for their off-pipe mixtures, in a list of their own at the direct-form tile size
+    std::vector<size_t> split;
+    if (mfma)
+        for (size_t k : good)
+            if (pcl_state_is_split(ctx, b->work_states[k])) split.push_back(k);
+    const std::vector<ScoreTile> tiles_s = split.empty() ? std::vector<ScoreTile>() : make_tiles(b, split, pcl_score_tile_frames(ctx->D, PCL_F32));
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
+    dev_free(b->d_tiles_s);
+    b->n_tiles_s = (int)tiles_s.size();
+    if (!tiles_s.empty()) {
+        TRY(dev_alloc(ctx, &b->d_tiles_s, tiles_s.size()));
+        HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_tiles_s, tiles_s.data(), tiles_s.size() * sizeof(ScoreTile)));
+    }
     dev_free(b->d_tile_flags);
     TRY(dev_alloc(ctx, &b->d_tile_flags, tiles.size()));
     b->n_tiles = (int)tiles.size();
@@ -920,6 +943,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
             TRY(pcl_launch_score_fixup(ctx, b, b->d_tiles, b->n_tiles, b->d_tile_flags));   // tiles with out-of-range features
 #endif
         } else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
+        TRY(pcl_launch_score_subset(ctx, b, b->d_tiles_s, b->n_tiles_s));         // split states: their off-pipe mixtures, log-added
         TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
     } else {
         TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));
@@ -1238,6 +1262,14 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max) {
     if (ctx->cond.empty()) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_model_conditioning: no model uploaded");
     if (cond) memcpy(cond, ctx->cond.data(), ctx->cond.size() * sizeof(float));
     if (cond_max) *cond_max = ctx->cond_max;
+    return PCL_OK;
+}
+
+int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (ctx->nbad.empty()) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_model_split_info: no model uploaded");
+    if (n_off) memcpy(n_off, ctx->nbad.data(), ctx->nbad.size() * sizeof(int));
+    if (limit) *limit = ctx->split_max;
     return PCL_OK;
 }
 

@@ -87,6 +87,17 @@ struct pcl_ctx {
     float *d_cond = nullptr;
     std::vector<float> cond;
     float cond_max = 96.f;
+    // Split states.  The limit is a property of single MIXTURES (one tight mixture far from the state's centre), and after an M-step most states
+    // have a few of them (tools/cond_probe.py: 7 % of the mixtures, every state).  A mixture with cond_m > cond_max is therefore taken OUT of
+    // the matrix-pipe layouts (written like a zero-weight mixture, left out of the state's feature scales, K0 and cond) and evaluated by the
+    // direct-form kernels over the state's compacted list of such mixtures, merged by a log-add (scoring) / added to the statistics
+    // (accumulate).  A state goes to the direct-form kernels as a whole only when more than split_max of its mixtures are out.
+    unsigned char *d_bad = nullptr;    // [J][Mpad] 1 = the mixture is off the matrix pipe
+    int *d_bad_idx = nullptr;          // [J][Mpad] the state's off-pipe mixtures in ascending order (first nbad[j] entries)
+    int *d_nbad = nullptr;             // [J]
+    std::vector<int> nbad;
+    float split_frac = 0.5f;           // env PCL_SPLIT_MAX: the share of a state's mixtures that may be off the pipe (0 = no splitting)
+    int split_max = 0;                 // = split_frac * M: mixtures per state that may be off the pipe (0: no splitting -- whole states, as before round 4)
     int model_gen = 0;           // bumped whenever the layouts (and cond) are re-derived
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
     double *mean64 = nullptr;    // float64 master copy of the model: mean, var (J*Mpad*D), weight (J*Mpad)
@@ -187,21 +198,22 @@ struct pcl_batch {
     DupRow *d_dups = nullptr;
     std::vector<int> work_states;
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
-    std::vector<int> acc_ws, acc_lo, acc_hi; // accumulate's state order (well-conditioned first)
+    std::vector<int> acc_ws, acc_lo, acc_hi, acc_split; // accumulate's state order (well-conditioned first)
     hipEvent_t ev_main = nullptr, ev_dp = nullptr;   // main stream -> stream_dp hand-over, and back
     bool dp_pending = false;                 // forward-backward queued on stream_dp and not yet joined
     hipEvent_t ev_fetch = nullptr, ev_fetch_src = nullptr;   // pcl_batch_fetch_async: copies done / the main stream at the time of the call
     bool fetch_pending = false;              // result copies queued on stream_d2h: the next compute call on this batch waits for them
     int *d_tile_flags = nullptr;             // split-f16 scoring: per tile, 1 = a scaled feature left the f16 range (rescored)
     ScoreTile *d_tiles_v = nullptr;          // MFMA mode only: tiles of ill-conditioned states for the VALU kernel
-    int n_segs = 0, n_tiles = 0, n_tiles_v = 0, tile_frames = 0, tile_gen = -1;
+    ScoreTile *d_tiles_s = nullptr;          // MFMA mode only: tiles of the split states for the subset launch (their off-pipe mixtures)
+    int n_segs = 0, n_tiles = 0, n_tiles_v = 0, n_tiles_s = 0, tile_frames = 0, tile_gen = -1;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
     double *nz_tmp = nullptr;                // nnz staging buffer for the sparse xi download
     // accumulate work lists (gmm_accumulate.hip): per-segment counts / offsets, per-state active-frame lists
     int *acc_cnt = nullptr;
     long long *acc_off = nullptr;
     ActiveFrame *acc_list = nullptr;
-    int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
+    int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr, *d_split_flag = nullptr;   // (split_flag: 1 = a split state, in accumulate order)
     size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
     // producer / consumer accumulate (gmm_accumulate_f16.hip): tile images in LDS order, per-state tile offsets, outlier masks
     // two sets: the producer of state group g + 1 runs on the auxiliary stream beside the consumer of group g
@@ -341,6 +353,7 @@ size_t pcl_acc16_image_bytes(int D);
 int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_split16_tile_frames();
 int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
+int pcl_launch_score_subset(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_dup_rows(pcl_ctx *ctx, pcl_batch *b);
@@ -353,7 +366,14 @@ int pcl_pipe_finish(pcl_ctx *ctx, int update_transitions);
 void pcl_pipe_release(pcl_ctx *ctx);
 int pcl_ensure_layouts(pcl_ctx *ctx, int need);
 enum { PCL_LAYOUT_P32 = 1, PCL_LAYOUT_P64 = 2, PCL_LAYOUT_PM32 = 4, PCL_LAYOUT_COND = 32, PCL_LAYOUT_PM16F = 128 };
-inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) { return !ctx->cond.empty() && ctx->cond[j] > ctx->cond_max; }
+inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) {
+    if (ctx->cond.empty()) return false;
+    if (ctx->split_max > 0 && !ctx->nbad.empty())              // split states: only too many off-pipe mixtures (or constants out of f16 range)
+        return ctx->nbad[j] > ctx->split_max || ctx->cond[j] >= 1.0e30f;
+    return ctx->cond[j] > ctx->cond_max;
+}
+inline bool pcl_state_is_split(const pcl_ctx *ctx, int j) { return !ctx->nbad.empty() && ctx->nbad[j] > 0 && !pcl_state_uses_valu(ctx, j); }
+inline float pcl_split_threshold(const pcl_ctx *ctx) { return ctx->split_max > 0 ? ctx->cond_max : 3.0e38f; }   // cond_m above this: off the pipe
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);
 int pcl_launch_mstep_range(pcl_ctx *ctx, double floor_var, int j_lo, int j_hi);

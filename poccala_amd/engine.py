@@ -313,6 +313,15 @@ class Engine(object):
         self._check(self._lib.pcl_model_conditioning(self._ctx, ptr(cond), ptr(cmax)))
         return cond, float(cmax[0])
 
+    def model_split_info(self):
+        """(n_off (J,) int32, limit): mixtures per state that are off the matrix-core path (their own conditioning is beyond
+        cond_max; the direct-form kernels evaluate them and the parts are merged); a state with more than `limit` of them
+        leaves the matrix cores as a whole."""
+        n_off = np.empty(self.J, dtype=np.int32)
+        lim = np.empty(1, dtype=np.int32)
+        self._check(self._lib.pcl_model_split_info(self._ctx, ptr(n_off), ptr(lim)))
+        return n_off, int(lim[0])
+
     # ------------------------------------------------------------------ RCCL
     def comm_unique_id(self):
         buf = np.zeros(128, dtype=np.uint8)

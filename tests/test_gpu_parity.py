@@ -712,6 +712,163 @@ def test_ill_conditioned_states_use_direct_form(eng):
     b.close()
 
 
+# ------------------------------------------------------------------ split states: single tight mixtures leave the matrix-core path
+def split_model(seed, units=4, M=64, D=39):
+    """The bench model with a few mixtures per state collapsed to a variance of 1e-3 .. 1e-2 (what an M-step leaves when a mixture
+    owns one or two frames): state j gets j % 4 * 3 of them -- none for every fourth state -- and the last state 40 of 64, more than
+    the share a split state may have (it goes to the direct-form kernels as a whole)."""
+    from poccala_amd import synth
+    rng = np.random.default_rng(seed)
+    mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
+    J = mean.shape[0]
+    tight = []
+    for j in range(J):
+        n = (j % 4) * 3 if j < J - 1 else 40
+        idx = np.sort(rng.choice(M, n, replace=False))
+        var[j, idx] = rng.uniform(1e-3, 1e-2, (n, D))
+        tight.append(idx)
+    return mean, var, w, trans, tight
+
+
+def mixture_conditioning(mean, var):
+    cen = mean.mean(axis=1, keepdims=True).astype(np.float32).astype(np.float64)
+    return 1.4426950408889634 * ((mean - cen) ** 2 * (0.5 / var)).sum(-1)
+
+
+def test_split_states_merge_both_kernels(eng):
+    """A state with a few tight mixtures stays on the matrix cores: those mixtures are evaluated by the direct-form kernels and merged
+    (ln(e^a + e^b) in scoring, += in the statistics).  Scores and E-step statistics against the oracle, frames drawn from the tight
+    mixtures as well as the broad ones; the classification the library reports; PCL_SPLIT_MAX=0 (whole states) agrees."""
+    import os
+    from poccala_amd import Engine, PCL_F32
+    from poccala_amd.engine import make_sentence_batch
+    rng = np.random.default_rng(78)
+    mean, var, w, trans, tight = split_model(902)
+    J, M, D = mean.shape
+    eng.load_model(mean, var, w)
+    cond, cmax = eng.model_conditioning()
+    n_off, limit = eng.model_split_info()
+    cm = mixture_conditioning(mean, var)
+    assert limit == M // 2
+    assert np.array_equal(n_off, [len(t) for t in tight]) and np.array_equal(n_off, (cm > cmax).sum(1))
+    assert ((cond > cmax) == (n_off > 0)).all()                      # cond stays the state's worst mixture
+    split = (n_off > 0) & (n_off <= limit)
+    assert split.sum() >= 6 and (n_off == 0).sum() >= 3 and n_off[-1] > limit
+    T = 40 * J
+    st = np.repeat(np.arange(J), 40)
+    comp = rng.integers(0, M, T)
+    for j in range(J):                                                # half of a state's frames sit on its tight mixtures (if it has any)
+        if len(tight[j]):
+            sel = np.flatnonzero(st == j)[::2]
+            comp[sel] = rng.choice(tight[j], len(sel))
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((T, D))).astype(np.float32)
+    eng.load_frames(x)
+    b = eng.batch([J + 2], [T], [0])
+    rows = np.concatenate([[-1], np.arange(J), [-2]]).astype(np.int32)
+    b.set_states([rows])
+    eng.enable_timing(True)
+    eng.kernel_time('score_subset')
+    b.score(PCL_F32)
+    assert eng.kernel_time('score_subset')[1] == 1                   # the subset launch ran
+    eng.enable_timing(False)
+    got = b.get('B')[0][1:-1]
+    ref = np.stack([po.gmm_point(x.astype(np.float64), mean[j], var[j], w[j]) for j in range(J)])
+    bound = f32_evaluation_bound(mean, var, w, x)
+    own = np.zeros(got.shape, dtype=bool)
+    own[st, np.arange(T)] = True
+    err = np.abs(got - ref)
+    assert (err[own] < F32_LOGLIK_ATOL + bound[own]).all()
+    assert_f32_class(got, ref, bound, what='split states:')
+    hold('split states f32', 'ln b (own frames)', got[own], ref[own], 5e-6, F32_LOGLIK_ATOL + bound[own])
+    b.close()
+
+    # the same scores from a context that never splits (whole states leave the pipe): both are within the bound of the oracle,
+    # and on the states without tight mixtures they are the same bits
+    os.environ['PCL_SPLIT_MAX'] = '0'
+    try:
+        e2 = Engine(0)
+    finally:
+        del os.environ['PCL_SPLIT_MAX']
+    try:
+        e2.load_model(mean, var, w)
+        n2, lim2 = e2.model_split_info()
+        assert lim2 == 0 and not n2.any()
+        e2.load_frames(x)
+        b2 = e2.batch([J + 2], [T], [0])
+        b2.set_states([rows])
+        b2.score(PCL_F32)
+        got2 = b2.get('B')[0][1:-1]
+        assert_f32_class(got2, ref, bound, what='whole states:')
+        assert np.array_equal(got2[n_off == 0], got[n_off == 0])
+        b2.close()
+    finally:
+        e2.close()
+
+    # E-step statistics: matrix-core pass + masked fix-up + subset pass into one statistics block
+    U, L, PER = 6, 3, 6
+    labels = [list(rng.integers(0, len(trans), L)) for _ in range(U)]
+    labels[0][0] = len(trans) - 1                                      # the unit whose last state is off the pipe as a whole
+    TU = L * (S - 2) * PER
+    lens = np.full(U, TU, dtype=np.int64)
+    begin = np.arange(U, dtype=np.int64) * TU
+    st = np.concatenate([np.repeat([unit * (S - 2) + k for unit in lab for k in range(S - 2)], PER) for lab in labels])
+    comp = rng.integers(0, M, len(st))
+    for i in range(0, len(st), 2):
+        if len(tight[st[i]]):
+            comp[i] = rng.choice(tight[st[i]])
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((len(st), D))).astype(np.float32)
+    eng.load_frames(x)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    model = oracle_model(mean, var, w, trans)
+    for fresh in (True, False):                                        # into a zeroed block, then on top of it (twice the sums)
+        b.score(PCL_F32)
+        b.forward_backward(fix_pi=False)
+        if fresh:
+            eng.stats_zero()
+        b.accumulate(PCL_F32)
+    stt = eng.stats_download()
+    refs = dict(acc=np.zeros((J, M)), alpha_acc=np.zeros(J), mean_acc=np.zeros((J, M, D)), cov_acc=np.zeros((J, M, D)))
+    lp = b.get('logp')
+    for u, lab in enumerate(labels):
+        xx = x[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        bw, accs, _ = po.estep_utterance(xx, list(lab), model)
+        np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=F32_RTOL)
+        for pos, unit in enumerate(lab):
+            for k in range(S - 2):
+                j = unit * (S - 2) + k
+                a = accs[pos].gmm[k]
+                for key in refs:
+                    refs[key][j] += 2.0 * np.exp(a[key])
+    off = np.zeros((J, M), dtype=bool)
+    for j in range(J):
+        off[j, tight[j]] = True
+    assert (refs['acc'][off] > 0).sum() > 20                           # the off-pipe mixtures carry real occupancy here
+    for key in refs:
+        scale = np.abs(refs[key]).max()
+        at = cov_acc_atol(refs['acc'], mean, var, scale * 1e-6) if key == 'cov_acc' else scale * 1e-6
+        hold('estep split states f32', key, stt[key], refs[key], F32_RTOL, at)
+    for key in ('acc', 'mean_acc', 'cov_acc'):                         # ... and the off-pipe mixtures on their own
+        scale = np.abs(refs[key][off]).max()
+        at = cov_acc_atol(refs['acc'], mean, var, scale * 1e-6)[off] if key == 'cov_acc' else scale * 1e-6
+        hold('estep split states f32', key + ' (off-pipe mixtures)', stt[key][off], refs[key][off], F32_RTOL, at)
+
+    # the M-step moves mixtures across the limit; the batch picks the new lists up
+    eng.mstep(1e-3)
+    n3, _ = eng.model_split_info()
+    m2, v2, w2 = eng.model_download()
+    cm2 = mixture_conditioning(m2, v2)
+    assert ((cm2 > 1.05 * cmax).sum(1) <= n3).all() and (n3 <= (cm2 > 0.95 * cmax).sum(1)).all()
+    b.score(PCL_F32)
+    Bm = b.get('B')
+    rws = [s_ for unit in labels[0] for s_ in range(unit * (S - 2), unit * (S - 2) + S - 2)]
+    xx = x[:TU].astype(np.float64)
+    for r, j in enumerate(rws):
+        with np.errstate(divide='ignore'):
+            refj = po.gmm_point(xx, m2[j], v2[j], w2[j])
+        np.testing.assert_allclose(Bm[0][r + 1], refj, rtol=5e-6, atol=2 * F32_LOGLIK_ATOL)
+    b.close()
+
+
 # ------------------------------------------------------------------ every f32 scoring kernel against the oracle
 # PCL_SCORE_VARIANT: 1 = direct form on the VALU, 3 = f32-input MFMA (strict f32), 7 = two-way f16 split with the constants
 # folded into the spare K slots (the default).  The variant is read when the context is created, so each gets its own engine.

@@ -13,9 +13,10 @@ labels = synth.make_labels(U, c['L'], c['units'], seed=2000)
 eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); eng.load_frames(frames)
 b = eng.label_batch(labels, lens, begin)
-names = ('score', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'mstep', 'derive')
+names = ('score', 'score_subset', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'mstep', 'derive')
 for it in range(4):
     cond, cmax = eng.model_conditioning()
+    n_off, lim = eng.model_split_info()
     m_, v_, w_ = eng.model_download()
     eng.sync()
     for k in names: eng.kernel_time(k)
@@ -24,7 +25,7 @@ for it in range(4):
     t1 = time.perf_counter()
     kt = {k: round(eng.kernel_time(k)[0], 3) for k in names}
     lp = b.get('logp'); st = eng.stats_download(moments=False)
-    print('iteration %d: cond max %.1f, states above %.0f: %d of %d; var min %.3g (floored %.2f%%), weights == 0: %.2f%%; E-step %.1f ms %s; mean logP %.2f; zero-occupancy mixtures %.2f%%'
-          % (it, cond.max(), cmax, int((cond > cmax).sum()), len(cond), v_.min(), 100 * np.mean(v_ <= 1.0000001e-3), 100 * np.mean(w_ == 0), (t1 - t0) * 1e3, kt, lp.mean(), 100 * np.mean(st['acc'] == 0)), flush=True)
+    print('iteration %d: off-pipe mixtures %.1f%% (limit %d per state: %d split states, %d whole states off); cond max %.1f, states above %.0f: %d of %d; var min %.3g (floored %.2f%%), weights == 0: %.2f%%; E-step %.1f ms %s; mean logP %.2f; zero-occupancy mixtures %.2f%%'
+          % (it, 100.0 * n_off.sum() / (len(n_off) * c['M']), lim, int(((n_off > 0) & (n_off <= lim)).sum()), int((n_off > lim).sum()), cond.max(), cmax, int((cond > cmax).sum()), len(cond), v_.min(), 100 * np.mean(v_ <= 1.0000001e-3), 100 * np.mean(w_ == 0), (t1 - t0) * 1e3, kt, lp.mean(), 100 * np.mean(st['acc'] == 0)), flush=True)
     eng.em_exchange(1e-3, None, True)
     b.refresh_transitions()
