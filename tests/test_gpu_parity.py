@@ -1148,6 +1148,9 @@ def _estep_fuzz(eng, seed, dims):
     units, M, U, L, PER = int(rng.integers(2, 6)), int(rng.integers(2, 70)), int(rng.integers(2, 7)), int(rng.integers(1, 4)), int(rng.integers(2, 6))
     mean, var, w, trans = synth.make_model(units, M, D, seed=seed)
     mean = mean * 2.0                                            # well separated mixtures: peaked mixture posteriors
+    if seed % 2:                                                 # odd seeds: a fifth of the mixtures collapsed (variance / 30 .. / 300): split states
+        tight = rng.random(var.shape[:2]) < 0.2
+        var[tight] /= 10.0 ** rng.uniform(1.5, 2.5, (int(tight.sum()), 1))
     labels = [list(rng.integers(0, units, L)) for _ in range(U)]
     TU = L * (S - 2) * PER
     lens = np.full(U, TU, dtype=np.int64)
