@@ -990,6 +990,56 @@ def test_score_variants_outlier_frames(eng_variant):
     np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)
 
 
+def test_estep_variants_split_states(eng_variant):
+    """E-step statistics of a model with tight mixtures under every scoring variant: 7 (f16 producer / consumer + masked fix-up + subset
+    pass), 3 (f32-input MFMA accumulate + subset pass), 1 (direct form for everything, nothing is split) -- all against the oracle."""
+    from poccala_amd import PCL_F32
+    from poccala_amd.engine import make_sentence_batch
+    eng = eng_variant
+    rng = np.random.default_rng(79)
+    mean, var, w, trans, tight = split_model(903, units=3, M=48)
+    J, M, D = mean.shape
+    eng.load_model(mean, var, w)
+    n_off, limit = eng.model_split_info()
+    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == M // 2
+    U, L, PER = 5, 3, 5
+    labels = [list(rng.integers(0, len(trans), L)) for _ in range(U)]
+    TU = L * (S - 2) * PER
+    lens = np.full(U, TU, dtype=np.int64)
+    begin = np.arange(U, dtype=np.int64) * TU
+    st = np.concatenate([np.repeat([unit * (S - 2) + k for unit in lab for k in range(S - 2)], PER) for lab in labels])
+    comp = rng.integers(0, M, len(st))
+    for i in range(0, len(st), 2):
+        if len(tight[st[i]]):
+            comp[i] = rng.choice(tight[st[i]])
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((len(st), D))).astype(np.float32)
+    eng.load_frames(x)
+    b, n = make_sentence_batch(eng, labels, lens, begin, trans)
+    b.score(PCL_F32)
+    b.forward_backward(fix_pi=False)
+    eng.stats_zero()
+    b.accumulate(PCL_F32)
+    stt = eng.stats_download()
+    model = oracle_model(mean, var, w, trans)
+    refs = dict(acc=np.zeros((J, M)), alpha_acc=np.zeros(J), mean_acc=np.zeros((J, M, D)), cov_acc=np.zeros((J, M, D)))
+    lp = b.get('logp')
+    for u, lab in enumerate(labels):
+        xx = x[begin[u]:begin[u] + lens[u]].astype(np.float64)
+        bw, accs, _ = po.estep_utterance(xx, list(lab), model)
+        np.testing.assert_allclose(lp[u], bw['logp'][0], rtol=F32_RTOL)
+        for pos, unit in enumerate(lab):
+            for k in range(S - 2):
+                j = unit * (S - 2) + k
+                a = accs[pos].gmm[k]
+                for key in refs:
+                    refs[key][j] += np.exp(a[key])
+    for key in refs:
+        scale = np.abs(refs[key]).max()
+        at = cov_acc_atol(refs['acc'], mean, var, scale * 1e-6) if key == 'cov_acc' else scale * 1e-6
+        hold('estep split states f32 (every scoring variant)', key, stt[key], refs[key], F32_RTOL, at)
+    b.close()
+
+
 # ------------------------------------------------------------------ two batches pipelined over the two streams
 def test_two_batches_pipelined_match_single_stream():
     """forward-backward runs on the library's second stream beside the scoring of another batch; interleaving two
