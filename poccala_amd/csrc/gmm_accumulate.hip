@@ -147,16 +147,18 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
     __shared__ real cf[FC];
     __shared__ double red[WG / 64];
 
-    const int w = blockIdx.y;
+    // subset launch: grid = (states, slices) -- with the slice in x most slices are empty (a state has ~100 off-pipe mixtures of the 1024
+    // allowed) and the workgroups that do have work sit on block indices 0, 4, 8, ...: two of the eight XCDs (measured: 8.7 ms against 2.2)
+    const bool subset = MASTER && mm.bad_idx != nullptr;
+    const int w = subset ? blockIdx.x : blockIdx.y, slice = subset ? blockIdx.y : blockIdx.x;
     if (state_flag && !state_flag[w]) return;                            // fix-up mode: nothing of this state was left out
     const int j = work_states[w];
     const long long beg = off[seg_lo[w]], end = off[seg_hi[w]];
     if (beg == end) return;
-    int m = blockIdx.x * WG + threadIdx.x;
+    int m = slice * WG + threadIdx.x;
     bool live = m < Mpad;
-    const bool subset = MASTER && mm.bad_idx != nullptr;
     if (MASTER && subset) {
-        if ((int)(blockIdx.x * WG) >= mm.nbad[j]) return;                  // (uniform: no lane of this slice has a mixture)
+        if (slice * WG >= mm.nbad[j]) return;                             // (uniform: no lane of this slice has a mixture)
         live = m < mm.nbad[j];
         m = live ? mm.bad_idx[(size_t)j * Mpad + m] : 0;
     }
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
         if ((int)threadIdx.x < nf) {
             const ActiveFrame a = list[f0 + threadIdx.x];
             cf[threadIdx.x] = ((fmask >> threadIdx.x) & 1u) ? (real)(a.coef * LOG2E) : (real)-INFINITY;
-            if (blockIdx.x == 0 && !tile_mask && !subset) galpha += a.lg;
+            if (slice == 0 && !tile_mask && !subset) galpha += a.lg;
         }
         __syncthreads();
         for (int f = 0; f < nf; ++f) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
             }
         }
     }
-    if (blockIdx.x == 0 && !tile_mask && !subset) {
+    if (slice == 0 && !tile_mask && !subset) {
         // deterministic block sum of the per-thread partial posteriors
         double v = galpha;
 #pragma unroll
@@ -570,7 +572,10 @@ void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *pa
 // split states among [first, first + count) of the accumulate order (split_flag marks them): their off-pipe mixtures over all their frames
 template <int D, int MINW>
 void launch_acc_subset_t(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int *split_flag) {
-    dim3 grid((std::max(ctx->split_max, 1) + WG - 1) / WG, (unsigned)count);
+    int most = 1;                                                         // slices for the state with the most off-pipe mixtures in this range
+    for (int k = first; k < first + count; ++k)
+        if (b->acc_split[k]) most = std::max(most, ctx->nbad[b->acc_ws[k]]);
+    dim3 grid((unsigned)count, (most + WG - 1) / WG);                     // (states, slices): see the kernel
     const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, float, MINW, true>), grid, dim3(WG), 0, ctx->stream, ctx->frames32, (const float *)nullptr,
                        (const float *)nullptr, ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0,
@@ -720,6 +725,13 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             worst += wtiles[k];
             biggest = std::max(biggest, (size_t)wtiles[k]);
         }
+        if (getenv("PCL_DEBUG_ACC")) {                       // distribution of the active-frame lists over the states (diagnostic)
+            std::vector<int> sorted(wtiles);
+            std::sort(sorted.begin(), sorted.end());
+            if (!sorted.empty())
+                fprintf(stderr, "[pcl] accumulate: %d states, active 32-frame tiles per state: min %d median %d p90 %d p99 %d max %d, total %zu\n", n_good,
+                        sorted.front(), sorted[sorted.size() / 2], sorted[sorted.size() * 9 / 10], sorted[sorted.size() * 99 / 100], sorted.back(), worst);
+        }
         const size_t by_budget = std::max<size_t>(budget / ib, 1);
         size_t cap_tiles = std::max(biggest, std::min(worst, by_budget));
         if (b->acc16_cap_tiles >= cap_tiles) cap_tiles = b->acc16_cap_tiles;                 // never shrink: the counts move from call to call
@@ -788,7 +800,11 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
             pcl_timer_end(ctx, "acc_consume");
             if (rc != PCL_OK) return rc;
             launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
-            if (n_split) launch_acc_subset(ctx, b, gfirst[g], gcount[g], b->d_split_flag);                    // the mixtures the pipe left out (split states)
+            if (n_split) {                                                                                    // the mixtures the pipe left out (split states)
+                pcl_timer_begin(ctx, "acc_subset");
+                launch_acc_subset(ctx, b, gfirst[g], gcount[g], b->d_split_flag);
+                pcl_timer_end(ctx, "acc_subset");
+            }
             if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));
             if (!overlap && g + 1 < G) { rc = produce(g + 1); if (rc != PCL_OK) return rc; }
             // a pipelined exchange is open (pcl_batch_accumulate_exchange): every state below the next group's first one has its

@@ -13,8 +13,8 @@ labels = synth.make_labels(U, c['L'], c['units'], seed=2000)
 eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); eng.load_frames(frames)
 b = eng.label_batch(labels, lens, begin)
-names = ('score', 'score_subset', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'mstep', 'derive')
-for it in range(4):
+names = ('score', 'score_subset', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'acc_consume', 'acc_subset', 'mstep', 'derive')
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     cond, cmax = eng.model_conditioning()
     n_off, lim = eng.model_split_info()
     m_, v_, w_ = eng.model_download()
