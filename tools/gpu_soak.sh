@@ -14,3 +14,4 @@ step 500 $O/fb_fuzz.log python tools/fb_linear_fuzz.py 0 150
 step 500 $O/parity_soak.log python tools/parity_soak.py 100 40
 step 500 $O/decode_fuzz.log python tools/decode_fuzz.py
 step 500 $O/soak_stream.log python tools/soak_stream_em.py
+step 700 $O/split_fuzz.log python tools/split_fuzz.py 100 60
