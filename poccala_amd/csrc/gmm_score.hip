@@ -74,8 +74,17 @@ struct MasterModel {
     const int *bad_idx, *nbad;
 };
 
+// (MASTER / SUBSET: three workgroups per CU -- the float64 row arithmetic of the staging took 205 VGPRs under a bound of two, and the subset
+//  launch's short workgroups need the third wave per SIMD to cover their prologues: 9.5 -> 7.2 ms per batch at 7 % off-pipe mixtures, with
+//  50 registers spilled in the staging; R = 2 x 4 workgroups 7.1, R = 3 x 4 23.7 (spills in the loop), R = 4 x 2 8.2)
+#ifndef PCL_RSUB
+#define PCL_RSUB 3          // frames per lane of the subset launch
+#endif
+#ifndef PCL_SUBSET_MINB
+#define PCL_SUBSET_MINB 3   // its workgroups per CU
+#endif
 template <int D, int R, int CH, typename real, bool MASTER = false, bool SUBSET = false>
-__global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict__ frames,
+__global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(real) == 4) ? 3 : 2) void gmm_score_kernel(const real *__restrict__ frames,
                                                           const real *__restrict__ params, int Mpad,
                                                           const ScoreTile *__restrict__ tiles,
                                                           const ScoreSeg *__restrict__ segs,
@@ -98,10 +107,20 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
         int v = tile.vstart + (wave * R + r) * 64 + lane;
         valid[r] = v < vend;
         if (!valid[r]) v = tile.vstart;  // any in-range frame: keeps loads safe, result discarded
-        int lo = tile.seg_lo, hi = tile.seg_hi - 1;  // last segment with vstart <= v
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+        // last segment with vstart <= v: tile.seg0 holds the tile's first frame, so it is seg0 or one of its next few successors (a tile
+        // of 768 frames spans ~3 utterances' runs): short dependent chains instead of the ~log2(#segments) of a search from seg_lo, which
+        // is most of the prologue of the short subset launches; the search only for what is left
+        int lo = tile.seg0, hi = tile.seg_hi - 1;
+#pragma unroll
+        for (int step = 0; step < 3; ++step)
+            if (lo < hi && segs[lo + 1].vstart <= v) ++lo; else hi = lo;
+        hi = tile.seg_hi - 1;
+        if (lo < hi && segs[lo + 1].vstart <= v) {
+            ++lo;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+            }
         }
         const ScoreSeg sg = segs[lo];
         const long long t = v - sg.vstart;
@@ -129,34 +148,47 @@ __global__ __launch_bounds__(WG, 2) void gmm_score_kernel(const real *__restrict
             constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
             const size_t jm0 = (size_t)tile.state * Mpad + c0;
             const size_t js0 = (size_t)tile.state * Mpad;
-            for (int i = threadIdx.x; i < n * D; i += WG) {
-                const int ml = i / D, d = i - ml * D;
-                const bool ok = SUBSET ? ((c0 + ml) < n_sub && d < mm.Dhost) : ((c0 + ml) < mm.M && d < mm.Dhost);
-                real sv = 0, cv = 0;
-                if (ok) {
-                    const size_t jm = SUBSET ? js0 + mm.bad_idx[js0 + c0 + ml] : jm0 + ml;
-                    const double v = mm.var64[jm * D + d], mu = mm.mean64[jm * D + d];
-                    const float a = (float)(-LOG2E * (0.5 / v));             // (derive_kernel: s = sqrt(-a) from the f32 coefficient)
-                    const float sf = sqrtf(-a);
-                    sv = (real)sf;
-                    cv = (real)(float)(-mu * (double)sf);
-                }
-                lds[ml * ROW + 2 * d] = sv;
-                lds[ml * ROW + 2 * d + 1] = cv;
-            }
-            for (int ml = threadIdx.x; ml < n; ml += WG) {
-                double k2 = -INFINITY;
-                const bool have = SUBSET ? (c0 + ml) < n_sub : ((c0 + ml) < mm.M && !(mm.bad && mm.bad[jm0 + ml]));
-                if (have) {
-                    const size_t jm = SUBSET ? js0 + mm.bad_idx[js0 + c0 + ml] : jm0 + ml;
-                    double tail = 0.0;                                       // util.py:29 (quirk Q1): sum(var); the log-determinant only on request
-                    for (int d = 0; d < mm.Dhost; ++d) {
-                        const double v = mm.var64[jm * D + d];
-                        tail += (mm.flags & PCL_MODEL_LOGDET) ? log(v) : v;
+            // 8 lanes per mixture, 32 mixtures per pass of the workgroup (derive_kernel's arrangement and its order of the per-mixture
+            // sums, so k2 has the bits of the derived rows): every load of a pass is in flight at once.  (The first version gave a
+            // mixture's constant to ONE thread -- 39 float64 loads in a row per chunk while three waves waited at the barrier: 55 % of
+            // the subset launch's time.)
+            const int sub = threadIdx.x & 7;
+            for (int ml = threadIdx.x >> 3; ml < (n + 31) / 32 * 32; ml += WG / 8) {
+                const bool in_chunk = ml < n;
+                const bool have = in_chunk && (SUBSET ? (c0 + ml) < n_sub : ((c0 + ml) < mm.M && !(mm.bad && mm.bad[jm0 + ml])));
+                const bool rows = in_chunk && (SUBSET ? (c0 + ml) < n_sub : (c0 + ml) < mm.M);      // (a mixture the pipe left out still gets its s, c)
+                size_t jm = jm0 + ml;
+                if (SUBSET && rows) jm = js0 + mm.bad_idx[js0 + c0 + ml];
+                double sumvar = 0.0, sumlog = 0.0;
+                for (int d = sub; d < D; d += 8) {
+                    real sv = 0, cv = 0;
+                    if (rows && d < mm.Dhost) {
+                        const double v = mm.var64[jm * D + d], mu = mm.mean64[jm * D + d];
+                        const float a = (float)(-LOG2E * (0.5 / v));             // (derive_kernel: s = sqrt(-a) from the f32 coefficient)
+                        const float sf = sqrtf(-a);
+                        sv = (real)sf;
+                        cv = (real)(float)(-mu * (double)sf);
+                        sumvar += v;
+                        if (mm.flags & PCL_MODEL_LOGDET) sumlog += log(v);
                     }
-                    k2 = LOG2E * (log(mm.w64[jm]) - 0.5 * mm.Dhost * LOG_2PI - 0.5 * tail);
+                    if (in_chunk) {
+                        lds[ml * ROW + 2 * d] = sv;
+                        lds[ml * ROW + 2 * d + 1] = cv;
+                    }
                 }
-                lds[ml * ROW + 2 * D] = (real)(float)k2;
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    sumvar += __shfl_xor(sumvar, o, 64);
+                    sumlog += __shfl_xor(sumlog, o, 64);
+                }
+                if (sub == 0 && in_chunk) {
+                    double k2 = -INFINITY;
+                    if (have) {                                                  // util.py:29 (quirk Q1): sum(var); the log-determinant only on request
+                        const double tail = (mm.flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;
+                        k2 = LOG2E * (log(mm.w64[jm]) - 0.5 * mm.Dhost * LOG_2PI - 0.5 * tail);
+                    }
+                    lds[ml * ROW + 2 * D] = (real)(float)k2;
+                }
             }
         } else {
             constexpr int VEC = 16 / sizeof(real);
@@ -261,12 +293,14 @@ void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *
 // (2 waves per SIMD => 256 VGPRs per lane).
 constexpr int r32(int D) { return D <= 40 ? PCL_R32 : 2; }
 constexpr int r64(int D) { return D <= 40 ? 2 : 1; }
+constexpr int rsub(int D) { return D <= 40 ? PCL_RSUB : 2; }
 
 }  // namespace
 
 int pcl_score_tile_frames(int D, int precision) {
     return WG * (precision == PCL_F64 ? r64(D) : r32(D));
 }
+int pcl_score_subset_tile_frames(int D) { return WG * rsub(D); }
 
 int pcl_launch_fill_virtual_rows(pcl_ctx *ctx, pcl_batch *b) {
     dim3 grid(8, b->U);
@@ -309,7 +343,7 @@ int pcl_launch_score_subset(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, 
     pcl_timer_begin(ctx, "score_subset");
     const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
     switch (ctx->D) {
-#define CASES(DD) case DD: hipLaunchKernelGGL((gmm_score_kernel<DD, r32(DD), PCL_CH32, float, true, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
+#define CASES(DD) case DD: hipLaunchKernelGGL((gmm_score_kernel<DD, rsub(DD), PCL_CH32, float, true, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
                                                (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, mm); break;
         CASES(13) CASES(26) CASES(39) CASES(47)
 #undef CASES

@@ -890,7 +890,7 @@ static int build_tiles(pcl_batch *b, int precision) {
     if (mfma)
         for (size_t k : good)
             if (pcl_state_is_split(ctx, b->work_states[k])) split.push_back(k);
-    const std::vector<ScoreTile> tiles_s = split.empty() ? std::vector<ScoreTile>() : make_tiles(b, split, pcl_score_tile_frames(ctx->D, PCL_F32));
+    const std::vector<ScoreTile> tiles_s = split.empty() ? std::vector<ScoreTile>() : make_tiles(b, split, pcl_score_subset_tile_frames(ctx->D));
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
     dev_free(b->d_tiles_s);

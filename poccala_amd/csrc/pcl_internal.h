@@ -354,6 +354,7 @@ int pcl_launch_score_split16(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles,
 int pcl_score_split16_tile_frames();
 int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
 int pcl_launch_score_subset(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);
+int pcl_score_subset_tile_frames(int D);
 int pcl_score_mfma_tile_frames();
 bool pcl_score_mfma_supported(int D);
 int pcl_launch_dup_rows(pcl_ctx *ctx, pcl_batch *b);
