@@ -294,7 +294,7 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
  * state's list of such mixtures and the two parts are merged -- ln(e^a + e^b) of the two partial log-sum-exps in scoring,
  * += into the same statistics in the accumulate pass -- so the result is the reference's sum over all mixtures
  * (Clustering.py:740-767, :653-680) whichever kernel evaluated a term.  A state leaves the matrix cores as a whole only when
- * more than *limit of its mixtures are out (env PCL_SPLIT_MAX = share of M, default 0.4 (the measured break-even of the two routes); 0 = whole states, as before).
+ * more than *limit of its mixtures are out (env PCL_SPLIT_MAX = share of M, default 0.5 (the measured break-even of the two routes: pipe 16 + subset 139 f against direct form 92 ms per batch at the bench shape); 0 = whole states, as before).
  * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
 int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
 

@@ -96,7 +96,7 @@ struct pcl_ctx {
     int *d_bad_idx = nullptr;          // [J][Mpad] the state's off-pipe mixtures in ascending order (first nbad[j] entries)
     int *d_nbad = nullptr;             // [J]
     std::vector<int> nbad;
-    float split_frac = 0.4f;           // env PCL_SPLIT_MAX: the share of a state's mixtures that may be off the pipe (0 = no splitting)
+    float split_frac = 0.5f;           // env PCL_SPLIT_MAX: the share of a state's mixtures that may be off the pipe (0 = no splitting)
     int split_max = 0;                 // = split_frac * M: mixtures per state that may be off the pipe (0: no splitting -- whole states, as before round 4)
     int model_gen = 0;           // bumped whenever the layouts (and cond) are re-derived
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)

@@ -749,7 +749,7 @@ def test_split_states_merge_both_kernels(eng):
     cond, cmax = eng.model_conditioning()
     n_off, limit = eng.model_split_info()
     cm = mixture_conditioning(mean, var)
-    assert limit == int(np.float32(0.4) * np.float32(M))
+    assert limit == int(np.float32(0.5) * np.float32(M))
     assert np.array_equal(n_off, [len(t) for t in tight]) and np.array_equal(n_off, (cm > cmax).sum(1))
     assert ((cond > cmax) == (n_off > 0)).all()                      # cond stays the state's worst mixture
     split = (n_off > 0) & (n_off <= limit)
@@ -1001,7 +1001,7 @@ def test_estep_variants_split_states(eng_variant):
     J, M, D = mean.shape
     eng.load_model(mean, var, w)
     n_off, limit = eng.model_split_info()
-    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == int(np.float32(0.4) * np.float32(M))
+    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == int(np.float32(0.5) * np.float32(M))
     U, L, PER = 5, 3, 5
     labels = [list(rng.integers(0, len(trans), L)) for _ in range(U)]
     TU = L * (S - 2) * PER
