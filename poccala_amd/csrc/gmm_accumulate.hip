@@ -106,6 +106,59 @@ __global__ void acc_fill_kernel(const ScoreSeg *__restrict__ segs, int n_segs, c
     }
 }
 
+// The same two steps with the posteriors read the way they lie: ln gamma and ln b are time-major per utterance (element (t, row) at
+// b_off + t N + row), so a wave per SEGMENT (one row, all t) takes one 8-byte value from each 64-byte line it touches and every line is
+// fetched by 8 different waves (acc_count 0.30 + acc_fill 0.67 ms per pass at the C4 shard).  Here a wave owns 8 ROWS of one utterance:
+// lane = 8 tt + r reads row r of frame 8 i + tt, eight lanes share a line; the per-row counts and ranks come from the ballot restricted to
+// the row's lanes (0x0101..01 << r), lower lanes = earlier frames, so the lists are the ones the segment kernels build, entry for entry.
+constexpr int ROWS_WPB = 4;   // waves (groups of 8 rows) per block
+__global__ void acc_count_rows_kernel(const UttDesc *__restrict__ utt, const int *__restrict__ seg_of_row, const double *__restrict__ lgam,
+                                      double thr, int *__restrict__ cnt) {
+    const UttDesc d = utt[blockIdx.y];
+    const int lane = threadIdx.x & 63, row0 = (blockIdx.x * ROWS_WPB + (threadIdx.x >> 6)) * 8;
+    if (row0 >= d.N) return;
+    const int r = lane & 7, tt = lane >> 3, row = row0 + r;
+    const int seg = row < d.N ? seg_of_row[d.vec_off + row] : -1;
+    int c = 0;
+    if (seg >= 0)
+        for (int t = tt; t < d.T; t += 8) c += lgam[d.b_off + (long long)t * d.N + row] >= thr;
+    c += __shfl_xor(c, 8, 64);
+    c += __shfl_xor(c, 16, 64);
+    c += __shfl_xor(c, 32, 64);
+    if (tt == 0 && seg >= 0) cnt[seg] = c;
+}
+
+__global__ void acc_fill_rows_kernel(const UttDesc *__restrict__ utt, const int *__restrict__ seg_of_row, const double *__restrict__ lgam,
+                                     const double *__restrict__ Bt, double thr, const long long *__restrict__ off, ActiveFrame *__restrict__ list) {
+    const UttDesc d = utt[blockIdx.y];
+    const int lane = threadIdx.x & 63, row0 = (blockIdx.x * ROWS_WPB + (threadIdx.x >> 6)) * 8;
+    if (row0 >= d.N) return;
+    const int r = lane & 7, tt = lane >> 3, row = row0 + r;
+    const int seg = row < d.N ? seg_of_row[d.vec_off + row] : -1;
+    long long pos = seg >= 0 ? off[seg] : 0;
+    const unsigned long long rowmask = 0x0101010101010101ull << r, below = (1ull << lane) - 1ull;
+    for (int t0 = 0; t0 < d.T; t0 += 8) {                       // (the trip count is uniform over the wave: every lane takes part in the ballot)
+        const int t = t0 + tt;
+        const bool in = seg >= 0 && t < d.T;
+        double lg = -INFINITY, lb = 0.0;
+        if (in) {
+            const long long i = d.b_off + (long long)t * d.N + row;
+            lg = lgam[i];
+            lb = Bt[i];
+        }
+        const bool keep = in && lg >= thr;
+        const unsigned long long mine = __ballot(keep) & rowmask;
+        if (keep) {
+            ActiveFrame a;
+            a.frame = d.frame0 + t;
+            a.coef = lg - lb;
+            a.lg = exp(lg);
+            list[pos + __popcll(mine & below)] = a;
+        }
+        pos += __popcll(mine);
+    }
+}
+
 template <typename real>
 struct Fast;
 template <>
@@ -703,10 +756,16 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     pcl_timer_begin(ctx, "accumulate");
     const int wpb = 4;
     dim3 gseg((b->n_segs + wpb - 1) / wpb);
-    hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, b->acc_cnt);
+    static const bool rows_on = !(getenv("PCL_ACC_ROWS") && atoi(getenv("PCL_ACC_ROWS")) == 0);      // 0: a wave per segment (rounds 1-3), A/B
+    const bool by_rows = rows_on && b->U <= 65535 && b->d_seg_of_row;                                // (grid.y = utterances)
+    const dim3 grows((b->max_N + 8 * ROWS_WPB - 1) / (8 * ROWS_WPB), (unsigned)b->U);
+    if (by_rows) hipLaunchKernelGGL(acc_count_rows_kernel, grows, dim3(64 * ROWS_WPB), 0, ctx->stream, b->d_utt, b->d_seg_of_row, b->lgam, thr, b->acc_cnt);
+    else hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, b->acc_cnt);
     hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
-    hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
-                       b->acc_off, b->acc_list);
+    if (by_rows) hipLaunchKernelGGL(acc_fill_rows_kernel, grows, dim3(64 * ROWS_WPB), 0, ctx->stream, b->d_utt, b->d_seg_of_row, b->lgam, b->Bt, thr,
+                                    b->acc_off, b->acc_list);
+    else hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
+                            b->acc_off, b->acc_list);
     if (mfma && n_good > 0 && ctx->score_variant == 7) {
         // producer / consumer on the f16 + bf16 matrix pipes (gmm_accumulate_f16.hip), in groups of states whose tile
         // images fit the image buffer (worst case: every frame of the state survives)

@@ -574,7 +574,7 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
     dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax); dev_free(b->fb_dump); dev_free(b->fb_part_m); dev_free(b->fb_part_e);
     dev_free(b->d_dups);
-    dev_free(b->d_segs); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tiles_s); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
+    dev_free(b->d_segs); dev_free(b->d_seg_of_row); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tiles_s); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
     return PCL_OK;
 }
@@ -733,12 +733,16 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
         }
         for (int st : touched) first_row[st] = -1;
     }
+    b->seg_of_row.assign((size_t)b->sumN, -1);
+    b->max_N = 0;
+    for (int u = 0; u < b->U; ++u) b->max_N = std::max(b->max_N, b->utt[u].N);
     for (int pass = 0; pass < 2; ++pass)                         // the scored rows of every state first, then the copies
         for (int u = 0; u < b->U; ++u) {
             const UttDesc &d = b->utt[u];
             for (int n = 0; n < d.N; ++n) {
                 const int st = row_state[d.vec_off + n];
                 if (st < 0 || (int)is_dup[d.vec_off + n] != pass) continue;
+                b->seg_of_row[d.vec_off + n] = fill[st];
                 ScoreSeg &s = b->segs[fill[st]++];
                 s.frame0 = d.frame0;
                 s.out0 = d.b_off + n;
@@ -774,6 +778,9 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     b->tile_frames = 0;
     TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
     if (b->n_segs) HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg)));
+    dev_free(b->d_seg_of_row);
+    TRY(dev_alloc(ctx, &b->d_seg_of_row, (size_t)b->sumN));
+    if (b->sumN) HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_seg_of_row, b->seg_of_row.data(), (size_t)b->sumN * sizeof(int)));
     auto up = b->launched ? pcl_h2d : pcl_h2d_fresh;             // (batch-lifetime buffers: fresh only while nothing was launched)
     HIPCHK(ctx, up(ctx, b->d_row_state, row_state, (size_t)b->sumN * sizeof(int32_t)));
     HIPCHK(ctx, up(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));

@@ -213,6 +213,9 @@ struct pcl_batch {
     int *acc_cnt = nullptr;
     long long *acc_off = nullptr;
     ActiveFrame *acc_list = nullptr;
+    std::vector<int> seg_of_row;              // (utterance, row) -> its segment (-1: not a GMM row); d_seg_of_row: the device copy (sumN ints)
+    int *d_seg_of_row = nullptr;
+    int max_N = 0;                            // rows of the largest sentence HMM of the batch
     int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr, *d_split_flag = nullptr;   // (split_flag: 1 = a split state, in accumulate order)
     size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
     // producer / consumer accumulate (gmm_accumulate_f16.hip): tile images in LDS order, per-state tile offsets, outlier masks
