@@ -20,3 +20,9 @@ for peaked in (False, True):
         h.update(np.ascontiguousarray(st[k]).tobytes())
     print('pass', int(peaked), h.hexdigest(), float(st['acc'].sum()))
     eng.em_exchange(1e-3, None, True); b.refresh_transitions()
+    hm = xxhash.xxh3_128()
+    for a in eng.model_download() + tuple(eng.model_conditioning()[:1]) + tuple(eng.model_split_info()[:1]):
+        hm.update(np.ascontiguousarray(a).tobytes())
+    b.score(PCL_F32)
+    hm.update(np.ascontiguousarray(np.concatenate([x.ravel() for x in b.get('B')])).tobytes())
+    print('model + conditioning + off-pipe counts + next scores after the M-step', hm.hexdigest())
