@@ -298,6 +298,12 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
  * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
 int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
 
+/* How much of a CU the matrix-core scoring kernel takes.  0 (default): three workgroups per CU, the fastest for the kernel alone.
+ * 2: two -- a third of the registers stays free for kernels of OTHER streams, which is what lets the token passing of chunk k-1
+ * (pcl_batch_decode, second stream) run beside the scoring of chunk k in a streamed decode (Decoder.py has no such loop: the
+ * reference decodes utterance by utterance, Decoder.py:146-187).  Same kernel, same results; applies to the launches that follow. */
+int pcl_score_occupancy(pcl_ctx *ctx, int workgroups_per_cu);
+
 /* ----------------------------------------------------------------- MFCC front-end (next row f4: the step before the path)
  * AudioProcessing.MFCC.mfcc (StatisticalModel/AudioProcessing.py:416-448) for U signals at once, float64:
  * pre-emphasis 0.98 (:184), framing sampletime/overlap (:201), per-FRAME window factor (:228, as the reference

@@ -113,6 +113,7 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
     if first is None:
         return
     inflight = []
+    engine.score_occupancy(2)                                      # the scoring of chunk k leaves room for the token passing of chunk k-1
     try:
         layout = pack(first)
         engine.swap_frames()                                       # chunk 0 is the current frame matrix
@@ -141,4 +142,5 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
             done = inflight.pop(0)
             yield _report(done.decode_unpack(done.decode_fetch()), tree)
     finally:
+        engine.score_occupancy(0)
         inflight[:] = []                                           # (an abandoned stream: the batches stay in the engine's pool)

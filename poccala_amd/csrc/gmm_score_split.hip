@@ -265,7 +265,12 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
 
 template <int D>
 void launch16_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles) {
-    hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32,
+    // pcl_score_occupancy(ctx, 2): dynamic LDS nobody reads, so that two instead of three scoring workgroups fit a CU and another kernel's
+    // waves -- the token passing of a streamed decode -- find registers beside them (config 5 streamed: 0.79 -> 0.87 M frames/s; the
+    // scoring kernel alone loses ~9 %, so the streamed decoder asks for it and nobody else does).  Per workgroup: 56 KB > 160 / 3.
+    constexpr size_t static_lds = 2 * (size_t)(2 * ((D + 7) / 8)) * 64 * 16;
+    const size_t pad = (ctx->score_wgs_per_cu == 2 && static_lds < (56u << 10)) ? (56u << 10) - static_lds : 0;
+    hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), pad, ctx->stream, ctx->frames32,
                        reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs,
                        b->Bt, b->d_tile_flags, ctx->kzero);
 }

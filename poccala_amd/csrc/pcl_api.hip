@@ -1272,6 +1272,13 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max) {
     return PCL_OK;
 }
 
+int pcl_score_occupancy(pcl_ctx *ctx, int workgroups_per_cu) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (workgroups_per_cu != 0 && workgroups_per_cu != 2) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_score_occupancy: 0 (default) or 2");
+    ctx->score_wgs_per_cu = workgroups_per_cu;
+    return PCL_OK;
+}
+
 int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit) {
     if (!ctx) return PCL_ERR_INVALID;
     if (ctx->nbad.empty()) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_model_split_info: no model uploaded");

@@ -80,6 +80,7 @@ struct pcl_ctx {
     hipStream_t stream_desc = nullptr; // descriptor uploads of batches that have nothing in flight (pcl_h2d_fresh)
     hipStream_t stream_d2h = nullptr;  // pcl_batch_fetch_async: results travel to the host beside the next step's kernels
     bool dp_async = true;              // env PCL_DP_STREAM=0: everything on one stream
+    int score_wgs_per_cu = 0;    // pcl_score_occupancy: 2 = the matrix-pipe scoring kernel leaves a third of each CU to kernels beside it
     int score_variant = 0;       // 7 = two-piece f16 split on the matrix pipe (default), 3 = f32-input MFMA (strict f32), 1 = direct form on the VALU
     // conditioning of the centred expansion the MFMA kernels use: cond[j] = max_m log2e sum_d (mu - c_j)^2 / (2 var),
     // the magnitude of the terms that cancel in it.  States above cond_max are scored / accumulated by the

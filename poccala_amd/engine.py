@@ -313,6 +313,11 @@ class Engine(object):
         self._check(self._lib.pcl_model_conditioning(self._ctx, ptr(cond), ptr(cmax)))
         return cond, float(cmax[0])
 
+    def score_occupancy(self, workgroups_per_cu):
+        """0: the scoring kernel fills the CUs (default); 2: it leaves a third of each CU's registers to kernels of other streams
+        (the streamed decoder's token passing).  Same results either way."""
+        self._check(self._lib.pcl_score_occupancy(self._ctx, int(workgroups_per_cu)))
+
     def model_split_info(self):
         """(n_off (J,) int32, limit): mixtures per state that are off the matrix-core path (their own conditioning is beyond
         cond_max; the direct-form kernels evaluate them and the parts are merged); a state with more than `limit` of them
