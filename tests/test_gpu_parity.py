@@ -610,6 +610,16 @@ def test_cabi_error_codes(eng):
     assert np.array_equal(b.lgamma_views(bufs['lgamma'])[0], b.get('lgamma')[0], equal_nan=True)
     assert np.array_equal(bufs['ksai_nz'], np.concatenate(b.get('ksai_nz')), equal_nan=True) and bufs['point'][0] == b.get('point')[0]
     assert 500.0 < eng.clock_probe(200) < 3000.0                     # the shader clock, measured on the device (MHz)
+    # the scoring kernel at two workgroups per CU (what the streamed decoder asks for): the same bits; anything but 0 / 2 is refused
+    B3 = b.get('B')[0].copy()
+    eng.score_occupancy(2)
+    try:
+        b.score()
+        assert np.array_equal(b.get('B')[0], B3, equal_nan=True)
+        with pytest.raises(PoccalaHipError, match='0 .default. or 2'):
+            eng.score_occupancy(5)
+    finally:
+        eng.score_occupancy(0)
     b.close()
     with pytest.raises(PoccalaHipError, match='has N=0'):
         eng.batch([0], [5])
