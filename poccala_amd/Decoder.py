@@ -10,6 +10,8 @@ word ends re-seed the first characters with a uniform language model, "all step,
 include/poccala_hip.h and in the tests' CPU restatement.  Parity: recursion, pruning, frame loop and in-word hand-over are pinned
 by golden G14 (the reference's own pieces, run with a stand-in for the missing import); D1-D5 are the builder's completion.
 """
+import os
+
 import numpy as np
 
 from ._lib import PCL_F32
@@ -113,12 +115,20 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
     if first is None:
         return
     inflight = []
-    engine.score_occupancy(2)                                      # the scoring of chunk k leaves room for the token passing of chunk k-1
+    # The scoring of chunk k leaves room for the token passing of chunk k-1 (Engine.score_occupancy) when that chunk's utterances are all
+    # of one length: its 417 decode workgroups then need the CUs for the whole chunk and take turns with the scoring workgroups unless
+    # those leave registers (+11 % on config 5's corpus).  Ragged chunks free CUs as their short utterances finish -- their token passing
+    # already runs in its stand-alone time, and a thinner scoring kernel only costs (-3 %).  POCCALA_STREAM_OCCUPANCY=0: never (A/B).
+    thin = os.environ.get('POCCALA_STREAM_OCCUPANCY', '2') != '0'
+
+    def room_for(prev_lens):
+        engine.score_occupancy(2 if thin and prev_lens is not None and len(prev_lens) and int(prev_lens.min()) == int(prev_lens.max()) else 0)
     try:
         layout = pack(first)
         engine.swap_frames()                                       # chunk 0 is the current frame matrix
         b = batch_for(layout[0], layout[1], 0, inflight)
         b.score(precision)
+        prev = layout[0]
         nxt = next(it, None)
         if nxt is not None:
             layout = pack(nxt)                                     # host packing + H2D of chunk 1 beside the GPU work
@@ -130,7 +140,9 @@ def decode_stream(chunks, tree, engine=None, precision=PCL_F32, beam_=None, cand
             if nxt is not None:
                 engine.swap_frames()                               # chunk k+1 is the current frame matrix
                 b = batch_for(layout[0], layout[1], k + 1, inflight)
+                room_for(prev)                                     # (chunk k is being decoded beside this launch)
                 b.score(precision)                                 # score(k+1): main stream, behind score(k)
+                prev = layout[0]
                 nxt = next(it, None)
                 if nxt is not None:
                     layout = pack(nxt)                             # chunk k+2 on its way (behind the last readers of its slot)
