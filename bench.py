@@ -1447,8 +1447,13 @@ def bench_c5_full(args, rank, world, local):
     of a strong split -- no collective on this path)."""
     from poccala_amd import Engine, synth
     from poccala_amd.distributed import Control
+    from poccala_amd.engine import device_count
     c = synth.CONFIGS['C5shard']
-    eng = Engine(int(os.environ.get('POCCALA_DEVICE', local)))
+    ndev = device_count()
+    dev = int(os.environ.get('POCCALA_DEVICE', local))
+    if os.environ.get('POCCALA_SHARE_DEVICE') and 0 < ndev < world:           # rehearsal: more ranks than devices
+        dev = dev % ndev
+    eng = Engine(dev)
     eng.enable_timing(True)
     ctl = Control(rank, world)
     tree, lx = synth.make_pronunciation_tree(args.words, c['units'])
