@@ -614,11 +614,8 @@ def main():
         lo, hi = cfg['U'] * k, cfg['U'] * (k + 1)
         batches.append(eng.label_batch(labels_all[lo:hi], lens_all[lo:hi], begin_all[lo:hi]))     # AcousticModel.embedded, in the library
     n_states = batches[0].N
-    if world > 1 or os.environ.get('POCCALA_FORCE_DIST'):          # FORCE_DIST: exercise RCCL at world 1
-        if shared or os.environ.get('POCCALA_NO_RCCL'):
-            eng.comm_init_host(rank, world, ctl.allgather_bytes)
-        else:
-            eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
+    # (the communicator is made AFTER the timed loop, under the watchdog below: the headline loop has no collective in it, and an RCCL
+    #  bootstrap that fails or never returns on some node must not take the line with it)
     comm = eng.comm_info()
     t_setup = time.perf_counter() - t_setup
     tl['upload_and_batches_s'] = time.perf_counter() - t_mark
@@ -776,7 +773,21 @@ def main():
     dog.daemon = True
     dog.start()
     extra = None
-    if args.extra:
+    comm_error = None
+    if world > 1 or os.environ.get('POCCALA_FORCE_DIST'):          # FORCE_DIST: exercise RCCL at world 1
+        try:
+            if shared or os.environ.get('POCCALA_NO_RCCL'):
+                eng.comm_init_host(rank, world, ctl.allgather_bytes)
+            else:
+                eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
+            comm = eng.comm_info()
+        except Exception as e:                 # noqa: reported, the E-step extras (which need the exchange) are skipped
+            import traceback
+            traceback.print_exc()
+            comm_error = 'communicator: %s: %s' % (type(e).__name__, e)
+    if comm_error:
+        extra = dict(error=comm_error)
+    elif args.extra:
         try:
             extra = extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frames, elapsed, P, cfg, pairs, t_setup, mean, var, w, trans,
                            dict(labels_all=labels_all, lens_all=lens_all, begin_all=begin_all, tl=tl, t_mark=t_mark))
