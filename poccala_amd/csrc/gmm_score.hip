@@ -88,12 +88,12 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
                                                           const real *__restrict__ params, int Mpad,
                                                           const ScoreTile *__restrict__ tiles,
                                                           const ScoreSeg *__restrict__ segs,
-                                                          double *__restrict__ out, const int *__restrict__ flags, MasterModel mm) {
+                                                          double *__restrict__ out, const int *__restrict__ flags, int n_tiles, MasterModel mm) {
     constexpr int ROW = (2 * D + 1 + 3) / 4 * 4;
     __shared__ __attribute__((aligned(16))) real lds[CH * ROW];
 
-    if (flags && !flags[blockIdx.x]) return;   // fix-up launch: only the tiles another kernel flagged
-    const ScoreTile tile = tiles[blockIdx.x];
+  auto score_tile = [&](const int ti) {
+    const ScoreTile tile = tiles[ti];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     if (tile.seg_lo >= tile.seg_hi) return;   // padding tile of the XCD-aware order
@@ -248,6 +248,32 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
             out[oidx[r]] = res;
         }
     }
+  };
+    if (!flags) {
+        score_tile(blockIdx.x);
+        return;
+    }
+    // Fix-up launch (the tiles a matrix-pipe kernel flagged: normally none).  A FIXED grid reads the flags in one coalesced round --
+    // thread t of workgroup b looks at tile b + t gridDim.x -- and rescans what it finds: a workgroup per tile that returns at once cost
+    // 30 us per scoring call at the C4 shard (72000 workgroups) and was 10 % of config 2's step.
+    __shared__ int todo[WG];
+    __shared__ int n_todo;
+    if (threadIdx.x == 0) n_todo = 0;
+    __syncthreads();
+    for (int base = blockIdx.x; base < n_tiles; base += WG * gridDim.x) {
+        const int ti = base + threadIdx.x * gridDim.x;
+        if (ti < n_tiles && flags[ti]) todo[atomicAdd(&n_todo, 1)] = ti;
+        __syncthreads();
+        const int n = n_todo;
+        // (the order of the list does not matter: tiles are independent and each writes its own outputs)
+        for (int k = 0; k < n; ++k) {
+            score_tile(todo[k]);
+            __syncthreads();                                                  // (the next tile's staging overwrites lds)
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) n_todo = 0;
+        __syncthreads();
+    }
 }
 
 // rows of the sentence HMMs that are not GMM states: entry -> 0, exit -> -inf
@@ -286,7 +312,7 @@ __global__ void transpose_kernel(const UttDesc *__restrict__ utt, const double *
 template <int D, int R, int CH, typename real>
 void launch_score_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *params, const ScoreTile *tiles, int n_tiles) {
     hipLaunchKernelGGL((gmm_score_kernel<D, R, CH, real>), dim3(n_tiles), dim3(WG), 0, ctx->stream, frames, params,
-                       ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, MasterModel{});
+                       ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, n_tiles, MasterModel{});
 }
 
 // frames per lane for each (D, precision); the tile is WG * R frames.  x[R][D] must stay in VGPRs
@@ -323,8 +349,9 @@ int pcl_launch_score_fixup(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, i
     if (tf % WG || (R != 1 && R != 2)) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: fix-up tile size mismatch");
     pcl_timer_begin(ctx, "score_fixup");
     const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, nullptr, nullptr};      // (no params32 needed: see MasterModel)
-#define LAUNCHF(DD, RR) hipLaunchKernelGGL((gmm_score_kernel<DD, RR, PCL_CH32, float, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
-                                           (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, flags, mm)
+    const int fix_grid = std::min(n_tiles, 1024);                        // (a fixed grid scans the flags: see the kernel)
+#define LAUNCHF(DD, RR) hipLaunchKernelGGL((gmm_score_kernel<DD, RR, PCL_CH32, float, true>), dim3(fix_grid), dim3(WG), 0, ctx->stream, ctx->frames32, \
+                                           (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, flags, n_tiles, mm)
 #define CASEF(DD) case DD: if (R == 1) LAUNCHF(DD, 1); else LAUNCHF(DD, 2); break;
     switch (ctx->D) {
         CASEF(13) CASEF(26) CASEF(39) CASEF(47)
@@ -344,7 +371,7 @@ int pcl_launch_score_subset(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, 
     const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
     switch (ctx->D) {
 #define CASES(DD) case DD: hipLaunchKernelGGL((gmm_score_kernel<DD, rsub(DD), PCL_CH32, float, true, true>), dim3(n_tiles), dim3(WG), 0, ctx->stream, ctx->frames32, \
-                                               (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, mm); break;
+                                               (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, (const int *)nullptr, n_tiles, mm); break;
         CASES(13) CASES(26) CASES(39) CASES(47)
 #undef CASES
         default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no subset scoring kernel for D=%d", ctx->D);
