@@ -120,3 +120,22 @@ def test_statistics_per_mixture_c2(prec, image_mb, peaked):
 def test_statistics_per_mixture_c4_shard(prec, peaked):
     """M = 2048, J = 3000: the bench workload (8 slice workgroups per state, 7 state groups at the default 2 GB image budget)."""
     run_case('C4shard', prec, None, peaked, n_extra=1, min_groups=0 if peaked else 3)
+
+
+def test_compaction_by_rows_keeps_the_bits():
+    """The active-frame lists built by rows (a wave owns 8 rows of an utterance) are the lists the segment kernels built, entry for
+    entry: statistics, the re-estimated model, its conditioning and the next scores of a ragged problem with duplicate label rows and
+    split states hash to the same value under PCL_ACC_ROWS=0 and =1 (the knob is read once per process: two processes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for rows in ('0', '1'):
+        env = dict(os.environ, PCL_ACC_ROWS=rows)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'acc_hash.py')], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith(('pass ', 'model '))]
+        assert len(lines) == 4, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1]
