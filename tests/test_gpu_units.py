@@ -803,6 +803,7 @@ def test_exchange_world_4_and_8_equals_single_rank(world, payload):
                 eng.stats_zero(); b.accumulate(PCL_F64); b.accumulate_hmm()
                 eng.em_exchange(1e-3, pay, True)
                 res['model'] = eng.model_download() + (eng.units_download(),)
+                res['split'] = (eng.model_conditioning()[0], eng.model_split_info()[0])     # (of ALL states, derived from the gathered model)
                 b.refresh_transitions(); b.score(PCL_F64); b.forward_backward()
                 res['lp'] = b.get('logp')
                 # (c) the same from the same start, pipelined
@@ -810,6 +811,7 @@ def test_exchange_world_4_and_8_equals_single_rank(world, payload):
                 b.score(PCL_F64); b.forward_backward(); eng.stats_zero(); b.accumulate_hmm()
                 b.accumulate_exchange(PCL_F64, 1e-3, pay, True, n_chunks=4)
                 res['model_pipe'] = eng.model_download() + (eng.units_download(),)
+                res['split_pipe'] = (eng.model_conditioning()[0], eng.model_split_info()[0])   # (derived range by range inside the pipe)
                 res['info'] = eng.comm_info()
                 b.close()
                 return res
@@ -833,5 +835,7 @@ def test_exchange_world_4_and_8_equals_single_rank(world, payload):
         for k in range(4):                                                   # every rank holds ONE model; the pipelined call gives the same bits
             assert np.array_equal(g['model'][k], ranks[0]['model'][k])
             assert np.array_equal(g['model_pipe'][k], g['model'][k]), (r, k)
+        for k in range(2):                                                   # ... and one classification of its mixtures (matrix pipe / direct form)
+            assert np.array_equal(g['split'][k], ranks[0]['split'][k]) and np.array_equal(g['split_pipe'][k], g['split'][k]), (r, k)
     lp = np.concatenate([g['lp'] for g in ranks])
     np.testing.assert_allclose(lp, single['lp'], rtol=1e-10 if payload == 'f64' else 1e-5)
