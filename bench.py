@@ -79,6 +79,8 @@ def parse():
                    help='HBM bytes per scoring launch from a separate rocprofv3 --pmc pass, corrected as MI355X_MICROARCH.md '
                         'prescribes (2 x FETCH_SIZE for the wide streaming reads + WRITE_SIZE); default: the figure committed in '
                         'profiles/ (tools/gpu_profile.sh)')
+    p.add_argument('--iters', type=int, default=0, help='--workload C4: EM iterations run IN SEQUENCE (each on the model the previous M-step left), reported per iteration')
+    p.add_argument('--c-covariance', type=float, default=1e-3, help='--workload C4: the variance floor of GMM.update_param (the reference driver passes 1e-6: init.py:30 -> Controller.py:151)')
     p.add_argument('--payload', default='auto', choices=['auto', 'f64', 'f32'],
                    help='wire format of the E-step exchange: auto = f32 when there is more than one rank (half the bytes on xGMI), f64 on one')
     return p.parse_args()
@@ -461,74 +463,150 @@ def sustained_loop(eng, batches, P, seconds, block=100):
     return n[0], total, blocks, clocks
 
 
-def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=3):
-    """SURVEY 8(d)'s end-to-end protocol on the headline's work: every step's frames come up over PCIe and its results go down,
-    both beside the kernels of the neighbouring steps.  Per step: H2D of the NEXT batch's frames into the frame slot that is not
-    being scored (copy stream) | score -> Viterbi (main stream) -> forward-backward (second stream) of this batch | D2H of ln P(O),
-    ln gamma_t(j) (all of it: 152 MB), the stored ln xi, the Viterbi paths and scores into page-locked buffers (download stream).
-    THREE batches and result sets in rotation (two frame slots): the forward-backward of step k runs beside the scoring of step
-    k+1 and its results leave during step k+2, so a batch's buffers are free again only two steps later; with two batches the
-    scoring of step k+2 waited for that download (17.3 instead of 15.7 ms per step)."""
+def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, depth=3, label_sets=8):
+    """The headline's loop as a corpus sweep runs it: the reference hands every worker a NEW (label, data) (AcousticModel.py:664-681
+    generator, :861-870 fan-out), so every step here CREATES its label batch (pcl_batch_create_labels: the sentence HMMs, the
+    state-major work lists, the scoring tiles at the first score, every lazily allocated buffer) from labels the library has not
+    seen in that form, scores it, runs its forward-backward, and DROPS the batch of `depth` steps ago -- all inside the timed
+    region, while the GPU works on the previous steps.  Frames stay resident (the contract's `value`; the PCIe-inclusive loop moves
+    them too).  Returns a dict; `value` is frames/s of this rank."""
+    from poccala_amd import synth
+    U, T = cfg['U'], cfg['T']
+    nb = len(lens_all) // U
+    sets = [np.stack(synth.make_labels(U, cfg['L'], cfg['units'], seed=31 + 7919 * rank + k)).astype(np.int32) for k in range(label_sets)]
+    live = []
+    host = dict(create=0.0, enqueue=0.0, close=0.0)
+
+    def one(k, timed):
+        lo = U * (k % nb)
+        t0 = time.perf_counter()
+        b = eng.label_batch(sets[k % label_sets].copy(), lens_all[lo:lo + U], begin_all[lo:lo + U])      # (.copy(): a new array every step)
+        t1 = time.perf_counter()
+        b.score(P)
+        b.forward_backward(fix_pi=False)
+        t2 = time.perf_counter()
+        live.append(b)
+        if len(live) > depth:
+            live.pop(0).close()
+        t3 = time.perf_counter()
+        if timed:
+            host['create'] += t1 - t0
+            host['enqueue'] += t2 - t1
+            host['close'] += t3 - t2
+    for k in range(warm):
+        one(k, False)
+    eng.sync()
+    eng.kernel_time('score'); eng.kernel_time('fb')
+    t0 = time.perf_counter()
+    for k in range(warm, warm + steps):
+        one(k, True)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    sc_ms, sc_n = eng.kernel_time('score')
+    # the results of a batch made inside the loop against a resident batch of the same labels and frames: the same bits
+    last_k = warm + steps - 1
+    got = live[-1].get('logp')
+    lo = U * (last_k % nb)
+    ref_b = eng.label_batch(sets[last_k % label_sets], lens_all[lo:lo + U], begin_all[lo:lo + U])
+    ref_b.score(P); ref_b.forward_backward(fix_pi=False)
+    same = bool(np.array_equal(got, ref_b.get('logp')))
+    ref_b.close()
+    for b in live:
+        b.close()
+    nfr = int(np.sum(lens_all[:U]))
+    return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, batches_alive=depth, label_sets=label_sets,
+                batch_create_ms=host['create'] / steps * 1e3, enqueue_ms=host['enqueue'] / steps * 1e3, batch_close_ms=host['close'] / steps * 1e3,
+                score_kernel_ms=sc_ms / max(sc_n, 1), same_bits_as_a_resident_batch=same,
+                what='every step creates its label batch (new labels), scores it, runs forward-backward and drops the batch of %d steps ago, inside the '
+                     'timed region; batch_create_ms / enqueue_ms / batch_close_ms = HOST time per step of the three calls (the GPU works on the previous '
+                     'steps meanwhile); frames resident' % depth)
+
+
+def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=4):
+    """SURVEY 8(d)'s end-to-end protocol on the headline's work, as a corpus sweep: every step's frames come up over PCIe, its label
+    batch is CREATED in the step (new labels: AcousticModel.py:664-681 hands every worker a new (label, data)), and its results go
+    down, all beside the kernels of the neighbouring steps.  Per step: H2D of the NEXT batch's frames into the frame slot that is
+    not being scored (copy stream) | pcl_batch_create_labels | score -> Viterbi (main stream) -> forward-backward (second stream) |
+    D2H of ln P(O), ln gamma_t(j) (all of it: 152 MB), the stored ln xi, the Viterbi paths and scores into page-locked buffers
+    (download stream) | the batch of three steps ago dropped.  THREE batches and result sets in flight (two frame slots): the
+    forward-backward of step k runs beside the scoring of step k+1 and its results leave during step k+2."""
+    from poccala_amd import synth
     U, T, NB = cfg['U'], cfg['T'], 3
     nfr = U * T
-    legs = set(os.environ.get('POCCALA_PCIE_LEGS', 'h2d,d2h,vit').split(','))     # diagnosis: drop a leg to see what it costs
+    legs = set(os.environ.get('POCCALA_PCIE_LEGS', 'h2d,d2h,vit,fresh').split(','))     # diagnosis: drop a leg to see what it costs
     pin = [eng.pinned_empty((nfr, cfg['D']), np.float32) for _ in range(2)]
     for k in range(2):
         pin[k][:] = frames[k * nfr:(k + 1) * nfr]
     begin = np.arange(U, dtype=np.int64) * T
+    lens = np.ascontiguousarray(lens_all[:U])
+    sets = [np.stack(synth.make_labels(U, cfg['L'], cfg['units'], seed=977 + k)).astype(np.int32) for k in range(8)]
     eng.stage_frames(pin[0])
     eng.swap_frames()
-    batches, res = [], []
-    for k in range(NB):
-        b = eng.label_batch(labels_all[(k % 2) * U:(k % 2 + 1) * U], lens_all[(k % 2) * U:(k % 2 + 1) * U], begin)
-        b.score(P); b.viterbi(); b.forward_backward(fix_pi=False)          # lazy buffers
-        batches.append(b)
-        res.append(b.result_buffers())
-    eng.sync()
     total = warm + steps
+    live = [None] * NB
+    res = [None] * NB
+    resident = None
+    if 'fresh' not in legs:                    # (diagnosis: the round-4 protocol, three resident batches in rotation)
+        resident = [eng.label_batch(sets[k], lens, begin) for k in range(NB)]
     eng.stage_frames(pin[0])
     t0 = None
+    host_create = 0.0
     for k in range(total):
         if k == warm:
             eng.sync()
             t0 = time.perf_counter()
+            host_create = 0.0
             eng.kernel_time('score'); eng.kernel_time('fb')
-        bt = batches[k % NB]
         eng.swap_frames()                      # chunk k is the current frame matrix (its copy had a whole step to arrive)
         if k + 1 < total and 'h2d' in legs:
             eng.stage_frames(pin[(k + 1) % 2])
         elif k + 1 < total:
             eng.stage_frames(pin[(k + 1) % 2][:1])                              # (diagnosis: a one-row chunk keeps the protocol, moves nothing)
-        if k >= NB and 'd2h' in legs:
-            bt.fetch_wait()                    # the host is done with this batch's previous results (a consumer would have read them)
+        old = live[k % NB]
+        if old is not None and 'd2h' in legs:
+            old.fetch_wait()                   # the host is done with that batch's results (a consumer would have read them)
+        tc = time.perf_counter()
+        if resident is not None:
+            bt = resident[k % NB]
+        else:
+            if old is not None:
+                old.close()
+            bt = eng.label_batch(sets[k % len(sets)].copy(), lens, begin)
+        host_create += time.perf_counter() - tc
+        live[k % NB] = bt
         bt.score(P)
         if 'vit' in legs:
             bt.viterbi()
         bt.forward_backward(fix_pi=False)
         if 'd2h' in legs:
+            if res[k % NB] is None:            # (page-locked, the engine's: one set per slot in flight)
+                res[k % NB] = bt.result_buffers(slot=k % NB)
             bt.fetch_async(res[k % NB] if 'vit' in legs else {q: v for q, v in res[k % NB].items() if q not in ('path', 'point')})
     if 'd2h' in legs:
-        for b in batches:
-            b.fetch_wait()
+        for b in live:
+            if b is not None:
+                b.fetch_wait()
     eng.sync()
     elapsed = time.perf_counter() - t0
     sc_ms, sc_n = eng.kernel_time('score')
     fb_ms, fb_n = eng.kernel_time('fb')
-    last = batches[(total - 1) % NB]
+    last = live[(total - 1) % NB]
     ok = None
     if 'd2h' in legs:
         ok = bool(np.array_equal(res[(total - 1) % NB]['logp'], last.get('logp')))
         if 'vit' in legs:
             ok = ok and bool(np.array_equal(res[(total - 1) % NB]['path'], np.concatenate(last.get('path'))))
-    bytes_down = int(sum(v.nbytes for v in res[0].values()))
-    for b in batches:
+    bytes_down = int(sum(v.nbytes for v in res[0].values())) if res[0] is not None else 0
+    for b in set(x for x in live if x is not None) | set(resident or []):
         b.close()
     eng.load_frames(frames)                    # back to the resident matrix the other measurements index
     return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, legs=sorted(legs), h2d_bytes_per_step=int(pin[0].nbytes),
                 d2h_bytes_per_step=bytes_down, results_intact=ok, score_kernel_ms=sc_ms / max(sc_n, 1), fb_span_ms=fb_ms / max(fb_n, 1),
-                what='per step: frames H2D (copy stream) | score + Viterbi + forward-backward | ln P(O), ln gamma_t(j), stored ln xi, Viterbi paths '
-                     'and scores D2H into page-locked memory (download stream); wall clock over the whole pipeline, the copies overlapped '
-                     'behind the neighbouring steps\' kernels; three batches / result sets in rotation')
+                batch_create_ms=host_create / steps * 1e3,
+                what='per step: frames H2D (copy stream) | the step\'s label batch created (new labels) | score + Viterbi + forward-backward | ln P(O), '
+                     'ln gamma_t(j), stored ln xi, Viterbi paths and scores D2H into page-locked memory (download stream) | the batch of three steps ago '
+                     'dropped; wall clock over the whole pipeline, the copies overlapped behind the neighbouring steps\' kernels; three batches / result '
+                     'sets in flight')
 
 
 def engine_with_variant(device, variant):
@@ -693,7 +771,7 @@ def main():
 
     # beside the headline, from the same resident batches (outside the timed region): the same loop held for >= 10 s, and the
     # end-to-end pipeline of SURVEY 8(d) with every step's frames and results crossing PCIe
-    sustained = pcie = None
+    sustained = pcie = fresh = None
     if args.sustain > 0 and not align and P == PCL_F32:
         t_mark2 = time.perf_counter()
         try:
@@ -707,6 +785,13 @@ def main():
         except Exception as e:                 # noqa: never the headline's problem
             sustained = dict(error=repr(e))
         tl['sustained_loop_s'] = time.perf_counter() - t_mark2
+        t_mark2 = time.perf_counter()
+        try:
+            fresh = fresh_batch_loop(eng, P, cfg, lens_all, begin_all, max(2 * args.steps, 40), rank=rank)
+            fresh['value'] = fresh['value'] * world        # (whole job: every rank sweeps its own shard; rank 0's clock)
+        except Exception as e:                 # noqa: never the headline's problem
+            fresh = dict(error=repr(e))
+        tl['fresh_batch_loop_s'] = time.perf_counter() - t_mark2
         t_mark2 = time.perf_counter()
         if world == 1 and not args.utts and nb >= 2:
             try:
@@ -743,6 +828,9 @@ def main():
         if sustained:
             out['value_sustained'] = sustained.get('value')
             out['sustained'] = sustained
+        if fresh:
+            out['value_fresh_batches'] = fresh.get('value')
+            out['fresh_batches'] = fresh
         if pcie:
             out['value_pcie_inclusive'] = pcie.get('value')
             out['pcie_inclusive'] = pcie
@@ -1254,7 +1342,7 @@ def c4_corpus_batch(k):
     return frames, lens, labels
 
 
-def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
+def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, em_iters=0):
     """Config 4 whole: ALL 8192 utterances through one EM iteration -- per batch of 1024: score -> forward-backward -> GMM
     statistics + per-unit transition accumulators, the 8 batches into ONE statistics block -> the exchange (reduce-scatter ->
     GMM.update_param on the owned states -> all-gather; one rank: the M-step) -> transition M-step -> the batches take the new
@@ -1273,13 +1361,37 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
     eng.load_model(mean, var, w)
     eng.load_units(np.stack(trans))
     eng.load_frames(frames)
-    batches, off = [], 0
+    batches, off, desc = [], 0, []
     for fr, lens, labels in parts:
         begin = off + np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))])
+        desc.append((np.stack(labels).astype(np.int32), lens, begin))      # what a fresh batch of this part is made from
         batches.append(eng.label_batch(labels, lens, begin))
         off += int(lens.sum())
     del frames, parts
     t_setup = time.perf_counter() - t0
+    nfr_all = C4_BATCHES * c['U'] * c['T']
+
+    def fresh_iteration():
+        """the iteration as a corpus sweep runs it (AcousticModel.py:842-882: every worker call gets a new (label, data), every
+        iteration builds its objects anew): each batch is CREATED here, scored, passed through forward-backward; then the statistics
+        passes, the exchange, and the batches are dropped -- the next iteration makes its own from the new transitions, so no
+        batch has to be refreshed.  Returns host seconds spent in batch creation."""
+        made, t_create = [], 0.0
+        eng.stats_zero()
+        for lab, lens, begin in desc:
+            tc = time.perf_counter()
+            bt = eng.label_batch(lab.copy(), lens, begin)
+            t_create += time.perf_counter() - tc
+            bt.score(P)
+            bt.forward_backward(fix_pi=False)
+            made.append(bt)
+        for bt in made:
+            bt.accumulate(P)
+            bt.accumulate_hmm()
+        eng.em_exchange(c_cov, payload, True)
+        for bt in made:
+            bt.close()
+        return t_create
 
     def estep():
         eng.stats_zero()
@@ -1292,7 +1404,7 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
 
     def iteration():
         estep()
-        eng.em_exchange(1e-3, payload, True)
+        eng.em_exchange(c_cov, payload, True)
         for bt in batches:
             bt.refresh_transitions()
 
@@ -1349,11 +1461,69 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
         bt.accumulate(P)
         bt.accumulate_hmm()
     tp = lap('accumulate_ms', tp)
-    eng.em_exchange(1e-3, payload, True)
+    eng.em_exchange(c_cov, payload, True)
     tp = lap('exchange_and_mstep_ms', tp)
     for bt in batches:
         bt.refresh_transitions()
     tp = lap('refresh_transitions_ms', tp)
+    # ---- the iteration with its batches created INSIDE the timed region, from the initial model (one untimed pass first: pool, clocks)
+    rewind()
+    fresh_iteration()
+    fresh_ms, fresh_create = [], []
+    for it in range(max(1, iters)):
+        rewind()
+        eng.sync()
+        ctl.barrier()
+        t1 = time.perf_counter()
+        tc = fresh_iteration()
+        eng.sync()
+        ctl.barrier()
+        fresh_ms.append(ctl.allreduce_max(time.perf_counter() - t1) * 1e3)
+        fresh_create.append(tc * 1e3)
+    # the model's statistics block of a fresh iteration against the resident one: the same bits (same lists, same order)
+    rewind()
+    estep()
+    st_res = eng.stats_download(moments=False)
+    rewind()
+    eng.stats_zero()
+    made = []
+    for lab, lens, begin in desc:
+        bt = eng.label_batch(lab.copy(), lens, begin)
+        bt.score(P); bt.forward_backward(fix_pi=False)
+        made.append(bt)
+    for bt in made:
+        bt.accumulate(P); bt.accumulate_hmm()
+    st_fr = eng.stats_download(moments=False)
+    for bt in made:
+        bt.close()
+    fresh_same = bool(np.array_equal(st_res['acc'], st_fr['acc']) and np.array_equal(st_res['alpha_acc'], st_fr['alpha_acc']))
+    del st_res, st_fr
+    # ---- EM iterations in sequence at this variance floor: what each iteration costs as the model sharpens
+    em_table = []
+    if em_iters:
+        rewind()
+        for it in range(em_iters):
+            n_off, off_limit = eng.model_split_info()
+            for k in names:
+                eng.kernel_time(k)
+            eng.sync()
+            ctl.barrier()
+            t1 = time.perf_counter()
+            iteration()
+            eng.sync()
+            ctl.barrier()
+            t_it = ctl.allreduce_max(time.perf_counter() - t1)
+            kt_it = {k: eng.kernel_time(k)[0] for k in names}
+            lp_it = np.concatenate([bt.get('logp') for bt in batches]) if batches else np.zeros(0)      # (of the E-step just run: under the model BEFORE this M-step)
+            m_, v_, w_ = eng.model_download()
+            em_table.append(dict(iteration=it + 1, ms=t_it * 1e3, frames_per_s=nfr_all / t_it,
+                                 mixtures_off_the_matrix_pipe=float(n_off.sum()) / float(len(n_off) * c['M']),
+                                 states_off_the_matrix_pipe=int((n_off > off_limit).sum()) if off_limit > 0 else None,
+                                 split_states=int(((n_off > 0) & (n_off <= off_limit)).sum()) if off_limit > 0 else None,
+                                 loglik_mean_rank0=float(lp_it.mean()) if len(lp_it) else None,
+                                 variances_at_the_floor_after=float(np.mean(v_ <= c_cov * 1.0000001)), kernel_ms_rank0=kt_it))
+            del m_, v_, w_
+        rewind()
     for bt in batches:                         # (untimed: the log-likelihoods under the model the timed iterations left)
         bt.score(P)
         bt.forward_backward(fix_pi=False)
@@ -1378,6 +1548,12 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None):
                                            'leaves the range of the centred f32-class expansion (cond_m > cond_max).  Round 4 splits such states: those mixtures alone are '
                                            'evaluated by the direct-form kernels and merged (score_subset), the state stays on the matrix pipe (before: the whole state '
                                            'left it, 5x slower).  After two more iterations on noise most mixtures sit at the variance floor and whole states do leave'),
+                fresh_batches=dict(ms_per_iteration=float(np.mean(fresh_ms)), frames_per_s=nfr / (float(np.mean(fresh_ms)) * 1e-3), iterations=len(fresh_ms),
+                                   batch_create_ms_per_iteration=float(np.mean(fresh_create)), statistics_same_bits_as_resident=fresh_same,
+                                   what='the same iteration with its 8 label batches CREATED inside the timed region (a corpus sweep hands every worker a new '
+                                        '(label, data), AcousticModel.py:664-681, 861-870) and dropped at its end; batch_create_ms = host time of the 8 '
+                                        'pcl_batch_create_labels calls, which run while the GPU scores the previous batch'),
+                c_covariance=c_cov, em_iterations=em_table,
                 what='the configuration BASELINE.json states (8192 utterances), not the per-GPU share the headline loop times; every timed iteration starts from the '
                      'initial model (re-uploaded outside the timed region)')
 
@@ -1436,12 +1612,16 @@ def bench_c4_full(args, rank, world, local):
         else:
             eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
     payload = resolve_payload(args, world)
-    r = run_c4_full(eng, ctl, PCL_F32 if args.precision == 'f32' else PCL_F64, payload, iters=max(1, args.steps), warm=max(1, args.warmup))
+    r = run_c4_full(eng, ctl, PCL_F32 if args.precision == 'f32' else PCL_F64, payload, iters=max(1, args.steps), warm=max(1, args.warmup),
+                    c_cov=args.c_covariance, em_iters=args.iters)
     if rank == 0:
         info = eng.device_info()
         print(json.dumps({'metric': 'frames/sec full Baum-Welch EM iteration (E-step + exchange + M-step), 39-d MFCC, 2048-mix, 8192 utterances',
-                          'value': r['value'], 'unit': 'frames/s', 'n_gpus': world, 'steps': r['iterations'], 'warmup': max(1, args.warmup),
-                          'ms_per_step': r['ms_per_iteration'], 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                          # value: the iteration with its label batches created inside the timed region (a corpus sweep); the round-4 figure on
+                          # batches made before the clock started is beside it
+                          'value': r['fresh_batches']['frames_per_s'], 'unit': 'frames/s', 'n_gpus': world, 'steps': r['fresh_batches']['iterations'], 'warmup': max(1, args.warmup),
+                          'ms_per_step': r['fresh_batches']['ms_per_iteration'], 'value_resident_batches': r['value'], 'ms_per_step_resident_batches': r['ms_per_iteration'],
+                          'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                           'dtype': DTYPE_NAME if args.precision == 'f32' else 'f64', 'data': 'synthetic',
                           'config': {'workload': 'C4: ' + r['shape'], 'device': info['name'], 'cus': info['cus'], 'payload': 'f32' if payload == PCL_F32 else 'f64',
                                      'transport': eng.comm_info()['transport']},

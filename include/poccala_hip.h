@@ -36,6 +36,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is what libpoccala_hip.so exports, nothing else
+ * (tests/test_cabi_loads.py holds exported pcl_* == declared). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct pcl_ctx pcl_ctx;
 typedef struct pcl_batch pcl_batch;
@@ -355,6 +360,9 @@ int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covarian
 int pcl_pipe_info(pcl_ctx *ctx, int *chunks, int *released_early);
 int pcl_comm_destroy(pcl_ctx *ctx);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

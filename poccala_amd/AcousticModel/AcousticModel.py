@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from ..Exceptions import NullLog
+from ..Exceptions import NullLog, UnitFileExistsError
 from .._lib import PCL_F32, PCL_F64
 from ..runtime import default_engine
 from ..StatisticalModel.Clustering import Clustering
@@ -34,6 +34,7 @@ class AcousticModel(DataInitialization):
         # the two workers at batched speed (multi_embedded_training_1 / multi_process_data below): what the calls queued
         self.__queued = {'train': [], 'align': []}
         self.__queued_frames = 0
+        self.__flush_registered = self.__warned_worker = False
         self.__data_files = 0
         self.flush_frames = 1 << 19            # flush by itself once this many frames are queued (bounds the host copy)
         self.worker_precision = None           # None: f32-class E-step, float64 alignment (bit-exact paths)
@@ -43,8 +44,21 @@ class AcousticModel(DataInitialization):
     loaded_units = property(lambda self: self.__loaded_units)
     statenum = property(lambda self: self.__state_num)
 
-    def load_unit(self, unit_file):
-        """Unit inventory file: line 1 description, then comma-separated units (AcousticModel.py:151-161)."""
+    def load_unit(self, unit_type=None, unit_file=None):
+        """AcousticModel.load_unit (AcousticModel.py:134-161): the inventory is the file `$unit_file_path/<unit_type>` (unit_type given:
+        it becomes the model's unit type); a missing file raises UnitFileExistsError; the parameter tree `<parameters path>/<unit_type>`
+        is created.  Line 1 of the file is a description, the rest comma-separated units.  `unit_file=` (keyword, not in the
+        reference) reads a file by its path instead and creates nothing."""
+        if unit_file is None:
+            if unit_type:
+                self.__unit_type = unit_type
+            base = os.environ.get('unit_file_path')
+            if base is None:
+                raise KeyError('unit_file_path')             # (the reference reads os.environ['unit_file_path'] at import, AcousticModel.py:25)
+            unit_file = os.path.abspath(base) + '/' + self.__unit_type
+            if not os.path.exists(unit_file):
+                raise UnitFileExistsError(self.__unit_type, self.log)
+            os.makedirs(os.path.join(self.__address, self.__unit_type), exist_ok=True)
         with open(unit_file) as f:
             f.readline()
             for line in f:
@@ -305,14 +319,58 @@ class AcousticModel(DataInitialization):
             out[u] = hmm
         return out
 
+    def _enqueue(self, kind, item):
+        """Queue one worker call.  The data are COPIED (the reference's Pool pickles them at call time, AcousticModel.py:865-870: a caller
+        may refill its feature buffer right after the call).  Inside a multiprocessing worker (the reference's own pattern:
+        pool.apply_async(self.multi_embedded_training_1, ...)) the process may end with the task, and multiprocessing children leave
+        through os._exit without running atexit handlers, so nothing is deferred there: the call is flushed at once (the
+        per-utterance rate; the batched rate needs the calls made from one process), with one warning."""
+        import multiprocessing as mp
+        self.__queued[kind].append(item)
+        self.__queued_frames += len(item[1])
+        if not self.__flush_registered:
+            import atexit
+            import weakref
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref()._flush_at_exit())
+            self.__flush_registered = True
+        if mp.parent_process() is not None:
+            if not self.__warned_worker:
+                import warnings
+                warnings.warn('poccala_amd.AcousticModel: multi_embedded_training_1 / multi_process_data called inside a multiprocessing worker; '
+                              'the deferred batch cannot outlive the task, so every call is flushed at once (one utterance per launch chain). '
+                              'Call the workers from one process and flush_workers() after the loop for the batched rate.', RuntimeWarning)
+                self.__warned_worker = True
+            self.flush_workers()
+        elif self.__queued_frames >= self.flush_frames:
+            self.flush_workers()
+
+    def _flush_at_exit(self):
+        """atexit: whatever is still queued is run and written (with a warning: the caller forgot flush_workers())."""
+        if self.__queued['train'] or self.__queued['align']:
+            import warnings
+            warnings.warn('poccala_amd.AcousticModel: %d queued worker calls were still waiting at interpreter exit; flushing them now '
+                          '(call flush_workers() after the loop)' % (len(self.__queued['train']) + len(self.__queued['align'])), RuntimeWarning)
+            try:
+                self.flush_workers()
+            except Exception as e:             # noqa: the interpreter is going down; say what is lost
+                warnings.warn('poccala_amd.AcousticModel: the exit flush failed, the queued accumulators are LOST: %r' % (e,), RuntimeWarning)
+
+    def __del__(self):
+        try:
+            q = self.__queued
+        except AttributeError:
+            return
+        if q['train'] or q['align']:
+            import warnings
+            warnings.warn('poccala_amd.AcousticModel: dropped with %d queued worker calls that were never flushed (flush_workers()): their '
+                          'accumulator / data files were NOT written' % (len(q['train']) + len(q['align'])), RuntimeWarning)
+
     def multi_embedded_training_1(self, label, data, init, *args):
         """AcousticModel.multi_embedded_training_1(label, data, init, show_q, load_num, file_count, fix_code)
         (AcousticModel.py:884-916), deferred: see flush_workers."""
         fix_code = int(args[3]) if len(args) > 3 else 0
-        self.__queued['train'].append((list(label), np.asarray(data), bool(init), fix_code))
-        self.__queued_frames += len(data)
-        if self.__queued_frames >= self.flush_frames:
-            self.flush_workers()
+        self._enqueue('train', (list(label), np.array(data, copy=True), bool(init), fix_code))
 
     def multi_process_data(self, label, data, init, *args):
         """AcousticModel.multi_process_data(label, data, init, load_num, file_count, fix_code) (AcousticModel.py:723-768):
@@ -321,10 +379,7 @@ class AcousticModel(DataInitialization):
         if init:
             self.eq_segment(np.asarray(data), list(label), mode='e', save=self.save_data)
             return
-        self.__queued['align'].append((list(label), np.asarray(data), False, 0))
-        self.__queued_frames += len(data)
-        if self.__queued_frames >= self.flush_frames:
-            self.flush_workers()
+        self._enqueue('align', (list(label), np.array(data, copy=True), False, 0))
 
     def save_data(self, unit, unit_data):
         """AcousticModel.__save_data (AcousticModel.py:331-351): one pickle per block under <unit>/data/ (the reference names the
@@ -346,10 +401,12 @@ class AcousticModel(DataInitialization):
         eng = self.worker_engine
         if queued['train']:
             lp_all, n_utt, n_fr = [], 0, 0
-            for fix_code in sorted({q[3] for q in queued['train']}):          # (one E-step per fix_code: it decides what is accumulated)
-                part = [q for q in queued['train'] if q[3] == fix_code]
+            # one E-step per (fix_code, init): fix_code decides what is accumulated, init whether the unit logs start afresh
+            # (init_unit(new_log=init), AcousticModel.py:897) -- every queued call keeps its own flag
+            for fix_code, init in sorted({(q[3], q[2]) for q in queued['train']}):
+                part = [q for q in queued['train'] if q[3] == fix_code and q[2] == init]
                 labels, datas = [q[0] for q in part], [q[1] for q in part]
-                units = self._worker_units(sorted({u for lab in labels for u in lab}), part[0][2])
+                units = self._worker_units(sorted({u for lab in labels for u in lab}), init)
                 stats, hmm_acc, logp = self.estep_batch(labels, datas, units, fix_code=fix_code,
                                                         precision=PCL_F32 if self.worker_precision is None else self.worker_precision, engine=eng)
                 self.save_batch_acc(stats, hmm_acc, units)

@@ -1,5 +1,6 @@
-"""The one exception of the reference that is raised on the hot path (Exceptions.py, raised at
-StatisticalModel/Clustering.py:749-751), with the reference's constructor signature."""
+"""The exceptions of the reference that the mirrored surface raises (Exceptions.py): DataDimensionError on the hot path
+(StatisticalModel/Clustering.py:749-751) and UnitFileExistsError from AcousticModel.load_unit (AcousticModel.py:142-143), with the
+reference's constructor signatures."""
 
 
 class DataDimensionError(Exception):
@@ -10,6 +11,20 @@ class DataDimensionError(Exception):
 
     def __str__(self):
         info = 'data dimension %s does not match model dimension %s' % (self.data_dimension, self.dimension)
+        if self.log is not None:
+            self.log.note(info, cls='e')
+        return info
+
+
+class UnitFileExistsError(FileExistsError):
+    """Exceptions.py:24-32."""
+
+    def __init__(self, unit_type, log=None):
+        self.unit_type = unit_type
+        self.log = log
+
+    def __str__(self):
+        info = 'unit file %s does not exist' % self.unit_type
         if self.log is not None:
             self.log.note(info, cls='e')
         return info

@@ -108,6 +108,23 @@ class Clustering(DataInitialization):
         def data(self):
             return self.__data
 
+        @data.setter
+        def data(self, data):
+            """Clustering.py:166-174 (the per-sample gamma it also resets belongs to the stand-alone EM, out of scope)."""
+            self.__data = np.array(data)
+
+        def add_data(self, data):
+            """Clustering.py:106-116.  The reference tests `if self.__data:`, which raises for an array of more than one row, so only
+            the first call on an empty object works there; here further calls append, which is what the line below it was written to do."""
+            if self.__data is not None and len(self.__data):
+                self.__data = np.append(self.__data, np.array(data), axis=0)
+            else:
+                self.__data = np.array(data)
+
+        def clear_data(self):
+            """Clustering.py:118-120."""
+            self.__data = None
+
         def diag_variance(self):
             return _diag_of(self.__covariance, self.__mix_level, self.__dimension)
 

@@ -325,9 +325,9 @@ int pcl_batch_create_labels(pcl_ctx *ctx, int U, const int32_t *label_len, const
     if (rc == PCL_OK) rc = dev_alloc(ctx, &b->occ_ptr, occ_ptr.size());
     if (rc == PCL_OK) rc = dev_alloc(ctx, &b->occ_utt, tot);
     if (rc == PCL_OK) rc = dev_alloc(ctx, &b->occ_row0, tot);
-    if (rc == PCL_OK && (pcl_h2d(ctx, b->occ_ptr, occ_ptr.data(), occ_ptr.size() * sizeof(int)) != hipSuccess ||
-                         pcl_h2d(ctx, b->occ_utt, occ_utt.data(), tot * sizeof(int)) != hipSuccess ||
-                         pcl_h2d(ctx, b->occ_row0, occ_row0.data(), tot * sizeof(int)) != hipSuccess)) {
+    if (rc == PCL_OK && (pcl_h2d_fresh(ctx, b->occ_ptr, occ_ptr.data(), occ_ptr.size() * sizeof(int)) != hipSuccess ||
+                         pcl_h2d_fresh(ctx, b->occ_utt, occ_utt.data(), tot * sizeof(int)) != hipSuccess ||
+                         pcl_h2d_fresh(ctx, b->occ_row0, occ_row0.data(), tot * sizeof(int)) != hipSuccess)) {
         pcl_set_error(ctx, "pcl_batch_create_labels: copy failed");
         rc = PCL_ERR_HIP;
     }

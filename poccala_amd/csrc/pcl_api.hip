@@ -125,6 +125,8 @@ void pcl_pool_free(void *p) {
     if (g_pool_cached > pool_limit()) pool_release_locked(pool_limit() / 2);
 }
 
+static int pcl_batch_reap(pcl_ctx *ctx, bool wait);   // frees the destroyed batches the GPU is done with (wait: all of them); returns how many are left
+
 extern "C" {
 
 // ================================================================ context
@@ -221,6 +223,10 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream_dp);
     hipStreamSynchronize(ctx->stream_aux);
+    if (ctx->stream_d2h) hipStreamSynchronize(ctx->stream_d2h);
+    pcl_batch_reap(ctx, true);
+    for (hipEvent_t ev : ctx->grave_events) hipEventDestroy(ev);
+    ctx->grave_events.clear();
     drop_timers(ctx);
     free_model(ctx);
     pcl_units_release(ctx);
@@ -248,6 +254,7 @@ int pcl_sync(pcl_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream_dp));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream_aux));
     if (ctx->stream_d2h) HIPCHK(ctx, hipStreamSynchronize(ctx->stream_d2h));
+    pcl_batch_reap(ctx, false);
     return PCL_OK;
 }
 
@@ -494,6 +501,7 @@ int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, co
     *out = nullptr;
     if (U <= 0 || !N || !T) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: bad arguments (U=%d)", U);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    pcl_batch_reap(ctx, false);                              // destroyed batches the GPU has finished with: their blocks first
     pcl_batch *b = new pcl_batch();
     b->ctx = ctx;
     b->U = U;
@@ -550,17 +558,11 @@ int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, co
     return PCL_OK;
 }
 
-int pcl_batch_destroy(pcl_batch *b) {
-    if (!b) return PCL_OK;
-    hipSetDevice(b->ctx->device);
-    // the GPU must be done with THIS batch: everything on the main and the copy stream, and on the second stream what the batch
-    // itself queued there and nobody has joined yet -- not another batch's recursion or decoder that is still running there
-    hipStreamSynchronize(b->ctx->stream);
-    hipStreamSynchronize(b->ctx->stream_aux);
-    if (b->dp_pending && b->ev_dp) hipEventSynchronize(b->ev_dp);
-    if (b->ev_fetch) { hipEventSynchronize(b->ev_fetch); hipEventDestroy(b->ev_fetch); }
-    if (b->ev_fetch_src) hipEventDestroy(b->ev_fetch_src);
+// Everything a batch owns goes back to the pool.  The caller has made sure the GPU is done with the batch.
+static void batch_free_now(pcl_batch *b) {
     pcl_free_synced_scope done;                              // the frees below skip their device-wide wait
+    if (b->ev_fetch) hipEventDestroy(b->ev_fetch);
+    if (b->ev_fetch_src) hipEventDestroy(b->ev_fetch_src);
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
     pcl_accumulate_release(b);
@@ -576,6 +578,71 @@ int pcl_batch_destroy(pcl_batch *b) {
     dev_free(b->d_dups);
     dev_free(b->d_segs); dev_free(b->d_seg_of_row); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tiles_s); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
+}
+
+static int pcl_batch_reap(pcl_ctx *ctx, bool wait) {
+    size_t keep = 0;
+    for (size_t g = 0; g < ctx->graves.size(); ++g) {
+        pcl_ctx::Grave &gr = ctx->graves[g];
+        bool done = true;
+        for (int k = 0; k < 4 && done; ++k)
+            if (gr.ev[k]) done = wait ? (hipEventSynchronize(gr.ev[k]) == hipSuccess) : (hipEventQuery(gr.ev[k]) == hipSuccess);
+        if (!done) {
+            if (keep != g) ctx->graves[keep] = gr;                // (graves[keep] was moved on or freed already)
+            ++keep;
+            continue;
+        }
+        for (int k = 0; k < 4; ++k)
+            if (gr.ev[k]) ctx->grave_events.push_back(gr.ev[k]);
+        batch_free_now(gr.b);
+    }
+    ctx->graves.resize(keep);
+    return (int)keep;
+}
+
+// The reference drops an utterance's objects when its worker returns (AcousticModel.py:884-916); a corpus sweep here drops the batch
+// of step k - 2 while the GPU works on step k.  Waiting for the streams at that point (what this function did through round 4:
+// 38 ms per call inside a sweep, tools/fresh_batch_probe.py) stalls the host that should be queueing step k + 1.  So: when the
+// streams the batch may have work on are idle, it is freed at once; otherwise one event per stream marks "everything queued so far"
+// and the batch waits in the context's list until they have completed (pcl_batch_reap).  The handle is dead for the caller either way.
+int pcl_batch_destroy(pcl_batch *b) {
+    if (!b) return PCL_OK;
+    pcl_ctx *ctx = b->ctx;
+    hipSetDevice(ctx->device);
+    pcl_batch_reap(ctx, false);
+    hipStream_t streams[4] = {ctx->stream, ctx->stream_dp, ctx->stream_aux, ctx->stream_d2h};
+    static const bool sync_destroy = getenv("PCL_DESTROY_SYNC") && atoi(getenv("PCL_DESTROY_SYNC")) != 0;   // A/B: rounds 1-4
+    bool idle = true;
+    for (int k = 0; k < 4 && idle; ++k)
+        if (streams[k] && hipStreamQuery(streams[k]) != hipSuccess) idle = false;
+    (void)hipGetLastError();                                 // (hipErrorNotReady is not an error)
+    if (sync_destroy && !idle) {
+        for (int k = 0; k < 4; ++k)
+            if (streams[k]) hipStreamSynchronize(streams[k]);
+        idle = true;
+    }
+    if (idle) {
+        batch_free_now(b);
+        return PCL_OK;
+    }
+    pcl_ctx::Grave gr{b, {nullptr, nullptr, nullptr, nullptr}};
+    for (int k = 0; k < 4; ++k) {
+        if (!streams[k]) continue;
+        hipEvent_t ev = nullptr;
+        if (!ctx->grave_events.empty()) {
+            ev = ctx->grave_events.back();
+            ctx->grave_events.pop_back();
+        } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            ev = nullptr;
+        }
+        if (!ev || hipEventRecord(ev, streams[k]) != hipSuccess) {      // no event: fall back to waiting for that stream
+            if (ev) ctx->grave_events.push_back(ev);
+            hipStreamSynchronize(streams[k]);
+            continue;
+        }
+        gr.ev[k] = ev;
+    }
+    ctx->graves.push_back(gr);
     return PCL_OK;
 }
 
@@ -612,16 +679,18 @@ int pcl_batch_upload_sparse(pcl_batch *b, const std::vector<int> &row_ptr, const
     TRY(dev_alloc(ctx, &b->csc_val, nz));
     TRY(dev_alloc(ctx, &b->xi_m, nz));
     TRY(dev_alloc(ctx, &b->xi_s, nz));
-    HIPCHK(ctx, pcl_h2d(ctx, b->row_ptr, row_ptr.data(), np * sizeof(int)));
-    HIPCHK(ctx, pcl_h2d(ctx, b->col_ptr, col_ptr.data(), np * sizeof(int)));
+    // (a batch that has launched nothing: its buffers are fresh, the copies need not queue behind the main stream's kernels)
+    auto up = b->launched ? pcl_h2d : pcl_h2d_fresh;
+    HIPCHK(ctx, up(ctx, b->row_ptr, row_ptr.data(), np * sizeof(int)));
+    HIPCHK(ctx, up(ctx, b->col_ptr, col_ptr.data(), np * sizeof(int)));
     if (nz) {
-        HIPCHK(ctx, pcl_h2d(ctx, b->col_idx, col_idx.data(), nz * sizeof(int)));
-        HIPCHK(ctx, pcl_h2d(ctx, b->row_idx, row_idx.data(), nz * sizeof(int)));
-        HIPCHK(ctx, pcl_h2d(ctx, b->csr_val, csr_val.data(), nz * sizeof(double)));
-        HIPCHK(ctx, pcl_h2d(ctx, b->csc_val, csc_val.data(), nz * sizeof(double)));
+        HIPCHK(ctx, up(ctx, b->col_idx, col_idx.data(), nz * sizeof(int)));
+        HIPCHK(ctx, up(ctx, b->row_idx, row_idx.data(), nz * sizeof(int)));
+        HIPCHK(ctx, up(ctx, b->csr_val, csr_val.data(), nz * sizeof(double)));
+        HIPCHK(ctx, up(ctx, b->csc_val, csc_val.data(), nz * sizeof(double)));
     }
-    HIPCHK(ctx, pcl_h2d(ctx, b->logpi, logpi, (size_t)b->sumN * sizeof(double)));
-    HIPCHK(ctx, pcl_h2d(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
+    HIPCHK(ctx, up(ctx, b->logpi, logpi, (size_t)b->sumN * sizeof(double)));
+    HIPCHK(ctx, up(ctx, b->d_utt, b->utt.data(), (size_t)b->U * sizeof(UttDesc)));
     b->have_trans = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;

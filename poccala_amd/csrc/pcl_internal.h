@@ -152,6 +152,15 @@ struct pcl_ctx {
     double pipe_c_cov = 0.0;
     std::map<std::string, KernelTimer> timers;
     bool timing = false;         // pcl_timing_enable / env PCL_TIMERS: record HIP events around every launch
+    // Batches the caller has destroyed while the GPU was still working on them (a corpus sweep drops the batch of step k - 2 while
+    // step k runs): pcl_batch_destroy records one event per stream the batch may have work on and returns; the memory goes back
+    // to the pool when those events have completed (pcl_batch_reap: on the next create / destroy, pcl_sync, pcl_destroy).
+    struct Grave {
+        struct pcl_batch *b;
+        hipEvent_t ev[4];
+    };
+    std::vector<Grave> graves;
+    std::vector<hipEvent_t> grave_events;   // spare events (hipEventCreate is not free)
 };
 
 struct pcl_batch {

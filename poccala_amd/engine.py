@@ -188,6 +188,9 @@ class Engine(object):
             if p.value == addr:
                 self._lib.pcl_host_free(self._ctx, p)
                 del self._pinned[k]
+                self._pinned_sizes.pop(addr, None)
+                for name in [n for n, a in self._pinned_named.items() if a.__array_interface__['data'][0] == addr]:
+                    del self._pinned_named[name]
                 return
         raise ValueError('not a pinned_empty() allocation of this engine')
 
@@ -383,18 +386,18 @@ class Engine(object):
     def stats_allreduce(self):
         self._check(self._lib.pcl_stats_allreduce(self._ctx))
 
-    def default_payload(self):
-        """Wire format of the E-step exchange when the caller does not choose: float32 as soon as there is a wire (SURVEY section 5 /
-        8e: the 1.94 GB of statistics and the model cross xGMI as f32, half the bytes; every rank continues from the same rounded
-        model; mean_acc travels as mean_acc - (bias + c_j) acc so that the rounding is not amplified), float64 on one rank."""
+    def wire_payload(self):
+        """The cheaper wire format of the E-step exchange for callers that opt in (bench.py --payload auto): float32 as soon as there is
+        a wire (the 1.94 GB of statistics and the model cross xGMI as f32, half the bytes; every rank continues
+        from the same rounded model; mean_acc travels as mean_acc - (bias + c_j) acc so that the rounding is not amplified), float64
+        on one rank.  NOT the default: with it the re-estimated model depends on the world size."""
         return PCL_F32 if self.comm_info()['nranks'] > 1 else PCL_F64
 
-    def em_exchange(self, c_covariance=1e-3, payload=None, update_transitions=False):
+    def em_exchange(self, c_covariance=1e-3, payload=PCL_F64, update_transitions=False):
         """reduce-scatter of the statistics by state range -> M-step on the owned states -> all-gather of the model
         (+ merge of the per-unit HMM accumulators, + the transition update on request).  One rank: the M-step.
-        payload: PCL_F32 / PCL_F64, None = default_payload()."""
-        if payload is None:
-            payload = self.default_payload()
+        payload: PCL_F64 (default: the reference's reducer is float64, LHMM.py:256-290 / Clustering.py:314-367, and the model then
+        does not depend on the world size) or PCL_F32 (half the bytes on the wire; `wire_payload()` picks it when there is a wire)."""
         self._check(self._lib.pcl_em_exchange(self._ctx, float(c_covariance), int(payload), 1 if update_transitions else 0))
         self._model_key = None
 
@@ -410,8 +413,12 @@ class Batch(object):
         self._b = C.c_void_p()
         if unit_ids is not None:
             # label-built: N_u = (S-2) L_u + 2 (AcousticModel.py:966); structure built by pcl_batch_create_labels
-            lens = np.array([len(l) for l in unit_ids], dtype=np.int32)
-            flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in unit_ids]), dtype=np.int32)
+            if isinstance(unit_ids, np.ndarray) and unit_ids.ndim == 2:      # equal-length labels as one (U, L) array: no per-utterance Python
+                lens = np.full(unit_ids.shape[0], unit_ids.shape[1], dtype=np.int32)
+                flat = np.ascontiguousarray(unit_ids, dtype=np.int32).reshape(-1)
+            else:
+                lens = np.array([len(l) for l in unit_ids], dtype=np.int32)
+                flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in unit_ids]), dtype=np.int32)
             self.N = ((engine.S - 2) * lens + 2).astype(np.int32)
             if self.N.shape != self.T.shape or self.N.size == 0 or frame_begin is None:
                 raise ValueError('labels, T and frame_begin must be equal-length, non-empty')
@@ -501,12 +508,10 @@ class Batch(object):
     def accumulate(self, precision=PCL_F32):
         self._check(self._lib.pcl_batch_accumulate(self._b, int(precision)))
 
-    def accumulate_exchange(self, precision=PCL_F32, c_covariance=1e-3, payload=None, update_transitions=False, n_chunks=8):
+    def accumulate_exchange(self, precision=PCL_F32, c_covariance=1e-3, payload=PCL_F64, update_transitions=False, n_chunks=8):
         """The last accumulate pass of an E-step and the exchange in one pipelined call (pcl_batch_accumulate_exchange): state
         chunks leave for reduce-scatter -> M-step -> all-gather -> derive as soon as the pass is done with them.
-        payload None = Engine.default_payload() (f32 on the wire when there is one)."""
-        if payload is None:
-            payload = self.eng.default_payload()
+        payload as in Engine.em_exchange (float64 unless the caller opts in to the f32 wire)."""
         self._check(self._lib.pcl_batch_accumulate_exchange(self._b, int(precision), float(c_covariance), int(payload),
                                                              1 if update_transitions else 0, int(n_chunks)))
         self.eng._model_key = None
@@ -561,28 +566,35 @@ class Batch(object):
         self._check(self._lib.pcl_batch_refresh_transitions(self._b))
 
     # ------------------------------------------------------------------ results on their way to the host while the GPU goes on
-    def result_buffers(self, want=('logp', 'lgamma', 'ksai_nz', 'path', 'point')):
-        """Page-locked destination arrays for fetch_async (kept with the engine until it closes)."""
-        pe = self.eng.pinned_empty
-        out = {}
-        if 'logp' in want:
-            out['logp'] = pe((self.U,), np.float64)
-        if 'lgamma' in want:
-            out['lgamma'] = pe((int(self._nt_off[-1]),), np.float64)
-        if 'ksai_nz' in want:
-            nnz = np.zeros(1, dtype=np.int64)        # (label-built batches: the library built the transition lists)
-            self._check(self._lib.pcl_batch_sizes(self._b, None, None, None, ptr(nnz)))
-            out['ksai_nz'] = pe((int(nnz[0]),), np.float64)
-        if 'path' in want:
-            out['path'] = pe((int(self._t_off[-1]),), np.int32)
-        if 'point' in want:
-            out['point'] = pe((self.U,), np.float64)
-        return out
+    def _result_shapes(self):
+        """name -> (elements, dtype) of fetch_async's destinations for THIS batch (pcl_batch_sizes)."""
+        nnz = np.zeros(1, dtype=np.int64)            # (label-built batches: the library built the transition lists)
+        self._check(self._lib.pcl_batch_sizes(self._b, None, None, None, ptr(nnz)))
+        return dict(logp=(self.U, np.float64), lgamma=(int(self._nt_off[-1]), np.float64), ksai_nz=(int(nnz[0]), np.float64),
+                    path=(int(self._t_off[-1]), np.int32), point=(self.U, np.float64))
+
+    def result_buffers(self, want=('logp', 'lgamma', 'ksai_nz', 'path', 'point'), slot=0):
+        """Page-locked destination arrays for fetch_async.  They belong to the ENGINE, one grow-only set per `slot` (a pipeline that
+        keeps k result sets in flight uses slots 0 .. k-1): calling this once per batch of a stream re-uses the slot's memory
+        instead of page-locking ~150 MB per call until the engine closes."""
+        shapes = self._result_shapes()
+        names = [k for k in ('logp', 'lgamma', 'ksai_nz', 'path', 'point') if k in want]
+        views = self.eng._pinned_views('fetch_results_%d' % slot, [((shapes[k][0],), shapes[k][1]) for k in names])
+        return dict(zip(names, views))
 
     def fetch_async(self, bufs):
         """Queue the device-to-host copies of the results named in `bufs` (result_buffers()) behind everything this batch has
         queued; returns at once.  fetch_wait() blocks until they have landed; the next compute call on this batch waits for them
-        on the device."""
+        on the device.  Every buffer is checked against this batch's sizes first: a stale or short buffer would otherwise be a
+        host-memory overrun written by an asynchronous DMA."""
+        shapes = self._result_shapes()
+        for k, a in bufs.items():
+            if k not in shapes:
+                raise KeyError('fetch_async: unknown result %r' % (k,))
+            n, dt = shapes[k]
+            if not isinstance(a, np.ndarray) or a.dtype != dt or a.size != n or not a.flags['C_CONTIGUOUS']:
+                raise ValueError('fetch_async: %s must be a C-contiguous %s array of %d elements (got %s %s)'
+                                 % (k, np.dtype(dt).name, n, getattr(a, 'dtype', type(a)), getattr(a, 'shape', '')))
         g = lambda k: ptr(bufs[k]) if k in bufs else None
         self._check(self._lib.pcl_batch_fetch_async(self._b, g('logp'), g('lgamma'), g('ksai_nz'), g('path'), g('point')))
 

@@ -1,7 +1,7 @@
 """Parity bookkeeping for the GPU tests: every comparison against the oracle that the north star bounds (1e-4 relative on
 log-likelihoods and gamma / xi occupancies in f32, and what follows from them: the E-step statistics and the re-estimated
 model) goes through `hold`, which ASSERTS the bound and RECORDS the measured worst case.  The session writes the records to
-profiles/r04_parity_report.json (and gpurun_out/, which is what travels back from the GPU box), so that the numbers the
+gpurun_out/r05_parity_report.json (what travels back from the GPU box; copied to profiles/ on request, see `write`), so that the numbers the
 asserts saw are on file, not only printed.
 
 A record: config / quantity -> {bound: {rtol, atol}, max_abs, max_rel (over entries with |want| > atol / rtol, i.e. where the
@@ -66,7 +66,7 @@ def hold(config, quantity, got, want, rtol, atol=0.0, note=None):
         rec['note'] = note
     msg = '%s / %s: %.3g of the bound (rtol %g, atol %g): max |d| %.3e, max relative %.3e' % (
         config, quantity, m['used'], rtol, atol, m['max_abs'], m['max_rel'])
-    if os.environ.get('POCCALA_PARITY_SOFT'):          # discovery runs: record every violation instead of stopping at the first
+    if SOFT:          # discovery runs: record every violation instead of stopping at the first; the SESSION fails at its end (conftest)
         if m['used'] > 1.0:
             rec['violated'] = True
             print('PARITY VIOLATION ' + msg)
@@ -80,25 +80,47 @@ def note(config, key, value):
     REPORT.setdefault(config, {})[key] = value
 
 
+SOFT = bool(os.environ.get('POCCALA_PARITY_SOFT'))
+REPORT_NAME = 'r05_parity_report.json'
+
+
+def violations():
+    """(config, quantity) of every record a soft-mode session saw over its bound."""
+    return [(c, q) for c, qs in REPORT.items() for q, r in qs.items() if isinstance(r, dict) and r.get('violated')]
+
+
 def write():
-    """profiles/r04_parity_report.json <- the records of this session merged INTO what the file already holds (a session that runs a
-    subset of the tests refreshes its configs and leaves the others), and the same body to gpurun_out/ (what travels back from the GPU box)."""
+    """gpurun_out/r05_parity_report.json <- the records of this session (gpurun_out/ is what travels back from the GPU box; it is
+    scratch).  The tracked copy profiles/r05_parity_report.json is written ONLY when POCCALA_PARITY_REPORT=1 asks for it (the full
+    suite on the GPU box at the end of a round), merged into what the file holds, so that ordinary test runs neither dirty the
+    repository nor overwrite the committed evidence.  The body says which mode the session ran in: in soft mode
+    (POCCALA_PARITY_SOFT, discovery runs) entries are recorded WITHOUT being asserted and the session fails at its end if any was
+    over its bound (conftest.pytest_sessionfinish)."""
     if not REPORT:
         return
-    main = os.path.join(ROOT, 'profiles', 'r04_parity_report.json')
-    merged = {}
-    try:
-        merged = dict(json.load(open(main)).get('configs', {}))
-    except (OSError, ValueError):
-        pass
-    merged.update(REPORT)
-    body = dict(what='measured worst cases of the GPU parity tests (tests/_parity.py): every entry was asserted against its bound in the run that wrote it',
-                contract='BASELINE.json north_star: log-likelihoods and gamma / xi occupancies within 1e-4 relative in f32, Viterbi bit-exact',
-                configs=merged)
-    for d in (os.path.join(ROOT, 'profiles'), os.path.join(ROOT, 'gpurun_out')):
+    bad = violations()
+
+    def body(configs):
+        return dict(what='measured worst cases of the GPU parity tests (tests/_parity.py)',
+                    mode='soft: entries recorded, NOT asserted one by one; the session fails at its end if any is over its bound' if SOFT
+                         else 'strict: every entry was asserted against its bound in the run that wrote it',
+                    violations=['%s / %s' % v for v in bad],
+                    contract='BASELINE.json north_star: log-likelihoods and gamma / xi occupancies within 1e-4 relative in f32, Viterbi bit-exact',
+                    configs=configs)
+    targets = [(os.path.join(ROOT, 'gpurun_out'), dict(REPORT))]
+    if os.environ.get('POCCALA_PARITY_REPORT') and not SOFT:
+        main = os.path.join(ROOT, 'profiles', REPORT_NAME)
+        merged = {}
+        try:
+            merged = dict(json.load(open(main)).get('configs', {}))
+        except (OSError, ValueError):
+            pass
+        merged.update(REPORT)
+        targets.append((os.path.join(ROOT, 'profiles'), merged))
+    for d, configs in targets:
         try:
             os.makedirs(d, exist_ok=True)
-            with open(os.path.join(d, 'r04_parity_report.json'), 'w') as f:
-                json.dump(body, f, indent=1, sort_keys=True)
+            with open(os.path.join(d, REPORT_NAME), 'w') as f:
+                json.dump(body(configs), f, indent=1, sort_keys=True)
         except OSError:
             pass

@@ -30,6 +30,15 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(L.PROTOTYPES) == names
 
 
+def test_exported_pcl_symbols_are_exactly_the_header():
+    """The converse of the test above: nothing named pcl_* leaves the library that the header does not
+    declare -- internal helpers (C++ arguments behind extern "C") stay hidden (-fvisibility=hidden, push(default) in the header)."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith('pcl_')})
+    assert exported == header_symbols()
+
+
 def test_no_gpu_fails_loudly():
     """Without a GPU the product path must raise, never fall back to a CPU implementation."""
     import ctypes

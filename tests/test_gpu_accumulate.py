@@ -6,7 +6,7 @@ The small-M end-to-end tests (test_gpu_parity.py::test_estep_*) cannot reach wha
 images of long active lists.  Here the device's OWN ln gamma_t(j) and ln b_j(o_t) go into the oracle's update_acc for every
 occurrence of a handful of states, so the comparison isolates the accumulate kernels: acc, alpha_acc, mean_acc, cov_acc per
 mixture, f32-class default (rtol 1e-4 -- the north-star bound --, atol 1e-6 of the state's largest entry) and PCL_F64 (1e-9);
-the measured worst cases go to profiles/r04_parity_report.json (tests/_parity.py)."""
+the measured worst cases go to gpurun_out/r05_parity_report.json (tests/_parity.py; profiles/ on request)."""
 import os
 
 import numpy as np

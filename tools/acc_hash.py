@@ -19,7 +19,7 @@ for peaked in (False, True):
     for k in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
         h.update(np.ascontiguousarray(st[k]).tobytes())
     print('pass', int(peaked), h.hexdigest(), float(st['acc'].sum()))
-    eng.em_exchange(1e-3, None, True); b.refresh_transitions()
+    eng.em_exchange(1e-3, update_transitions=True); b.refresh_transitions()
     hm = xxhash.xxh3_128()
     for a in eng.model_download() + tuple(eng.model_conditioning()[:1]) + tuple(eng.model_split_info()[:1]):
         hm.update(np.ascontiguousarray(a).tobytes())

@@ -30,5 +30,5 @@ for it in range(4):
           % (it, 100 * live.mean(), np.round(q, 1), {k: round(v, 4) for k, v in frac.items()}, int((np.where(live, cm, 0).max(axis=1) <= 96).sum()), J,
              np.median(cm2[live]), cm2[live].max(), np.median(v_[live]), v_.min()), flush=True)
     eng.stats_zero(); b.score(PCL_F32); b.forward_backward(); b.accumulate(PCL_F32); b.accumulate_hmm()
-    eng.em_exchange(1e-3, None, True)
+    eng.em_exchange(1e-3, update_transitions=True)
     b.refresh_transitions()

@@ -7,6 +7,7 @@ import numpy as np
 from poccala_amd import Engine, PCL_F32, synth
 c = synth.CONFIGS['C4shard']
 U = int(sys.argv[1]) if len(sys.argv) > 1 else c['U']
+C_COV = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3          # the reference's driver passes 1e-6 (init.py:30 -> Controller.py:151)
 mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
 frames, lens, begin = synth.make_frames(U, c['T'], c['D'], seed=1000)
 labels = synth.make_labels(U, c['L'], c['units'], seed=2000)
@@ -26,6 +27,6 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     kt = {k: round(eng.kernel_time(k)[0], 3) for k in names}
     lp = b.get('logp'); st = eng.stats_download(moments=False)
     print('iteration %d: off-pipe mixtures %.1f%% (limit %d per state: %d split states, %d whole states off); cond max %.1f, states above %.0f: %d of %d; var min %.3g (floored %.2f%%), weights == 0: %.2f%%; E-step %.1f ms %s; mean logP %.2f; zero-occupancy mixtures %.2f%%'
-          % (it, 100.0 * n_off.sum() / (len(n_off) * c['M']), lim, int(((n_off > 0) & (n_off <= lim)).sum()), int((n_off > lim).sum()), cond.max(), cmax, int((cond > cmax).sum()), len(cond), v_.min(), 100 * np.mean(v_ <= 1.0000001e-3), 100 * np.mean(w_ == 0), (t1 - t0) * 1e3, kt, lp.mean(), 100 * np.mean(st['acc'] == 0)), flush=True)
-    eng.em_exchange(1e-3, None, True)
+          % (it, 100.0 * n_off.sum() / (len(n_off) * c['M']), lim, int(((n_off > 0) & (n_off <= lim)).sum()), int((n_off > lim).sum()), cond.max(), cmax, int((cond > cmax).sum()), len(cond), v_.min(), 100 * np.mean(v_ <= C_COV * 1.0000001), 100 * np.mean(w_ == 0), (t1 - t0) * 1e3, kt, lp.mean(), 100 * np.mean(st['acc'] == 0)), flush=True)
+    eng.em_exchange(C_COV, update_transitions=True)
     b.refresh_transitions()
