@@ -62,7 +62,10 @@ def parse():
     p.add_argument('--steps', type=int, default=5)
     p.add_argument('--warmup', type=int, default=1)
     p.add_argument('--workload', default='C4shard', help='poccala_amd.synth.CONFIGS key')
-    p.add_argument('--utts', type=int, default=0, help='override utterances per GPU')
+    p.add_argument('--utts', type=int, default=0, help='override utterances per GPU (--workload C4: per batch)')
+    p.add_argument('--mix', type=int, default=0, help='override mixtures per state (rehearsals of the control flow on a small model; not the named configuration)')
+    p.add_argument('--units', type=int, default=0, help='override the number of units (rehearsals)')
+    p.add_argument('--c4-batches', type=int, default=0, help='--workload C4: batches of the corpus (default 8 = config 4; rehearsals use fewer)')
     p.add_argument('--precision', default='f32', choices=['f32', 'f64'])
     p.add_argument('--batches', type=int, default=2,
                    help='resident utterance batches (each of the full per-GPU size) that successive steps alternate between, as a '
@@ -474,7 +477,7 @@ def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, de
     U, T = cfg['U'], cfg['T']
     nb = len(lens_all) // U
     sets = [np.stack(synth.make_labels(U, cfg['L'], cfg['units'], seed=31 + 7919 * rank + k)).astype(np.int32) for k in range(label_sets)]
-    live = []
+    live, seen = [], [0.0]
     host = dict(create=0.0, enqueue=0.0, close=0.0)
 
     def one(k, timed):
@@ -484,10 +487,15 @@ def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, de
         t1 = time.perf_counter()
         b.score(P)
         b.forward_backward(fix_pi=False)
+        res = b.result_buffers(('logp',), slot=k % (depth + 1))      # the sweep's consumer reads every batch's ln P(O): on its way behind the kernels
+        b.fetch_async(res)
         t2 = time.perf_counter()
-        live.append(b)
+        live.append((b, res))
         if len(live) > depth:
-            live.pop(0).close()
+            old, r = live.pop(0)
+            old.fetch_wait()                   # that batch's results are on the host: its work is done, it is dropped and its memory reused
+            seen[0] += float(r['logp'][0])
+            old.close()
         t3 = time.perf_counter()
         if timed:
             host['create'] += t1 - t0
@@ -505,21 +513,22 @@ def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, de
     sc_ms, sc_n = eng.kernel_time('score')
     # the results of a batch made inside the loop against a resident batch of the same labels and frames: the same bits
     last_k = warm + steps - 1
-    got = live[-1].get('logp')
+    got = live[-1][0].get('logp')
     lo = U * (last_k % nb)
     ref_b = eng.label_batch(sets[last_k % label_sets], lens_all[lo:lo + U], begin_all[lo:lo + U])
     ref_b.score(P); ref_b.forward_backward(fix_pi=False)
     same = bool(np.array_equal(got, ref_b.get('logp')))
     ref_b.close()
-    for b in live:
+    for b, _ in live:
         b.close()
     nfr = int(np.sum(lens_all[:U]))
     return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, batches_alive=depth, label_sets=label_sets,
                 batch_create_ms=host['create'] / steps * 1e3, enqueue_ms=host['enqueue'] / steps * 1e3, batch_close_ms=host['close'] / steps * 1e3,
                 score_kernel_ms=sc_ms / max(sc_n, 1), same_bits_as_a_resident_batch=same,
-                what='every step creates its label batch (new labels), scores it, runs forward-backward and drops the batch of %d steps ago, inside the '
-                     'timed region; batch_create_ms / enqueue_ms / batch_close_ms = HOST time per step of the three calls (the GPU works on the previous '
-                     'steps meanwhile); frames resident' % depth)
+                what='every step creates its label batch (new labels), scores it, runs forward-backward, queues its ln P(O) for the host, and -- once the '
+                     'results of the batch of %d steps ago have landed -- drops that batch, all inside the timed region; batch_create_ms / enqueue_ms / '
+                     'batch_close_ms = HOST time per step (the GPU works on the previous steps meanwhile; close includes the wait for the old batch\'s '
+                     'results, which is what keeps the host from running ahead of the GPU without bound); frames resident' % depth)
 
 
 def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=4):
@@ -646,6 +655,11 @@ def main():
     cfg = dict(synth.CONFIGS[args.workload])
     if args.utts:
         cfg['U'] = args.utts
+    if args.mix:
+        cfg['M'] = args.mix
+    if args.units:
+        cfg['units'] = args.units
+    reduced = bool(args.utts or args.mix or args.units)
     t_setup = time.perf_counter()
     tl = {}                                           # where the wall-clock of this run goes (extra.timeline_s)
     t_mark = time.perf_counter()
@@ -704,6 +718,8 @@ def main():
         args.extra = 0                                # (the extras measure the E-step)
     elapsed, score_ms, score_n, fb_ms, fb_n = timed_steps(eng, batches, P, align, args.warmup, args.steps, barrier)
     elapsed = ctl.allreduce_max(elapsed)
+    if os.environ.get('POCCALA_TEST_DIE_RANK') == str(rank):      # tests/test_gpu_a_bench_ranks.py: a rank that dies behind the timed loop
+        os._exit(7)
     # the dynamic-programming kernels ALONE (outside the timed region): inside the loop their HIP events span the time their
     # workgroups wait for register-file room beside the next step's scoring waves, not the time they work
     dp_alone_ms = None
@@ -742,7 +758,7 @@ def main():
     # algorithmic HBM bytes per scoring launch: frames once + parameters of the states with work once + B written once
     alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + scored_pairs * 8
     traffic, traffic_raw = args.traffic_bytes, None
-    if traffic is None and args.workload == 'C4shard' and not args.utts and P == PCL_F32 and score_variant == 7:
+    if traffic is None and args.workload == 'C4shard' and not reduced and P == PCL_F32 and score_variant == 7:
         traffic, traffic_raw = committed_traffic()
     roofline = dict(bound='mfma', achieved=achieved, peak=score_peak, unit='TFLOP/s',
                     frac=(achieved / score_peak) if achieved else None,
@@ -793,7 +809,7 @@ def main():
             fresh = dict(error=repr(e))
         tl['fresh_batch_loop_s'] = time.perf_counter() - t_mark2
         t_mark2 = time.perf_counter()
-        if world == 1 and not args.utts and nb >= 2:
+        if world == 1 and not reduced and nb >= 2:
             try:
                 pcie = pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, max(args.steps, 20))
             except Exception as e:             # noqa
@@ -806,7 +822,7 @@ def main():
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': DTYPE_NAME if P == PCL_F32 else 'f64', 'data': 'synthetic',
-            'config': {'workload': ('%s: %d utterances/GPU x %d frames, D=%d MFCC, M=%d mixtures, %d units (J=%d tied GMM states), '
+            'config': {'workload': ('REDUCED for a rehearsal, not the named configuration -- ' if reduced else '') + ('%s: %d utterances/GPU x %d frames, D=%d MFCC, M=%d mixtures, %d units (J=%d tied GMM states), '
                                     'L=%d units/utterance (N=%d-state sentence HMMs); GMM scoring of the %d label states of every frame '
                                     + ('+ Viterbi forced alignment (LHMM.viterbi, bit-exact given the emissions)' if align else
                                        '+ Baum-Welch forward-backward pass loop (3 passes, xi/gamma/pi/posteriors)'))
@@ -863,6 +879,8 @@ def main():
     extra = None
     comm_error = None
     if world > 1 or os.environ.get('POCCALA_FORCE_DIST'):          # FORCE_DIST: exercise RCCL at world 1
+        if os.environ.get('POCCALA_TEST_HANG_COMM'):               # tests: a communicator bootstrap that never returns -> the watchdog's job
+            time.sleep(1e6)
         try:
             if shared or os.environ.get('POCCALA_NO_RCCL'):
                 eng.comm_init_host(rank, world, ctl.allgather_bytes)
@@ -1052,7 +1070,7 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
                                           'pieces each, per-mixture running power-of-two scale; round 2: 45 with bf16 x3 moments) per 32 frames x 32 mixtures of '
                                           'the SURVIVING pairs.  Bench features are random N(0,1): flat posteriors, ~78 % of the pairs survive the exact '
                                           'underflow compaction; aligned speech is peaked: extra.estep_peaked'))
-    if ctl.world == 1 and P == PCL_F32 and not args.utts:
+    if ctl.world == 1 and P == PCL_F32 and not (args.utts or args.mix or args.units):
         more['frames'] = frames
         extra.update(side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs, more))
         more['tl']['total_before_line_s'] = time.perf_counter() - T_PROCESS_START
@@ -1332,31 +1350,32 @@ class _Solo(object):
 C4_BATCHES = 8            # 8 x 1024 utterances = the 8192 of config 4
 
 
-def c4_corpus_batch(k):
+def c4_corpus_batch(k, c=None):
     """batch k of the 8192-utterance corpus of config 4: (frames (307200, 39) f32, lens, labels); seeded by k alone, so that any
     split over ranks sees the same corpus."""
     from poccala_amd import synth
-    c = synth.CONFIGS['C4shard']
+    c = c or synth.CONFIGS['C4shard']
     frames, lens, _ = synth.make_frames(c['U'], c['T'], c['D'], seed=1000 + k)
     labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2000 + k)
     return frames, lens, labels
 
 
-def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, em_iters=0):
+def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, em_iters=0, cfg=None, n_batches=None):
     """Config 4 whole: ALL 8192 utterances through one EM iteration -- per batch of 1024: score -> forward-backward -> GMM
     statistics + per-unit transition accumulators, the 8 batches into ONE statistics block -> the exchange (reduce-scatter ->
     GMM.update_param on the owned states -> all-gather; one rank: the M-step) -> transition M-step -> the batches take the new
     transitions (AcousticModel.py:842-882: the Pool over the corpus, then multi_embedded_training_2).  The batches are dealt
     round-robin to the ranks (strong scaling: --workload C4 --gpus N); on one GPU all 8 are resident.  Returns a dict."""
     from poccala_amd import synth
-    c = synth.CONFIGS['C4shard']
+    c = cfg or synth.CONFIGS['C4shard']
+    C4_BATCHES = n_batches or globals()['C4_BATCHES']          # (rehearsals of the control flow run fewer, smaller batches)
     rank, world = ctl.rank, ctl.world
     mine = [k for k in range(C4_BATCHES) if k % world == rank]
     t0 = time.perf_counter()
     if model is None:
         model = synth.make_model(c['units'], c['M'], c['D'], seed=1)
     mean, var, w, trans = model
-    parts = [c4_corpus_batch(k) for k in mine]
+    parts = [c4_corpus_batch(k, c) for k in mine]
     frames = np.concatenate([p_[0] for p_ in parts], axis=0) if parts else np.zeros((1, c['D']), dtype=np.float32)
     eng.load_model(mean, var, w)
     eng.load_units(np.stack(trans))
@@ -1612,8 +1631,14 @@ def bench_c4_full(args, rank, world, local):
         else:
             eng.comm_init(rank, world, ctl.broadcast(eng.comm_unique_id() if rank == 0 else None, src=0))
     payload = resolve_payload(args, world)
+    from poccala_amd import synth
+    cfg = dict(synth.CONFIGS['C4shard'])
+    for key, val in (('U', args.utts), ('M', args.mix), ('units', args.units)):
+        if val:
+            cfg[key] = val
+    reduced = bool(args.utts or args.mix or args.units or args.c4_batches)
     r = run_c4_full(eng, ctl, PCL_F32 if args.precision == 'f32' else PCL_F64, payload, iters=max(1, args.steps), warm=max(1, args.warmup),
-                    c_cov=args.c_covariance, em_iters=args.iters)
+                    c_cov=args.c_covariance, em_iters=args.iters, cfg=cfg, n_batches=args.c4_batches or None)
     if rank == 0:
         info = eng.device_info()
         print(json.dumps({'metric': 'frames/sec full Baum-Welch EM iteration (E-step + exchange + M-step), 39-d MFCC, 2048-mix, 8192 utterances',
@@ -1623,8 +1648,9 @@ def bench_c4_full(args, rank, world, local):
                           'ms_per_step': r['fresh_batches']['ms_per_iteration'], 'value_resident_batches': r['value'], 'ms_per_step_resident_batches': r['ms_per_iteration'],
                           'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                           'dtype': DTYPE_NAME if args.precision == 'f32' else 'f64', 'data': 'synthetic',
-                          'config': {'workload': 'C4: ' + r['shape'], 'device': info['name'], 'cus': info['cus'], 'payload': 'f32' if payload == PCL_F32 else 'f64',
-                                     'transport': eng.comm_info()['transport']},
+                          'config': {'workload': ('REDUCED for a rehearsal, not the named configuration -- ' if reduced else '') + 'C4: ' + r['shape'],
+                                     'device': info['name'], 'cus': info['cus'], 'payload': 'f32' if payload == PCL_F32 else 'f64',
+                                     'transport': eng.comm_info()['transport'], 'rccl_nranks': eng.comm_info()['rccl_nranks']},
                           'detail': r}))
         sys.stdout.flush()
     ctl.barrier()

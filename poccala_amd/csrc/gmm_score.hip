@@ -41,6 +41,12 @@ constexpr int WG = 256;  // 4 waves
 #ifndef PCL_CH32
 #define PCL_CH32 64   // mixtures per LDS chunk (f32)
 #endif
+#ifndef PCL_PDE_D1
+#define PCL_PDE_D1 4    // partial-distance elimination: features before the first / second test (0 = off; D2 <= D1: one test)
+#endif
+#ifndef PCL_PDE_D2
+#define PCL_PDE_D2 10
+#endif
 constexpr int GROUP = PCL_GROUP;  // mixtures per LSE rescale (Mpad is a multiple of 4 >= this)
 
 template <typename real>
@@ -137,6 +143,19 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
         sm[r] = 0;
     }
 
+    // partial-distance elimination (see the mixture loop): the float launches only -- the float64 parity mode evaluates everything
+    constexpr bool PDE = sizeof(real) == 4 && PCL_PDE_D1 > 0 && D > PCL_PDE_D1;
+    constexpr int PD1 = PCL_PDE_D1, PD2 = (PCL_PDE_D2 > PCL_PDE_D1 && PCL_PDE_D2 < D) ? PCL_PDE_D2 : PCL_PDE_D1;
+    constexpr int PDE_MARGIN = 40;                                   // log2 units: 2^-40 of a term the sum holds
+    real ref2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ref2[r] = Fast<real>::neg_big();
+        if (PDE && SUBSET) {                                         // the rest of the state, as the matrix pipe left it (ln -> log2)
+            const double old = out[oidx[r]];
+            if (old > -1.0e30) ref2[r] = (real)(old * 1.4426950408889634074);
+        }
+    }
     static_assert(!SUBSET || MASTER, "the subset launch makes its rows from the master copy");
     const real *pbase = params + (size_t)tile.state * Mpad * ROW;
     const int n_sub = SUBSET ? mm.nbad[tile.state] : 0;
@@ -201,25 +220,61 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
         __syncthreads();
         for (int m = 0; m < n; m += GROUP) {
             real v[GROUP][R];
+            // Partial-distance elimination (f32 launches).  q only grows with every feature, so k2 - q after the first D1 (then D2) features
+            // is an UPPER bound of the mixture's value; when for every frame of the wavefront that bound is already 2^-PDE_MARGIN below
+            // a value the frame's sum is known to hold (its running maximum, or what the matrix pipe wrote for the rest of a split
+            // state), the rest of the features cannot change any sum -- a term that far below adds nothing to an f32 sum that holds
+            // its maximum's 1 -- and the wavefront skips them (mixtures are wave-uniform here: one ballot, no divergence).  The sums
+            // keep their bits.  What it is for: re-estimated models whose mixtures have collapsed onto single frames (variances at the
+            // floor of GMM.update_param, Clustering.py:682-693; the reference's driver passes 1e-6, init.py:30): such a mixture is
+            // 1e5 .. 1e6 nats away from every frame but its own, and after a few features that is settled.
+            real thr[R];
+            if (PDE) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) thr[r] = Fast<real>::max(mx[r], ref2[r]) - (real)PDE_MARGIN;
+            }
+            bool any_alive = !PDE;
 #pragma unroll
             for (int g = 0; g < GROUP; ++g) {
                 const real *p = &lds[(m + g) * ROW];
+                const real k2 = p[2 * D];
                 real q[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) q[r] = 0;
+                auto feats = [&](const int d0, const int d1) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const real s = p[2 * d], c = p[2 * d + 1];
+                    for (int d = d0; d < d1; ++d) {
+                        const real s = p[2 * d], c = p[2 * d + 1];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const real y = Fast<real>::fma(x[r][d], s, c);
-                        q[r] = Fast<real>::fma(y, y, q[r]);
+                        for (int r = 0; r < R; ++r) {
+                            const real y = Fast<real>::fma(x[r][d], s, c);
+                            q[r] = Fast<real>::fma(y, y, q[r]);
+                        }
                     }
-                }
-                const real k2 = p[2 * D];
+                };
+                auto dead = [&]() {                                              // wave-uniform: no frame of the wavefront can still be reached
+                    bool alive = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) v[g][r] = k2 - q[r];
+                    for (int r = 0; r < R; ++r) alive |= (k2 - q[r] >= thr[r]);
+                    return __builtin_amdgcn_ballot_w64(alive) == 0ull;
+                };
+                bool gone = false;
+                if (PDE) {
+                    feats(0, PD1);
+                    gone = dead();
+                    if (!gone && PD2 > PD1) {
+                        feats(PD1, PD2);
+                        gone = dead();
+                    }
+                    if (!gone) feats(PD2 > PD1 ? PD2 : PD1, D);
+                } else {
+                    feats(0, D);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[g][r] = gone ? -(real)INFINITY : k2 - q[r];
+                any_alive |= !gone;
             }
+            if (!any_alive) continue;                                            // (all four gone: the update below would multiply by 1 and add zeros)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 real gm = v[0][r];

@@ -938,6 +938,8 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     if (ctx->dp_async) {
         HIPCHK(ctx, hipEventRecord(b->ev_dp, ctx->stream_dp));
         b->dp_pending = true;
+    } else {
+        HIPCHK(ctx, pcl_batch_mark(b));
     }
     b->have_dec = true;
     return PCL_OK;

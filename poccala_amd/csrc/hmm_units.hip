@@ -294,6 +294,7 @@ int pcl_batch_create_labels(pcl_ctx *ctx, int U, const int32_t *label_len, const
         if (labels[i] < 0 || labels[i] >= ctx->n_units) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create_labels: unit id %d outside [0,%d)", labels[i], ctx->n_units);
     pcl_batch *b = nullptr;
     TRY(pcl_batch_create(ctx, U, N.data(), T, frame_begin, &b));
+    pcl_desc_group uploads(ctx);                                   // every descriptor array below: staged, one wait at the end
     b->from_labels = true;
     b->label_len.assign(label_len, label_len + U);
     b->labels.assign(labels, labels + tot);
@@ -331,8 +332,13 @@ int pcl_batch_create_labels(pcl_ctx *ctx, int U, const int32_t *label_len, const
         pcl_set_error(ctx, "pcl_batch_create_labels: copy failed");
         rc = PCL_ERR_HIP;
     }
+    if (rc == PCL_OK && uploads.finish() != hipSuccess) {
+        pcl_set_error(ctx, "pcl_batch_create_labels: copy failed");
+        rc = PCL_ERR_HIP;
+    }
     if (rc != PCL_OK) {
         const std::string keep = ctx->err;
+        (void)uploads.finish();
         pcl_batch_destroy(b);
         ctx->err = keep;
         return rc;
@@ -370,6 +376,7 @@ int pcl_batch_accumulate_hmm(pcl_batch *b) {
                        b->occ_utt, b->occ_row0, e, ctx->S, ctx->hmm_ksai, ctx->hmm_gamma);
     pcl_timer_end(ctx, "hmm_acc");
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, pcl_batch_mark(b));
     return PCL_OK;
 }
 

@@ -225,8 +225,8 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipStreamSynchronize(ctx->stream_aux);
     if (ctx->stream_d2h) hipStreamSynchronize(ctx->stream_d2h);
     pcl_batch_reap(ctx, true);
-    for (hipEvent_t ev : ctx->grave_events) hipEventDestroy(ev);
-    ctx->grave_events.clear();
+    if (ctx->desc_pin) hipHostFree(ctx->desc_pin);
+    ctx->desc_pin = nullptr;
     drop_timers(ctx);
     free_model(ctx);
     pcl_units_release(ctx);
@@ -565,6 +565,7 @@ static void batch_free_now(pcl_batch *b) {
     if (b->ev_fetch_src) hipEventDestroy(b->ev_fetch_src);
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
+    if (b->ev_mark) hipEventDestroy(b->ev_mark);
     pcl_accumulate_release(b);
     pcl_batch_units_release(b);
     pcl_batch_decode_release(b);
@@ -580,69 +581,45 @@ static void batch_free_now(pcl_batch *b) {
     delete b;
 }
 
+// has the GPU finished the batch's own work on every stream it used?  (wait: block until it has)
+static bool batch_work_done(pcl_batch *b, bool wait) {
+    hipEvent_t evs[3] = {b->ev_mark, b->ev_dp, b->ev_fetch};
+    bool done = true;
+    for (hipEvent_t ev : evs) {
+        if (!ev) continue;
+        const hipError_t e = wait ? hipEventSynchronize(ev) : hipEventQuery(ev);      // (an event never recorded reads as complete)
+        if (e != hipSuccess) done = false;
+        if (!done && !wait) break;
+    }
+    (void)hipGetLastError();                                 // (hipErrorNotReady is not an error)
+    return done;
+}
+
 static int pcl_batch_reap(pcl_ctx *ctx, bool wait) {
     size_t keep = 0;
     for (size_t g = 0; g < ctx->graves.size(); ++g) {
-        pcl_ctx::Grave &gr = ctx->graves[g];
-        bool done = true;
-        for (int k = 0; k < 4 && done; ++k)
-            if (gr.ev[k]) done = wait ? (hipEventSynchronize(gr.ev[k]) == hipSuccess) : (hipEventQuery(gr.ev[k]) == hipSuccess);
-        if (!done) {
-            if (keep != g) ctx->graves[keep] = gr;                // (graves[keep] was moved on or freed already)
-            ++keep;
-            continue;
-        }
-        for (int k = 0; k < 4; ++k)
-            if (gr.ev[k]) ctx->grave_events.push_back(gr.ev[k]);
-        batch_free_now(gr.b);
+        pcl_batch *b = ctx->graves[g];
+        if (batch_work_done(b, wait)) batch_free_now(b);
+        else ctx->graves[keep++] = b;
     }
     ctx->graves.resize(keep);
     return (int)keep;
 }
 
 // The reference drops an utterance's objects when its worker returns (AcousticModel.py:884-916); a corpus sweep here drops the batch
-// of step k - 2 while the GPU works on step k.  Waiting for the streams at that point (what this function did through round 4:
-// 38 ms per call inside a sweep, tools/fresh_batch_probe.py) stalls the host that should be queueing step k + 1.  So: when the
-// streams the batch may have work on are idle, it is freed at once; otherwise one event per stream marks "everything queued so far"
-// and the batch waits in the context's list until they have completed (pcl_batch_reap).  The handle is dead for the caller either way.
+// of step k - 3 while the GPU works on step k.  Waiting for the streams at that point (what this function did through round 4:
+// 38 ms per call inside a sweep, tools/fresh_batch_probe.py) stalls the host that should be queueing step k + 1.  So the batch
+// is freed at once when ITS OWN last work has completed -- the events it left behind its main-stream work (pcl_batch_mark), its
+// recursion on the second stream and its result copies, not what later batches queued behind them -- and otherwise waits in the
+// context's list until it has (pcl_batch_reap).  The handle is dead for the caller either way.
 int pcl_batch_destroy(pcl_batch *b) {
     if (!b) return PCL_OK;
     pcl_ctx *ctx = b->ctx;
     hipSetDevice(ctx->device);
     pcl_batch_reap(ctx, false);
-    hipStream_t streams[4] = {ctx->stream, ctx->stream_dp, ctx->stream_aux, ctx->stream_d2h};
-    static const bool sync_destroy = getenv("PCL_DESTROY_SYNC") && atoi(getenv("PCL_DESTROY_SYNC")) != 0;   // A/B: rounds 1-4
-    bool idle = true;
-    for (int k = 0; k < 4 && idle; ++k)
-        if (streams[k] && hipStreamQuery(streams[k]) != hipSuccess) idle = false;
-    (void)hipGetLastError();                                 // (hipErrorNotReady is not an error)
-    if (sync_destroy && !idle) {
-        for (int k = 0; k < 4; ++k)
-            if (streams[k]) hipStreamSynchronize(streams[k]);
-        idle = true;
-    }
-    if (idle) {
-        batch_free_now(b);
-        return PCL_OK;
-    }
-    pcl_ctx::Grave gr{b, {nullptr, nullptr, nullptr, nullptr}};
-    for (int k = 0; k < 4; ++k) {
-        if (!streams[k]) continue;
-        hipEvent_t ev = nullptr;
-        if (!ctx->grave_events.empty()) {
-            ev = ctx->grave_events.back();
-            ctx->grave_events.pop_back();
-        } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            ev = nullptr;
-        }
-        if (!ev || hipEventRecord(ev, streams[k]) != hipSuccess) {      // no event: fall back to waiting for that stream
-            if (ev) ctx->grave_events.push_back(ev);
-            hipStreamSynchronize(streams[k]);
-            continue;
-        }
-        gr.ev[k] = ev;
-    }
-    ctx->graves.push_back(gr);
+    static const bool sync_destroy = getenv("PCL_DESTROY_SYNC") && atoi(getenv("PCL_DESTROY_SYNC")) != 0;   // A/B: rounds 1-4 (wait here)
+    if (batch_work_done(b, sync_destroy)) batch_free_now(b);
+    else ctx->graves.push_back(b);
     return PCL_OK;
 }
 
@@ -970,6 +947,7 @@ static int build_tiles(pcl_batch *b, int precision) {
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
     dev_free(b->d_tiles_s);
+    pcl_desc_group uploads(ctx);                                   // the tile lists: staged, one wait at the end
     b->n_tiles_s = (int)tiles_s.size();
     if (!tiles_s.empty()) {
         TRY(dev_alloc(ctx, &b->d_tiles_s, tiles_s.size()));
@@ -987,6 +965,7 @@ static int build_tiles(pcl_batch *b, int precision) {
         TRY(dev_alloc(ctx, &b->d_tiles_v, tiles_v.size()));
         HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_tiles_v, tiles_v.data(), tiles_v.size() * sizeof(ScoreTile)));
     }
+    HIPCHK(ctx, uploads.finish());
     return PCL_OK;
 }
 
@@ -1025,6 +1004,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
         TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));
     }
     TRY(pcl_launch_dup_rows(ctx, b));                              // rows of a state an utterance's label names again
+    HIPCHK(ctx, pcl_batch_mark(b));
     b->have_B = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;
@@ -1067,6 +1047,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
         b->dp_pending = true;
     } else {
         TRY(pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold));
+        HIPCHK(ctx, pcl_batch_mark(b));
     }
     b->have_fb = true;
     b->have_post = true;
@@ -1106,6 +1087,7 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
     } else {
         TRY(batch_join(b));
         TRY(pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0));
+        HIPCHK(ctx, pcl_batch_mark(b));
     }
     b->have_vit = true;
     return PCL_OK;
@@ -1302,6 +1284,7 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     }
     const int rc = pcl_launch_accumulate(ctx, b, precision);
     ctx->stats_fresh = false;
+    if (rc == PCL_OK) HIPCHK(ctx, pcl_batch_mark(b));
     return rc;
 }
 

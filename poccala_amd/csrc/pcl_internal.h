@@ -3,6 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include <map>
 #include <string>
@@ -153,14 +156,15 @@ struct pcl_ctx {
     std::map<std::string, KernelTimer> timers;
     bool timing = false;         // pcl_timing_enable / env PCL_TIMERS: record HIP events around every launch
     // Batches the caller has destroyed while the GPU was still working on them (a corpus sweep drops the batch of step k - 2 while
-    // step k runs): pcl_batch_destroy records one event per stream the batch may have work on and returns; the memory goes back
-    // to the pool when those events have completed (pcl_batch_reap: on the next create / destroy, pcl_sync, pcl_destroy).
-    struct Grave {
-        struct pcl_batch *b;
-        hipEvent_t ev[4];
-    };
-    std::vector<Grave> graves;
-    std::vector<hipEvent_t> grave_events;   // spare events (hipEventCreate is not free)
+    // step k runs): pcl_batch_destroy returns at once; the memory goes back to the pool when the batch's OWN last work on every
+    // stream has completed (its events: ev_mark / ev_dp / ev_fetch; pcl_batch_reap on the next create / destroy, pcl_sync, pcl_destroy).
+    std::vector<struct pcl_batch *> graves;
+    // Descriptor uploads of a batch under construction (pcl_desc_group): the arrays are packed into ONE page-locked staging buffer and
+    // queued as asynchronous copies on stream_desc, with one wait at the end of the group -- pcl_batch_create_labels made 16 separate
+    // synchronous copies from pageable memory (5.3 ms of host time per 1024-utterance batch beside a busy GPU, tools/fresh_batch_probe.py).
+    char *desc_pin = nullptr;
+    size_t desc_pin_cap = 0, desc_pin_used = 0;
+    int desc_group = 0;          // > 0: inside a group, pcl_h2d_fresh stages and does not wait
 };
 
 struct pcl_batch {
@@ -210,6 +214,7 @@ struct pcl_batch {
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
     std::vector<int> acc_ws, acc_lo, acc_hi, acc_split; // accumulate's state order (well-conditioned first)
     hipEvent_t ev_main = nullptr, ev_dp = nullptr;   // main stream -> stream_dp hand-over, and back
+    hipEvent_t ev_mark = nullptr;            // the main stream behind the last work this batch queued there (pcl_batch_mark): what pcl_batch_destroy waits for -- not the work later batches queued behind it
     bool dp_pending = false;                 // forward-backward queued on stream_dp and not yet joined
     hipEvent_t ev_fetch = nullptr, ev_fetch_src = nullptr;   // pcl_batch_fetch_async: copies done / the main stream at the time of the call
     bool fetch_pending = false;              // result copies queued on stream_d2h: the next compute call on this batch waits for them
@@ -329,8 +334,54 @@ static inline hipError_t pcl_h2d(pcl_ctx *ctx, void *dst, const void *src, size_
 static inline hipError_t pcl_h2d_fresh(pcl_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return hipSuccess;
     if (!ctx->stream_desc) return pcl_h2d(ctx, dst, src, bytes);
+    if (ctx->desc_group > 0) {                                       // inside a pcl_desc_group: staged, asynchronous, waited for at its end
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (ctx->desc_pin_used + need > ctx->desc_pin_cap) {
+            hipError_t e = hipStreamSynchronize(ctx->stream_desc);   // what is staged so far has to land before the buffer is reused
+            if (e != hipSuccess) return e;
+            ctx->desc_pin_used = 0;
+            if (need > ctx->desc_pin_cap) {
+                if (ctx->desc_pin) (void)hipHostFree(ctx->desc_pin);
+                ctx->desc_pin = nullptr;
+                ctx->desc_pin_cap = 0;
+                const size_t cap = std::max<size_t>((size_t)16 << 20, need * 2);
+                e = hipHostMalloc((void **)&ctx->desc_pin, cap, hipHostMallocDefault);
+                if (e != hipSuccess) return e;
+                ctx->desc_pin_cap = cap;
+            }
+        }
+        char *stage = ctx->desc_pin + ctx->desc_pin_used;
+        memcpy(stage, src, bytes);
+        ctx->desc_pin_used += need;
+        return hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream_desc);
+    }
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream_desc);
     return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream_desc);
+}
+// Scope of a batch's descriptor uploads: every pcl_h2d_fresh inside is staged and asynchronous; `finish` waits once for all of them
+// (the destructor does too, for the error paths).  Groups nest: the outermost one waits.
+struct pcl_desc_group {
+    pcl_ctx *ctx;
+    bool open;
+    explicit pcl_desc_group(pcl_ctx *c) : ctx(c), open(true) { ++ctx->desc_group; }
+    hipError_t finish() {
+        if (!open) return hipSuccess;
+        open = false;
+        if (--ctx->desc_group > 0) return hipSuccess;
+        ctx->desc_pin_used = 0;
+        return ctx->stream_desc ? hipStreamSynchronize(ctx->stream_desc) : hipSuccess;
+    }
+    ~pcl_desc_group() { (void)finish(); }
+};
+
+// Called at the end of every entry point that queues main-stream work reading or writing the batch's buffers (the auxiliary
+// stream's producers are always joined by a main-stream consumer queued behind them).
+static inline hipError_t pcl_batch_mark(pcl_batch *b) {
+    if (!b->ev_mark) {
+        hipError_t e = hipEventCreateWithFlags(&b->ev_mark, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    return hipEventRecord(b->ev_mark, b->ctx->stream);
 }
 
 // shared by pcl_api.hip and hmm_units.hip (C linkage, internal)

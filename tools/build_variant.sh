@@ -16,7 +16,7 @@ for o in poccala_amd/csrc/*.o; do
 done
 for f in "$@"; do
   b=$(basename $f .hip); slp=""; [ $b = gmm_score_split ] && slp=-fno-slp-vectorize
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $slp $flags -c poccala_amd/csrc/$b.hip -o build_ab/$name/$b.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $slp $flags -c poccala_amd/csrc/$b.hip -o build_ab/$name/$b.o
   objs="$objs build_ab/$name/$b.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_ab/lib_$name.so $objs -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib

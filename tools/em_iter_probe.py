@@ -26,7 +26,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     t1 = time.perf_counter()
     kt = {k: round(eng.kernel_time(k)[0], 3) for k in names}
     lp = b.get('logp'); st = eng.stats_download(moments=False)
-    print('iteration %d: off-pipe mixtures %.1f%% (limit %d per state: %d split states, %d whole states off); cond max %.1f, states above %.0f: %d of %d; var min %.3g (floored %.2f%%), weights == 0: %.2f%%; E-step %.1f ms %s; mean logP %.2f; zero-occupancy mixtures %.2f%%'
-          % (it, 100.0 * n_off.sum() / (len(n_off) * c['M']), lim, int(((n_off > 0) & (n_off <= lim)).sum()), int((n_off > lim).sum()), cond.max(), cmax, int((cond > cmax).sum()), len(cond), v_.min(), 100 * np.mean(v_ <= C_COV * 1.0000001), 100 * np.mean(w_ == 0), (t1 - t0) * 1e3, kt, lp.mean(), 100 * np.mean(st['acc'] == 0)), flush=True)
+    import xxhash
+    hb = xxhash.xxh3_64(np.ascontiguousarray(np.concatenate([x.ravel() for x in b.get('B')[::32]])).tobytes()).hexdigest()
+    hs = xxhash.xxh3_64(np.ascontiguousarray(st['acc']).tobytes()).hexdigest()
+    print('iteration %d: off-pipe mixtures %.1f%% (limit %d per state: %d split states, %d whole states off); cond max %.1f, states above %.0f: %d of %d; var min %.3g (floored %.2f%%), weights == 0: %.2f%%; E-step %.1f ms %s; mean logP %.2f; zero-occupancy mixtures %.2f%%; hash(B) %s hash(acc) %s'
+          % (it, 100.0 * n_off.sum() / (len(n_off) * c['M']), lim, int(((n_off > 0) & (n_off <= lim)).sum()), int((n_off > lim).sum()), cond.max(), cmax, int((cond > cmax).sum()), len(cond), v_.min(), 100 * np.mean(v_ <= C_COV * 1.0000001), 100 * np.mean(w_ == 0), (t1 - t0) * 1e3, kt, lp.mean(), 100 * np.mean(st['acc'] == 0), hb, hs), flush=True)
     eng.em_exchange(C_COV, update_transitions=True)
     b.refresh_transitions()

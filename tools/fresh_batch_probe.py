@@ -42,12 +42,14 @@ def fresh(check=False):
         b = eng.label_batch(pool[k % len(pool)], lens_all[U * (k % 2):U * (k % 2 + 1)], begin_all[U * (k % 2):U * (k % 2 + 1)])
         t1 = time.perf_counter(); b.score(PCL_F32)
         t2 = time.perf_counter(); b.forward_backward()
+        res = b.result_buffers(('logp',), slot=k % (depth + 1)); b.fetch_async(res)
         t3 = time.perf_counter()
-        live.append((k, b))
+        live.append((k, b, res))
         if len(live) > depth:
-            kk, old = live.pop(0)
+            kk, old, r = live.pop(0)
+            old.fetch_wait()
             if check and kk < 8:
-                logp[kk] = old.get('logp')
+                logp[kk] = r['logp'].copy()
             old.close()
         t4 = time.perf_counter()
         if timed:
@@ -60,7 +62,7 @@ def fresh(check=False):
         one(k, True)
     eng.sync()
     el = time.perf_counter() - t0
-    for _, b in live:
+    for _, b, _r in live:
         b.close()
     live.clear()
     return el / steps * 1e3, {k: v / steps * 1e3 for k, v in host.items()}, logp
