@@ -37,7 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 T_PROCESS_START = time.perf_counter()
-CPU_SAMPLE_FRAMES = 16            # frames per utterance in the CPU baseline sample (the vectorised leg is DRAM bound with every core busy: ~1.2 s per frame)
+CPU_SAMPLE_FRAMES = 150           # frames per utterance in the CPU baseline sample (half an utterance per core: ~5 s of the cache-blocked vectorised leg)
 CPU_FAITHFUL_ROWS = 12            # label states (of 60) the reference's per-mixture loop nest is timed on, scaled to all of them
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
@@ -150,10 +150,7 @@ def _cpu_vectorised_utt(u):
         t0 = time.perf_counter()
         rows = [np.zeros(x.shape[0])]
         for (mean, var, w) in gmms_per_row:
-            out = np.empty(x.shape[0])
-            for s in range(0, x.shape[0], 25):                      # chunked: bounds the (T,M,D) temporary
-                out[s:s + 25] = po.gmm_point(x[s:s + 25], mean, var, w)
-            rows.append(out)
+            rows.append(po.gmm_point_blocked(x, mean, var, w))      # the reference's arithmetic, evaluated in cache-sized blocks
         rows.append(np.full(x.shape[0], -np.inf))
         b = np.array(rows)
         po.baum_welch(a, pi, [b])
@@ -170,14 +167,9 @@ def _cpu_gemm_utt(u):
     x, gmms_per_row, a, pi = _cpu_job(u)
     with threadpool_limits(limits=1):
         t0 = time.perf_counter()
-        xe = np.concatenate([x * x, x, np.ones((x.shape[0], 1))], axis=1)             # (T, 2D+1)
         rows = [np.zeros(x.shape[0])]
         for (mean, var, w) in gmms_per_row:
-            d = mean.shape[1]
-            with np.errstate(divide='ignore'):
-                k = np.log(w) - d / 2.0 * po.LOG_2PI - 0.5 * var.sum(1) - 0.5 * (mean * mean / var).sum(1)
-            p = np.concatenate([-0.5 / var, mean / var, k[:, None]], axis=1)           # (M, 2D+1)
-            rows.append(po.lse(xe @ p.T, axis=1))
+            rows.append(po.gmm_point_gemm(x, mean, var, w))
         rows.append(np.full(x.shape[0], -np.inf))
         po.baum_welch(a, pi, [np.array(rows)])
         return time.perf_counter() - t0, x.shape[0]
@@ -233,21 +225,26 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
     frames_done = int(sum(n for _, n in vec))
     nfr, nrows = vec[0][1], 3 * len(labels[0])
     faithful = n_utt / float(max(per_frame))                       # every core one frame at a time, the slowest core sets the rate
-    return dict(value=frames_done / max(t for t, _ in vec), unit='frames/s', cores=n_utt, kind='port', ipc_excluded=True,
-                sample='first %d frames of %d utterances (one utterance per core, forked workers reading the job from inherited memory, '
-                       'timed inside the workers: frames / slowest worker), vectorised float64 NumPy oracle: score %d label states x %d '
-                       'mixtures + 3-pass forward-backward' % (nfr, n_utt, nrows, cfg['M']),
+    vec_value, gemm_value = frames_done / max(t for t, _ in vec), frames_done / max(t for t, _ in gemm)
+    lead = 'gemm' if gemm_value >= vec_value else 'vectorised'
+    common = ('first %d frames of %d utterances (one utterance per core, forked workers reading the job from inherited memory, timed inside the '
+              'workers: frames / slowest worker); score %d label states x %d mixtures + 3-pass forward-backward' % (nfr, n_utt, nrows, cfg['M']))
+    legs = dict(gemm='oracle.gmm_point_gemm: the expanded quadratic form as one float64 BLAS GEMM per state, 1 thread per worker -- the STRONGEST CPU formulation '
+                     'of this path (what an optimised CPU implementation would do; not the reference\'s order of operations)',
+                vectorised='oracle.gmm_point_blocked: the reference\'s arithmetic (subtract, scale, square, sum; util.py:22-31) vectorised in float64 NumPy and '
+                           'evaluated in cache-sized blocks of 16 frames x 128 mixtures',
+                faithful='the reference as written: its loop nest (per frame x per mixture NumPy calls, per-(t,j) LSE): 1 frame x %d of the %d label states '
+                         'of scoring (scaled to all of them) + one faithful forward/backward lattice of %d frames per core, frames/s = cores / slowest '
+                         'core\'s seconds per frame' % (len(labels[0]) * 3 // max(1, len(labels[0]) * 3 // CPU_FAITHFUL_ROWS), nrows, nfr))
+    return dict(value=max(vec_value, gemm_value), unit='frames/s', cores=n_utt, kind='port', ipc_excluded=True, value_leg=lead,
+                sample=common + '; value = the strongest of the CPU legs: ' + legs[lead],
+                vectorised_value=vec_value, vectorised_sample=legs['vectorised'],
+                gemm_value=gemm_value, gemm_sample=legs['gemm'],
+                faithful_value=faithful, faithful_sample=legs['faithful'],
                 worker_s=dict(vectorised_max=max(t for t, _ in vec), vectorised_mean=float(np.mean([t for t, _ in vec])),
                               gemm_max=max(t for t, _ in gemm), gemm_mean=float(np.mean([t for t, _ in gemm])),
                               faithful_s_per_frame_max=float(max(per_frame)), faithful_s_per_frame_mean=float(np.mean(per_frame))),
-                leg_wall_s=t_leg,
-                gemm_value=frames_done / max(t for t, _ in gemm),
-                gemm_sample='same sample, expanded quadratic form as one float64 BLAS GEMM per state (1 thread per worker): an '
-                            'optimised CPU formulation, not the reference arithmetic',
-                faithful_value=faithful,
-                faithful_sample='reference loop nest (per frame x per mixture NumPy calls, per-(t,j) LSE): 1 frame x %d of the %d label states '
-                                'of scoring (scaled to all of them) + one faithful forward/backward lattice of %d frames per core, frames/s = cores / '
-                                'slowest core\'s seconds per frame' % (len(labels[0]) * 3 // max(1, len(labels[0]) * 3 // CPU_FAITHFUL_ROWS), nrows, nfr))
+                leg_wall_s=t_leg)
 
 
 # per scoring kernel: name, the peak its arithmetic is priced against, and what that peak means
@@ -269,6 +266,44 @@ KERNELS = {
         'Gaussian: see executed_mfma_tflops.  On random operands the chip holds ~1.7-1.8 GHz under this kernel (2.4 GHz spec), '
         'matrix pipe 60-67 % busy (profiles/)'),
 }
+
+
+def make_roofline(score_variant, score_avg_ms, launches, scored_pairs, label_pairs, M, D, alg_bytes, traffic, traffic_raw, fb_avg_ms, dp_alone_ms):
+    """The `roofline` object of the line, from the measured average launch time of the dominant kernel (HIP events on the library's
+    stream inside the timed region) and the ALGORITHMIC work of a launch: scored (frame, state) pairs x M x (3D + 4) flop.
+    Every fraction a reader may want is here, each against a named denominator: `frac` = achieved / peak where `peak` is what
+    `frac_denominator` says; `frac_of_f16_dense_peak` = the same algorithmic rate against the guide's raw dense f16 MFMA peak;
+    `frac_executed` = the MFMA flops the kernel actually issues (480 per Gaussian for 121 algorithmic) against that raw peak.
+    The caller adds the loop-level figures (sustained, strict f32, PCIe inclusive, fresh batches) before the line is printed."""
+    name, peak, note = KERNELS.get(score_variant, KERNELS[1])
+    flop = scored_pairs * M * (3 * D + 4)
+    achieved = flop / (score_avg_ms * 1e-3) / 1e12 if score_avg_ms else None
+    executed = (scored_pairs * M * 480 / (score_avg_ms * 1e-3) / 1e12) if score_avg_ms and score_variant == 7 else None
+    return dict(bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s',
+                frac=(achieved / peak) if achieved else None,
+                frac_denominator=('%.1f TFLOP/s = dense f16 MFMA peak 2516.6 / 3 (an f32-class product costs three f16 products): a modelling choice, not a '
+                                  'hardware roof; the raw-peak fractions are beside it' % peak) if score_variant == 7 else '%.1f TFLOP/s' % peak,
+                frac_of_f16_dense_peak=(achieved / BF16_MFMA_PEAK_TFLOPS) if achieved else None,
+                frac_executed=(executed / BF16_MFMA_PEAK_TFLOPS) if executed else None,
+                frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
+                traffic=traffic,
+                traffic_source='separate rocprofv3 --pmc passes of this command (FETCH_SIZE; WRITE_SIZE), per launch of the scoring kernel, '
+                               'corrected as MI355X_MICROARCH.md prescribes for gfx950: 2 x FETCH_SIZE (the parameter stream is 16-B-per-lane '
+                               'global_load_lds, tallied at half its bytes) + WRITE_SIZE; raw counters in traffic_raw; summary in profiles/',
+                traffic_raw=traffic_raw,
+                traffic_over_algorithmic=(traffic / alg_bytes) if traffic else None,
+                kernel=name, kernel_avg_ms=score_avg_ms, launches=launches,
+                flop_per_launch=flop, executed_mfma_tflops=executed,
+                scored_pairs=scored_pairs, label_pairs=label_pairs,
+                note=note + '  SURVEY 8(d) priced this path against the 157.3 TFLOP/s FP32 vector roof; the contraction now runs on the '
+                            'f16 matrix pipe, so that roof no longer applies (frac_of_f32_mfma_peak > 1).  frac uses peak = f16 dense MFMA peak / 3; '
+                            'frac_of_f16_dense_peak and frac_executed use the raw 2516.6.',
+                hbm_algorithmic_bytes_per_launch=alg_bytes,
+                hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_avg_ms else None,
+                fb_kernel_avg_ms=fb_avg_ms, fb_kernel_alone_ms=dp_alone_ms,
+                fb_note='fb_kernel_avg_ms = HIP-event span of the forward-backward launches INSIDE the timed loop, where their workgroups wait for '
+                        'register-file room beside the next step\'s scoring waves (the step time does not wait for them); fb_kernel_alone_ms = the same '
+                        'kernels with nothing beside them')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -751,37 +786,16 @@ def main():
     pairs = int(((n_states - 2).astype(np.int64) * lens.astype(np.int64)).sum())
     # a label that names a unit twice has the same (frames, state) pair on two rows: the library scores it ONCE and copies the row
     # (the reference scores it once per label position).  The scoring kernel's rate is quoted on what it computed.
-    scored_pairs = int(sum(3 * len(set(np.asarray(lab).tolist())) * int(t) for lab, t in zip(labels, lens)))
-    flop_per_launch = scored_pairs * cfg['M'] * (3 * cfg['D'] + 4)
+    # (mean over the resident batches: the kernel's average launch time is over all of them)
+    scored_pairs = int(round(sum(3 * len(set(np.asarray(lab).tolist())) * int(t) for lab, t in zip(labels_all, lens_all)) / nb))
     score_avg_ms = score_ms / max(score_n, 1)
-    achieved = flop_per_launch / (score_avg_ms * 1e-3) / 1e12 if score_n else None
     # algorithmic HBM bytes per scoring launch: frames once + parameters of the states with work once + B written once
     alg_bytes = frames_per_rank * cfg['D'] * 4 + len(set(np.concatenate(labels).tolist())) * 3 * cfg['M'] * (2 * cfg['D'] + 1) * 4 + scored_pairs * 8
     traffic, traffic_raw = args.traffic_bytes, None
     if traffic is None and args.workload == 'C4shard' and not reduced and P == PCL_F32 and score_variant == 7:
         traffic, traffic_raw = committed_traffic()
-    roofline = dict(bound='mfma', achieved=achieved, peak=score_peak, unit='TFLOP/s',
-                    frac=(achieved / score_peak) if achieved else None,
-                    traffic=traffic,
-                    traffic_source='separate rocprofv3 --pmc passes of this command (FETCH_SIZE; WRITE_SIZE), per launch of the scoring kernel, '
-                                   'corrected as MI355X_MICROARCH.md prescribes for gfx950: 2 x FETCH_SIZE (the parameter stream is 16-B-per-lane '
-                                   'global_load_lds, tallied at half its bytes) + WRITE_SIZE; raw counters in traffic_raw; summary in profiles/',
-                    traffic_raw=traffic_raw,
-                    kernel=score_kernel_name,
-                    kernel_avg_ms=score_avg_ms, launches=score_n,
-                    flop_per_launch=flop_per_launch,
-                    executed_mfma_tflops=(scored_pairs * cfg['M'] * 480 / (score_avg_ms * 1e-3) / 1e12) if score_n and score_variant == 7 else None,
-                    scored_pairs=scored_pairs, label_pairs=pairs,
-                    frac_of_f32_mfma_peak=(achieved / FP32_VECTOR_PEAK_TFLOPS) if achieved else None,
-                    note=score_note + '  SURVEY 8(d) priced this path against the 157.3 TFLOP/s FP32 vector roof; the contraction now runs on the '
-                                      'f16 matrix pipe, so that roof no longer applies (frac_of_f32_mfma_peak > 1) and peak is the f16 dense MFMA peak / 3.',
-                    hbm_algorithmic_bytes_per_launch=alg_bytes,
-                    hbm_frac=(alg_bytes / (score_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if score_n else None,
-                    fb_kernel_avg_ms=fb_ms / max(fb_n, 1),
-                    fb_kernel_alone_ms=dp_alone_ms,
-                    fb_note='fb_kernel_avg_ms = HIP-event span of hmm_fb2_kernel + hmm_post_kernel INSIDE the timed loop, where their workgroups wait for '
-                            'register-file room beside the next step\'s scoring waves (the step time does not wait for them); fb_kernel_alone_ms = the same '
-                            'two kernels with nothing beside them')
+    roofline = make_roofline(score_variant, score_avg_ms if score_n else None, score_n, scored_pairs, pairs, cfg['M'], cfg['D'], alg_bytes, traffic, traffic_raw,
+                             fb_ms / max(fb_n, 1), dp_alone_ms)
 
     info = eng.device_info()                   # (not from the watchdog thread: the main thread may be inside the runtime)
 
@@ -841,6 +855,12 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        rf = out['roofline'] = dict(roofline)      # the loop-level figures the driver's record should keep (it keeps this object whole)
+        rf['sustained_value'] = sustained.get('value') if sustained else None
+        rf['fresh_batches_value'] = fresh.get('value') if fresh else None
+        rf['pcie_inclusive_value'] = pcie.get('value') if pcie else None
+        sf_ = (extra or {}).get('strict_f32') or {}
+        rf['strict_f32_value'], rf['strict_f32_frac'] = sf_.get('value'), sf_.get('frac')
         if sustained:
             out['value_sustained'] = sustained.get('value')
             out['sustained'] = sustained
@@ -859,8 +879,9 @@ def main():
                 out['value_strict_f32'] = sf['value']
                 out['ms_per_step_strict_f32'] = sf['ms_per_step']
         if cpu:
-            out['gpu_over_cpu'] = {'vs_vectorised_port': value / cpu['value'], 'vs_faithful_loop_nest': value / cpu['faithful_value'],
-                                   'vs_blas_gemm_formulation': value / cpu['gemm_value']}
+            out['gpu_over_cpu'] = {'vs_cpu_baseline_value': value / cpu['value'], 'vs_blas_gemm_formulation': value / cpu['gemm_value'],
+                                   'vs_reference_arithmetic_vectorised': value / cpu['vectorised_value'], 'vs_reference_as_written': value / cpu['faithful_value'],
+                                   'note': 'a GPU / CPU ratio says nothing about kernel quality (the roofline fractions do); north_star asks >= 200 against the reference CPU path'}
         return json.dumps(out)
 
     # The timed number is final here.  What follows (the E-step with its exchange, side measurements) is outside the timed region and
@@ -914,18 +935,35 @@ def main():
     dog.cancel()
 
 
+def scoring_kernel_sha16():
+    """Identity of the dominant kernel's CODE: sha256 over the anonymous namespace of gmm_score_split.hip -- the kernel, its helpers and
+    its compile-time constants -- with comments and white space removed, plus the compiler flags the Makefile gives that file.  The
+    launch side of the file (tile size helpers, the host launcher) is not part of it: an edit there cannot change what a PMC pass
+    measured (round 4 hashed the whole file and a launch-side commit nulled the traffic figure of the driver's line)."""
+    import hashlib
+    import re
+    src = open(os.path.join(ROOT, 'poccala_amd', 'csrc', 'gmm_score_split.hip')).read()
+    body = src[src.index('namespace {'):src.index('}  // namespace')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    body = re.sub(r'//[^\n]*', '', body)
+    body = re.sub(r'\s+', ' ', body).strip()
+    mk = open(os.path.join(ROOT, 'poccala_amd', 'csrc', 'Makefile')).read()
+    flags = ' '.join(sorted(l.split('=', 1)[1].strip() for l in mk.splitlines() if l.startswith('CXXFLAGS =') or l.startswith('FLAGS_gmm_score_split')))
+    return hashlib.sha256((body + '\x00' + flags).encode()).hexdigest()[:16]
+
+
 def committed_traffic():
     """HBM bytes per scoring launch from the committed PMC passes of this command (counters cannot be read from inside the
     run): (corrected bytes, {'FETCH_SIZE_bytes', 'WRITE_SIZE_bytes', 'file', ...}) or (None, {'stale': ...}).  The summary
-    records the sha256 of the scoring kernel's source it was taken from; when the source has changed since, the figure is
-    withheld (traffic = null) instead of being passed off as a measurement of the current kernel."""
-    import hashlib
-    src = os.path.join(ROOT, 'poccala_amd', 'csrc', 'gmm_score_split.hip')
+    records the identity of the kernel code it was taken from (scoring_kernel_sha16); when the kernel has changed since, the figure
+    is withheld (traffic = null) instead of being passed off as a measurement of the current kernel."""
     try:
-        now = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]
-    except OSError:
+        now = scoring_kernel_sha16()
+    except (OSError, ValueError):
         now = None
-    for name in ('r04_bench_summary.txt', 'r03_bench_summary.txt', 'r02_bench_summary.txt'):
+    import glob
+    names = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_summary.txt'))), reverse=True)
+    for name in names:
         try:
             fetch = write = sha = None
             for line in open(os.path.join(ROOT, 'profiles', name)):
@@ -933,13 +971,13 @@ def committed_traffic():
                     fetch = float(line.split('per-dispatch=')[1]) * 1024.0            # rocprofv3 reports KiB
                 if 'gmm_score_split16_kernel' in line and 'WRITE_SIZE' in line:
                     write = float(line.split('per-dispatch=')[1]) * 1024.0
-                if line.startswith('kernel_source_sha16'):
+                if line.startswith('kernel_code_sha16'):
                     sha = line.split()[-1]
             if fetch is not None and write is not None:
-                if sha is not None and now is not None and sha != now:
-                    return None, dict(stale='profiles/%s was taken from gmm_score_split.hip %s, the source is now %s: re-run tools/gpu_profile.sh'
+                if sha is None or now is None or sha != now:
+                    return None, dict(stale='profiles/%s was taken from kernel code %s, the kernel is now %s: re-run tools/gpu_profile.sh'
                                             % (name, sha, now))
-                return 2.0 * fetch + write, dict(FETCH_SIZE_bytes=fetch, WRITE_SIZE_bytes=write, file='profiles/' + name, kernel_source_sha16=sha)
+                return 2.0 * fetch + write, dict(FETCH_SIZE_bytes=fetch, WRITE_SIZE_bytes=write, file='profiles/' + name, kernel_code_sha16=sha)
         except (OSError, ValueError, IndexError):
             pass
     return None, None

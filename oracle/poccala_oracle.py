@@ -102,6 +102,36 @@ def gmm_point(x, mean, var, w, record=False):
     return (out, comp) if record else out
 
 
+def gmm_point_blocked(x, mean, var, w, m_chunk=128, t_chunk=16):
+    """gmm_point evaluated in blocks of t_chunk frames x m_chunk mixtures, so that the (t, m, D) temporaries of
+    gmm_component_loglik stay in a core's cache (16 x 128 x 39 float64 = 640 KB) instead of streaming through DRAM
+    (25 x 2048 x 39 = 16 MB per temporary, which is what every core of a many-core host then fights over).  The arithmetic per
+    (frame, mixture) is gmm_component_loglik's, element for element, and the log-sum-exp runs over the assembled (T, M) record:
+    the same bits as gmm_point (tests/test_oracle_golden.py).  Timing use (bench.py cpu_baseline)."""
+    x = np.asarray(x, np.float64)
+    T, M = x.shape[0], mean.shape[0]
+    comp = np.empty((T, M))
+    for t0 in range(0, T, t_chunk):
+        for m0 in range(0, M, m_chunk):
+            comp[t0:t0 + t_chunk, m0:m0 + m_chunk] = gmm_component_loglik(x[t0:t0 + t_chunk], mean[m0:m0 + m_chunk], var[m0:m0 + m_chunk], w[m0:m0 + m_chunk])
+    return lse(comp, axis=1)
+
+
+def gmm_point_gemm(x, mean, var, w):
+    """The same log-likelihoods through the EXPANDED quadratic form, one float64 GEMM per state:
+    ln w - D/2 ln 2pi - 1/2 sum var - 1/2 sum_d (x_d^2 / var_d - 2 x_d mu_d / var_d + mu_d^2 / var_d).  Not the reference's
+    order of operations (util.py:22-31 subtracts first) -- it is the formulation the GPU kernels use, and what an optimised CPU
+    implementation of this path would do (BLAS); agrees with gmm_point to ~1e-12 relative on well-scaled data
+    (tests/test_oracle_golden.py).  Timing use (bench.py cpu_baseline, the strongest CPU leg)."""
+    x = np.asarray(x, np.float64)
+    d = mean.shape[1]
+    xe = np.concatenate([x * x, x, np.ones((x.shape[0], 1))], axis=1)               # (T, 2D+1)
+    with np.errstate(divide='ignore'):
+        k = np.log(w) - d / 2.0 * LOG_2PI - 0.5 * var.sum(1) - 0.5 * (mean * mean / var).sum(1)
+    p = np.concatenate([-0.5 / var, mean / var, k[:, None]], axis=1)                 # (M, 2D+1)
+    return lse(xe @ p.T, axis=1)
+
+
 def faithful_gmm_point(x_t, mean, var, w):
     """Same arithmetic as gmm_point for ONE frame, with the reference's loop
     nest: one NumPy-level Gaussian evaluation per mixture, list append, scalar

@@ -146,14 +146,15 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
     // partial-distance elimination (see the mixture loop): the float launches only -- the float64 parity mode evaluates everything
     constexpr bool PDE = sizeof(real) == 4 && PCL_PDE_D1 > 0 && D > PCL_PDE_D1;
     constexpr int PD1 = PCL_PDE_D1, PD2 = (PCL_PDE_D2 > PCL_PDE_D1 && PCL_PDE_D2 < D) ? PCL_PDE_D2 : PCL_PDE_D1;
-    constexpr int PDE_MARGIN = 40;                                   // log2 units: 2^-40 of a term the sum holds
+    constexpr int PDE_MARGIN = 40;                                   // log2 units below the lane's own running maximum: nothing for an f32 sum that holds that maximum's 1
+    constexpr int PDE_MARGIN_PIPE = 64;                              // ... below the matrix pipe's part of a split state: the two parts are merged in float64
     real ref2[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         ref2[r] = Fast<real>::neg_big();
         if (PDE && SUBSET) {                                         // the rest of the state, as the matrix pipe left it (ln -> log2)
             const double old = out[oidx[r]];
-            if (old > -1.0e30) ref2[r] = (real)(old * 1.4426950408889634074);
+            if (old > -1.0e30) ref2[r] = (real)(old * 1.4426950408889634074) - (real)PDE_MARGIN_PIPE;
         }
     }
     static_assert(!SUBSET || MASTER, "the subset launch makes its rows from the master copy");
@@ -221,60 +222,79 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
         for (int m = 0; m < n; m += GROUP) {
             real v[GROUP][R];
             // Partial-distance elimination (f32 launches).  q only grows with every feature, so k2 - q after the first D1 (then D2) features
-            // is an UPPER bound of the mixture's value; when for every frame of the wavefront that bound is already 2^-PDE_MARGIN below
-            // a value the frame's sum is known to hold (its running maximum, or what the matrix pipe wrote for the rest of a split
-            // state), the rest of the features cannot change any sum -- a term that far below adds nothing to an f32 sum that holds
-            // its maximum's 1 -- and the wavefront skips them (mixtures are wave-uniform here: one ballot, no divergence).  The sums
-            // keep their bits.  What it is for: re-estimated models whose mixtures have collapsed onto single frames (variances at the
-            // floor of GMM.update_param, Clustering.py:682-693; the reference's driver passes 1e-6, init.py:30): such a mixture is
-            // 1e5 .. 1e6 nats away from every frame but its own, and after a few features that is settled.
+            // is an UPPER bound of the mixture's value; when for every frame of the wavefront that bound is already 2^-40 below the
+            // frame's running maximum (a term that far below adds nothing to an f32 sum that holds its maximum's 1) or 2^-64 below what
+            // the matrix pipe wrote for the rest of a split state (the two parts are merged in float64), the rest of the features
+            // cannot change any result and the wavefront skips them (mixtures are wave-uniform here: a ballot, no divergence).  The
+            // results keep their bits (tools/em_iter_probe.py hashes them under -DPCL_PDE_D1=0).  What it is for: re-estimated models
+            // whose mixtures have collapsed onto single frames (variances at the floor of GMM.update_param, Clustering.py:682-693; the
+            // reference's driver passes 1e-6, init.py:30): such a mixture is 1e5 .. 1e6 nats away from every frame but its own, and
+            // after a few features that is settled.
             real thr[R];
             if (PDE) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) thr[r] = Fast<real>::max(mx[r], ref2[r]) - (real)PDE_MARGIN;
+                for (int r = 0; r < R; ++r) thr[r] = Fast<real>::max(mx[r] - (real)PDE_MARGIN, ref2[r]);
             }
-            bool any_alive = !PDE;
+            real q[GROUP][R], k2[GROUP];
+            auto feats = [&](const int g, const int d0, const int d1) {
+                const real *p = &lds[(m + g) * ROW];
+#pragma unroll
+                for (int d = d0; d < d1; ++d) {
+                    const real s = p[2 * d], c = p[2 * d + 1];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const real y = Fast<real>::fma(x[r][d], s, c);
+                        q[g][r] = Fast<real>::fma(y, y, q[g][r]);
+                    }
+                }
+            };
+            auto alive = [&](const int g) {                                      // can mixture g still reach one of this lane's frames?
+                bool a = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) a |= (k2[g] - q[g][r] >= thr[r]);
+                return a;
+            };
 #pragma unroll
             for (int g = 0; g < GROUP; ++g) {
-                const real *p = &lds[(m + g) * ROW];
-                const real k2 = p[2 * D];
-                real q[R];
+                k2[g] = lds[(m + g) * ROW + 2 * D];
 #pragma unroll
-                for (int r = 0; r < R; ++r) q[r] = 0;
-                auto feats = [&](const int d0, const int d1) {
-#pragma unroll
-                    for (int d = d0; d < d1; ++d) {
-                        const real s = p[2 * d], c = p[2 * d + 1];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const real y = Fast<real>::fma(x[r][d], s, c);
-                            q[r] = Fast<real>::fma(y, y, q[r]);
-                        }
-                    }
-                };
-                auto dead = [&]() {                                              // wave-uniform: no frame of the wavefront can still be reached
-                    bool alive = false;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) alive |= (k2 - q[r] >= thr[r]);
-                    return __builtin_amdgcn_ballot_w64(alive) == 0ull;
-                };
-                bool gone = false;
-                if (PDE) {
-                    feats(0, PD1);
-                    gone = dead();
-                    if (!gone && PD2 > PD1) {
-                        feats(PD1, PD2);
-                        gone = dead();
-                    }
-                    if (!gone) feats(PD2 > PD1 ? PD2 : PD1, D);
-                } else {
-                    feats(0, D);
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) v[g][r] = gone ? -(real)INFINITY : k2 - q[r];
-                any_alive |= !gone;
+                for (int r = 0; r < R; ++r) q[g][r] = 0;
             }
-            if (!any_alive) continue;                                            // (all four gone: the update below would multiply by 1 and add zeros)
+            bool gone[GROUP];
+            if (PDE) {
+                // the first PD1 features of all four mixtures, then ONE wave-uniform decision for the group (the common case of a collapsed
+                // model: nothing of the group can matter to any frame of the wavefront); four decisions in a row, each waiting for its
+                // own compare to reach the scalar unit, cost more than the features they saved
+                bool a[GROUP], any = false;
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) feats(g, 0, PD1);
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) {
+                    a[g] = alive(g);
+                    any |= a[g];
+                }
+                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;         // (the update below would multiply by 1 and add zeros)
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) {
+                    gone[g] = __builtin_amdgcn_ballot_w64(a[g]) == 0ull;
+                    if (!gone[g] && PD2 > PD1) {
+                        feats(g, PD1, PD2);
+                        gone[g] = __builtin_amdgcn_ballot_w64(alive(g)) == 0ull;
+                    }
+                    if (!gone[g]) feats(g, PD2 > PD1 ? PD2 : PD1, D);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g) {
+                    feats(g, 0, D);
+                    gone[g] = false;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[g][r] = gone[g] ? -(real)INFINITY : k2[g] - q[g][r];
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 real gm = v[0][r];

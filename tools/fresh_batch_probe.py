@@ -17,21 +17,32 @@ pool = [synth.make_labels(U, c['L'], c['units'], seed=100 + k) for k in range(8)
 eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); eng.load_frames(frames)
 
-def resident():
-    bs = [eng.label_batch(pool[k], lens_all[U * k:U * (k + 1)], begin_all[U * k:U * (k + 1)]) for k in range(2)]
+def resident(fetch=False, nres=2):
+    bs = [eng.label_batch(pool[k], lens_all[U * (k % 2):U * (k % 2 + 1)], begin_all[U * (k % 2):U * (k % 2 + 1)]) for k in range(nres)]
+    res = [b.result_buffers(('logp',), slot=k) for k, b in enumerate(bs)]
     for b in bs:
         b.score(PCL_F32); b.forward_backward()
     eng.sync()
+    def step(k):
+        b = bs[k % nres]
+        if fetch and k >= nres:
+            b.fetch_wait()
+        b.score(PCL_F32); b.forward_backward()
+        if fetch:
+            b.fetch_async(res[k % nres])
     for k in range(5):
-        bs[k % 2].score(PCL_F32); bs[k % 2].forward_backward()
+        step(k)
     eng.sync()
+    eng.kernel_time('score'); eng.kernel_time('fb')
     t0 = time.perf_counter()
-    for k in range(steps):
-        bs[k % 2].score(PCL_F32); bs[k % 2].forward_backward()
+    for k in range(5, 5 + steps):
+        step(k)
     eng.sync()
     el = time.perf_counter() - t0
+    kt = (eng.kernel_time('score'), eng.kernel_time('fb'))
     for b in bs:
         b.close()
+    print('  resident(fetch=%s, %d batches): %.3f ms/step, score kernel %.3f ms, fb span %.3f ms' % (fetch, nres, el / steps * 1e3, kt[0][0] / max(kt[0][1], 1), kt[1][0] / max(kt[1][1], 1)))
     return el / steps * 1e3
 
 def fresh(check=False):
@@ -57,11 +68,14 @@ def fresh(check=False):
     for k in range(8):
         one(k, False)
     eng.sync()
+    eng.kernel_time('score'); eng.kernel_time('fb')
     t0 = time.perf_counter()
     for k in range(8, 8 + steps):
         one(k, True)
     eng.sync()
     el = time.perf_counter() - t0
+    kt = (eng.kernel_time('score'), eng.kernel_time('fb'))
+    print('  fresh: %.3f ms/step, score kernel %.3f ms, fb span %.3f ms' % (el / steps * 1e3, kt[0][0] / max(kt[0][1], 1), kt[1][0] / max(kt[1][1], 1)))
     for _, b, _r in live:
         b.close()
     live.clear()
@@ -71,6 +85,7 @@ r = resident()
 f, host, logp = fresh(check=True)
 r2 = resident()
 f2, host2, _ = fresh()
+resident(fetch=True); resident(fetch=True, nres=4); resident(nres=4)
 print('%s: resident %.3f / %.3f ms per step; fresh batch every step %.3f / %.3f ms (ratio %.3f); host ms per step %s' % (name, r, r2, f, f2, min(r, r2) / min(f, f2), {k: round(v, 3) for k, v in host2.items()}))
 # same bits as a resident batch of the same labels
 ok = True

@@ -48,9 +48,13 @@ def pick(kt, name):
 out = ['# rocprofv3 summaries, %s: python3 bench.py --steps 20 --warmup 2 --cpu-baseline 0 --extra 0 --sustain 0 (one MI355X, C4 shard)' % RND,
        '# produced by tools/gpu_profile.sh + tools/make_profile_summary.py; one --kernel-trace --stats pass and separate --pmc passes',
        '', '## --kernel-trace --stats (%s_bench_kernel_stats.csv)' % RND]
-import hashlib
-_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'poccala_amd', 'csrc', 'gmm_score_split.hip')
-out.insert(2, 'kernel_source_sha16 gmm_score_split.hip %s' % hashlib.sha256(open(_src, 'rb').read()).hexdigest()[:16])   # bench.py withholds `traffic` when the source has moved on
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root)
+import bench as _bench                       # (no GPU call at import)
+from poccala_amd import synth as _synth
+# identity of the kernel CODE the passes measured (its body and compile flags, not the launch side of the file): bench.py withholds
+# `traffic` when the kernel has changed since
+out.insert(2, 'kernel_code_sha16 gmm_score_split16_kernel %s' % _bench.scoring_kernel_sha16())
 kt, lines = kernel_stats('bench_trace', '%s_bench_kernel_stats.csv' % RND)
 out += lines + ['', '## --pmc passes (<= 4 counters per pass, no trace domains), per-dispatch averages']
 lines, val = counters(['bench_fetch', 'bench_write', 'bench_clk', 'bench_sq1', 'bench_sq2'], ['gmm_score_split16_kernel', 'hmm_fbl_kernel', 'hmm_postl_kernel', 'hmm_emis_pack_kernel'])
@@ -58,13 +62,18 @@ out += lines
 try:
     v = val['gmm_score_split16_kernel']
     ms = pick(kt, 'gmm_score_split16_kernel')
-    pairs, M, D = 18432000, 2048, 39
+    # the (frame, state) pairs a launch SCORES: a label that names a unit twice is scored once and copied (bench.py: scored_pairs), mean over
+    # the two resident batches the profiled command alternates between (seeds as in bench.py main(), rank 0)
+    _c = _synth.CONFIGS['C4shard']
+    _labels = _synth.make_labels(_c['U'] * 2, _c['L'], _c['units'], seed=2)
+    pairs = int(round(sum(3 * len(set(l.tolist())) * _c['T'] for l in _labels) / 2))
+    M, D = _c['M'], _c['D']
     flop = pairs * M * (3 * D + 4)
     fetch, write = v['FETCH_SIZE'] * 1024, v['WRITE_SIZE'] * 1024
     cyc = v['GRBM_GUI_ACTIVE'] / 8
-    out += ['', '## derived (gmm_score_split16_kernel<39,2>, 18,432,000 (frame,state) pairs x 2048 mixtures per launch)',
-            'kernel %.2f ms/launch (trace pass) -> %.1f TFLOP/s algorithmic (%.4f TFLOP/launch) = %.3f of 838.9 (f16 MFMA peak / 3 split products), %.2f x the f32-input MFMA peak 157.3'
-            % (ms, flop / ms / 1e9, flop / 1e12, flop / ms / 1e9 / 838.9, flop / ms / 1e9 / 157.3),
+    out += ['', '## derived (gmm_score_split16_kernel<39,2>, %d scored (frame,state) pairs x 2048 mixtures per launch; 18,432,000 label pairs, repeats are copied)' % pairs,
+            'kernel %.2f ms/launch (trace pass) -> %.1f TFLOP/s algorithmic (%.4f TFLOP/launch) = %.3f of the dense f16 MFMA peak 2516.6 = %.3f of 838.9 (that peak / 3 split products), %.2f x the f32-input MFMA peak 157.3'
+            % (ms, flop / ms / 1e9, flop / 1e12, flop / ms / 1e9 / 2516.6, flop / ms / 1e9 / 838.9, flop / ms / 1e9 / 157.3),
             'executed MFMA work: 15 x v_mfma_f32_32x32x16 per 1024 Gaussians = %.0f TFLOP/s of f16 MFMA flops = %.2f of the 2516.6 dense peak' % (pairs * M * 480 / ms / 1e9, pairs * M * 480 / ms / 1e9 / 2516.6),
             'GRBM_GUI_ACTIVE %.4g (sum of 8 XCDs) -> %.3g cycles -> clock held %.2f GHz over %.2f ms; SQ_VALU_MFMA_BUSY_CYCLES %.4g / 1024 SIMDs = %.3g cycles -> matrix pipe %.0f %% busy'
             % (v['GRBM_GUI_ACTIVE'], cyc, cyc / ms / 1e6, ms, v['SQ_VALU_MFMA_BUSY_CYCLES'], v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024, 100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc),
