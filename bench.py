@@ -1566,12 +1566,15 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
             eng.sync()
             ctl.barrier()
             t1 = time.perf_counter()
-            iteration()
+            estep()
+            lp_it = np.concatenate([bt.get('logp') for bt in batches]) if batches else np.zeros(0)      # (of this E-step: under the model BEFORE this M-step; 8 KB per batch)
+            eng.em_exchange(c_cov, payload, True)
+            for bt in batches:
+                bt.refresh_transitions()
             eng.sync()
             ctl.barrier()
             t_it = ctl.allreduce_max(time.perf_counter() - t1)
             kt_it = {k: eng.kernel_time(k)[0] for k in names}
-            lp_it = np.concatenate([bt.get('logp') for bt in batches]) if batches else np.zeros(0)      # (of the E-step just run: under the model BEFORE this M-step)
             m_, v_, w_ = eng.model_download()
             em_table.append(dict(iteration=it + 1, ms=t_it * 1e3, frames_per_s=nfr_all / t_it,
                                  mixtures_off_the_matrix_pipe=float(n_off.sum()) / float(len(n_off) * c['M']),

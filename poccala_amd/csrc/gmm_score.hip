@@ -42,10 +42,10 @@ constexpr int WG = 256;  // 4 waves
 #define PCL_CH32 64   // mixtures per LDS chunk (f32)
 #endif
 #ifndef PCL_PDE_D1
-#define PCL_PDE_D1 4    // partial-distance elimination: features before the first / second test (0 = off; D2 <= D1: one test)
+#define PCL_PDE_D1 6    // partial-distance elimination: features before the first / second test (0 = off; D2 <= D1: one test); (6,16) / (4,10) / (2,8) / (3,-) measured 35.2 / 36.8 / 37.3 / 42.4 ms against 105 on the collapsed C4 model
 #endif
 #ifndef PCL_PDE_D2
-#define PCL_PDE_D2 10
+#define PCL_PDE_D2 16
 #endif
 constexpr int GROUP = PCL_GROUP;  // mixtures per LSE rescale (Mpad is a multiple of 4 >= this)
 
@@ -235,66 +235,48 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
 #pragma unroll
                 for (int r = 0; r < R; ++r) thr[r] = Fast<real>::max(mx[r] - (real)PDE_MARGIN, ref2[r]);
             }
-            real q[GROUP][R], k2[GROUP];
-            auto feats = [&](const int g, const int d0, const int d1) {
+            bool any_alive = !PDE;
+#pragma unroll
+            for (int g = 0; g < GROUP; ++g) {
                 const real *p = &lds[(m + g) * ROW];
+                const real k2 = p[2 * D];
+                real q[R];
 #pragma unroll
-                for (int d = d0; d < d1; ++d) {
-                    const real s = p[2 * d], c = p[2 * d + 1];
+                for (int r = 0; r < R; ++r) q[r] = 0;
+                auto feats = [&](const int d0, const int d1) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const real y = Fast<real>::fma(x[r][d], s, c);
-                        q[g][r] = Fast<real>::fma(y, y, q[g][r]);
+                    for (int d = d0; d < d1; ++d) {
+                        const real s = p[2 * d], c = p[2 * d + 1];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const real y = Fast<real>::fma(x[r][d], s, c);
+                            q[r] = Fast<real>::fma(y, y, q[r]);
+                        }
                     }
-                }
-            };
-            auto alive = [&](const int g) {                                      // can mixture g still reach one of this lane's frames?
-                bool a = false;
+                };
+                auto dead = [&]() {                                              // wave-uniform: no frame of the wavefront can still be reached
+                    bool alive = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) a |= (k2[g] - q[g][r] >= thr[r]);
-                return a;
-            };
-#pragma unroll
-            for (int g = 0; g < GROUP; ++g) {
-                k2[g] = lds[(m + g) * ROW + 2 * D];
-#pragma unroll
-                for (int r = 0; r < R; ++r) q[g][r] = 0;
-            }
-            bool gone[GROUP];
-            if (PDE) {
-                // the first PD1 features of all four mixtures, then ONE wave-uniform decision for the group (the common case of a collapsed
-                // model: nothing of the group can matter to any frame of the wavefront); four decisions in a row, each waiting for its
-                // own compare to reach the scalar unit, cost more than the features they saved
-                bool a[GROUP], any = false;
-#pragma unroll
-                for (int g = 0; g < GROUP; ++g) feats(g, 0, PD1);
-#pragma unroll
-                for (int g = 0; g < GROUP; ++g) {
-                    a[g] = alive(g);
-                    any |= a[g];
-                }
-                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;         // (the update below would multiply by 1 and add zeros)
-#pragma unroll
-                for (int g = 0; g < GROUP; ++g) {
-                    gone[g] = __builtin_amdgcn_ballot_w64(a[g]) == 0ull;
-                    if (!gone[g] && PD2 > PD1) {
-                        feats(g, PD1, PD2);
-                        gone[g] = __builtin_amdgcn_ballot_w64(alive(g)) == 0ull;
+                    for (int r = 0; r < R; ++r) alive |= (k2 - q[r] >= thr[r]);
+                    return __builtin_amdgcn_ballot_w64(alive) == 0ull;
+                };
+                bool gone = false;
+                if (PDE) {
+                    feats(0, PD1);
+                    gone = dead();
+                    if (!gone && PD2 > PD1) {
+                        feats(PD1, PD2);
+                        gone = dead();
                     }
-                    if (!gone[g]) feats(g, PD2 > PD1 ? PD2 : PD1, D);
+                    if (!gone) feats(PD2 > PD1 ? PD2 : PD1, D);
+                } else {
+                    feats(0, D);
                 }
-            } else {
 #pragma unroll
-                for (int g = 0; g < GROUP; ++g) {
-                    feats(g, 0, D);
-                    gone[g] = false;
-                }
+                for (int r = 0; r < R; ++r) v[g][r] = gone ? -(real)INFINITY : k2 - q[r];
+                any_alive |= !gone;
             }
-#pragma unroll
-            for (int g = 0; g < GROUP; ++g) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) v[g][r] = gone[g] ? -(real)INFINITY : k2[g] - q[g][r];
-            }
+            if (!any_alive) continue;                                            // (all four gone: the update below would multiply by 1 and add zeros)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 real gm = v[0][r];
