@@ -37,7 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 T_PROCESS_START = time.perf_counter()
-CPU_SAMPLE_FRAMES = 150           # frames per utterance in the CPU baseline sample (half an utterance per core: ~5 s of the cache-blocked vectorised leg)
+CPU_SAMPLE_FRAMES = 60            # frames per utterance in the CPU baseline sample (a fifth of an utterance per core: ~20 s of the cache-blocked vectorised leg with every core busy)
 CPU_FAITHFUL_ROWS = 12            # label states (of 60) the reference's per-mixture loop nest is timed on, scaled to all of them
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
@@ -501,13 +501,16 @@ def sustained_loop(eng, batches, P, seconds, block=100):
     return n[0], total, blocks, clocks
 
 
-def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, depth=3, label_sets=8):
+def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, depth=3, label_sets=8, resident=None, rounds=2):
     """The headline's loop as a corpus sweep runs it: the reference hands every worker a NEW (label, data) (AcousticModel.py:664-681
     generator, :861-870 fan-out), so every step here CREATES its label batch (pcl_batch_create_labels: the sentence HMMs, the
     state-major work lists, the scoring tiles at the first score, every lazily allocated buffer) from labels the library has not
-    seen in that form, scores it, runs its forward-backward, and DROPS the batch of `depth` steps ago -- all inside the timed
-    region, while the GPU works on the previous steps.  Frames stay resident (the contract's `value`; the PCIe-inclusive loop moves
-    them too).  Returns a dict; `value` is frames/s of this rank."""
+    seen in that form, scores it, runs its forward-backward, queues its ln P(O) for the host and -- once the results of the batch
+    of `depth` steps ago have landed -- DROPS that batch, all inside the timed region, while the GPU works on the previous steps.
+    Frames stay resident (the contract's `value`; the PCIe-inclusive loop moves them too).
+    `resident` (the headline's batches): the same number of steps on THEM right before each fresh block (`rounds` blocks of each,
+    alternating), so that the ratio compares two loops in the same thermal / clock state -- after the 10-second sustained loop the
+    chip runs ~3 % below the short headline loop.  Returns a dict; `value` is frames/s of this rank."""
     from poccala_amd import synth
     U, T = cfg['U'], cfg['T']
     nb = len(lens_all) // U
@@ -536,18 +539,38 @@ def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, de
             host['create'] += t1 - t0
             host['enqueue'] += t2 - t1
             host['close'] += t3 - t2
+
+    def resident_block(n):
+        for k in range(n):
+            bt = resident[k % len(resident)]
+            bt.score(P)
+            bt.forward_backward(fix_pi=False)
     for k in range(warm):
         one(k, False)
     eng.sync()
-    eng.kernel_time('score'); eng.kernel_time('fb')
-    t0 = time.perf_counter()
-    for k in range(warm, warm + steps):
-        one(k, True)
-    eng.sync()
-    elapsed = time.perf_counter() - t0
-    sc_ms, sc_n = eng.kernel_time('score')
+    t_fresh = t_res = 0.0
+    sc_ms = sc_n = 0
+    k = warm
+    per = max(1, steps // rounds)
+    for _ in range(rounds):
+        if resident:
+            eng.sync()
+            t0 = time.perf_counter()
+            resident_block(per)
+            eng.sync()
+            t_res += time.perf_counter() - t0
+        eng.kernel_time('score')
+        t0 = time.perf_counter()
+        for _k in range(per):
+            one(k, True)
+            k += 1
+        eng.sync()
+        t_fresh += time.perf_counter() - t0
+        a, bn = eng.kernel_time('score')
+        sc_ms, sc_n = sc_ms + a, sc_n + bn
+    steps = per * rounds
     # the results of a batch made inside the loop against a resident batch of the same labels and frames: the same bits
-    last_k = warm + steps - 1
+    last_k = k - 1
     got = live[-1][0].get('logp')
     lo = U * (last_k % nb)
     ref_b = eng.label_batch(sets[last_k % label_sets], lens_all[lo:lo + U], begin_all[lo:lo + U])
@@ -557,13 +580,19 @@ def fresh_batch_loop(eng, P, cfg, lens_all, begin_all, steps, rank=0, warm=8, de
     for b, _ in live:
         b.close()
     nfr = int(np.sum(lens_all[:U]))
-    return dict(value=nfr * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps, batches_alive=depth, label_sets=label_sets,
-                batch_create_ms=host['create'] / steps * 1e3, enqueue_ms=host['enqueue'] / steps * 1e3, batch_close_ms=host['close'] / steps * 1e3,
-                score_kernel_ms=sc_ms / max(sc_n, 1), same_bits_as_a_resident_batch=same,
-                what='every step creates its label batch (new labels), scores it, runs forward-backward, queues its ln P(O) for the host, and -- once the '
-                     'results of the batch of %d steps ago have landed -- drops that batch, all inside the timed region; batch_create_ms / enqueue_ms / '
-                     'batch_close_ms = HOST time per step (the GPU works on the previous steps meanwhile; close includes the wait for the old batch\'s '
-                     'results, which is what keeps the host from running ahead of the GPU without bound); frames resident' % depth)
+    out = dict(value=nfr * steps / t_fresh, ms_per_step=t_fresh / steps * 1e3, steps=steps, batches_alive=depth, label_sets=label_sets,
+               batch_create_ms=host['create'] / steps * 1e3, enqueue_ms=host['enqueue'] / steps * 1e3, batch_close_ms=host['close'] / steps * 1e3,
+               score_kernel_ms=sc_ms / max(sc_n, 1), same_bits_as_a_resident_batch=same,
+               what='every step creates its label batch (new labels), scores it, runs forward-backward, queues its ln P(O) for the host, and -- once the '
+                    'results of the batch of %d steps ago have landed -- drops that batch, all inside the timed region; batch_create_ms / enqueue_ms / '
+                    'batch_close_ms = HOST time per step (the GPU works on the previous steps meanwhile; close includes the wait for the old batch\'s '
+                    'results, which is what keeps the host from running ahead of the GPU without bound); frames resident' % depth)
+    if resident:
+        out['resident_ms_per_step_beside'] = t_res / steps * 1e3
+        out['fresh_over_resident'] = t_res / t_fresh
+        out['what'] += '; resident_ms_per_step_beside = the headline\'s loop on its resident batches in blocks of %d steps alternating with the fresh blocks ' \
+                       '(same clock state); fresh_over_resident = the ratio of the two rates' % per
+    return out
 
 
 def pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, steps, warm=4):
@@ -817,7 +846,7 @@ def main():
         tl['sustained_loop_s'] = time.perf_counter() - t_mark2
         t_mark2 = time.perf_counter()
         try:
-            fresh = fresh_batch_loop(eng, P, cfg, lens_all, begin_all, max(2 * args.steps, 40), rank=rank)
+            fresh = fresh_batch_loop(eng, P, cfg, lens_all, begin_all, max(4 * args.steps, 80), rank=rank, resident=batches)
             fresh['value'] = fresh['value'] * world        # (whole job: every rank sweeps its own shard; rank 0's clock)
         except Exception as e:                 # noqa: never the headline's problem
             fresh = dict(error=repr(e))
@@ -1537,6 +1566,26 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
         ctl.barrier()
         fresh_ms.append(ctl.allreduce_max(time.perf_counter() - t1) * 1e3)
         fresh_create.append(tc * 1e3)
+    # where a fresh iteration's wall clock goes (one more, untimed, with a device sync between its phases)
+    fresh_phases = {}
+    rewind()
+    eng.sync()
+    tp = time.perf_counter()
+    eng.stats_zero()
+    made = []
+    for lab, lens, begin in desc:
+        bt = eng.label_batch(lab.copy(), lens, begin)
+        bt.score(P); bt.forward_backward(fix_pi=False)
+        made.append(bt)
+    eng.sync(); fresh_phases['create_score_forward_backward_ms'] = (time.perf_counter() - tp) * 1e3; tp = time.perf_counter()
+    for bt in made:
+        bt.accumulate(P); bt.accumulate_hmm()
+    eng.sync(); fresh_phases['accumulate_ms'] = (time.perf_counter() - tp) * 1e3; tp = time.perf_counter()
+    eng.em_exchange(c_cov, payload, True)
+    eng.sync(); fresh_phases['exchange_and_mstep_ms'] = (time.perf_counter() - tp) * 1e3; tp = time.perf_counter()
+    for bt in made:
+        bt.close()
+    fresh_phases['close_ms'] = (time.perf_counter() - tp) * 1e3
     # the model's statistics block of a fresh iteration against the resident one: the same bits (same lists, same order)
     rewind()
     estep()
@@ -1609,7 +1658,7 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
                                            'evaluated by the direct-form kernels and merged (score_subset), the state stays on the matrix pipe (before: the whole state '
                                            'left it, 5x slower).  After two more iterations on noise most mixtures sit at the variance floor and whole states do leave'),
                 fresh_batches=dict(ms_per_iteration=float(np.mean(fresh_ms)), frames_per_s=nfr / (float(np.mean(fresh_ms)) * 1e-3), iterations=len(fresh_ms),
-                                   batch_create_ms_per_iteration=float(np.mean(fresh_create)), statistics_same_bits_as_resident=fresh_same,
+                                   batch_create_ms_per_iteration=float(np.mean(fresh_create)), statistics_same_bits_as_resident=fresh_same, phase_ms_rank0=fresh_phases,
                                    what='the same iteration with its 8 label batches CREATED inside the timed region (a corpus sweep hands every worker a new '
                                         '(label, data), AcousticModel.py:664-681, 861-870) and dropped at its end; batch_create_ms = host time of the 8 '
                                         'pcl_batch_create_labels calls, which run while the GPU scores the previous batch'),

@@ -103,6 +103,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                           '(or make -C poccala_amd/csrc).  There is no CPU fallback.' % LIB_PATH)
+    # A context owns five HIP streams (main, dynamic programming, producer / frame staging, descriptors, downloads).  The runtime
+    # multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: two of the five then share a queue, and a command
+    # that waits for an event (the download of step k waits for its forward-backward) holds up whatever sits behind it in that
+    # queue (the scoring kernel of step k + 1).  Read when the HIP runtime starts: set before the library (and with it
+    # libamdhip64) is loaded, unless the caller has chosen a value.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is not exported

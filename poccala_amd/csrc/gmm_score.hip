@@ -144,7 +144,9 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
     }
 
     // partial-distance elimination (see the mixture loop): the float launches only -- the float64 parity mode evaluates everything
-    constexpr bool PDE = sizeof(real) == 4 && PCL_PDE_D1 > 0 && D > PCL_PDE_D1;
+    // -- and not the subset launch of a split state: its mixtures are tight but rarely collapsed (a state whose mixtures have collapsed is off
+    //    the pipe as a whole), few groups skip, and the tests cost its three-wave build more than they save (15.8 against 7.3 ms per batch)
+    constexpr bool PDE = sizeof(real) == 4 && !SUBSET && PCL_PDE_D1 > 0 && D > PCL_PDE_D1;
     constexpr int PD1 = PCL_PDE_D1, PD2 = (PCL_PDE_D2 > PCL_PDE_D1 && PCL_PDE_D2 < D) ? PCL_PDE_D2 : PCL_PDE_D1;
     constexpr int PDE_MARGIN = 40;                                   // log2 units below the lane's own running maximum: nothing for an f32 sum that holds that maximum's 1
     constexpr int PDE_MARGIN_PIPE = 64;                              // ... below the matrix pipe's part of a split state: the two parts are merged in float64

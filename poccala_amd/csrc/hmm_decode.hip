@@ -874,7 +874,7 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
         a.upair = w; w += (size_t)U * 2 * cap;
         a.flag = w; w += (size_t)U * cap;
         a.dst = w; w += (size_t)U * cap;
-        if (use_lr) {                                // meta [U][2][cap] int4 | src [U][2][cap] | the seg_* arrays
+        if (use_lr) {                                // node, hist, upair [U][2][cap] each (as above) | 2 U cap spare | src [U][2][cap] | the seg_* arrays
             a.dst = b->dec_work + (size_t)U * 8 * cap;
             a.flag = nullptr;
             w = a.dst + (size_t)U * 2 * cap;

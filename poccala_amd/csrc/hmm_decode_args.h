@@ -14,10 +14,10 @@ struct DecArgs {
     int n_nodes, n_roots, n_units, S, cap, candidate, min_distinct, Tmax;
     double beam, lpi1, lpi2;        // ln(1/N) for one- and two-unit nodes, from the caller's np.log
     double *score, *p;              // [U][2][cap], [U][2][cap][8] (general kernel: 8 per token; left-to-right kernel: [6][cap])
-    int *node, *hist, *upair;       // [U][2][cap]          (general kernel)
-    int4 *meta;                     // [U][2][cap] (node, history, upair, -)   (left-to-right kernel)
+    int *node, *hist, *upair;       // [U][2][cap]          (both kernels)
+    int4 *meta;                     // (round 3-4: the left-to-right kernel's [U][2][cap] (node, history, upair, -) record; unused since round 5)
     int *flag, *dst;                // [U][cap]: bit 0 finished, bit 1 pruned (this frame); where a token's p sits in the other p buffer
-                                    // (left-to-right kernel: dst = [U][2][cap], | fresh << 31; no flags)
+                                    // (left-to-right kernel: dst = src [U][2][cap]: where token i's state sits in the other buffers, | fresh << 31; no flags)
     int *seg_ofs, *seg_cptr, *seg_hist;   // [U][cap + 2]: the frame's donors as segments of the flattened (donor, child) list
     double *seg_score;
     int *slot;                      // [U][n_nodes]: live token of a node, or -1

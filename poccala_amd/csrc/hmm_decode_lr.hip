@@ -6,8 +6,11 @@
 // recursion  p_j = max_i(p_i + ln A_ij) + B_j  (Decoder.py:278-283) has two finite terms per state, the entry state is
 // -inf from its second step on and the exit state always, so a token is SIX float64 values and a step is a short serial
 // chain one lane can run: no cross-lane traffic at all (the general kernel spends half its step in ds_bpermute and
-// LDS reads of the 8 x 8 predecessor table), and every array pass is one coalesced access per field:
-//     score [2][cap] f64 | p [2][6][cap] f64 (state-major) | meta [2][cap] int4 (node, history, unit pair) | src [2][cap]
+// LDS reads of the 8 x 8 predecessor table), and every array pass is one access per field, 4 or 8 bytes per lane (round 5: the int4
+// meta record became three int arrays, so a 64-byte line serves 16 tokens' node / history / unit pair):
+//     score [2][cap] f64 | p [2][6][cap] f64 (state-major) | node, hist, upair [2][cap] i32 | src [2][cap]
+// Two buffers of each, ONE parity: a frame reads a token's state where the previous frame left it (through its src entry) and writes
+// it at the token's dense index into the other buffers; the end of a frame compacts only the index list.
 // Terms the general kernel adds with ln A = -inf are -inf there and absent here; max and + are exact, so the bits agree.
 //
 // The kernel is bound by the LATENCY of dependent memory round trips (a frame is a chain of phases, 300 frames a chain of
@@ -15,7 +18,8 @@
 // all the loads of a lane's tokens before it uses any.  A frame, for the workgroup of one utterance (wave w owns tokens
 // [w C, (w+1) C), lane l its tokens w C + 64 k + l, so an ORDERED prefix over the tokens is a ballot per 64 tokens plus one
 // exchange of wave totals):
-//   A   every live token steps: src of all rows, then per group of 2 rows old p / meta / score, step, stores.  Finished
+//   A   every live token steps: src of all rows, then per group of 2 rows the old p / score / node / history / unit pair (gathered
+//       through src: an ascending sequence with gaps, nearly coalesced), step, dense stores of all of them.  Finished
 //       tokens = donors: appended, in token order, to the wave's donor list in LDS (token, node, history, score) -> barrier
 //   A2  a lane per donor: the node's children (one gather), child offsets inside the wave, the wave's best / first
 //       word-end donor                                                                                           -> barrier
@@ -25,7 +29,7 @@
 //       first step at once (:135-140), by the same thread                                                        -> 2 barriers per 2048 pairs
 //   E   pruning (Decoder.py:159-167) over the old unfinished tokens, keys in registers: 12-bit radix digit below the keys'
 //       common prefix, then the few keys of the selected bin ranked directly in LDS                               -> 6 barriers
-//   F   stable compaction of score + meta + src into the other buffers (p stays where the step wrote it)         -> 2 barriers
+//   F   stable compaction of the index list (src) + the node -> token map; nothing else moves                    -> 2 barriers
 #include <math.h>
 #include <stdio.h>
 
@@ -141,7 +145,9 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
     // two buffers of each token array, picked by arithmetic (an indexed pointer array would live in scratch)
     auto scb = [&](int b) { return a.score + ((size_t)u * 2 + b) * cap; };
     auto pb = [&](int b) { return a.p + ((size_t)u * 2 + b) * cap * 8; };
-    auto mtb = [&](int b) { return a.meta + ((size_t)u * 2 + b) * cap; };
+    auto ndb = [&](int b) { return a.node + ((size_t)u * 2 + b) * cap; };
+    auto hsb = [&](int b) { return a.hist + ((size_t)u * 2 + b) * cap; };
+    auto upb = [&](int b) { return a.upair + ((size_t)u * 2 + b) * cap; };
     auto srb = [&](int b) { return a.dst + ((size_t)u * 2 + b) * cap; };
     int *seg_ofs = a.seg_ofs + (size_t)u * (cap + 2), *seg_cptr = a.seg_cptr + (size_t)u * (cap + 2), *seg_hist = a.seg_hist + (size_t)u * (cap + 2);
     double *seg_score = a.seg_score + (size_t)u * (cap + 2);
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
     __syncthreads();
 
     // ---- frame 0: every first-character node starts (D3) and takes its first step
-    int cur = 0, pcur = 0, n = min(a.n_roots, cap), ovf = a.n_roots > cap, nh = 0;
+    int cur = 0, n = min(a.n_roots, cap), ovf = a.n_roots > cap, nh = 0;
     for (int i = tid; i < n; i += LW) {
         const int node = a.roots[i];
         const int4 info = ninfo[node];
@@ -187,7 +193,9 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
 #pragma unroll
         for (int j = 0; j < NE; ++j) pb(0)[(size_t)j * cap + i] = pn[j];
         scb(0)[i] = 0.0 + best;
-        mtb(0)[i] = make_int4(node, -1, info.w, 0);
+        ndb(0)[i] = node;
+        hsb(0)[i] = -1;
+        upb(0)[i] = info.w;
         srb(0)[i] = i | FRESH;
         slot[node] = i;
     }
@@ -195,11 +203,16 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
     if (tid == 0) a.trace[(size_t)u * a.Tmax] = n;
 
     for (int t = 1; t < T; ++t) {
-        double *__restrict__ sc = scb(cur);
-        double *__restrict__ p = pb(pcur ^ 1);
-        const double *__restrict__ pin = pb(pcur);
-        int4 *__restrict__ mt = mtb(cur);
+        // every token array has two buffers of one parity: this frame READS a token's state where the previous frame left it (buffers
+        // `cur`, at the index its src entry names) and WRITES it at the token's dense index into the other buffers; what the end of the
+        // frame compacts is only the list of those indices
+        const double *__restrict__ sc_o = scb(cur);
+        const double *__restrict__ pin = pb(cur);
+        const int *__restrict__ nd_o = ndb(cur), *__restrict__ hs_o = hsb(cur), *__restrict__ up_o = upb(cur);
         const int *__restrict__ sr = srb(cur);
+        double *__restrict__ sc = scb(cur ^ 1);
+        double *__restrict__ p = pb(cur ^ 1);
+        int *__restrict__ nd = ndb(cur ^ 1), *__restrict__ hs = hsb(cur ^ 1), *__restrict__ up = upb(cur ^ 1);
         const double *Bs = Bsl + (t & 1) * NbP;
         // the next frame's emission row: on its way now, into LDS at the end of the frame
         double bnext[2] = {0.0, 0.0};
@@ -239,15 +252,17 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
             for (int kb = 0; kb < KMAX; kb += G) {
                 if (kb * 64 < C) {                                 // (wave-uniform)
                     double po[G][NE], so[G];
-                    int4 m[G];
+                    int mn[G], mh[G], mu[G];                          // node, history, unit pair
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const int i = w0 + (kb + g) * 64 + lane, s = srcv[kb + g] & 0x7fffffff;
                         const bool ok = (kb + g) * 64 < C && i < n;
 #pragma unroll
                         for (int j = 0; j < NE; ++j) po[g][j] = ok ? pin[(size_t)j * cap + s] : -INFINITY;
-                        m[g] = ok ? mt[i] : make_int4(0, -1, (int)0xffff0000, 0);
-                        so[g] = ok ? sc[i] : 0.0;
+                        mn[g] = ok ? nd_o[s] : 0;
+                        mh[g] = ok ? hs_o[s] : -1;
+                        mu[g] = ok ? up_o[s] : (int)0xffff0000;
+                        so[g] = ok ? sc_o[s] : 0.0;
                     }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
@@ -256,20 +271,23 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
                             const bool ok = i < n;
                             double pn[NE], best;
                             int fin;
-                            lr_step(tab, Bs, m[g].z, false, srcv[kb + g] < 0, lpi1, lpi2, po[g], pn, best, fin);
+                            lr_step(tab, Bs, mu[g], false, srcv[kb + g] < 0, lpi1, lpi2, po[g], pn, best, fin);
                             const double sn = so[g] + best;        // score += max_j p_j (Decoder.py:285)
                             if (ok) {
 #pragma unroll
                                 for (int j = 0; j < NE; ++j) p[(size_t)j * cap + i] = pn[j];
                                 sc[i] = sn;
+                                nd[i] = mn[g];
+                                hs[i] = mh[g];
+                                up[i] = mu[g];
                             }
                             const bool don = ok && fin;
                             const unsigned long long mask = __ballot(don);
                             if (mask != 0ull) {                    // (a few per cent of the tokens finish in a frame)
                                 if (don) {
                                     finmask |= 1u << (kb + g);
-                                    put(dcount + __popcll(mask & lt_mask), i, m[g].x, m[g].y, sn);
-                                    slot[m[g].x] = -1;             // a finished token is no live target (a new one for its node is mapped in F)
+                                    put(dcount + __popcll(mask & lt_mask), i, mn[g], mh[g], sn);
+                                    slot[mn[g]] = -1;              // a finished token is no live target (a new one for its node is mapped in F)
                                 }
                                 dcount += __popcll(mask);
                             }
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
                 if (val[x] && sidx[x] >= 0) {
                     if (ds[x] > sc[sidx[x]]) {
                         sc[sidx[x]] = ds[x];
-                        ((int *)&mt[sidx[x]])[1] = dh[x];
+                        hs[sidx[x]] = dh[x];
                     }
                 }
                 nmask[x] = __ballot(val[x] && sidx[x] < 0);
@@ -484,7 +502,9 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
 #pragma unroll
                         for (int j = 0; j < NE; ++j) p[(size_t)j * cap + pos] = pn[j];
                         sc[pos] = ds[x] + best;
-                        mt[pos] = make_int4(child[x], dh[x], upn[x], 0);
+                        nd[pos] = child[x];
+                        hs[pos] = dh[x];
+                        up[pos] = upn[x];
                     }
                 }
                 created += tot;
@@ -697,9 +717,10 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
             }
         }
         STAMP(4)
-        // ---- F: stable compaction: the survivors of the old tokens, then the new ones; the node -> token map follows
-        double *__restrict__ scn = scb(cur ^ 1);
-        int4 *__restrict__ mtn = mtb(cur ^ 1);
+        // ---- F: stable compaction of the INDEX LIST: the survivors of the old tokens, then the new ones; the node -> token map follows.
+        //      Scores, nodes, histories, unit pairs and p stay where this frame wrote them: the next frame's step gathers them through
+        //      the list (an ascending sequence with the pruned tokens' gaps: nearly coalesced) and writes them dense again -- round 4
+        //      moved score + meta here as well (24 B in, 24 B out per token and frame, and a dependent load round)
         int *__restrict__ srn = srb(cur ^ 1);
         const unsigned int dead = finmask | prunemask;
         int keep_cnt = 0;
@@ -722,26 +743,21 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
             const bool old = i < n && !((finmask >> k) & 1u), keep = old && !((prunemask >> k) & 1u);
             const unsigned long long mask = __ballot(keep);
             if (old) {
-                const int4 mm = mt[i];
+                const int node = nd[i];
                 if (keep) {
                     const int to = krun + __popcll(mask & lt_mask);
-                    scn[to] = sc[i];
-                    mtn[to] = mm;
-                    srn[to] = i;                                   // where the token's p sits in this frame's p buffer
-                    slot[mm.x] = to;
+                    srn[to] = i;                                   // where the token's state sits in this frame's buffers
+                    slot[node] = to;
                 } else {
-                    slot[mm.x] = -1;                               // pruned (a live target all frame long: nobody else maps its node)
+                    slot[node] = -1;                               // pruned (a live target all frame long: nobody else maps its node)
                 }
             }
             krun += __popcll(mask);
         }
         for (int j = tid; j < n_new; j += LW) {
             const int i = n + j, to = n_keep + j;
-            const int4 mm = mt[i];
-            scn[to] = sc[i];
-            mtn[to] = mm;
             srn[to] = i | FRESH;
-            slot[mm.x] = to;
+            slot[nd[i]] = to;
         }
         if (t + 1 < T) {                                           // the next frame's emission row
             double *Bn = Bsl + ((t + 1) & 1) * NbP;
@@ -757,12 +773,12 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
         STAMP(5)
         n = n_keep + n_new;
         cur ^= 1;
-        pcur ^= 1;
         if (tid == 0) a.trace[(size_t)u * a.Tmax + t] = n;
     }
-    // ---- transfer (Decoder.py:175-187): the `candidate` best tokens, ties in token order
+    // ---- transfer (Decoder.py:175-187): the `candidate` best tokens, ties in token order (token k's state sits at index src[k] of the
+    //      buffers the last frame wrote)
     const double *sc = scb(cur);
-    const int4 *mt = mtb(cur);
+    const int *nd = ndb(cur), *hs = hsb(cur), *srf = srb(cur);
     int *taken = srb(cur ^ 1);                                     // (the idle src buffer: 4 = taken)
     for (int i = tid; i < n; i += LW) taken[i] = 0;
     __syncthreads();
@@ -770,11 +786,13 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
     for (int cc = 0; cc < a.candidate && cc < n; ++cc) {
         double b = -INFINITY;
         int bi = NONE;
-        for (int i = tid; i < n; i += LW)
-            if (taken[i] != 4 && (bi == NONE || sc[i] > b)) {       // (strictly greater keeps the earliest on ties)
-                b = sc[i];
+        for (int i = tid; i < n; i += LW) {
+            const double v = sc[srf[i] & 0x7fffffff];
+            if (taken[i] != 4 && (bi == NONE || v > b)) {          // (strictly greater keeps the earliest on ties)
+                b = v;
                 bi = i;
             }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ob = __shfl_xor(b, o, 64);
@@ -797,10 +815,10 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
                     g = red_d[w];
                     gi = red_i[w];
                 }
-            const int4 mm = mt[gi];
-            a.out_node[(size_t)u * a.candidate + cc] = mm.x;
-            a.out_score[(size_t)u * a.candidate + cc] = sc[gi];
-            a.out_hist[(size_t)u * a.candidate + cc] = mm.y;
+            const int at = srf[gi] & 0x7fffffff;
+            a.out_node[(size_t)u * a.candidate + cc] = nd[at];
+            a.out_score[(size_t)u * a.candidate + cc] = sc[at];
+            a.out_hist[(size_t)u * a.candidate + cc] = hs[at];
             taken[gi] = 4;
         }
         ++n_out;

@@ -133,6 +133,9 @@ extern "C" {
 int pcl_init(int device, pcl_ctx **out) {
     if (!out) PCL_FAIL(nullptr, PCL_ERR_INVALID, "pcl_init: out is NULL");
     *out = nullptr;
+    // five streams per context on the runtime's default of four hardware queues would make two of them share one (see poccala_amd/_lib.py);
+    // honoured only if the HIP runtime has not started yet -- a C caller that initialises HIP first exports GPU_MAX_HW_QUEUES=8 itself
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0)
