@@ -613,12 +613,12 @@ void launch_acc_t(pcl_ctx *ctx, pcl_batch *b, const real *frames, const real *pa
     if (tile_mask && sizeof(real) == 4) {                              // the masked fix-up: rows from the master copy
         const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, nullptr, nullptr};
         hipLaunchKernelGGL((gmm_accumulate_kernel<D, float, MINW, true>), grid, dim3(WG), 0, ctx->stream, (const float *)frames, (const float *)nullptr,
-                           (const float *)nullptr, ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0,
+                           (const float *)nullptr, ctx->Mpad, b->ctx->acc.d_work_states + first, b->ctx->acc.d_seg_lo + first, b->ctx->acc.d_seg_hi + first, b->ctx->acc.acc_off, b->ctx->acc.acc_list, 100.0,
                            ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag, mm);
         return;
     }
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, real, MINW>), grid, dim3(WG), 0, ctx->stream, frames, params, means,
-                       ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0, ctx->st_acc,
+                       ctx->Mpad, b->ctx->acc.d_work_states + first, b->ctx->acc.d_seg_lo + first, b->ctx->acc.d_seg_hi + first, b->ctx->acc.acc_off, b->ctx->acc.acc_list, 100.0, ctx->st_acc,
                        ctx->st_alpha, ctx->st_mean, ctx->st_cov, tile_off, tile_mask, state_flag, AccMaster{});
 }
 
@@ -631,7 +631,7 @@ void launch_acc_subset_t(pcl_ctx *ctx, pcl_batch *b, int first, int count, const
     dim3 grid((unsigned)count, (most + WG - 1) / WG);                     // (states, slices): see the kernel
     const AccMaster mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
     hipLaunchKernelGGL((gmm_accumulate_kernel<D, float, MINW, true>), grid, dim3(WG), 0, ctx->stream, ctx->frames32, (const float *)nullptr,
-                       (const float *)nullptr, ctx->Mpad, b->d_work_states + first, b->d_seg_lo + first, b->d_seg_hi + first, b->acc_off, b->acc_list, 100.0,
+                       (const float *)nullptr, ctx->Mpad, b->ctx->acc.d_work_states + first, b->ctx->acc.d_seg_lo + first, b->ctx->acc.d_seg_hi + first, b->ctx->acc.acc_off, b->ctx->acc.acc_list, 100.0,
                        ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov, (const int *)nullptr, (const unsigned int *)nullptr, split_flag + first, mm);
 }
 void launch_acc_subset(pcl_ctx *ctx, pcl_batch *b, int first, int count, const int *split_flag) {
@@ -663,30 +663,31 @@ bool device_dim_supported(int D) { return D == 13 || D == 26 || D == 39 || D == 
 
 }  // namespace
 
-void pcl_accumulate_release(pcl_batch *b) {
-    dev_free(b->acc_cnt);
-    dev_free(b->acc_off);
-    dev_free(b->acc_list);
-    dev_free(b->d_work_states);
-    dev_free(b->d_seg_lo);
-    dev_free(b->d_seg_hi);
-    dev_free(b->d_split_flag);
+void pcl_accumulate_release(pcl_ctx *ctx) {
+    struct { pcl_ctx *ctx; } bb{ctx}, *b = &bb;              // (the body below names the members through b->ctx->acc)
+    dev_free(b->ctx->acc.acc_cnt);
+    dev_free(b->ctx->acc.acc_off);
+    dev_free(b->ctx->acc.acc_list);
+    dev_free(b->ctx->acc.d_work_states);
+    dev_free(b->ctx->acc.d_seg_lo);
+    dev_free(b->ctx->acc.d_seg_hi);
+    dev_free(b->ctx->acc.d_split_flag);
     for (int k = 0; k < 2; ++k) {
-        dev_free(b->acc16_images[k]);
-        dev_free(b->acc16_tile_off[k]);
-        dev_free(b->acc16_tile_mask[k]);
-        dev_free(b->acc16_state_flag[k]);
-        if (b->acc16_ev_prod[k]) (void)hipEventDestroy(b->acc16_ev_prod[k]);
-        if (b->acc16_ev_cons[k]) (void)hipEventDestroy(b->acc16_ev_cons[k]);
-        b->acc16_images[k] = nullptr; b->acc16_tile_off[k] = nullptr; b->acc16_tile_mask[k] = nullptr; b->acc16_state_flag[k] = nullptr;
-        b->acc16_ev_prod[k] = b->acc16_ev_cons[k] = nullptr;
+        dev_free(b->ctx->acc.acc16_images[k]);
+        dev_free(b->ctx->acc.acc16_tile_off[k]);
+        dev_free(b->ctx->acc.acc16_tile_mask[k]);
+        dev_free(b->ctx->acc.acc16_state_flag[k]);
+        if (b->ctx->acc.acc16_ev_prod[k]) (void)hipEventDestroy(b->ctx->acc.acc16_ev_prod[k]);
+        if (b->ctx->acc.acc16_ev_cons[k]) (void)hipEventDestroy(b->ctx->acc.acc16_ev_cons[k]);
+        b->ctx->acc.acc16_images[k] = nullptr; b->ctx->acc.acc16_tile_off[k] = nullptr; b->ctx->acc.acc16_tile_mask[k] = nullptr; b->ctx->acc.acc16_state_flag[k] = nullptr;
+        b->ctx->acc.acc16_ev_prod[k] = b->ctx->acc.acc16_ev_cons[k] = nullptr;
     }
-    if (b->acc16_ev_start) (void)hipEventDestroy(b->acc16_ev_start);
-    b->acc16_ev_start = nullptr;
-    b->acc16_cap_tiles = b->acc16_cap_states = 0;
-    b->acc_cnt = nullptr; b->acc_off = nullptr; b->acc_list = nullptr;
-    b->d_work_states = b->d_seg_lo = b->d_seg_hi = b->d_split_flag = nullptr;
-    b->acc_cap_list = b->acc_cap_segs = b->acc_cap_states = 0;
+    if (b->ctx->acc.acc16_ev_start) (void)hipEventDestroy(b->ctx->acc.acc16_ev_start);
+    b->ctx->acc.acc16_ev_start = nullptr;
+    b->ctx->acc.acc16_cap_tiles = b->ctx->acc.acc16_cap_states = 0;
+    b->ctx->acc.acc_cnt = nullptr; b->ctx->acc.acc_off = nullptr; b->ctx->acc.acc_list = nullptr;
+    b->ctx->acc.d_work_states = b->ctx->acc.d_seg_lo = b->ctx->acc.d_seg_hi = b->ctx->acc.d_split_flag = nullptr;
+    b->ctx->acc.acc_cap_list = b->ctx->acc.acc_cap_segs = b->ctx->acc.acc_cap_states = 0;
 }
 
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
@@ -696,32 +697,32 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         const ScoreSeg &last = b->segs[b->state_seg_hi[k] - 1];
         cap += (size_t)last.vstart + last.len;
     }
-    if (b->acc_cap_segs < (size_t)b->n_segs + 1) {
-        dev_free(b->acc_cnt);
-        dev_free(b->acc_off);
-        b->acc_cnt = nullptr; b->acc_off = nullptr;
-        TRY(dev_alloc(ctx, &b->acc_cnt, (size_t)(((size_t)b->n_segs + 1))));
-        TRY(dev_alloc(ctx, &b->acc_off, (size_t)b->n_segs + 1));
-        b->acc_cap_segs = (size_t)b->n_segs + 1;
+    if (b->ctx->acc.acc_cap_segs < (size_t)b->n_segs + 1) {
+        dev_free(b->ctx->acc.acc_cnt);
+        dev_free(b->ctx->acc.acc_off);
+        b->ctx->acc.acc_cnt = nullptr; b->ctx->acc.acc_off = nullptr;
+        TRY(dev_alloc(ctx, &b->ctx->acc.acc_cnt, (size_t)(((size_t)b->n_segs + 1))));
+        TRY(dev_alloc(ctx, &b->ctx->acc.acc_off, (size_t)b->n_segs + 1));
+        b->ctx->acc.acc_cap_segs = (size_t)b->n_segs + 1;
     }
-    if (b->acc_cap_list < cap) {
-        dev_free(b->acc_list);
-        b->acc_list = nullptr;
-        TRY(dev_alloc(ctx, &b->acc_list, (size_t)(cap)));
-        b->acc_cap_list = cap;
+    if (b->ctx->acc.acc_cap_list < cap) {
+        dev_free(b->ctx->acc.acc_list);
+        b->ctx->acc.acc_list = nullptr;
+        TRY(dev_alloc(ctx, &b->ctx->acc.acc_list, (size_t)(cap)));
+        b->ctx->acc.acc_cap_list = cap;
     }
     const size_t ns = b->work_states.size();
-    if (b->acc_cap_states < ns) {
-        dev_free(b->d_work_states);
-        dev_free(b->d_seg_lo);
-        dev_free(b->d_seg_hi);
-        dev_free(b->d_split_flag);
-        b->d_work_states = b->d_seg_lo = b->d_seg_hi = b->d_split_flag = nullptr;
-        TRY(dev_alloc(ctx, &b->d_split_flag, (size_t)(ns)));
-        TRY(dev_alloc(ctx, &b->d_work_states, (size_t)(ns)));
-        TRY(dev_alloc(ctx, &b->d_seg_lo, (size_t)(ns)));
-        TRY(dev_alloc(ctx, &b->d_seg_hi, (size_t)(ns)));
-        b->acc_cap_states = ns;
+    if (b->ctx->acc.acc_cap_states < ns) {
+        dev_free(b->ctx->acc.d_work_states);
+        dev_free(b->ctx->acc.d_seg_lo);
+        dev_free(b->ctx->acc.d_seg_hi);
+        dev_free(b->ctx->acc.d_split_flag);
+        b->ctx->acc.d_work_states = b->ctx->acc.d_seg_lo = b->ctx->acc.d_seg_hi = b->ctx->acc.d_split_flag = nullptr;
+        TRY(dev_alloc(ctx, &b->ctx->acc.d_split_flag, (size_t)(ns)));
+        TRY(dev_alloc(ctx, &b->ctx->acc.d_work_states, (size_t)(ns)));
+        TRY(dev_alloc(ctx, &b->ctx->acc.d_seg_lo, (size_t)(ns)));
+        TRY(dev_alloc(ctx, &b->ctx->acc.d_seg_hi, (size_t)(ns)));
+        b->ctx->acc.acc_cap_states = ns;
     }
     // MFMA mode: well-conditioned states first (MFMA kernel), then the ill-conditioned ones (direct-form VALU kernel)
     const int D = ctx->D;
@@ -744,10 +745,10 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     const int n_bad = (int)ns - n_good;
     // the staging vectors live in the batch: the copies below are asynchronous from pageable memory only until the
     // call returns on this runtime, but keeping them alive costs nothing
-    HIPCHK(ctx, hipMemcpyAsync(b->d_work_states, b->acc_ws.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_lo, b->acc_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_seg_hi, b->acc_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    if (n_split) HIPCHK(ctx, hipMemcpyAsync(b->d_split_flag, b->acc_split.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->ctx->acc.d_work_states, b->acc_ws.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->ctx->acc.d_seg_lo, b->acc_lo.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->ctx->acc.d_seg_hi, b->acc_hi.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (n_split) HIPCHK(ctx, hipMemcpyAsync(b->ctx->acc.d_split_flag, b->acc_split.data(), ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 
     // a frame survives unless every gamma_t(j,m) <= gamma_t(j) underflows to exactly 0 in the
     // kernel's arithmetic (f32: 2^-149, f64: 2^-1074)
@@ -759,13 +760,13 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     static const bool rows_on = !(getenv("PCL_ACC_ROWS") && atoi(getenv("PCL_ACC_ROWS")) == 0);      // 0: a wave per segment (rounds 1-3), A/B
     const bool by_rows = rows_on && b->U <= 65535 && b->d_seg_of_row;                                // (grid.y = utterances)
     const dim3 grows((b->max_N + 8 * ROWS_WPB - 1) / (8 * ROWS_WPB), (unsigned)b->U);
-    if (by_rows) hipLaunchKernelGGL(acc_count_rows_kernel, grows, dim3(64 * ROWS_WPB), 0, ctx->stream, b->d_utt, b->d_seg_of_row, b->lgam, thr, b->acc_cnt);
-    else hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, b->acc_cnt);
-    hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->acc_cnt, b->n_segs, b->acc_off);
+    if (by_rows) hipLaunchKernelGGL(acc_count_rows_kernel, grows, dim3(64 * ROWS_WPB), 0, ctx->stream, b->d_utt, b->d_seg_of_row, b->lgam, thr, b->ctx->acc.acc_cnt);
+    else hipLaunchKernelGGL(acc_count_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, thr, b->ctx->acc.acc_cnt);
+    hipLaunchKernelGGL(acc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->ctx->acc.acc_cnt, b->n_segs, b->ctx->acc.acc_off);
     if (by_rows) hipLaunchKernelGGL(acc_fill_rows_kernel, grows, dim3(64 * ROWS_WPB), 0, ctx->stream, b->d_utt, b->d_seg_of_row, b->lgam, b->Bt, thr,
-                                    b->acc_off, b->acc_list);
+                                    b->ctx->acc.acc_off, b->ctx->acc.acc_list);
     else hipLaunchKernelGGL(acc_fill_kernel, gseg, dim3(64 * wpb), 0, ctx->stream, b->d_segs, b->n_segs, b->lgam, b->Bt, thr,
-                            b->acc_off, b->acc_list);
+                            b->ctx->acc.acc_off, b->ctx->acc.acc_list);
     if (mfma && n_good > 0 && ctx->score_variant == 7) {
         // producer / consumer on the f16 + bf16 matrix pipes (gmm_accumulate_f16.hip), in groups of states whose tile
         // images fit the image buffer (worst case: every frame of the state survives)
@@ -775,7 +776,7 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         // kernel) -- on peaked posteriors a tenth of the frames survive, and sizing the groups for the worst case made
         // eight half-empty launches, each with its parameter prologue and statistics flush, out of one
         std::vector<long long> off_h((size_t)b->n_segs + 1);
-        HIPCHK(ctx, hipMemcpyAsync(off_h.data(), b->acc_off, off_h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(off_h.data(), b->ctx->acc.acc_off, off_h.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<int> wtiles(n_good);
         size_t worst = 0, biggest = 0;
@@ -793,34 +794,34 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         }
         const size_t by_budget = std::max<size_t>(budget / ib, 1);
         size_t cap_tiles = std::max(biggest, std::min(worst, by_budget));
-        if (b->acc16_cap_tiles >= cap_tiles) cap_tiles = b->acc16_cap_tiles;                 // never shrink: the counts move from call to call
+        if (b->ctx->acc.acc16_cap_tiles >= cap_tiles) cap_tiles = b->ctx->acc.acc16_cap_tiles;                 // never shrink: the counts move from call to call
         else cap_tiles = std::max(cap_tiles, std::min(cap_tiles + cap_tiles / 4, std::max(by_budget, biggest)));   // grow with headroom
-        if (b->acc16_cap_tiles < cap_tiles) {
+        if (b->ctx->acc.acc16_cap_tiles < cap_tiles) {
             for (int k = 0; k < 2; ++k) {
-                dev_free(b->acc16_images[k]);
-                dev_free(b->acc16_tile_mask[k]);
-                b->acc16_images[k] = nullptr; b->acc16_tile_mask[k] = nullptr;
-                b->acc16_images[k] = pcl_pool_alloc(ctx->device, cap_tiles * ib);
-                if (!b->acc16_images[k]) PCL_FAIL(ctx, PCL_ERR_NOMEM, "device memory: %zu bytes of tile images", cap_tiles * ib);
-                TRY(dev_alloc(ctx, &b->acc16_tile_mask[k], cap_tiles));
+                dev_free(b->ctx->acc.acc16_images[k]);
+                dev_free(b->ctx->acc.acc16_tile_mask[k]);
+                b->ctx->acc.acc16_images[k] = nullptr; b->ctx->acc.acc16_tile_mask[k] = nullptr;
+                b->ctx->acc.acc16_images[k] = pcl_pool_alloc(ctx->device, cap_tiles * ib);
+                if (!b->ctx->acc.acc16_images[k]) PCL_FAIL(ctx, PCL_ERR_NOMEM, "device memory: %zu bytes of tile images", cap_tiles * ib);
+                TRY(dev_alloc(ctx, &b->ctx->acc.acc16_tile_mask[k], cap_tiles));
             }
-            b->acc16_cap_tiles = cap_tiles;
+            b->ctx->acc.acc16_cap_tiles = cap_tiles;
         }
-        if (b->acc16_cap_states < (size_t)n_good + 1) {
+        if (b->ctx->acc.acc16_cap_states < (size_t)n_good + 1) {
             for (int k = 0; k < 2; ++k) {
-                dev_free(b->acc16_tile_off[k]);
-                dev_free(b->acc16_state_flag[k]);
-                b->acc16_tile_off[k] = b->acc16_state_flag[k] = nullptr;
-                TRY(dev_alloc(ctx, &b->acc16_tile_off[k], (size_t)(((size_t)n_good + 1))));
-                TRY(dev_alloc(ctx, &b->acc16_state_flag[k], (size_t)(((size_t)n_good + 1))));
+                dev_free(b->ctx->acc.acc16_tile_off[k]);
+                dev_free(b->ctx->acc.acc16_state_flag[k]);
+                b->ctx->acc.acc16_tile_off[k] = b->ctx->acc.acc16_state_flag[k] = nullptr;
+                TRY(dev_alloc(ctx, &b->ctx->acc.acc16_tile_off[k], (size_t)(((size_t)n_good + 1))));
+                TRY(dev_alloc(ctx, &b->ctx->acc.acc16_state_flag[k], (size_t)(((size_t)n_good + 1))));
             }
-            b->acc16_cap_states = (size_t)n_good + 1;
+            b->ctx->acc.acc16_cap_states = (size_t)n_good + 1;
         }
-        if (!b->acc16_ev_start) {
-            HIPCHK(ctx, hipEventCreateWithFlags(&b->acc16_ev_start, hipEventDisableTiming));
+        if (!b->ctx->acc.acc16_ev_start) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&b->ctx->acc.acc16_ev_start, hipEventDisableTiming));
             for (int k = 0; k < 2; ++k) {
-                HIPCHK(ctx, hipEventCreateWithFlags(&b->acc16_ev_prod[k], hipEventDisableTiming));
-                HIPCHK(ctx, hipEventCreateWithFlags(&b->acc16_ev_cons[k], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&b->ctx->acc.acc16_ev_prod[k], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&b->ctx->acc.acc16_ev_cons[k], hipEventDisableTiming));
             }
         }
         // groups of states: (first, count, worst-case tiles)
@@ -839,35 +840,35 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         // bound, the consumer matrix-pipe bound, and a consumer workgroup leaves registers for one small wave per SIMD)
         static const bool overlap = !(getenv("PCL_ACC_OVERLAP") && atoi(getenv("PCL_ACC_OVERLAP")) == 0);
         hipStream_t ps = overlap ? ctx->stream_aux : ctx->stream;
-        HIPCHK(ctx, hipEventRecord(b->acc16_ev_start, ctx->stream));            // the active-frame lists are complete
-        if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ps, b->acc16_ev_start, 0));
+        HIPCHK(ctx, hipEventRecord(b->ctx->acc.acc16_ev_start, ctx->stream));            // the active-frame lists are complete
+        if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ps, b->ctx->acc.acc16_ev_start, 0));
         const int G = (int)gfirst.size();
         bool ascending = true;
         for (int k = 1; k < n_good; ++k) ascending = ascending && b->acc_ws[k - 1] < b->acc_ws[k];
         auto produce = [&](int g) -> int {
             const int buf = g & 1;
-            if (overlap && g >= 2) HIPCHK(ctx, hipStreamWaitEvent(ps, b->acc16_ev_cons[buf], 0));      // the buffer set is free again
+            if (overlap && g >= 2) HIPCHK(ctx, hipStreamWaitEvent(ps, b->ctx->acc.acc16_ev_cons[buf], 0));      // the buffer set is free again
             const int rc = pcl_launch_acc16_produce(ctx, b, gfirst[g], gcount[g], gtiles[g], buf, ps);
             if (rc != PCL_OK) return rc;
-            if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_prod[buf], ps));
+            if (overlap) HIPCHK(ctx, hipEventRecord(b->ctx->acc.acc16_ev_prod[buf], ps));
             return PCL_OK;
         };
         if (G > 0) { const int rc = produce(0); if (rc != PCL_OK) return rc; }
         for (int g = 0; g < G; ++g) {
             const int buf = g & 1;
             if (overlap && g + 1 < G) { const int rc = produce(g + 1); if (rc != PCL_OK) return rc; }
-            if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->acc16_ev_prod[buf], 0));
+            if (overlap) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->ctx->acc.acc16_ev_prod[buf], 0));
             pcl_timer_begin(ctx, "acc_consume");                                 // one entry per state group (timing mode only)
             int rc = pcl_launch_acc16_consume(ctx, b, gfirst[g], gcount[g], buf, ctx->stats_fresh, ctx->stream);
             pcl_timer_end(ctx, "acc_consume");
             if (rc != PCL_OK) return rc;
-            launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->acc16_tile_off[buf], b->acc16_tile_mask[buf], b->acc16_state_flag[buf]);   // the frames the images left out
+            launch_acc_f32(ctx, b, gfirst[g], gcount[g], b->ctx->acc.acc16_tile_off[buf], b->ctx->acc.acc16_tile_mask[buf], b->ctx->acc.acc16_state_flag[buf]);   // the frames the images left out
             if (n_split) {                                                                                    // the mixtures the pipe left out (split states)
                 pcl_timer_begin(ctx, "acc_subset");
-                launch_acc_subset(ctx, b, gfirst[g], gcount[g], b->d_split_flag);
+                launch_acc_subset(ctx, b, gfirst[g], gcount[g], b->ctx->acc.d_split_flag);
                 pcl_timer_end(ctx, "acc_subset");
             }
-            if (overlap) HIPCHK(ctx, hipEventRecord(b->acc16_ev_cons[buf], ctx->stream));
+            if (overlap) HIPCHK(ctx, hipEventRecord(b->ctx->acc.acc16_ev_cons[buf], ctx->stream));
             if (!overlap && g + 1 < G) { rc = produce(g + 1); if (rc != PCL_OK) return rc; }
             // a pipelined exchange is open (pcl_batch_accumulate_exchange): every state below the next group's first one has its
             // final statistics behind what is queued now -- its chunks may leave (states come in ascending order; states of the
@@ -879,11 +880,11 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
         const int nblocks = (nslice == 8) ? ((ns + 7) / 8) * 64 : ns * nslice;
 #define LAUNCH_MFMA(DD)                                                                                                   \
     hipLaunchKernelGGL((gmm_accumulate_mfma_kernel<DD, PCL_ACC_T16 != 0>), dim3(nblocks), dim3(AW * 64), 0, ctx->stream, ctx->frames32, ctx->pm32, \
-                       ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, b->d_work_states, b->d_seg_lo, b->d_seg_hi,   \
-                       b->acc_off, b->acc_list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
+                       ctx->centers32, ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, b->ctx->acc.d_work_states, b->ctx->acc.d_seg_lo, b->ctx->acc.d_seg_hi,   \
+                       b->ctx->acc.acc_off, b->ctx->acc.acc_list, 100.0, ctx->st_acc, ctx->st_alpha, ctx->st_mean, ctx->st_cov)
         if (D == 47) LAUNCH_MFMA(47); else if (D == 39) LAUNCH_MFMA(39); else if (D == 26) LAUNCH_MFMA(26); else LAUNCH_MFMA(13);
 #undef LAUNCH_MFMA
-        if (n_split) launch_acc_subset(ctx, b, 0, n_good, b->d_split_flag);
+        if (n_split) launch_acc_subset(ctx, b, 0, n_good, b->ctx->acc.d_split_flag);
     }
     if (precision == PCL_F32) {
         const int first = mfma ? n_good : 0, count = mfma ? n_bad : (int)ns;

@@ -529,13 +529,13 @@ size_t pcl_acc16_image_bytes(int D) {
 // the producer (into buffer set `buf`) ...
 int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int max_tiles, int buf, hipStream_t stream) {
     if (ns == 0) return PCL_OK;
-    const int *ws = b->d_work_states + first, *lo = b->d_seg_lo + first, *hi = b->d_seg_hi + first;
-    hipLaunchKernelGGL(acc16_tiles_kernel, dim3(1), dim3(1024), 0, stream, lo, hi, b->acc_off, ns, b->acc16_tile_off[buf], b->acc16_state_flag[buf]);
+    const int *ws = b->ctx->acc.d_work_states + first, *lo = b->ctx->acc.d_seg_lo + first, *hi = b->ctx->acc.d_seg_hi + first;
+    hipLaunchKernelGGL(acc16_tiles_kernel, dim3(1), dim3(1024), 0, stream, lo, hi, b->ctx->acc.acc_off, ns, b->ctx->acc.acc16_tile_off[buf], b->ctx->acc.acc16_state_flag[buf]);
     const int pgrid = std::min(max_tiles, std::max(ctx->cus, 1) * 16);
 #define PRODUCE16(DD)                                                                                                         \
     hipLaunchKernelGGL((acc16_producer_kernel<DD>), dim3(pgrid), dim3(256), 0, stream, ctx->frames32, ctx->centers32, ctx->fscale, \
-                       ctx->kzero, ns, ws, lo, hi, b->acc_off, b->acc_list, b->acc16_tile_off[buf], 0, reinterpret_cast<uint4 *>(b->acc16_images[buf]),  \
-                       b->acc16_tile_mask[buf], b->acc16_state_flag[buf])
+                       ctx->kzero, ns, ws, lo, hi, b->ctx->acc.acc_off, b->ctx->acc.acc_list, b->ctx->acc.acc16_tile_off[buf], 0, reinterpret_cast<uint4 *>(b->ctx->acc.acc16_images[buf]),  \
+                       b->ctx->acc.acc16_tile_mask[buf], b->ctx->acc.acc16_state_flag[buf])
     switch (ctx->D) {
         case 47: PRODUCE16(47); break;
         case 39: PRODUCE16(39); break;
@@ -553,11 +553,11 @@ int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
     if (ns == 0) return PCL_OK;
     const int nmt = ctx->Mpad32 / 32, nslice = (nmt + AW - 1) / AW;
     const int nblocks = ((ns + 7) / 8) * 8 * nslice;
-    const int *ws = b->d_work_states + first;
+    const int *ws = b->ctx->acc.d_work_states + first;
 #define CONSUME16F(DD, FR)                                                                                                    \
     hipLaunchKernelGGL((acc16_consumer_kernel<DD, FR>), dim3(nblocks), dim3(AW * 64), 0, stream,                              \
-                       reinterpret_cast<const uint4 *>(b->acc16_images[buf]), reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->centers32, ctx->fscale, \
-                       ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, ws, b->acc16_tile_off[buf], 0, 100.0, ctx->st_acc, ctx->st_alpha,      \
+                       reinterpret_cast<const uint4 *>(b->ctx->acc.acc16_images[buf]), reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->centers32, ctx->fscale, \
+                       ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, ws, b->ctx->acc.acc16_tile_off[buf], 0, 100.0, ctx->st_acc, ctx->st_alpha,      \
                        ctx->st_mean, ctx->st_cov)
 #define CONSUME16(DD)                     \
     do {                                  \

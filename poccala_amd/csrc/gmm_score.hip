@@ -47,6 +47,9 @@ constexpr int WG = 256;  // 4 waves
 #ifndef PCL_PDE_D2
 #define PCL_PDE_D2 16
 #endif
+#ifndef PCL_PDE_SUBSET
+#define PCL_PDE_SUBSET 0   // the test in the subset launch of split states (A/B: tools/build_variant.sh)
+#endif
 constexpr int GROUP = PCL_GROUP;  // mixtures per LSE rescale (Mpad is a multiple of 4 >= this)
 
 template <typename real>
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(WG, SUBSET ? PCL_SUBSET_MINB : (MASTER && sizeof(re
     // partial-distance elimination (see the mixture loop): the float launches only -- the float64 parity mode evaluates everything
     // -- and not the subset launch of a split state: its mixtures are tight but rarely collapsed (a state whose mixtures have collapsed is off
     //    the pipe as a whole), few groups skip, and the tests cost its three-wave build more than they save (15.8 against 7.3 ms per batch)
-    constexpr bool PDE = sizeof(real) == 4 && !SUBSET && PCL_PDE_D1 > 0 && D > PCL_PDE_D1;
+    constexpr bool PDE = sizeof(real) == 4 && (!SUBSET || PCL_PDE_SUBSET) && PCL_PDE_D1 > 0 && D > PCL_PDE_D1;
     constexpr int PD1 = PCL_PDE_D1, PD2 = (PCL_PDE_D2 > PCL_PDE_D1 && PCL_PDE_D2 < D) ? PCL_PDE_D2 : PCL_PDE_D1;
     constexpr int PDE_MARGIN = 40;                                   // log2 units below the lane's own running maximum: nothing for an f32 sum that holds that maximum's 1
     constexpr int PDE_MARGIN_PIPE = 64;                              // ... below the matrix pipe's part of a split state: the two parts are merged in float64

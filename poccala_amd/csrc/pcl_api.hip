@@ -125,6 +125,42 @@ void pcl_pool_free(void *p) {
     if (g_pool_cached > pool_limit()) pool_release_locked(pool_limit() / 2);
 }
 
+// ---------------------------------------------------------------- descriptor uploads (pcl_desc_group, pcl_internal.h)
+namespace {
+__global__ void desc_copy_kernel(DescCopyArgs a, const char *__restrict__ stage) {
+    const int e = blockIdx.y;
+    if (e >= a.n) return;
+    const unsigned long long n = a.bytes[e];
+    const char *src = stage + a.off[e];
+    char *dst = (char *)a.dst[e];
+    const unsigned long long n16 = n / 16;                            // (staging offsets and pool blocks are 256-byte aligned)
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * blockDim.x)
+        ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    if (blockIdx.x == 0)
+        for (unsigned long long i = n16 * 16 + threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+hipError_t pcl_desc_flush(pcl_ctx *ctx) {
+    ctx->desc_pin_used = 0;
+    if (ctx->desc_n == 0) return hipSuccess;
+    static_assert(PCL_DESC_MAX == 24, "pcl_ctx::desc_dst");
+    DescCopyArgs a;
+    a.n = ctx->desc_n;
+    for (int k = 0; k < ctx->desc_n; ++k) {
+        a.dst[k] = ctx->desc_dst[k];
+        a.off[k] = ctx->desc_off[k];
+        a.bytes[k] = ctx->desc_bytes[k];
+    }
+    ctx->desc_n = 0;
+    void *dev_stage = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dev_stage, ctx->desc_pin, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(desc_copy_kernel, dim3(32, a.n), dim3(256), 0, ctx->stream_desc, a, (const char *)dev_stage);
+    e = hipGetLastError();
+    return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream_desc);
+}
+
 static int pcl_batch_reap(pcl_ctx *ctx, bool wait);   // frees the destroyed batches the GPU is done with (wait: all of them); returns how many are left
 
 extern "C" {
@@ -188,6 +224,7 @@ int pcl_init(int device, pcl_ctx **out) {
 }
 
 static void free_model(pcl_ctx *ctx) {
+    pcl_accumulate_release(ctx);                                 // (sized for the model's states and mixtures)
     dev_free(ctx->params32);
     dev_free(ctx->params64);
     dev_free(ctx->mean32);
@@ -569,7 +606,6 @@ static void batch_free_now(pcl_batch *b) {
     if (b->ev_dp) hipEventDestroy(b->ev_dp);
     if (b->ev_main) hipEventDestroy(b->ev_main);
     if (b->ev_mark) hipEventDestroy(b->ev_mark);
-    pcl_accumulate_release(b);
     pcl_batch_units_release(b);
     pcl_batch_decode_release(b);
     dev_free(b->d_utt); dev_free(b->Bt); dev_free(b->alpha); dev_free(b->beta); dev_free(b->lgam);

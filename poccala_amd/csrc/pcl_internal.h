@@ -61,8 +61,30 @@ struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 
+// Scratch of the accumulate pass (gmm_accumulate.hip, gmm_accumulate_f16.hip): everything here is rebuilt by every pass and dead when the
+// pass's last kernel has run, and the passes of a context are serialised on its main stream (the auxiliary stream's producers are
+// joined by the consumers) -- so it belongs to the CONTEXT, grow-only, not to the batch: rounds 2-4 gave every batch its own (4 GB of
+// tile images + up to 442 MB of active-frame lists: 35 GB for the 8 resident batches of config 4, and a corpus sweep that makes a
+// batch per step allocated them per step).
+struct AccScratch {
+    // work lists: per-segment counts / offsets, per-state active-frame lists, the accumulate order of the states
+    int *acc_cnt = nullptr;
+    long long *acc_off = nullptr;
+    ActiveFrame *acc_list = nullptr;
+    int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr, *d_split_flag = nullptr;   // (split_flag: 1 = a split state, in accumulate order)
+    size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
+    // producer / consumer: tile images in LDS order, per-state tile offsets, outlier masks; two sets: the producer of state group g + 1
+    // runs on the auxiliary stream beside the consumer of group g
+    void *acc16_images[2] = {nullptr, nullptr};
+    int *acc16_tile_off[2] = {nullptr, nullptr}, *acc16_state_flag[2] = {nullptr, nullptr};
+    unsigned int *acc16_tile_mask[2] = {nullptr, nullptr};
+    hipEvent_t acc16_ev_prod[2] = {nullptr, nullptr}, acc16_ev_cons[2] = {nullptr, nullptr}, acc16_ev_start = nullptr;
+    size_t acc16_cap_tiles = 0, acc16_cap_states = 0;
+};
+
 struct pcl_ctx {
     int device = 0;
+    AccScratch acc;
     hipStream_t stream = nullptr;
     std::string err;
     int cus = 0;
@@ -162,9 +184,15 @@ struct pcl_ctx {
     // Descriptor uploads of a batch under construction (pcl_desc_group): the arrays are packed into ONE page-locked staging buffer and
     // queued as asynchronous copies on stream_desc, with one wait at the end of the group -- pcl_batch_create_labels made 16 separate
     // synchronous copies from pageable memory (5.3 ms of host time per 1024-utterance batch beside a busy GPU, tools/fresh_batch_probe.py).
+    // The copy itself is a KERNEL on stream_desc that reads the staging buffer over PCIe, not hipMemcpyAsync: the copy engines serve
+    // their queue in order, and in a pipeline that also moves frames up and results down the descriptors sat behind the NEXT step's
+    // frame upload, which waits for its slot's last reader -- 15 ms per pcl_batch_create_labels (bench.py pcie_inclusive_loop).
     char *desc_pin = nullptr;
     size_t desc_pin_cap = 0, desc_pin_used = 0;
     int desc_group = 0;          // > 0: inside a group, pcl_h2d_fresh stages and does not wait
+    void *desc_dst[24];          // the staged entries of the open group (PCL_DESC_MAX)
+    unsigned long long desc_off[24], desc_bytes[24];
+    int desc_n = 0;
 };
 
 struct pcl_batch {
@@ -224,22 +252,10 @@ struct pcl_batch {
     int n_segs = 0, n_tiles = 0, n_tiles_v = 0, n_tiles_s = 0, tile_frames = 0, tile_gen = -1;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
     double *nz_tmp = nullptr;                // nnz staging buffer for the sparse xi download
-    // accumulate work lists (gmm_accumulate.hip): per-segment counts / offsets, per-state active-frame lists
-    int *acc_cnt = nullptr;
-    long long *acc_off = nullptr;
-    ActiveFrame *acc_list = nullptr;
     std::vector<int> seg_of_row;              // (utterance, row) -> its segment (-1: not a GMM row); d_seg_of_row: the device copy (sumN ints)
     int *d_seg_of_row = nullptr;
     int max_N = 0;                            // rows of the largest sentence HMM of the batch
-    int *d_work_states = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr, *d_split_flag = nullptr;   // (split_flag: 1 = a split state, in accumulate order)
-    size_t acc_cap_list = 0, acc_cap_segs = 0, acc_cap_states = 0;
-    // producer / consumer accumulate (gmm_accumulate_f16.hip): tile images in LDS order, per-state tile offsets, outlier masks
-    // two sets: the producer of state group g + 1 runs on the auxiliary stream beside the consumer of group g
-    void *acc16_images[2] = {nullptr, nullptr};
-    int *acc16_tile_off[2] = {nullptr, nullptr}, *acc16_state_flag[2] = {nullptr, nullptr};
-    unsigned int *acc16_tile_mask[2] = {nullptr, nullptr};
-    hipEvent_t acc16_ev_prod[2] = {nullptr, nullptr}, acc16_ev_cons[2] = {nullptr, nullptr}, acc16_ev_start = nullptr;
-    size_t acc16_cap_tiles = 0, acc16_cap_states = 0;
+    // (the accumulate pass's device work lists and tile images are the CONTEXT's scratch since round 5: pcl_ctx::acc)
     // decoder state (hmm_decode.hip): token buffers, node -> token map, scratch, results
     double *dec_f64 = nullptr;
     int *dec_slot = nullptr, *dec_work = nullptr, *dec_int = nullptr;
@@ -331,15 +347,24 @@ static inline hipError_t pcl_h2d(pcl_ctx *ctx, void *dst, const void *src, size_
 // Descriptors into a buffer NO queued kernel can be reading (freshly allocated, or any buffer of a batch that has not launched
 // anything yet): a stream of their own, so that creating a batch in the middle of a stream of chunks does not wait for the
 // scoring kernel that happens to run on the main stream (28 ms per new batch in the C5 pipeline).  Complete at return.
+// One launch copies every staged array of a descriptor group from the page-locked staging buffer (the kernel reads host memory
+// over PCIe) to its device array: pcl_api.hip.  entries: (dst, offset into the staging buffer, bytes).
+constexpr int PCL_DESC_MAX = 24;
+struct DescCopyArgs {
+    void *dst[PCL_DESC_MAX];
+    unsigned long long off[PCL_DESC_MAX], bytes[PCL_DESC_MAX];
+    int n;
+};
+hipError_t pcl_desc_flush(pcl_ctx *ctx);      // launch the pending entries on stream_desc and wait for them
+
 static inline hipError_t pcl_h2d_fresh(pcl_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return hipSuccess;
     if (!ctx->stream_desc) return pcl_h2d(ctx, dst, src, bytes);
-    if (ctx->desc_group > 0) {                                       // inside a pcl_desc_group: staged, asynchronous, waited for at its end
+    if (ctx->desc_group > 0) {                                       // inside a pcl_desc_group: staged, copied by ONE kernel at its end
         const size_t need = (bytes + 255) & ~(size_t)255;
-        if (ctx->desc_pin_used + need > ctx->desc_pin_cap) {
-            hipError_t e = hipStreamSynchronize(ctx->stream_desc);   // what is staged so far has to land before the buffer is reused
+        if (ctx->desc_pin_used + need > ctx->desc_pin_cap || ctx->desc_n == PCL_DESC_MAX) {
+            hipError_t e = pcl_desc_flush(ctx);                      // what is staged so far has to land before the buffer is reused
             if (e != hipSuccess) return e;
-            ctx->desc_pin_used = 0;
             if (need > ctx->desc_pin_cap) {
                 if (ctx->desc_pin) (void)hipHostFree(ctx->desc_pin);
                 ctx->desc_pin = nullptr;
@@ -350,16 +375,19 @@ static inline hipError_t pcl_h2d_fresh(pcl_ctx *ctx, void *dst, const void *src,
                 ctx->desc_pin_cap = cap;
             }
         }
-        char *stage = ctx->desc_pin + ctx->desc_pin_used;
-        memcpy(stage, src, bytes);
+        memcpy(ctx->desc_pin + ctx->desc_pin_used, src, bytes);
+        ctx->desc_dst[ctx->desc_n] = dst;
+        ctx->desc_off[ctx->desc_n] = ctx->desc_pin_used;
+        ctx->desc_bytes[ctx->desc_n] = bytes;
+        ++ctx->desc_n;
         ctx->desc_pin_used += need;
-        return hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream_desc);
+        return hipSuccess;
     }
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream_desc);
     return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream_desc);
 }
-// Scope of a batch's descriptor uploads: every pcl_h2d_fresh inside is staged and asynchronous; `finish` waits once for all of them
-// (the destructor does too, for the error paths).  Groups nest: the outermost one waits.
+// Scope of a batch's descriptor uploads: every pcl_h2d_fresh inside is staged; `finish` copies and waits once for all of them
+// (the destructor does too, for the error paths).  Groups nest: the outermost one copies.
 struct pcl_desc_group {
     pcl_ctx *ctx;
     bool open;
@@ -368,8 +396,7 @@ struct pcl_desc_group {
         if (!open) return hipSuccess;
         open = false;
         if (--ctx->desc_group > 0) return hipSuccess;
-        ctx->desc_pin_used = 0;
-        return ctx->stream_desc ? hipStreamSynchronize(ctx->stream_desc) : hipSuccess;
+        return pcl_desc_flush(ctx);
     }
     ~pcl_desc_group() { (void)finish(); }
 };
@@ -407,7 +434,7 @@ int pcl_launch_regroup(pcl_ctx *ctx, pcl_batch *b, const int32_t *d_row_unit, in
 int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst);
 int pcl_launch_clock_probe(pcl_ctx *ctx, int spin_us, unsigned long long *d_out);
 int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision);
-void pcl_accumulate_release(pcl_batch *b);
+void pcl_accumulate_release(pcl_ctx *ctx);           // the context's accumulate scratch (pcl_destroy, pcl_model_upload)
 int pcl_launch_transpose(pcl_ctx *ctx, pcl_batch *b, const double *src, double *dst, int to_time_major);
 int pcl_score_tile_frames(int D, int precision);
 int pcl_launch_score_mfma(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles);

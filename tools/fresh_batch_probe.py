@@ -81,10 +81,14 @@ def fresh(check=False):
     live.clear()
     return el / steps * 1e3, {k: v / steps * 1e3 for k, v in host.items()}, logp
 
+if os.environ.get('PROBE_TRACE'):
+    resident(fetch=True); resident(fetch=False); f, host, logp = fresh(); eng.close(); sys.exit(0)
 r = resident()
 f, host, logp = fresh(check=True)
 r2 = resident()
 f2, host2, _ = fresh()
+if os.environ.get('PROBE_TRACE'):
+    resident(fetch=True); resident(fetch=False); sys.exit(0)
 resident(fetch=True); resident(fetch=True, nres=4); resident(nres=4)
 print('%s: resident %.3f / %.3f ms per step; fresh batch every step %.3f / %.3f ms (ratio %.3f); host ms per step %s' % (name, r, r2, f, f2, min(r, r2) / min(f, f2), {k: round(v, 3) for k, v in host2.items()}))
 # same bits as a resident batch of the same labels
