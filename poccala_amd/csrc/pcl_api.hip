@@ -241,6 +241,8 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->d_bad_idx);
     dev_free(ctx->d_nbad);
     ctx->nbad.clear();
+    if (ctx->zero_pending && ctx->ev_zero) (void)hipEventSynchronize(ctx->ev_zero);
+    ctx->zero_pending = false;
     dev_free(ctx->stats);
     ctx->st_acc = ctx->st_alpha = ctx->st_mean = ctx->st_cov = nullptr;
     ctx->J = ctx->M = ctx->Mpad = 0;
@@ -265,6 +267,8 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipStreamSynchronize(ctx->stream_aux);
     if (ctx->stream_d2h) hipStreamSynchronize(ctx->stream_d2h);
     pcl_batch_reap(ctx, true);
+    if (ctx->ev_zero) hipEventDestroy(ctx->ev_zero);
+    if (ctx->ev_zero_src) hipEventDestroy(ctx->ev_zero_src);
     if (ctx->desc_pin) hipHostFree(ctx->desc_pin);
     ctx->desc_pin = nullptr;
     drop_timers(ctx);
@@ -1292,7 +1296,22 @@ int pcl_stats_zero(pcl_ctx *ctx) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_zero: no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(ctx->stats, 0, ctx->stats_len * sizeof(double), ctx->stream));
+    static const bool zero_async = !(getenv("PCL_ZERO_ASYNC") && atoi(getenv("PCL_ZERO_ASYNC")) == 0);      // 0: on the main stream (rounds 1-4; A/B)
+    if (zero_async && ctx->stream_aux) {
+        // beside whatever the main stream does next (an E-step starts with the scoring of its first batch, which does not touch the block):
+        // behind everything queued so far (the block's last readers), on the auxiliary stream
+        if (!ctx->ev_zero) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_zero, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_zero_src, hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_zero_src, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_zero_src, 0));
+        HIPCHK(ctx, hipMemsetAsync(ctx->stats, 0, ctx->stats_len * sizeof(double), ctx->stream_aux));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_zero, ctx->stream_aux));
+        ctx->zero_pending = true;
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(ctx->stats, 0, ctx->stats_len * sizeof(double), ctx->stream));
+    }
     ctx->stats_fresh = true;
     if (ctx->hmm_ksai) return pcl_hmm_acc_zero(ctx);      // the per-unit transition accumulators restart at ln 0 (LHMM.py:84-85)
     return PCL_OK;
@@ -1321,6 +1340,7 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
         TRY(ensure_frames64(ctx));
         TRY(pcl_ensure_layouts(ctx, PCL_LAYOUT_P64));
     }
+    HIPCHK(ctx, pcl_stats_join(ctx));
     const int rc = pcl_launch_accumulate(ctx, b, precision);
     ctx->stats_fresh = false;
     if (rc == PCL_OK) HIPCHK(ctx, pcl_batch_mark(b));
@@ -1331,6 +1351,7 @@ int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covarian
     if (!b) return PCL_ERR_INVALID;
     pcl_ctx *ctx = b->ctx;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: no model uploaded");
+    HIPCHK(ctx, pcl_stats_join(ctx));
     if (payload != PCL_F64 && payload != PCL_F32) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate_exchange: payload %d", payload);
     if (n_chunks < 1) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_accumulate_exchange: n_chunks %d", n_chunks);
     if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_accumulate_exchange: pcl_comm_init was not called");
@@ -1351,6 +1372,7 @@ int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covarian
 int pcl_mstep(pcl_ctx *ctx, double c_covariance) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_mstep: no model uploaded");
+    HIPCHK(ctx, pcl_stats_join(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return pcl_launch_mstep(ctx, c_covariance);
 }
@@ -1410,6 +1432,7 @@ int pcl_accumulate_prune(pcl_ctx *ctx, double log2_threshold) {
 int pcl_stats_download(pcl_ctx *ctx, double *acc, double *alpha_acc, double *mean_acc, double *cov_acc) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_download: no model uploaded");
+    HIPCHK(ctx, pcl_stats_join(ctx));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // [acc | alpha | mean | cov]: only as far as the caller asks (the two moment blocks are 99 % of the bytes)
     const size_t need = cov_acc ? ctx->stats_len : mean_acc ? (size_t)(ctx->st_cov - ctx->stats) : (size_t)(ctx->st_mean - ctx->stats);

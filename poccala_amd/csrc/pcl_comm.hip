@@ -399,6 +399,7 @@ int pcl_comm_info(pcl_ctx *ctx, int *rank, int *nranks, int *transport, int *rcc
 int pcl_stats_allreduce(pcl_ctx *ctx) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_allreduce: no model uploaded");
+    HIPCHK(ctx, pcl_stats_join(ctx));
     if (ctx->transport == 0) {
         if (ctx->nranks == 1) return PCL_OK;   // single GPU: nothing to merge
         PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_allreduce: pcl_comm_init was not called");
@@ -416,6 +417,7 @@ int pcl_stats_allreduce(pcl_ctx *ctx) {
 int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_transitions) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: no model uploaded");
+    HIPCHK(ctx, pcl_stats_join(ctx));
     if (payload != PCL_F64 && payload != PCL_F32) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_em_exchange: payload %d", payload);
     if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: pcl_comm_init was not called");
     if (update_transitions && !ctx->hmm_ksai) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_em_exchange: update_transitions without pcl_units_upload");
