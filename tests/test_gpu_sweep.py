@@ -1,0 +1,171 @@
+"""A corpus sweep hands every worker call a NEW (label, data) (AcousticModel.py:664-681 generator, :861-870 fan-out): batches are
+created while the GPU works on the previous ones and dropped when their results have been read.  What round 5 built for that --
+descriptor uploads staged and copied by one kernel, pcl_batch_destroy that parks a batch until ITS OWN last work has completed,
+the accumulate pass's scratch owned by the context, pcl_stats_zero beside the scoring -- must not change a bit of any result.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from poccala_amd import Engine, synth
+    units, M, D, U, T, L = 12, 96, 39, 48, 120, 6
+    mean, var, w, trans = synth.make_model(units, M, D, seed=401)
+    frames, lens, begin = synth.make_frames(2 * U, T, D, seed=402, ragged=True)
+    sets = [synth.make_labels(U, L, units, seed=410 + k) for k in range(5)]
+    eng = Engine(0)
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack(trans))
+    eng.load_frames(frames)
+    yield dict(eng=eng, U=U, lens=lens, begin=begin, sets=sets, model=(mean, var, w, trans))
+    eng.close()
+
+
+def _reference(setup, k, P):
+    """the results of label set k on a batch nobody hurries: created, run, read, closed with the device idle"""
+    eng, U = setup['eng'], setup['U']
+    half = k % 2
+    eng.sync()
+    b = eng.label_batch(setup['sets'][k % len(setup['sets'])], setup['lens'][U * half:U * (half + 1)], setup['begin'][U * half:U * (half + 1)])
+    b.score(P)
+    b.forward_backward(fix_pi=False)
+    b.viterbi()
+    out = dict(logp=b.get('logp'), B=np.concatenate([x.ravel() for x in b.get('B')]), lgamma=np.concatenate([x.ravel() for x in b.get('lgamma')]),
+               path=np.concatenate(b.get('path')), npass=b.get('npass'))
+    b.close()
+    eng.sync()
+    return out
+
+
+def test_batches_made_and_dropped_inside_a_busy_stream_give_the_same_bits(setup):
+    """30 steps: create (new labels every step, as one (U, L) array and as a list of arrays), score, forward-backward, Viterbi,
+    results on their way; the batch of three steps ago is read and dropped while later steps are queued.  Every step's results
+    equal those of an unhurried batch of the same labels, bit for bit."""
+    from poccala_amd import PCL_F32
+    eng, U = setup['eng'], setup['U']
+    refs = {k: _reference(setup, k, PCL_F32) for k in range(len(setup['sets']) * 2)}
+    live = []
+    checked = 0
+    for step in range(30):
+        k = step % (len(setup['sets']) * 2)
+        half = k % 2
+        labels = setup['sets'][k % len(setup['sets'])]
+        if step % 2:
+            labels = np.stack(labels).astype(np.int32)                 # the (U, L) fast path
+        b = eng.label_batch(labels, setup['lens'][U * half:U * (half + 1)], setup['begin'][U * half:U * (half + 1)])
+        b.score(PCL_F32)
+        b.forward_backward(fix_pi=False)
+        b.viterbi()
+        res = b.result_buffers(slot=step % 4)
+        b.fetch_async(res)
+        live.append((k, b, res))
+        if len(live) > 3:
+            kk, old, r = live.pop(0)
+            old.fetch_wait()
+            ref = refs[kk]
+            assert np.array_equal(r['logp'], ref['logp'])
+            assert np.array_equal(r['path'], ref['path'])
+            got = np.concatenate([v.ravel() for v in old.lgamma_views(r['lgamma'])])
+            assert np.array_equal(got, ref['lgamma'], equal_nan=True)
+            old.close()                                                # parked or freed: the handle is dead either way
+            checked += 1
+    for kk, b, r in live:
+        b.fetch_wait()
+        assert np.array_equal(r['logp'], refs[kk]['logp'])
+        b.close()
+    assert checked == 27
+    eng.sync()
+
+
+def test_a_dropped_batch_is_parked_until_its_own_work_is_done(setup):
+    """close() right behind the launches, without reading anything: the batch's kernels are still queued or running, its memory
+    must not be handed to the next batch before they finish.  The next batches are created at once (from the pool) and checked;
+    a context-wide sync then frees what was parked.  Destroying with PCL_DESTROY_SYNC semantics is not needed for correctness."""
+    from poccala_amd import PCL_F32
+    eng, U = setup['eng'], setup['U']
+    refs = {k: _reference(setup, k, PCL_F32) for k in range(4)}
+    for rep in range(6):
+        doomed = []
+        for k in range(4):
+            half = k % 2
+            b = eng.label_batch(setup['sets'][k], setup['lens'][U * half:U * (half + 1)], setup['begin'][U * half:U * (half + 1)])
+            b.score(PCL_F32)
+            b.forward_backward(fix_pi=False)
+            doomed.append(b)
+        for b in doomed[:3]:
+            b.close()                                                  # three of the four die with their work in flight
+        keep = doomed[3]
+        more = eng.label_batch(setup['sets'][1], setup['lens'][U:2 * U], setup['begin'][U:2 * U])       # takes blocks from the pool right away
+        more.score(PCL_F32)
+        more.forward_backward(fix_pi=False)
+        assert np.array_equal(keep.get('logp'), refs[3]['logp'])
+        assert np.array_equal(more.get('logp'), refs[1]['logp'])
+        assert np.array_equal(np.concatenate([x.ravel() for x in more.get('B')]), refs[1]['B'])
+        keep.close()
+        more.close()
+    eng.sync()
+
+
+def test_the_accumulate_scratch_of_the_context_serves_every_batch(setup):
+    """Three batches accumulate into ONE statistics block through the context's work lists and tile images, in turn, with the
+    statistics cleared on the auxiliary stream beside the first scoring: the block equals the sum of three single-batch blocks
+    bit for bit (acc, alpha_acc: float64 sums in a fixed order), whether the batches are resident or made and dropped on the way."""
+    from poccala_amd import PCL_F32
+    eng, U = setup['eng'], setup['U']
+
+    def batch(k):
+        half = k % 2
+        return eng.label_batch(setup['sets'][k], setup['lens'][U * half:U * (half + 1)], setup['begin'][U * half:U * (half + 1)])
+    singles = []
+    for k in range(3):
+        b = batch(k)
+        eng.stats_zero()
+        b.score(PCL_F32); b.forward_backward(fix_pi=False); b.accumulate(PCL_F32); b.accumulate_hmm()
+        singles.append((eng.stats_download(), eng.hmm_acc_download()))
+        b.close()
+    # resident: all three alive, passes interleaved with scoring
+    bs = [batch(k) for k in range(3)]
+    eng.stats_zero()
+    for b in bs:
+        b.score(PCL_F32); b.forward_backward(fix_pi=False)
+    for b in bs:
+        b.accumulate(PCL_F32); b.accumulate_hmm()
+    st_res = eng.stats_download()
+    for b in bs:
+        b.close()
+    # made and dropped on the way
+    eng.stats_zero()
+    for k in range(3):
+        b = batch(k)
+        b.score(PCL_F32); b.forward_backward(fix_pi=False); b.accumulate(PCL_F32); b.accumulate_hmm()
+        b.close()
+    st_fresh = eng.stats_download()
+    for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+        assert np.array_equal(st_res[key], st_fresh[key]), key
+    want = sum(s[0]['alpha_acc'] for s in singles)
+    np.testing.assert_allclose(st_res['alpha_acc'], want, rtol=1e-13)
+    np.testing.assert_allclose(st_res['acc'], sum(s[0]['acc'] for s in singles), rtol=1e-12, atol=1e-300)
+
+
+def test_a_model_reupload_between_passes_rebuilds_the_scratch(setup):
+    """pcl_model_upload releases the context's accumulate scratch (it is sized for the model); the next pass rebuilds it."""
+    from poccala_amd import PCL_F32, synth
+    eng, U = setup['eng'], setup['U']
+    mean, var, w, trans = setup['model']
+    b = eng.label_batch(setup['sets'][0], setup['lens'][:U], setup['begin'][:U])
+    eng.stats_zero()
+    b.score(PCL_F32); b.forward_backward(fix_pi=False); b.accumulate(PCL_F32)
+    first = eng.stats_download(moments=False)
+    b.close()
+    m2, v2, w2, _ = synth.make_model(mean.shape[0] // 3, mean.shape[1], mean.shape[2], seed=499)
+    eng.load_model(m2, v2, w2)
+    eng.load_model(mean, var, w)
+    b = eng.label_batch(setup['sets'][0], setup['lens'][:U], setup['begin'][:U])
+    eng.stats_zero()
+    b.score(PCL_F32); b.forward_backward(fix_pi=False); b.accumulate(PCL_F32)
+    again = eng.stats_download(moments=False)
+    b.close()
+    assert np.array_equal(first['acc'], again['acc']) and np.array_equal(first['alpha_acc'], again['alpha_acc'])
