@@ -822,9 +822,7 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     hipStream_t main_stream = ctx->stream;
     if (ctx->dp_async) {
         if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
-        if (!b->ev_main) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(b->ev_main, ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0));
+        HIPCHK(ctx, pcl_dp_follows_main(b));
     }
     struct StreamSwap {                                                        // the launches below and their timer use ctx->stream
         pcl_ctx *c;

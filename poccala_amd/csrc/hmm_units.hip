@@ -336,6 +336,19 @@ int pcl_batch_create_labels(pcl_ctx *ctx, int U, const int32_t *label_len, const
         pcl_set_error(ctx, "pcl_batch_create_labels: copy failed");
         rc = PCL_ERR_HIP;
     }
+    if (rc == PCL_OK && ctx->stream_desc && pcl_fewer_markers()) {
+        // the constant entry / exit rows of the emission matrix (AcousticModel.py:218-219), here instead of in front of the batch's first
+        // scoring launch: on the descriptor stream, beside whatever the main stream is doing (the buffer is fresh, nobody reads it yet)
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream_desc;
+        rc = pcl_launch_fill_virtual_rows(ctx, b);
+        ctx->stream = main_stream;
+        if (rc == PCL_OK && hipStreamSynchronize(ctx->stream_desc) != hipSuccess) {
+            pcl_set_error(ctx, "pcl_batch_create_labels: fill failed");
+            rc = PCL_ERR_HIP;
+        }
+        if (rc == PCL_OK) b->virt_rows_filled = true;
+    }
     if (rc != PCL_OK) {
         const std::string keep = ctx->err;
         (void)uploads.finish();

@@ -1048,6 +1048,7 @@ int pcl_batch_score(pcl_batch *b, int precision) {
     }
     TRY(pcl_launch_dup_rows(ctx, b));                              // rows of a state an utterance's label names again
     HIPCHK(ctx, pcl_batch_mark(b));
+    b->mark_is_score = true;
     b->have_B = true;
     b->have_fb = b->have_vit = false;
     return PCL_OK;
@@ -1078,9 +1079,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
         // stream_dp waits for everything queued on the main stream so far (the scoring of this batch), runs the
         // recursion, and leaves an event for whoever touches the batch next
         if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
-        if (!b->ev_main) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(b->ev_main, ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0));
+        HIPCHK(ctx, pcl_dp_follows_main(b));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream_dp;                      // the launcher and its timer use ctx->stream
         const int rc = pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold);
@@ -1091,6 +1090,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
     } else {
         TRY(pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold));
         HIPCHK(ctx, pcl_batch_mark(b));
+        b->mark_is_score = false;
     }
     b->have_fb = true;
     b->have_post = true;
@@ -1117,9 +1117,7 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
         // the NEXT batch's scoring; in order with a forward-backward of the same batch already queued there (round 4: on the main
         // stream the 0.35 ms recursion sat between two scoring kernels -- config 3's step is score + Viterbi)
         if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
-        if (!b->ev_main) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
-        HIPCHK(ctx, hipEventRecord(b->ev_main, ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0));
+        HIPCHK(ctx, pcl_dp_follows_main(b));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream_dp;                      // the launcher and its timer use ctx->stream
         const int rc = pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0);
@@ -1131,6 +1129,7 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
         TRY(batch_join(b));
         TRY(pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0));
         HIPCHK(ctx, pcl_batch_mark(b));
+        b->mark_is_score = false;
     }
     b->have_vit = true;
     return PCL_OK;
@@ -1243,10 +1242,15 @@ int pcl_batch_fetch_async(pcl_batch *b, double *logp, double *lgamma_tm, double 
         HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_fetch_src, hipEventDisableTiming));
     }
     hipStream_t ds = ctx->stream_d2h;
-    // behind what the batch has queued: the main stream as of now (scoring, Viterbi), the second stream's forward-backward
-    HIPCHK(ctx, hipEventRecord(b->ev_fetch_src, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_fetch_src, 0));
-    if (b->dp_pending) HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_dp, 0));
+    // behind what the batch has queued: the second stream's recursion (which itself waited for the batch's scoring) when one is
+    // pending -- no packet on the main stream then --, else the main stream as of now
+    if (b->dp_pending && pcl_fewer_markers()) {
+        HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_dp, 0));
+    } else {
+        HIPCHK(ctx, hipEventRecord(b->ev_fetch_src, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_fetch_src, 0));
+        if (b->dp_pending) HIPCHK(ctx, hipStreamWaitEvent(ds, b->ev_dp, 0));
+    }
     if (ksai_nz) {
         if (!b->nz_tmp) TRY(dev_alloc(ctx, &b->nz_tmp, (size_t)b->nnz));
         hipStream_t main_stream = ctx->stream;
@@ -1344,7 +1348,7 @@ int pcl_batch_accumulate(pcl_batch *b, int precision) {
     const int rc = pcl_launch_accumulate(ctx, b, precision);
     ctx->stats_fresh = false;
     if (rc == PCL_OK) HIPCHK(ctx, pcl_batch_mark(b));
-    return rc;
+    return rc;                                               // (accumulate writes nothing the recursion reads: mark_is_score stays)
 }
 
 int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covariance, int payload, int update_transitions, int n_chunks) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -246,6 +247,7 @@ struct pcl_batch {
     ScoreTile *d_tiles = nullptr;            // tiles for the precision last scored with (MFMA kernel in MFMA mode)
     std::vector<int> acc_ws, acc_lo, acc_hi, acc_split; // accumulate's state order (well-conditioned first)
     hipEvent_t ev_main = nullptr, ev_dp = nullptr;   // main stream -> stream_dp hand-over, and back
+    bool mark_is_score = false;              // ev_mark sits right behind this batch's last scoring: the second stream may wait for IT instead of a new record on the main stream
     hipEvent_t ev_mark = nullptr;            // the main stream behind the last work this batch queued there (pcl_batch_mark): what pcl_batch_destroy waits for -- not the work later batches queued behind it
     bool dp_pending = false;                 // forward-backward queued on stream_dp and not yet joined
     hipEvent_t ev_fetch = nullptr, ev_fetch_src = nullptr;   // pcl_batch_fetch_async: copies done / the main stream at the time of the call
@@ -420,6 +422,23 @@ static inline hipError_t pcl_batch_mark(pcl_batch *b) {
         if (e != hipSuccess) return e;
     }
     return hipEventRecord(b->ev_mark, b->ctx->stream);
+}
+
+// Fewer packets between two scoring launches on the main queue (tools/trace_gaps.py: every event record is a marker the command
+// processor handles between the kernels): the recursion on the second stream waits for the event pcl_batch_score left (ev_mark), and
+// pcl_batch_fetch_async for the recursion's event, instead of each recording one more on the main stream.  PCL_FEWER_MARKERS=0: as rounds 1-4.
+static inline bool pcl_fewer_markers() {
+    static const bool on = !(getenv("PCL_FEWER_MARKERS") && atoi(getenv("PCL_FEWER_MARKERS")) == 0);
+    return on;
+}
+// stream_dp behind this batch's main-stream work
+static inline hipError_t pcl_dp_follows_main(pcl_batch *b) {
+    pcl_ctx *ctx = b->ctx;
+    hipError_t e;
+    if (pcl_fewer_markers() && b->mark_is_score && b->ev_mark) return hipStreamWaitEvent(ctx->stream_dp, b->ev_mark, 0);
+    if (!b->ev_main && (e = hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(b->ev_main, ctx->stream)) != hipSuccess) return e;
+    return hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0);
 }
 
 // shared by pcl_api.hip and hmm_units.hip (C linkage, internal)
