@@ -147,3 +147,65 @@ def test_save_acc_file_writes_np_save_bytes_and_never_overwrites(tmp_path):
     assert os.path.basename(save_acc_file(d, 'GMM_acc', 1700000001, np.zeros(2))) == 'GMM_acc_1700000001001.npy'
     t = np.arange(6.).reshape(2, 3).T                                     # not C-contiguous: written in C order
     assert np.array_equal(np.load(save_acc_file(d, 'GMM_acc', 1700000002, t)), t)
+
+
+def test_load_unit_has_the_reference_semantics(tmp_path, monkeypatch):
+    """AcousticModel.load_unit(unit_type=None) (AcousticModel.py:134-161): `$unit_file_path/<unit_type>`, the unit type taken over when
+    given, UnitFileExistsError for a missing file, the parameter directory of the type created; unit_file= reads a path."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    from poccala_amd.Exceptions import UnitFileExistsError
+    units = tmp_path / 'Unit'
+    units.mkdir()
+    (units / 'XIF_tone').write_text('a description line\nb,p,m\na0,a1\n')
+    (units / 'IF').write_text('another\nzh,ch\n')
+    monkeypatch.setenv('unit_file_path', str(units))
+    params = tmp_path / 'PARAMS'
+    am = AcousticModel(None, 'XIF_tone', parameters_path=str(params))
+    am.load_unit()
+    assert am.loaded_units == ['b', 'p', 'm', 'a0', 'a1'] and (params / 'XIF_tone').is_dir()
+    am.load_unit('IF')                                       # the unit type is taken over (AcousticModel.py:140-141)
+    assert am.loaded_units[-2:] == ['zh', 'ch'] and (params / 'IF').is_dir()
+    assert am.unit_path('zh').endswith('/IF/zh')
+    with pytest.raises(UnitFileExistsError):
+        am.load_unit('nothing_here')
+    am2 = AcousticModel(None, 'XIF_tone', parameters_path=str(params))
+    am2.load_unit(unit_file=str(units / 'IF'))
+    assert am2.loaded_units == ['zh', 'ch']
+
+
+def test_gmm_data_holder_methods():
+    """Clustering.GMM.add_data / clear_data / data setter (Clustering.py:106-120, 166-174)."""
+    from poccala_amd.StatisticalModel.Clustering import Clustering
+    g = Clustering.GMM(None, dimension=3, mix_level=2)
+    assert g.data is None
+    g.add_data([[1., 2., 3.], [4., 5., 6.]])
+    g.add_data(np.ones((1, 3)))
+    assert g.data.shape == (3, 3)
+    g.clear_data()
+    assert g.data is None
+    g.data = [[0., 0., 0.]]
+    assert g.data.shape == (1, 3)
+
+
+def test_worker_shim_copies_what_it_queues_and_warns_when_dropped(tmp_path):
+    """The deferred workers (AcousticModel.multi_embedded_training_1 / multi_process_data) copy the caller's data at call time -- the
+    reference's Pool pickled them (AcousticModel.py:865-870), a caller may refill its buffer -- keep every call's own (fix_code, init),
+    and a model dropped with calls still queued says so instead of losing them silently."""
+    import gc
+    import warnings
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    am = AcousticModel(None, 'XIF_tone', parameters_path=str(tmp_path))
+    am.flush_frames = 1 << 30
+    buf = np.zeros((7, 39), dtype=np.float32)
+    am.multi_embedded_training_1(['a', 'b'], buf, True, False, 1, 2, 2)
+    buf[:] = 9.0                                             # the caller refills its buffer
+    am.multi_embedded_training_1(['a'], buf, False, False, 2, 2, 0)
+    q = am._AcousticModel__queued['train']
+    assert [(x[2], x[3]) for x in q] == [(True, 2), (False, 0)]
+    assert q[0][1].max() == 0.0 and q[1][1].min() == 9.0 and q[0][1] is not buf
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        am._AcousticModel__queued = {'train': q, 'align': []}
+        del am
+        gc.collect()
+    assert any('never flushed' in str(x.message) for x in w)
