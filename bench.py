@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 T_PROCESS_START = time.perf_counter()
 CPU_SAMPLE_FRAMES = 60            # frames per utterance in the CPU baseline sample (a fifth of an utterance per core: ~20 s of the cache-blocked vectorised leg with every core busy)
+CPU_GEMM_FRAMES = 300             # ... and in the GEMM leg's: the whole utterance (seconds per core)
 CPU_FAITHFUL_ROWS = 12            # label states (of 60) the reference's per-mixture loop nest is timed on, scaled to all of them
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32 matrix (v_mfma_f32_*_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6    # 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
@@ -129,13 +130,13 @@ def spawn_ranks(args):
 _CPU_JOBS = None      # set by cpu_baseline() BEFORE the pool forks: the workers read their job by index, nothing is pickled
 
 
-def _cpu_job(u):
+def _cpu_job(u, nfr=None):
     """(frames (T,D) f64, [(mean, var, w)] of the label's states, A, pi) of sample utterance u, from the forked globals."""
     from poccala_amd.engine import embedded_structure
     cfg, mean, var, w, trans, frames, lens, begin, labels = _CPU_JOBS
     e = 3
     lab = labels[u]
-    x = frames[begin[u]:begin[u] + min(int(lens[u]), CPU_SAMPLE_FRAMES)].astype(np.float64)   # bounded sample
+    x = frames[begin[u]:begin[u] + min(int(lens[u]), nfr or CPU_SAMPLE_FRAMES)].astype(np.float64)   # bounded sample
     gm = [(mean[i * e + k], var[i * e + k], w[i * e + k]) for i in lab for k in range(e)]
     a, pi = embedded_structure(len(lab), [trans[i] for i in lab])
     return x, gm, a, pi
@@ -164,7 +165,7 @@ def _cpu_gemm_utt(u):
     implementation of the same mathematics would do on these cores."""
     from threadpoolctl import threadpool_limits
     from oracle import poccala_oracle as po
-    x, gmms_per_row, a, pi = _cpu_job(u)
+    x, gmms_per_row, a, pi = _cpu_job(u, CPU_GEMM_FRAMES)      # the whole utterance: the per-state parameter preparation is paid once per utterance, as in a real job
     with threadpool_limits(limits=1):
         t0 = time.perf_counter()
         rows = [np.zeros(x.shape[0])]
@@ -225,10 +226,11 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
     frames_done = int(sum(n for _, n in vec))
     nfr, nrows = vec[0][1], 3 * len(labels[0])
     faithful = n_utt / float(max(per_frame))                       # every core one frame at a time, the slowest core sets the rate
-    vec_value, gemm_value = frames_done / max(t for t, _ in vec), frames_done / max(t for t, _ in gemm)
+    vec_value, gemm_value = frames_done / max(t for t, _ in vec), int(sum(n for _, n in gemm)) / max(t for t, _ in gemm)
     lead = 'gemm' if gemm_value >= vec_value else 'vectorised'
-    common = ('first %d frames of %d utterances (one utterance per core, forked workers reading the job from inherited memory, timed inside the '
-              'workers: frames / slowest worker); score %d label states x %d mixtures + 3-pass forward-backward' % (nfr, n_utt, nrows, cfg['M']))
+    common = ('%d utterances, one per core (forked workers reading the job from inherited memory, timed inside the workers: frames / slowest worker): '
+              'the first %d frames of each in the vectorised leg, the first %d (the whole utterance) in the GEMM leg; score %d label states x %d '
+              'mixtures + 3-pass forward-backward' % (n_utt, nfr, gemm[0][1], nrows, cfg['M']))
     legs = dict(gemm='oracle.gmm_point_gemm: the expanded quadratic form as one float64 BLAS GEMM per state, 1 thread per worker -- the STRONGEST CPU formulation '
                      'of this path (what an optimised CPU implementation would do; not the reference\'s order of operations)',
                 vectorised='oracle.gmm_point_blocked: the reference\'s arithmetic (subtract, scale, square, sum; util.py:22-31) vectorised in float64 NumPy and '
