@@ -1022,6 +1022,7 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     eng.sync()
     barrier()
     batch = batches[0]
+    eng.kernel_time('viterbi')                 # (the PCIe-inclusive loop left its launches in the timer)
     t1 = time.perf_counter()
     batch.viterbi()
     eng.sync()
@@ -1033,7 +1034,8 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
     batch.regroup(row_unit, 3)
     t_regroup = time.perf_counter() - t1
     rg_ms, _ = eng.kernel_time('regroup')
-    vit_ms, _ = eng.kernel_time('viterbi')
+    vit_ms, vit_n = eng.kernel_time('viterbi')
+    vit_ms /= max(vit_n, 1)
     # PCIe legs the timed region excludes (the whole resident frame matrix, per batch)
     t1 = time.perf_counter()
     eng.load_frames(frames)
