@@ -834,7 +834,7 @@ int pcl_batch_decode(pcl_batch *b, double beam, int min_distinct, int candidate,
     // left-to-right units (every model the reference builds): one lane per token, hmm_decode_lr.hip; PCL_DEC_GENERAL=1 keeps
     // the general kernel (the parity tests run both against the restatement)
     const char *force_general = getenv("PCL_DEC_GENERAL");
-    const bool use_lr = !(force_general && atoi(force_general)) && pcl_decode_lr_applicable(ctx, J + 2, cap);
+    const bool use_lr = !(force_general && atoi(force_general)) && pcl_decode_lr_applicable(ctx, J + 2, cap, Tm);
     if (b->dec_cap != cap || b->dec_cand != candidate || b->dec_nodes != ctx->lex_nodes) {
         pcl_batch_decode_release(b);
         // doubles per utterance: score 2 cap | p 2 cap NS | seg_score cap + 2;  ints: node, hist, upair 2 cap each | flag, dst cap each |

@@ -41,5 +41,5 @@ __device__ __forceinline__ int pcl_wave_sum(int v) {
 
 // hmm_decode_lr.hip: true when every unit matrix is left-to-right (row 0 reaches state 1 only, an emitting state itself and
 // its successor only) and S = 5 -- then the fast kernel gives the general kernel's bits and pcl_decode_lr_launch runs it.
-bool pcl_decode_lr_applicable(const pcl_ctx *ctx, int n_rows, int cap);
+bool pcl_decode_lr_applicable(const pcl_ctx *ctx, int n_rows, int cap, int t_max);
 int pcl_decode_lr_launch(pcl_ctx *ctx, const DecArgs &a, int U, int n_rows);

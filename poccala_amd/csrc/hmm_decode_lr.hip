@@ -29,7 +29,8 @@
 //       first step at once (:135-140), by the same thread                                                        -> 2 barriers per 2048 pairs
 //   E   pruning (Decoder.py:159-167) over the old unfinished tokens, keys in registers: 12-bit radix digit below the keys'
 //       common prefix, then the few keys of the selected bin ranked directly in LDS                               -> 6 barriers
-//   F   stable compaction of the index list (src) + the node -> token map; nothing else moves                    -> 2 barriers
+//   F   stable compaction of the index list (src); nothing else moves, and the node -> token map is stamped per frame by
+//       the step itself (round 5: entries of another frame are stale and read as "no token")                                   -> 2 barriers
 #include <math.h>
 #include <stdio.h>
 
@@ -52,6 +53,7 @@ constexpr int HB = 12, HBINS = 1 << HB, BPT = HBINS / LW;    // radix digit of t
 constexpr int CAND = 1024;          // keys of the selected bin ranked directly
 constexpr int DLW = 128;            // donors of a wave whose list entries live in LDS (more: in the utterance's seg_* arrays in HBM)
 constexpr int NONE = 0x7fffffff;
+constexpr int SLOT_BITS = 14;       // node -> token map entry = (frame << SLOT_BITS) | dense token index (cap <= 16 LW = 8192 < 2^14), -1 = none
 constexpr int FRESH = (int)0x80000000;   // src: the token's last step was its first (its entry state still holds ln pi)
 #ifndef PCL_DECLR_G
 #define PCL_DECLR_G 2
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
         hsb(0)[i] = -1;
         upb(0)[i] = info.w;
         srb(0)[i] = i | FRESH;
-        slot[node] = i;
+        // (the node -> token map is written by every frame's step for the tokens that step in it, stamped with the frame: frame 0 needs none)
     }
     __syncthreads();
     if (tid == 0) a.trace[(size_t)u * a.Tmax] = n;
@@ -282,12 +284,16 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
                                 up[i] = mu[g];
                             }
                             const bool don = ok && fin;
+                            // the node -> token map of THIS frame: (frame << SLOT_BITS) | dense index for a token that stepped and goes on,
+                            // -1 for one that finished (no live target: a new one for its node may be made by the pairs below).  An entry
+                            // of another frame's stamp is stale (its token was pruned, or never stepped again) and reads as "no token":
+                            // nothing has to be cleared or re-mapped when the frame's survivors are compacted
+                            if (ok) slot[mn[g]] = don ? -1 : ((t << SLOT_BITS) | i);
                             const unsigned long long mask = __ballot(don);
                             if (mask != 0ull) {                    // (a few per cent of the tokens finish in a frame)
                                 if (don) {
                                     finmask |= 1u << (kb + g);
                                     put(dcount + __popcll(mask & lt_mask), i, mn[g], mh[g], sn);
-                                    slot[mn[g]] = -1;              // a finished token is no live target (a new one for its node is mapped in F)
                                 }
                                 dcount += __popcll(mask);
                             }
@@ -468,7 +474,8 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
             }
 #pragma unroll
             for (int x = 0; x < PMAX; ++x) {
-                sidx[x] = val[x] ? slot[child[x]] : 0;
+                const int sv = val[x] ? slot[child[x]] : -1;       // this frame's stamp, or the node has no live token
+                sidx[x] = (sv >= 0 && (sv >> SLOT_BITS) == t) ? (sv & ((1 << SLOT_BITS) - 1)) : -1;
                 upn[x] = val[x] ? ninfo[child[x]].w : 0;
             }
             unsigned long long nmask[PMAX];
@@ -717,7 +724,8 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
             }
         }
         STAMP(4)
-        // ---- F: stable compaction of the INDEX LIST: the survivors of the old tokens, then the new ones; the node -> token map follows.
+        // ---- F: stable compaction of the INDEX LIST: the survivors of the old tokens, then the new ones (the node -> token map is
+        //      re-stamped by the next frame's step: nothing to follow here).
         //      Scores, nodes, histories, unit pairs and p stay where this frame wrote them: the next frame's step gathers them through
         //      the list (an ascending sequence with the pruned tokens' gaps: nearly coalesced) and writes them dense again -- round 4
         //      moved score + meta here as well (24 B in, 24 B out per token and frame, and a dependent load round)
@@ -742,23 +750,10 @@ __global__ __launch_bounds__(LW) PCL_DECLR_WAVES_ATTR void hmm_decode_lr_kernel(
             const int i = w0 + k * 64 + lane;
             const bool old = i < n && !((finmask >> k) & 1u), keep = old && !((prunemask >> k) & 1u);
             const unsigned long long mask = __ballot(keep);
-            if (old) {
-                const int node = nd[i];
-                if (keep) {
-                    const int to = krun + __popcll(mask & lt_mask);
-                    srn[to] = i;                                   // where the token's state sits in this frame's buffers
-                    slot[node] = to;
-                } else {
-                    slot[node] = -1;                               // pruned (a live target all frame long: nobody else maps its node)
-                }
-            }
+            if (keep) srn[krun + __popcll(mask & lt_mask)] = i;    // where the token's state sits in this frame's buffers
             krun += __popcll(mask);
         }
-        for (int j = tid; j < n_new; j += LW) {
-            const int i = n + j, to = n_keep + j;
-            srn[to] = i | FRESH;
-            slot[nd[i]] = to;
-        }
+        for (int j = tid; j < n_new; j += LW) srn[n_keep + j] = (n + j) | FRESH;
         if (t + 1 < T) {                                           // the next frame's emission row
             double *Bn = Bsl + ((t + 1) & 1) * NbP;
             if (pre) {
@@ -845,8 +840,9 @@ size_t lr_dyn_bytes(const pcl_ctx *ctx, int n_rows) {
 
 }  // namespace
 
-bool pcl_decode_lr_applicable(const pcl_ctx *ctx, int n_rows, int cap) {
-    if (ctx->S != 5 || cap > 16 * LW) return false;
+bool pcl_decode_lr_applicable(const pcl_ctx *ctx, int n_rows, int cap, int t_max) {
+    if (ctx->S != 5 || cap > 16 * LW || cap > (1 << SLOT_BITS)) return false;
+    if (t_max >= (1 << (31 - SLOT_BITS))) return false;            // (the frame stamp of the node -> token map: utterances of up to 131071 frames)
     if (lr_dyn_bytes(ctx, n_rows) + LR_STATIC_LDS > LR_LDS_BUDGET) return false;
     const double *lt = ctx->unit_logtrans.data();
     for (int u = 0; u < ctx->n_units; ++u)
