@@ -1301,7 +1301,9 @@ int pcl_stats_zero(pcl_ctx *ctx) {
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_stats_zero: no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     static const bool zero_async = !(getenv("PCL_ZERO_ASYNC") && atoi(getenv("PCL_ZERO_ASYNC")) == 0);      // 0: on the main stream (rounds 1-4; A/B)
-    if (zero_async && ctx->stream_aux) {
+    // (a small block -- the one-unit models of the per-object drop-in route -- is cleared in microseconds where it is: the hop to another
+    //  queue and back costs more than that)
+    if (zero_async && ctx->stream_aux && ctx->stats_len * sizeof(double) >= ((size_t)64 << 20)) {
         // beside whatever the main stream does next (an E-step starts with the scoring of its first batch, which does not touch the block):
         // behind everything queued so far (the block's last readers), on the auxiliary stream
         if (!ctx->ev_zero) {
