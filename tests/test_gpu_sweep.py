@@ -169,3 +169,38 @@ def test_a_model_reupload_between_passes_rebuilds_the_scratch(setup):
     again = eng.stats_download(moments=False)
     b.close()
     assert np.array_equal(first['acc'], again['acc']) and np.array_equal(first['alpha_acc'], again['alpha_acc'])
+
+
+def test_descriptor_staging_grows_in_the_middle_of_a_batch():
+    """A label batch whose descriptor arrays exceed the 16-MiB staging buffer (and whose single arrays exceed what is left of it):
+    pcl_h2d_fresh flushes what is staged, grows the buffer and goes on, in the middle of pcl_batch_create_labels.  The batch must
+    equal the same utterances created as four smaller batches (whose arrays fit) -- ln P(O) and Viterbi paths bit for bit."""
+    from poccala_amd import Engine, PCL_F32, synth
+    units, M, D, U, T, L = 40, 8, 13, 6000, 12, 60
+    mean, var, w, trans = synth.make_model(units, M, D, seed=77)
+    frames, lens, begin = synth.make_frames(U, T, D, seed=78)
+    labels = np.stack(synth.make_labels(U, L, units, seed=79)).astype(np.int32)
+    eng = Engine(0)
+    try:
+        eng.load_model(mean, var, w)
+        eng.load_units(np.stack(trans))
+        eng.load_frames(frames)
+        nseg = U * L * 3
+        assert nseg * 32 > (16 << 20)                       # the segment list alone is larger than the initial staging buffer
+
+        def run(lo, hi):
+            b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi])
+            b.score(PCL_F32)
+            b.forward_backward(fix_pi=False)
+            b.viterbi()
+            out = (b.get('logp'), np.concatenate(b.get('path')))
+            b.close()
+            return out
+        big = run(0, U)
+        parts = [run(k * U // 4, (k + 1) * U // 4) for k in range(4)]
+        assert np.array_equal(big[0], np.concatenate([p[0] for p in parts]))
+        assert np.array_equal(big[1], np.concatenate([p[1] for p in parts]))
+        again = run(0, U)                                    # (the buffer has grown: no flush in the middle this time)
+        assert np.array_equal(big[0], again[0]) and np.array_equal(big[1], again[1])
+    finally:
+        eng.close()
