@@ -130,7 +130,8 @@ namespace {
 __global__ void desc_copy_kernel(DescCopyArgs a, const char *__restrict__ stage) {
     const int e = blockIdx.y;
     if (e >= a.n) return;
-    const unsigned long long n = a.bytes[e];
+    const unsigned long long n = a.bytes[e];                          // (0: the entry was superseded by a later upload of the same array)
+    if (n == 0) return;
     const char *src = stage + a.off[e];
     char *dst = (char *)a.dst[e];
     const unsigned long long n16 = n / 16;                            // (staging offsets and pool blocks are 256-byte aligned)

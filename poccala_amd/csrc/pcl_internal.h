@@ -382,6 +382,12 @@ static inline hipError_t pcl_h2d_fresh(pcl_ctx *ctx, void *dst, const void *src,
             }
         }
         memcpy(ctx->desc_pin + ctx->desc_pin_used, src, bytes);
+        // ONE kernel copies all pending entries side by side: two entries with the same destination would race.  A later upload of an array
+        // replaces the earlier one (pcl_batch_create_labels uploads the utterance descriptors twice: before and after the transition
+        // offsets are known -- when the first version won, every utterance read utterance 0's transitions: wrong results as soon as the
+        // unit matrices differ, tests/test_gpu_sweep.py::test_the_queueing_knobs_do_not_move_a_bit)
+        for (int k = 0; k < ctx->desc_n; ++k)
+            if (ctx->desc_dst[k] == dst) ctx->desc_bytes[k] = 0;
         ctx->desc_dst[ctx->desc_n] = dst;
         ctx->desc_off[ctx->desc_n] = ctx->desc_pin_used;
         ctx->desc_bytes[ctx->desc_n] = bytes;

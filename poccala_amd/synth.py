@@ -27,6 +27,18 @@ def flat_start_transmat(s=S):
     return a
 
 
+def random_left_right_transmat(rng, s=S):
+    """a left-to-right unit matrix with its own self-loop probabilities (what a transition M-step leaves): tests use it where every unit
+    having the SAME flat-start matrix would hide a mix-up between utterances or units."""
+    a = np.zeros((s, s))
+    a[0, 1] = 1.0
+    for j in range(1, s - 1):
+        x = rng.uniform(0.2, 0.8)
+        a[j, j] = x
+        a[j, j + 1] = 1.0 - x
+    return a
+
+
 def make_model(units, M, D, seed=1, s=S, dtype=np.float64):
     """(mean, var, weight) for J = units*(S-2) GMM states, and the per-unit transition matrices."""
     rng = np.random.default_rng(seed)

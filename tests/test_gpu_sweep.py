@@ -14,6 +14,8 @@ def setup():
     from poccala_amd import Engine, synth
     units, M, D, U, T, L = 12, 96, 39, 48, 120, 6
     mean, var, w, trans = synth.make_model(units, M, D, seed=401)
+    rng = np.random.default_rng(403)
+    trans = [synth.random_left_right_transmat(rng) for _ in range(units)]      # every unit its own matrix: a mix-up between utterances shows
     frames, lens, begin = synth.make_frames(2 * U, T, D, seed=402, ragged=True)
     sets = [synth.make_labels(U, L, units, seed=410 + k) for k in range(5)]
     eng = Engine(0)
@@ -178,6 +180,8 @@ def test_descriptor_staging_grows_in_the_middle_of_a_batch():
     from poccala_amd import Engine, PCL_F32, synth
     units, M, D, U, T, L = 40, 8, 13, 6000, 12, 60
     mean, var, w, trans = synth.make_model(units, M, D, seed=77)
+    rng = np.random.default_rng(80)
+    trans = [synth.random_left_right_transmat(rng) for _ in range(units)]
     frames, lens, begin = synth.make_frames(U, T, D, seed=78)
     labels = np.stack(synth.make_labels(U, L, units, seed=79)).astype(np.int32)
     eng = Engine(0)
@@ -204,3 +208,49 @@ def test_descriptor_staging_grows_in_the_middle_of_a_batch():
         assert np.array_equal(big[0], again[0]) and np.array_equal(big[1], again[1])
     finally:
         eng.close()
+
+
+def test_the_queueing_knobs_do_not_move_a_bit():
+    """PCL_DESTROY_SYNC=1 (wait in pcl_batch_destroy, rounds 1-4), PCL_FEWER_MARKERS=0 (one event record per hand-over on the main
+    stream), PCL_ZERO_ASYNC=0 (pcl_stats_zero on the main stream), GPU_MAX_HW_QUEUES=4 (the runtime's default): each only changes where
+    and when work is queued.  The same sweep (tests/_sweep_hash.py: batches made and dropped, E-step, exchange, second iteration)
+    under each of them, in a process of its own (the knobs are read once), gives one and the same hash."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for name, env in (('default', {}), ('destroy_sync', {'PCL_DESTROY_SYNC': '1'}), ('markers', {'PCL_FEWER_MARKERS': '0'}),
+                      ('zero_main', {'PCL_ZERO_ASYNC': '0'}), ('hw_queues_4', {'GPU_MAX_HW_QUEUES': '4'})):
+        p = subprocess.run([sys.executable, os.path.join(root, 'tests', '_sweep_hash.py')], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=300, cwd=root)
+        assert p.returncode == 0, (name, p.stderr[-1500:])
+        got = [l for l in p.stdout.splitlines() if l.startswith('SWEEPHASH')]
+        assert len(got) == 1, (name, p.stdout[-500:])
+        lines[name] = got[0]
+    assert len(set(lines.values())) == 1, lines
+
+
+def test_fresh_label_batches_with_unit_matrices_of_their_own(setup):
+    """Regression (round 5): pcl_batch_create_labels uploads the utterance descriptors twice -- before and after the transition offsets
+    are known -- and the staged copy kernel copied both versions side by side; when the first one won, every utterance read utterance
+    0's transitions.  Invisible while every unit has the flat-start matrix; here every unit has its own.  40 fresh batches against the
+    host-built batch of the same labels (engine.make_sentence_batch: per-utterance matrices, uploaded one array at a time)."""
+    from poccala_amd import PCL_F32
+    from poccala_amd.engine import make_sentence_batch
+    eng, U = setup['eng'], setup['U']
+    mean, var, w, trans = setup['model']
+    units = eng.units_download()
+    labels = setup['sets'][2]
+    hb, _ = make_sentence_batch(eng, labels, setup['lens'][:U], setup['begin'][:U], list(units))
+    hb.score(PCL_F32)
+    hb.forward_backward(fix_pi=False)
+    want_lp, want_lg = hb.get('logp'), np.concatenate([x.ravel() for x in hb.get('lgamma')])
+    hb.close()
+    for i in range(40):
+        b = eng.label_batch(labels, setup['lens'][:U], setup['begin'][:U])
+        b.score(PCL_F32)
+        b.forward_backward(fix_pi=False)
+        assert np.array_equal(b.get('logp'), want_lp), i
+        assert np.array_equal(np.concatenate([x.ravel() for x in b.get('lgamma')]), want_lg, equal_nan=True), i
+        b.close()
