@@ -1608,6 +1608,25 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
         bt.close()
     fresh_same = bool(np.array_equal(st_res['acc'], st_fr['acc']) and np.array_equal(st_res['alpha_acc'], st_fr['alpha_acc']))
     del st_res, st_fr
+    # ... and once more on the model ONE EM iteration leaves (every unit its own transition matrix by then: a fresh batch that mixed up
+    # utterances or units would show here and not on the flat-start model above -- a bug of round 5 did exactly that)
+    iteration()
+    estep()
+    st_res = eng.stats_download(moments=False)
+    eng.stats_zero()
+    made = []
+    for lab, lens, begin in desc:
+        bt = eng.label_batch(lab.copy(), lens, begin)
+        bt.score(P); bt.forward_backward(fix_pi=False)
+        made.append(bt)
+    for bt in made:
+        bt.accumulate(P); bt.accumulate_hmm()
+    st_fr = eng.stats_download(moments=False)
+    for bt in made:
+        bt.close()
+    fresh_same_after = bool(np.array_equal(st_res['acc'], st_fr['acc']) and np.array_equal(st_res['alpha_acc'], st_fr['alpha_acc']))
+    del st_res, st_fr
+    rewind()
     # ---- EM iterations in sequence at this variance floor: what each iteration costs as the model sharpens
     em_table = []
     if em_iters:
@@ -1662,7 +1681,7 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
                                            'evaluated by the direct-form kernels and merged (score_subset), the state stays on the matrix pipe (before: the whole state '
                                            'left it, 5x slower).  After two more iterations on noise most mixtures sit at the variance floor and whole states do leave'),
                 fresh_batches=dict(ms_per_iteration=float(np.mean(fresh_ms)), frames_per_s=nfr / (float(np.mean(fresh_ms)) * 1e-3), iterations=len(fresh_ms),
-                                   batch_create_ms_per_iteration=float(np.mean(fresh_create)), statistics_same_bits_as_resident=fresh_same, phase_ms_rank0=fresh_phases,
+                                   batch_create_ms_per_iteration=float(np.mean(fresh_create)), statistics_same_bits_as_resident=fresh_same, statistics_same_bits_after_an_em_iteration=fresh_same_after, phase_ms_rank0=fresh_phases,
                                    what='the same iteration with its 8 label batches CREATED inside the timed region (a corpus sweep hands every worker a new '
                                         '(label, data), AcousticModel.py:664-681, 861-870) and dropped at its end; batch_create_ms = host time of the 8 '
                                         'pcl_batch_create_labels calls, which run while the GPU scores the previous batch'),

@@ -134,5 +134,6 @@ def test_bench_config4_strong_scaling_line_two_ranks():
     nfr = 4 * 48 * 300
     assert d['value'] == pytest.approx(nfr / (d['ms_per_step'] * 1e-3), rel=1e-9)
     assert r['fresh_batches']['statistics_same_bits_as_resident'] is True
+    assert r['fresh_batches']['statistics_same_bits_after_an_em_iteration'] is True
     assert len(r['em_iterations']) == 2 and all(e['ms'] > 0 for e in r['em_iterations'])
     assert r['kernel_ms_per_iteration_rank0']['reduce_scatter'] >= 0 and r['kernel_ms_per_iteration_rank0']['all_gather'] >= 0
