@@ -247,10 +247,27 @@ def test_fresh_label_batches_with_unit_matrices_of_their_own(setup):
     hb.forward_backward(fix_pi=False)
     want_lp, want_lg = hb.get('logp'), np.concatenate([x.ravel() for x in hb.get('lgamma')])
     hb.close()
+    busy = eng.label_batch(setup['sets'][0], setup['lens'][U:2 * U], setup['begin'][U:2 * U])
     for i in range(40):
+        for _ in range(3):                                              # the copy kernel of the create below runs beside these
+            busy.score(PCL_F32)
+            busy.forward_backward(fix_pi=False)
         b = eng.label_batch(labels, setup['lens'][:U], setup['begin'][:U])
         b.score(PCL_F32)
         b.forward_backward(fix_pi=False)
         assert np.array_equal(b.get('logp'), want_lp), i
         assert np.array_equal(np.concatenate([x.ravel() for x in b.get('lgamma')]), want_lg, equal_nan=True), i
         b.close()
+    busy.close()
+
+
+@pytest.mark.parametrize('seed', [3, 11, 27])
+def test_randomised_sweep_equals_its_unhurried_twin(seed):
+    """tools/sweep_fuzz.py, three seeds x 25 steps: random batch shapes, operations, drop distances (some with work in flight), fetched
+    results, EM iterations with either variance floor in between -- every result of the sweeping engine equals the engine that does one
+    thing at a time with a device sync around it, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import sweep_fuzz
+    assert sweep_fuzz.run_seed(seed, 25) == []
