@@ -531,7 +531,9 @@ int pcl_launch_acc16_produce(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
     if (ns == 0) return PCL_OK;
     const int *ws = b->ctx->acc.d_work_states + first, *lo = b->ctx->acc.d_seg_lo + first, *hi = b->ctx->acc.d_seg_hi + first;
     hipLaunchKernelGGL(acc16_tiles_kernel, dim3(1), dim3(1024), 0, stream, lo, hi, b->ctx->acc.acc_off, ns, b->ctx->acc.acc16_tile_off[buf], b->ctx->acc.acc16_state_flag[buf]);
-    const int pgrid = std::min(max_tiles, std::max(ctx->cus, 1) * 16);
+    // (max_tiles = 0: no frame of the group's states survived -- a batch scored by a collapsed model can have such groups; a grid of 0 is an
+    //  invalid launch, tools/sweep_fuzz.py seed 514 -- one workgroup then finds nothing to do)
+    const int pgrid = std::max(1, std::min(max_tiles, std::max(ctx->cus, 1) * 16));
 #define PRODUCE16(DD)                                                                                                         \
     hipLaunchKernelGGL((acc16_producer_kernel<DD>), dim3(pgrid), dim3(256), 0, stream, ctx->frames32, ctx->centers32, ctx->fscale, \
                        ctx->kzero, ns, ws, lo, hi, b->ctx->acc.acc_off, b->ctx->acc.acc_list, b->ctx->acc.acc16_tile_off[buf], 0, reinterpret_cast<uint4 *>(b->ctx->acc.acc16_images[buf]),  \

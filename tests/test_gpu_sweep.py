@@ -261,13 +261,14 @@ def test_fresh_label_batches_with_unit_matrices_of_their_own(setup):
     busy.close()
 
 
-@pytest.mark.parametrize('seed', [3, 11, 27])
-def test_randomised_sweep_equals_its_unhurried_twin(seed):
-    """tools/sweep_fuzz.py, three seeds x 25 steps: random batch shapes, operations, drop distances (some with work in flight), fetched
-    results, EM iterations with either variance floor in between -- every result of the sweeping engine equals the engine that does one
-    thing at a time with a device sync around it, bit for bit."""
+@pytest.mark.parametrize('seed,steps', [(3, 25), (11, 25), (27, 25), (514, 60)])
+def test_randomised_sweep_equals_its_unhurried_twin(seed, steps):
+    """tools/sweep_fuzz.py: random batch shapes, operations, drop distances (some with work in flight), fetched results, EM iterations
+    with either variance floor in between -- every result of the sweeping engine equals the engine that does one thing at a time with a
+    device sync around it, bit for bit.  Seed 514 is the one that found an accumulate pass whose state group had NO surviving frame
+    (a collapsed model): the tile-image producer was launched with a grid of 0 (invalid configuration), rounds 2-5."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import sweep_fuzz
-    assert sweep_fuzz.run_seed(seed, 25) == []
+    assert sweep_fuzz.run_seed(seed, steps) == []
