@@ -49,9 +49,9 @@ def run_seed(seed, steps, verbose=False):
         return out
 
     for step in range(steps):
-        U = int(rng.integers(3, 50))
-        L = int(rng.integers(1, 9))
-        lens = rng.integers(8, 60, size=U).astype(np.int32)
+        U = int(rng.integers(1, 50))
+        L = int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(20, 30))      # now and then sentence HMMs of more than 64 states
+        lens = rng.integers(1 if rng.random() < 0.1 else 8, 60, size=U).astype(np.int32)         # (one-frame utterances too)
         begin = rng.integers(0, F - 60, size=U).astype(np.int64)          # utterances may overlap in the frame matrix: they only read it
         labels = [rng.integers(0, units, size=L) for _ in range(U)]
         if rng.random() < 0.5:
@@ -66,6 +66,7 @@ def run_seed(seed, steps, verbose=False):
         if 'fb' in ops and rng.random() < 0.6:
             ops.add('acc')
         fix_pi = bool(rng.random() < 0.3)
+        P = PCL_F64 if rng.random() < 0.15 else PCL_F32                                          # the float64 parity mode now and then
         # ---- B: unhurried
         B.sync()
         bb = B.label_batch(labels, lens, begin)
@@ -127,6 +128,9 @@ def run_seed(seed, steps, verbose=False):
             c_cov = float(rng.choice([1e-3, 1e-6]))
             A.em_exchange(c_cov, update_transitions=True)
             B.em_exchange(c_cov, update_transitions=True)
+            if rng.random() < 0.3:                                   # a model upload in mid-sweep (the statistics block and the scratch are rebuilt)
+                mm, vv, ww = B.model_download()
+                A.load_model(mm, vv, ww); B.load_model(mm, vv, ww)
             for x, y, nm in zip(A.model_download() + (A.units_download(),), B.model_download() + (B.units_download(),), ('mean', 'var', 'weight', 'transitions')):
                 if not np.array_equal(x, y):
                     bad.append('re-estimated %s differ at step %d (seed %d)' % (nm, step, seed))
