@@ -214,7 +214,14 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                     const _Float16 r1 = (_Float16)__builtin_fminf(__builtin_fmaxf(-(ref[c] + gp), -FMAXH), FMAXH);
                     const float nref = -(float)r1, dl = nref - ref[c];
                     ref_ovf |= __builtin_fabsf(nref) > 5.0e4f;
+                    // (in two half-steps: this path is entered when a sum overflows, i.e. with dl ~ 128, and exp2(-128) is a denormal that
+                    //  v_exp_f32 flushes to 0 -- which dropped everything summed so far, up to a third of the frame's mass, rounds 1-5)
+#ifdef PCL_LSE_FLUSH_REPRO                                    // mutation build (tests are expected to FAIL on it): rounds 1-5
                     s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-dl);
+#else
+                    const float hs = __builtin_amdgcn_exp2f(-0.5f * dl);
+                    s = (mt == 0) ? 0.f : (s * hs) * hs;
+#endif
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[c][r] -= dl;
                     ref[c] = nref;

@@ -267,6 +267,7 @@ int pcl_destroy(pcl_ctx *ctx) {
     hipStreamSynchronize(ctx->stream_dp);
     hipStreamSynchronize(ctx->stream_aux);
     if (ctx->stream_d2h) hipStreamSynchronize(ctx->stream_d2h);
+    if (ctx->stream_desc) hipStreamSynchronize(ctx->stream_desc);     // a descriptor copy still reading desc_pin
     pcl_batch_reap(ctx, true);
     if (ctx->ev_zero) hipEventDestroy(ctx->ev_zero);
     if (ctx->ev_zero_src) hipEventDestroy(ctx->ev_zero_src);

@@ -42,7 +42,7 @@ class Engine(object):
         self.F = 0
         self._model_key = self._frames_key = None
         self._stream_pool, self._stream_pinned = {}, [None]       # Decoder.decode_stream: batches per chunk shape, staging buffer
-        self._batches = []   # weak refs to live batches: destroyed before the context
+        self._batches = weakref.WeakSet()   # live batches: destroyed before the context (a sweep makes millions: dead ones leave by themselves)
         self._pinned = []    # page-locked host allocations (pinned_empty)
         self._pinned_sizes, self._pinned_named = {}, {}
         self._staged = None
@@ -54,11 +54,9 @@ class Engine(object):
 
     def close(self):
         if getattr(self, '_ctx', None):
-            for ref in list(self._batches):
-                b = ref()
-                if b is not None:
-                    b.close()
-            self._batches = []
+            for b in list(self._batches):
+                b.close()
+            self._batches = weakref.WeakSet()
             self._stream_pool, self._stream_pinned = {}, [None]
             for p in self._pinned:
                 self._lib.pcl_host_free(self._ctx, p)
@@ -436,7 +434,7 @@ class Batch(object):
             fb = None if frame_begin is None else as_c(frame_begin, np.int64).reshape(-1)
             engine._check(self._lib.pcl_batch_create(engine._ctx, self.U, ptr(self.N), ptr(self.T), ptr(fb),
                                                      C.byref(self._b)))
-        engine._batches.append(weakref.ref(self))
+        engine._batches.add(self)
         n64, t64 = self.N.astype(np.int64), self.T.astype(np.int64)
         self._nt_off = np.concatenate([[0], np.cumsum(n64 * t64)])
         self._nn_off = np.concatenate([[0], np.cumsum(n64 * n64)])

@@ -1030,6 +1030,42 @@ def test_score_variants_match_oracle(eng_variant, M, D):
     np.testing.assert_allclose(got, ref, rtol=5e-6, atol=F32_LOGLIK_ATOL)
 
 
+def far_frame_problem(gap, runner_up, R=30.0, M=96, D=39, T=70, seed=0):
+    """One state whose mixtures all sit near its centre (|mu - c| = 3.2 sigma: well inside the matrix pipe's conditioning limit) and frames
+    R sigma out along one direction e: ln N_m(x) - ln N_best(x) = R (p_m - p_best) with p_m = mu_m . e, so the spread over the mixtures is
+    set by the projections: the first tile `gap` nats below the best mixture (third tile), a runner-up `runner_up` below it (second tile)."""
+    rng = np.random.default_rng(seed)
+    e = np.zeros(D)
+    e[0] = 1.0
+    C, p_best = 3.2, 3.0
+    p = np.full(M, p_best - (gap + 40.0) / R)
+    p[:32] = p_best - gap / R - rng.uniform(0, 0.3, 32) / R
+    p[40] = p_best - runner_up / R
+    p[77] = p_best
+    u = rng.standard_normal((M, D))
+    u[:, 0] = 0.0
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    mean = (p[:, None] * e[None, :] + np.sqrt(C * C - p * p)[:, None] * u)[None]
+    var = np.ones((1, M, D))
+    w = np.full((1, M), 1.0 / M)
+    x = (R * e[None, :] + 0.003 * rng.standard_normal((T, D))).astype(np.float32)
+    return mean, var, w, x
+
+
+@pytest.mark.parametrize('gap,runner_up', [(70.0, 1.0), (89.2, 1.0), (90.0, 2.0), (91.0, 3.0), (130.0, 1.0)])
+def test_score_best_mixture_far_above_the_first_tile(eng_variant, gap, runner_up):
+    """The matrix-pipe kernels sum exp2(v - ref) with ref = the best of the frame's FIRST 32 mixtures and raise ref only when a sum
+    overflows f32 (2^128: 88.7 nats above ref).  Here the best mixture sits in the third tile, `gap` nats above everything in the
+    first, and a runner-up `runner_up` nats below it in the second.  With 88.7 + runner_up > gap > 88.7 the runner-up was summed
+    without an overflow, the best one then overflowed, and the sum so far was rescaled by exp2(-128) -- a denormal that v_exp_f32
+    flushes to zero: the runner-up was lost, ln b short by up to ln 1.37 = 0.31 nats (rounds 1-5, both matrix-pipe variants; found by
+    tests/test_gpu_fuzz_oracle.py on a model with skewed weights; the mutation build -DPCL_LSE_FLUSH_REPRO fails this test).  Such a
+    spread needs a frame far from the state's centre (the mixtures themselves are within the conditioning limit of it)."""
+    mean, var, w, x = far_frame_problem(gap, runner_up)
+    got, ref = score_all_states(eng_variant, mean, var, w, x)
+    assert_f32_class(got, ref, f32_evaluation_bound(mean, var, w, x), what='best mixture %g nats above the first tile:' % gap)
+
+
 def test_score_variants_wide_dynamic_range(eng_variant):
     """Variances from 1e-3 (the reference's floor) to 1e3 inside one state, a common offset, per-dimension scales six
     decades apart: the power-of-two feature scaling of the f16 kernel and the centring of all of them."""
