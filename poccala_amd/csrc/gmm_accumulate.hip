@@ -566,7 +566,7 @@ __global__ __launch_bounds__(AW * 64, 2) void gmm_accumulate_mfma_kernel(
             const double c = (double)cen[d], dl = means64[o] - c;
             const double S0 = (double)s0, S1 = (double)s1, S2 = (double)s2v;
             st_mean[o] += S1 + (c + bias) * S0;                            // Clustering.py:669-672
-            st_cov[o] += S2 - 2.0 * dl * S1 + dl * dl * S0;                // Clustering.py:674-678
+            st_cov[o] += fmax(S2 - 2.0 * dl * S1 + dl * dl * S0, 0.0);     // Clustering.py:674-678 (never negative: gmm_accumulate_f16.hip)
         }
         if (m < M && cidx == 2 * D) st_acc[(size_t)j * Mpad + m] += (double)s2v;   // Clustering.py:665
     };

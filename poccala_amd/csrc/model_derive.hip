@@ -26,7 +26,7 @@ __device__ __forceinline__ int ordered_bits(float f) {
 
 // One workgroup per state, one visit: what the layouts need to know about a state as a whole before any of them can be
 // written -- its expansion centre c_j[d] = (float) mean_m mu[j,m,d]; the exact power-of-two scale of every feature of the
-// split-f16 layout (gmm_score_split.hip): fscale[j][h][d] = 2^e, e = floor(log2 max_m |coef_m,h,d|), coef = -log2e/(2 var)
+// split-f16 layout (gmm_score_split.hip): fscale[j][h][d] = 2^e, e = floor(log2 max_m |coef_m,h,d|) (less a shift for states of very unequal variances, below), coef = -log2e/(2 var)
 // (h = 0) or log2e (mu - c)/var (h = 1), so that the scaled coefficients fill [1, 2) and the frame features carry the range;
 // and K0_j = max_m k'_m (log2 units) of the centred expansion, which the folded-constant layout keeps k'_m relative to
 // (k'_m - K0_j in two f16 pieces, K0_j added back in f64).  Two phases over the state's 1.3 MB (the second finds them in L2):
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
                                                              unsigned char *__restrict__ bad, int *__restrict__ bad_idx, int *__restrict__ nbad) {
     __shared__ double part[64 * 40];
     __shared__ float cen[64];
-    __shared__ unsigned long long fbits[2][64];
+    __shared__ unsigned long long fbits[2][64], fminb[64];
     __shared__ int kbits;
     const int j = j0 + blockIdx.x, tid = threadIdx.x;            // (j0: a state range re-derived on its own, pcl_launch_derive_range)
     const double *mu = mean64 + (size_t)j * Mpad * D, *vr = var64 + (size_t)j * Mpad * D;
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         part[r * 64 + d] = s;
     }
     if (tid < 128) fbits[tid >> 6][tid & 63] = 0ull;
+    if (tid < 64) fminb[tid] = 0x7ff0000000000000ull;            // +inf
     if (tid == 0) kbits = (int)0x80808080;                       // below every real value
     __syncthreads();
     if (tid < D) {
@@ -65,9 +66,12 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
     __syncthreads();
     // ---- (B)
     const int ml = tid >> 3, sub = tid & 7;
-    double mx0[8], mx1[8];
+    double mx0[8], mx1[8], mn0[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) mx0[k] = mx1[k] = 0.0;
+    for (int k = 0; k < 8; ++k) {
+        mx0[k] = mx1[k] = 0.0;
+        mn0[k] = INFINITY;
+    }
     float kmax = -INFINITY;
     bool any = false;
     for (int m0 = 0; m0 < M; m0 += PRE_T / 8) {
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
             for (int k = 0; k < 8; ++k) {
                 mx0[k] = fmax(mx0[k], t0[k]);
                 mx1[k] = fmax(mx1[k], t1[k]);
+                if (real_m && t0[k] > 0.0) mn0[k] = fmin(mn0[k], t0[k]);
             }
         }
         if (sub == 0 && real_m && !off_pipe) {
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         if (dd < D) {
             atomicMax(&fbits[0][dd], (unsigned long long)__double_as_longlong(mx0[k]));
             atomicMax(&fbits[1][dd], (unsigned long long)__double_as_longlong(mx1[k]));
+            atomicMin(&fminb[dd], (unsigned long long)__double_as_longlong(mn0[k]));
         }
     }
     if (any) atomicMax(&kbits, ordered_bits(kmax));
@@ -132,6 +138,21 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         const double mx = (dd < Dhost && dd < 64) ? __longlong_as_double((long long)fbits[h][dd]) : 0.0;
         int ex = 1;
         if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)
+        // A state whose on-pipe mixtures differ widely in variance: with the LARGEST coefficient of a feature in [1, 2) the wide mixtures'
+        // coefficients sink into f16's subnormals (second piece below 2^-14: a' = 2^-13 keeps 12 bits, measured 1.7e-4 nats on a state with
+        // variances over four decades, tests/test_gpu_fuzz_oracle.py).  f16 has as much room above 2 as below 1, so the scale goes to the
+        // middle of the feature's coefficient range (minus one octave: ratios up to 8 keep the round 1-5 scale and bits): a' in
+        // [2^-L, 2^L], the term's error ~ 2^(L-25) (term + 1) instead of 2^(2L-25) term; L <= 7 (variance ratios up to 2^14).
+        {
+            const double mxa = (dd < Dhost && dd < 64) ? __longlong_as_double((long long)fbits[0][dd]) : 0.0;
+            const double mna = (dd < Dhost && dd < 64) ? __longlong_as_double((long long)fminb[dd]) : 0.0;
+            if (mxa > 0.0 && mxa < 1e300 && mna > 0.0 && mna <= mxa) {
+                int ea, eb;
+                (void)frexp(mxa, &ea);
+                (void)frexp(mna, &eb);
+                ex -= min(max((ea - eb) / 2 - 1, 0), 7);
+            }
+        }
         ex = min(max(ex - 1, -60), 60);
         fscale[((size_t)j * 2 + h) * (KS8 * 8) + dd] = (float)ldexp(1.0, ex);
     }

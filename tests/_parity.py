@@ -55,7 +55,10 @@ def cov_acc_atol(acc, mean, var, floor):
 def hold(config, quantity, got, want, rtol, atol=0.0, note=None):
     """assert |got - want| <= atol + rtol |want| on every finite entry (same finite pattern) and record the measured worst case.
     atol: a number, or an array broadcastable to the data (recorded by its maximum)."""
-    m = measure(got, want, rtol, atol)
+    try:
+        m = measure(got, want, rtol, atol)
+    except AssertionError as e:
+        raise AssertionError('%s / %s: %s' % (config, quantity, e)) from None
     atol = float(np.max(atol)) if np.ndim(atol) else atol
     rec = REPORT.setdefault(config, {}).setdefault(quantity, dict(bound=dict(rtol=rtol, atol=atol), max_abs=0.0, max_rel=0.0, used=0.0, n=0))
     rec['bound'] = dict(rtol=max(rec['bound']['rtol'], rtol), atol=max(rec['bound']['atol'], atol))

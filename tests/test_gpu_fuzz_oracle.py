@@ -2,9 +2,11 @@
 a handful of small shapes; this one draws the shape: feature dimension (every one the device kernels are built for), mixtures per state from 1
 to a few tile widths (so m-tiles end mid-tile), units, ragged utterances down to one frame, labels with repeated units, random left-to-right
 or dense unit matrices, frames that are noise / sampled from the model / carry outliers far outside the f16 range of the matrix-pipe path,
-mixtures that have collapsed to the variance floor.  Per case: emissions, ln P(O), pass counts, ln gamma, xi, the Viterbi path, the GMM and the
-per-unit statistics and the re-estimated model (LHMM.py:335-609, Clustering.py:653-693) against oracle/poccala_oracle.py, float64 mode at
-1e-9 and the default mode at the north star's 1e-4.
+mixtures that have collapsed to the variance floor, weights down to 1e-12.  Per case: emissions, ln P(O), pass counts, ln gamma, the Viterbi
+path, the GMM and the per-unit statistics and both M-steps (LHMM.py:335-609, Clustering.py:653-693) against oracle/poccala_oracle.py, stage by
+stage (run_case says what is held against what), in the float64 mode and in the default mode.
+Found so far: the matrix-pipe scoring kernels dropping the mass summed so far when a later mixture tile overflowed the running sum
+(test_gpu_parity.py::test_score_best_mixture_far_above_the_first_tile).
 
    python tests/test_gpu_fuzz_oracle.py [cases] [first seed]      -- a longer sweep on the GPU box"""
 import os
@@ -84,14 +86,23 @@ def lnb_bound(model, lab, x):
 
 
 def run_case(eng, seed, prec):
+    """What is held, and against what:
+      emissions        device  vs  oracle                                  float64 mode 1e-12, default mode the f32-class bound
+      forward-backward device  vs  oracle ON THE DEVICE'S EMISSIONS        1e-9 in both modes (all DP state is float64): ln P(O), pass count,
+                                                                           ln gamma_t(j), the per-unit ksai_acc / gamma_acc
+      Viterbi          device  vs  oracle on the device's emissions        bit for bit
+      GMM statistics   device  vs  oracle's update_acc fed the device's ln gamma and ln b   float64 1e-9, default 1e-4 (+ the cov_acc term) + twice what
+                                                                           the draw's emissions lost against float64
+      both M-steps     device  vs  oracle's update_param ON THE DEVICE'S STATISTICS         1e-9
+    and in float64 mode the chain is also held end to end (ln P(O) against the oracle on its own emissions)."""
     from poccala_amd import PCL_F32, PCL_F64
     c = draw(seed)
     f32 = prec == 'f32'
     P = PCL_F32 if f32 else PCL_F64
-    rt = F32_RTOL if f32 else 1e-9
     cfg = 'oracle fuzz %s' % prec
     mean, var, w, trans, labels, lens, begin, frames = (c[k] for k in ('mean', 'var', 'w', 'trans', 'labels', 'lens', 'begin', 'frames'))
     units, M, D = c['units'], c['M'], c['D']
+    fix_code = 1 if c['fix_pi'] else 0
     eng.load_model(mean, var, w)
     eng.load_units(np.stack(trans))
     eng.load_frames(frames)
@@ -109,71 +120,90 @@ def run_case(eng, seed, prec):
     J = units * E
     refs = dict(acc=np.zeros((J, M)), alpha_acc=np.zeros(J), mean_acc=np.zeros((J, M, D)), cov_acc=np.zeros((J, M, D)))
     rk, rg = np.full((units, E, S), -np.inf), np.full((units, E), -np.inf)
-    worst_bound = 0.0
-    checks = []
+    e_max, bmax, impossible = 0.0, 1.0, 0
     for u, lab in enumerate(labels):
         x = frames[begin[u]:begin[u] + lens[u]].astype(np.float64)
-        bw, accs, (_, a, bref, pi) = po.estep_utterance(x, list(lab), model, fix_code=1 if c['fix_pi'] else 0)
+        _, a, bref, pi = po.score_label(x, list(lab), model)
         assert np.all(Bd[u][0] == 0.0) and np.all(np.isneginf(Bd[u][-1]))
+        bmax = max(bmax, float(np.abs(bref[1:-1]).max()))
         if f32:
-            bound = lnb_bound(model, lab, x)
-            worst_bound = max(worst_bound, float(bound.max()))
-            hold(cfg, 'ln b_j(o_t)', Bd[u][1:-1], bref[1:-1], 5e-6, F32_LOGLIK_ATOL + bound)
+            hold(cfg, 'ln b_j(o_t)', Bd[u][1:-1], bref[1:-1], 1e-5, F32_LOGLIK_ATOL + lnb_bound(model, lab, x))
+            fin = np.isfinite(bref[1:-1])
+            e_max = max(e_max, float(np.abs(Bd[u][1:-1] - bref[1:-1])[fin].max()))
         else:
             hold(cfg, 'ln b_j(o_t)', Bd[u][1:-1], bref[1:-1], 1e-12, 1e-11)
-            assert int(npass[u]) == int(bw['n_pass']), (seed, u, npass[u], bw['n_pass'])
-        # the Viterbi path on the device's own emissions (the contract of LHMM.viterbi), bit for bit
+        # float64 rounding of sums of emissions of this size: what 1e-9 has to be widened by for frames thousands of sigma out
+        rt = max(1e-9, 16 * 2.2e-16 * bmax * lens[u])
+        # ---- the DP on the device's emissions
+        with np.errstate(all='ignore'):
+            bw = po.baum_welch(a, pi, [Bd[u]], fix_code=fix_code)
         rp, rpath = po.viterbi(a, pi, Bd[u])
         assert np.array_equal(path[u].astype(np.float64), rpath) and rp == point[u], (seed, u)
+        if not np.isfinite(bw['logp'][0]):           # an utterance too short for its label: P(O) = 0.  The reference goes on with NaNs; the library adds nothing
+            assert np.isneginf(logp[u]), (seed, u, logp[u])
+            impossible += 1
+            continue
+        one_frame = lens[u] == 1                     # the reference's xi sum is empty: its HMM accumulators come out NaN (the library adds nothing to them);
+        if one_frame:                                # its GMM accumulators are fine
+            assert np.isnan(bw['ksai']).all()
+            impossible += 1
+        hold(cfg, 'ln P(O) (device emissions)', logp[u], bw['logp'][0], rt, rt)
+        assert int(npass[u]) == int(bw['n_pass']), (seed, u, npass[u], bw['n_pass'])
         l = bw['alpha'][0] + bw['beta'][0]
         with np.errstate(all='ignore'):
             lg = l - po.lse(l, axis=0)[None, :]
-        checks.append((u, bw['logp'][0], np.exp(lg)))
+        hold(cfg, 'gamma_t(j) normalised (device emissions)', np.exp(lgam[u]), np.exp(lg), 10 * rt, 1e-12)
+        if not f32:                                  # end to end
+            with np.errstate(all='ignore'):
+                hold(cfg, 'ln P(O)', logp[u], po.baum_welch(a, pi, [bref], fix_code=fix_code)['logp'][0], rt, rt)
+        accs = [po.UnitAcc(S, model[int(v)]['gmms']) for v in lab]
+        # the statistics of the oracle's update_acc given the device's occupancies and emissions (f32 mode: its own mixture likelihoods are exact)
+        po.update_acc(bw, [Bd[u]], [x], accs, [model[int(v)]['gmms'] for v in lab], fix_code=fix_code, s=S)
         for pos, unit in enumerate(lab):
-            rk[unit] = np.logaddexp(rk[unit], accs[pos].ksai_acc)
-            rg[unit] = np.logaddexp(rg[unit], accs[pos].gamma_acc)
+            if not one_frame:
+                rk[unit] = np.logaddexp(rk[unit], accs[pos].ksai_acc)
+                rg[unit] = np.logaddexp(rg[unit], accs[pos].gamma_acc)
             for k in range(E):
                 for key in refs:
                     with np.errstate(all='ignore'):
                         refs[key][unit * E + k] += np.exp(accs[pos].gmm[k][key])
-    # In the default mode everything behind the emissions is held to the north star's 1e-4 when the emissions CAN be that good: a draw
-    # whose f32 evaluation bound is itself above 2e-5 nats (variances at 1e-6 under |x| ~ 1, far outliers) is held on its emissions only --
-    # the float64 run of the same seed holds its logic.
-    downstream = (not f32) or worst_bound < 2e-5
-    c['downstream'] = downstream
-    if not downstream:
-        b.close()
-        return c
-    for u, lp_ref, g_ref in checks:
-        hold(cfg, 'ln P(O)', logp[u], lp_ref, rt, rt)
-        hold(cfg, 'gamma_t(j) normalised', np.exp(lgam[u]), g_ref, rt, 1e-6 if f32 else 1e-12)
-    hold(cfg, 'per-unit ksai_acc (log)', ks, rk, 1e-5 if f32 else 1e-10, 1e-5 if f32 else 1e-10)
-    hold(cfg, 'per-unit gamma_acc (log)', ga, rg, 1e-5 if f32 else 1e-10, 1e-5 if f32 else 1e-10)
-    for key in refs:
+    c['impossible'] = impossible
+    rt = max(1e-9, 16 * 2.2e-16 * bmax * int(lens.max()))
+    hold(cfg, 'per-unit ksai_acc (log)', ks, rk, rt, 100 * rt)
+    hold(cfg, 'per-unit gamma_acc (log)', ga, rg, rt, 100 * rt)
+    # GMM statistics
+    # default mode: the north star's 1e-4, widened by what THIS draw's emissions lost against float64 (1.5e-5 nats at the BASELINE configs;
+    # up to 2e-4 for states whose mixtures' variances span three decades, 1e-2 for variances at the 1e-6 floor under |x| ~ 1 -- in any f32
+    # evaluation: the posteriors gamma_t(j,m) = w_m N_m / b_j inherit it)
+    srt = F32_RTOL + 2.0 * e_max if f32 else 10 * rt
+    c['statistics rtol'] = srt
+    for key in (refs if srt < 1e-2 else ()):         # (frames thousands of sigma out: |ln b| ~ 1e7, an f32 evaluation is off by nats, the posteriors are not comparable)
         scale = float(np.abs(refs[key]).max())
         at = scale * (1e-6 if f32 else 1e-13)
         if key == 'cov_acc' and f32:
             at = cov_acc_atol(refs['acc'], mean, var, at)
-        hold(cfg, key, st[key], refs[key], rt, at)
-    # both M-steps (Clustering.py:682-693, LHMM.py:519-520)
+        hold(cfg, key, st[key], refs[key], srt, at)
+    # both M-steps on the device's own statistics (Clustering.py:682-693, LHMM.py:519-520)
     eng.em_exchange(c['c_cov'], update_transitions=True)
     nm, nv, nw = eng.model_download()
     nt = eng.units_download()
-    mrt = 1e-8 if not f32 else F32_RTOL
-    for j in sorted(set(int(u) * E + k for lab in labels for u in lab for k in range(E))):
-        if refs['alpha_acc'][j] < 1e-200:
+    for j in range(J):
+        if not st['alpha_acc'][j] > 0.0:             # a state no frame reached keeps its model
+            assert np.array_equal(nm[j], mean[j]) and np.array_equal(nv[j], var[j]) and np.array_equal(nw[j], w[j]), (seed, j)
             continue
-        seen = refs['acc'][j] > 1e-3 * refs['acc'][j].max()      # mixtures with a meaningful occupancy (the rest: 0 / 0 in the reference)
-        rw = refs['acc'][j] / refs['alpha_acc'][j]
-        rm = refs['mean_acc'][j] / refs['acc'][j][:, None] - 100.0
-        rv = np.maximum(refs['cov_acc'][j] / refs['acc'][j][:, None], c['c_cov'])
-        hold(cfg, 're-estimated weights', nw[j][seen], rw[seen], mrt, 1e-12)
-        hold(cfg, 're-estimated means', nm[j][seen], rm[seen], mrt, 1e-4 if f32 else 1e-8)
-        hold(cfg, 're-estimated variances', nv[j][seen], rv[seen], 10 * mrt, c['c_cov'] * (1e-2 if f32 else 1e-8))
+        seen = st['acc'][j] > 0.0
+        with np.errstate(all='ignore'):
+            rw, rm, rv = po.gmm_update_param({k: np.log(st[k][j]) for k in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc')}, c_covariance=c['c_cov'])
+        hold(cfg, 're-estimated weights', nw[j], np.where(seen, rw, 0.0), 1e-9, 1e-300)
+        hold(cfg, 're-estimated means', nm[j][seen], rm[seen], 1e-9, 1e-9)
+        hold(cfg, 're-estimated variances', nv[j][seen], rv[seen], 1e-9, 1e-300)
+        assert np.array_equal(nm[j][~seen], mean[j][~seen]) and np.array_equal(nv[j][~seen], var[j][~seen]), (seed, j)
+        assert (st['cov_acc'][j] >= 0.0).all(), (seed, j)        # a sum of gamma (o - mu)^2
     for unit in range(units):
-        if np.isfinite(rg[unit]).all():
-            np.testing.assert_allclose(nt[unit], po.hmm_update_param(trans[unit], rk[unit], rg[unit]), rtol=1e-3 if f32 else 1e-8, atol=1e-12,
-                                       err_msg='seed %d unit %d' % (seed, unit))
+        if np.isfinite(ga[unit]).all():
+            np.testing.assert_allclose(nt[unit], po.hmm_update_param(trans[unit], ks[unit], ga[unit]), rtol=1e-9, atol=1e-300, err_msg='seed %d unit %d' % (seed, unit))
+        elif np.isneginf(ga[unit]).all():            # a unit nobody passed through keeps its matrix
+            assert np.array_equal(nt[unit], trans[unit]), (seed, unit)
     b.close()
     return c
 
@@ -186,12 +216,18 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize('seed', list(range(9000, 9016)))
+# the first 24 draws, and the draws that found something (28: the flushed rescale of the matrix-pipe log-sum-exp; 39 / 52 / 66 / 110 / 119 / 159:
+# states with variances over three decades -> the f16 feature scale centred; 10 / 82: a cov_acc share a hair below zero; 36 / 266: one-frame
+# utterances; 41 / 50 / 291: frames thousands of sigma out)
+SEEDS = list(range(24)) + [28, 36, 39, 41, 50, 52, 66, 82, 110, 119, 159, 266, 291]
+
+
+@pytest.mark.parametrize('seed', SEEDS)
 def test_random_estep_against_the_oracle_f64(eng, seed):
     run_case(eng, seed, 'f64')
 
 
-@pytest.mark.parametrize('seed', list(range(9000, 9016)))
+@pytest.mark.parametrize('seed', SEEDS)
 def test_random_estep_against_the_oracle_default_precision(eng, seed):
     run_case(eng, seed, 'f32')
 
@@ -206,7 +242,7 @@ if __name__ == '__main__':
         for prec in ('f64', 'f32'):
             try:
                 c = run_case(e, s, prec)
-                print('seed %d %s ok  (units %d M %d D %d U %d L %d %s / %s%s)' % (s, prec, c['units'], c['M'], c['D'], c['U'], c['L'], c['kind'], c['fkind'], '' if c['downstream'] else ', emissions only'), flush=True)
+                print('seed %d %s ok  (units %d M %d D %d U %d L %d %s / %s%s)' % (s, prec, c['units'], c['M'], c['D'], c['U'], c['L'], c['kind'], c['fkind'], (', statistics at %.1e' % c['statistics rtol'] if c['statistics rtol'] > 1.5e-4 else '') + (', %d utterances the reference cannot handle' % c['impossible'] if c['impossible'] else '')), flush=True)
             except Exception as ex:          # noqa: BLE001 -- a sweep: report and go on
                 failed += 1
                 print('seed %d %s FAILED: %s' % (s, prec, str(ex).splitlines()[0][:300]), flush=True)
