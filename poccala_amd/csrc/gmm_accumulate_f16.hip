@@ -492,7 +492,7 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
                 const double S2 = ldexp((double)ST[ct][r], Ei) / (double)fs[d], S1 = ldexp((double)ST[ct][r + 4], Ei) / (double)fs[KS * 8 + d];
                 const double vm = S1 + (cc + bias) * S0;                           // Clustering.py:669-672
                 // Clustering.py:674-678: a sum of gamma (o - mu)^2, never negative.  The raw-moment form can come out a hair below zero
-                // (measured down to -2.6e-6 acc, tests/test_gpu_fuzz_oracle.py) when a mixture's few frames sit on its mean in one
+                // (measured down to -2.6e-6 acc, tests/test_gpu_fuzz_estep.py) when a mixture's few frames sit on its mean in one
                 // dimension; as ln(cov_acc) in a reference-format accumulator file that would be a NaN.  Each pass's share is clamped.
                 const double vc = fmax(S2 - 2.0 * dl * S1 + dl * dl * S0, 0.0);
                 if (FRESH) {

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WG, PCL_MFMA_MINW) void gmm_score_mfma_kernel(const
                 if ((mt == 0 || gp > 0.f) && gp > -INFINITY) {
                     // first tile: gp << 0, 0 * exp2(-gp) would be 0 * inf.  Later: this path is entered when a sum overflows, i.e. with gp ~ 128,
                     // and exp2(-128) is a denormal that v_exp_f32 flushes to 0 -- which dropped everything summed so far, up to a third of the
-                    // frame's mass (rounds 1-5; found by tests/test_gpu_fuzz_oracle.py).  Two half-steps stay normal up to gp = 252.
+                    // frame's mass (rounds 1-5; found by tests/test_gpu_fuzz_estep.py).  Two half-steps stay normal up to gp = 252.
 #ifdef PCL_LSE_FLUSH_REPRO                                    // mutation build (tests are expected to FAIL on it): rounds 1-5
                     s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-gp);
 #else

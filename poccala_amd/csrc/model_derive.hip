@@ -140,7 +140,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         if (mx > 0.0 && mx < 1e300) (void)frexp(mx, &ex);     // mx = f 2^ex, f in [0.5, 1)
         // A state whose on-pipe mixtures differ widely in variance: with the LARGEST coefficient of a feature in [1, 2) the wide mixtures'
         // coefficients sink into f16's subnormals (second piece below 2^-14: a' = 2^-13 keeps 12 bits, measured 1.7e-4 nats on a state with
-        // variances over four decades, tests/test_gpu_fuzz_oracle.py).  f16 has as much room above 2 as below 1, so the scale goes to the
+        // variances over four decades, tests/test_gpu_fuzz_estep.py).  f16 has as much room above 2 as below 1, so the scale goes to the
         // middle of the feature's coefficient range (minus one octave: ratios up to 8 keep the round 1-5 scale and bits): a' in
         // [2^-L, 2^L], the term's error ~ 2^(L-25) (term + 1) instead of 2^(2L-25) term; L <= 7 (variance ratios up to 2^14).
         {

@@ -8,7 +8,7 @@ stage (run_case says what is held against what), in the float64 mode and in the 
 Found so far: the matrix-pipe scoring kernels dropping the mass summed so far when a later mixture tile overflowed the running sum
 (test_gpu_parity.py::test_score_best_mixture_far_above_the_first_tile).
 
-   python tests/test_gpu_fuzz_oracle.py [cases] [first seed]      -- a longer sweep on the GPU box"""
+   python tests/test_gpu_fuzz_estep.py [cases] [first seed]      -- a longer sweep on the GPU box"""
 import os
 import sys
 

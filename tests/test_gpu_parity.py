@@ -1059,7 +1059,7 @@ def test_score_best_mixture_far_above_the_first_tile(eng_variant, gap, runner_up
     first, and a runner-up `runner_up` nats below it in the second.  With 88.7 + runner_up > gap > 88.7 the runner-up was summed
     without an overflow, the best one then overflowed, and the sum so far was rescaled by exp2(-128) -- a denormal that v_exp_f32
     flushes to zero: the runner-up was lost, ln b short by up to ln 1.37 = 0.31 nats (rounds 1-5, both matrix-pipe variants; found by
-    tests/test_gpu_fuzz_oracle.py on a model with skewed weights; the mutation build -DPCL_LSE_FLUSH_REPRO fails this test).  Such a
+    tests/test_gpu_fuzz_estep.py on a model with skewed weights; the mutation build -DPCL_LSE_FLUSH_REPRO fails this test).  Such a
     spread needs a frame far from the state's centre (the mixtures themselves are within the conditioning limit of it)."""
     mean, var, w, x = far_frame_problem(gap, runner_up)
     got, ref = score_all_states(eng_variant, mean, var, w, x)
