@@ -54,3 +54,40 @@ def test_mfcc_non_power_of_two_nfft():
     got = mfcc_batch([sig], 16000, nfft=500, d1=True)[0]
     ref = mo.mfcc(sig, 16000, nfft=500, d1=True)
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_mfcc_random_shapes_match_the_oracle(seed):
+    """Random batches: signal lengths from one window to a few seconds, sampling rates, FFT sizes (powers of two and not), filter-bank and
+    cepstrum sizes, frame length / overlap, stretches of digital silence (ln 0 = -inf in the reference, AudioProcessing.py:172-180)."""
+    from poccala_amd.StatisticalModel.AudioProcessing import mfcc_batch
+    rng = np.random.default_rng(900 + seed)
+    rate = int(rng.choice([8000, 16000, 22050]))
+    sampletime = float(rng.choice([0.025, 0.02, 0.032]))
+    overlap = float(rng.choice([0.5, 0.25, 0.6]))
+    win = int(rate * sampletime)
+    nfft = int(rng.choice([n for n in (256, 512, 1024, 500, 640) if n >= win] or [1024]))
+    filterbanks = int(rng.choice([20, 26, 40]))
+    vec_num = int(rng.choice([12, 13]))
+    d1 = bool(rng.random() < 0.7)
+    d2 = d1 and bool(rng.random() < 0.6)
+    cal_energy = bool(rng.random() < 0.7)
+    sigs = []
+    for _ in range(int(rng.integers(1, 7))):
+        n = int(rng.choice([win, win + 1, 2 * win, int(rng.integers(win, 3 * rate))]))
+        s = np.round(10.0 ** rng.uniform(1, 4) * rng.standard_normal(n)).astype(np.int16)
+        if rng.random() < 0.3 and n > 4 * win:
+            a = int(rng.integers(0, n - 3 * win))
+            s[a:a + 3 * win] = 0                                 # digital silence: whole frames of zeros
+        sigs.append(s)
+    got = mfcc_batch(sigs, rate, vec_num=vec_num, sampletime=sampletime, overlap=overlap, nfft=nfft, filterbanks=filterbanks,
+                     cal_energy=cal_energy, d1=d1, d2=d2)
+    for s, gmat in zip(sigs, got):
+        with np.errstate(all='ignore'):
+            ref = mo.mfcc(s, rate, vec_num=vec_num, sampletime=sampletime, overlap=overlap, nfft=nfft, filterbanks=filterbanks,
+                          cal_energy=cal_energy, d1=d1, d2=d2)
+        assert gmat.shape == ref.shape, (seed, gmat.shape, ref.shape)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(gmat), fin), seed
+        assert np.array_equal(np.isnan(gmat), np.isnan(ref)), seed
+        np.testing.assert_allclose(gmat[fin], ref[fin], rtol=1e-8, atol=1e-7)
