@@ -34,14 +34,15 @@ __device__ __forceinline__ int ordered_bits(float f) {
 //   (B) 8 lanes per mixture, 64 mixtures per step, the per-mixture sums in derive_kernel's order (so k'_m has its bits).
 // (Round 1 did this with three launches of 39..128 busy threads per state and a write-free pass of derive_kernel: 5.0 ms.)
 constexpr int PRE_T = 512;
-__global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
+__global__ __launch_bounds__(PRE_T, 4) void state_prepass_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
                                                              const double *__restrict__ w64, int M, int Mpad, int D, int Dhost, int KS8,
                                                              int flags, float *__restrict__ centers, float *__restrict__ fscale,
                                                              double *__restrict__ kzero, int j0, float cond_split,
                                                              unsigned char *__restrict__ bad, int *__restrict__ bad_idx, int *__restrict__ nbad) {
     __shared__ double part[64 * 40];
     __shared__ float cen[64];
-    __shared__ unsigned long long fbits[2][64], fminb[64];
+    __shared__ unsigned long long fbits[2][64];
+    __shared__ unsigned int fminb[64];                           // smallest biased exponent of a feature's quadratic coefficient over the on-pipe mixtures
     __shared__ int kbits;
     const int j = j0 + blockIdx.x, tid = threadIdx.x;            // (j0: a state range re-derived on its own, pcl_launch_derive_range)
     const double *mu = mean64 + (size_t)j * Mpad * D, *vr = var64 + (size_t)j * Mpad * D;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         part[r * 64 + d] = s;
     }
     if (tid < 128) fbits[tid >> 6][tid & 63] = 0ull;
-    if (tid < 64) fminb[tid] = 0x7ff0000000000000ull;            // +inf
+    if (tid < 64) fminb[tid] = 0x7ffu;
     if (tid == 0) kbits = (int)0x80808080;                       // below every real value
     __syncthreads();
     if (tid < D) {
@@ -66,12 +67,13 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
     __syncthreads();
     // ---- (B)
     const int ml = tid >> 3, sub = tid & 7;
-    double mx0[8], mx1[8], mn0[8];
+    double mx0[8], mx1[8];
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    us2 emin[4];                                                 // (exponents only, two per register: eight doubles more cost the kernel a wave per SIMD and 0.7 ms)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        mx0[k] = mx1[k] = 0.0;
-        mn0[k] = INFINITY;
-    }
+    for (int k = 0; k < 8; ++k) mx0[k] = mx1[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) emin[k] = us2{0x7ff, 0x7ff};
     float kmax = -INFINITY;
     bool any = false;
     for (int m0 = 0; m0 < M; m0 += PRE_T / 8) {
@@ -108,7 +110,14 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
             for (int k = 0; k < 8; ++k) {
                 mx0[k] = fmax(mx0[k], t0[k]);
                 mx1[k] = fmax(mx1[k], t1[k]);
-                if (real_m && t0[k] > 0.0) mn0[k] = fmin(mn0[k], t0[k]);
+            }
+            if (real_m) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned short e0 = t0[2 * k] > 0.0 ? (unsigned short)((__double_as_longlong(t0[2 * k]) >> 52) & 0x7ff) : (unsigned short)0x7ff;
+                    const unsigned short e1 = t0[2 * k + 1] > 0.0 ? (unsigned short)((__double_as_longlong(t0[2 * k + 1]) >> 52) & 0x7ff) : (unsigned short)0x7ff;
+                    emin[k] = __builtin_elementwise_min(emin[k], us2{e0, e1});
+                }
             }
         }
         if (sub == 0 && real_m && !off_pipe) {
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         if (dd < D) {
             atomicMax(&fbits[0][dd], (unsigned long long)__double_as_longlong(mx0[k]));
             atomicMax(&fbits[1][dd], (unsigned long long)__double_as_longlong(mx1[k]));
-            atomicMin(&fminb[dd], (unsigned long long)__double_as_longlong(mn0[k]));
+            atomicMin(&fminb[dd], (unsigned int)emin[k >> 1][k & 1]);
         }
     }
     if (any) atomicMax(&kbits, ordered_bits(kmax));
@@ -145,12 +154,12 @@ __global__ __launch_bounds__(PRE_T) void state_prepass_kernel(const double *__re
         // [2^-L, 2^L], the term's error ~ 2^(L-25) (term + 1) instead of 2^(2L-25) term; L <= 7 (variance ratios up to 2^14).
         {
             const double mxa = (dd < Dhost && dd < 64) ? __longlong_as_double((long long)fbits[0][dd]) : 0.0;
-            const double mna = (dd < Dhost && dd < 64) ? __longlong_as_double((long long)fminb[dd]) : 0.0;
-            if (mxa > 0.0 && mxa < 1e300 && mna > 0.0 && mna <= mxa) {
-                int ea, eb;
+            const unsigned int emn = (dd < Dhost && dd < 64) ? fminb[dd] : 0x7ffu;
+            if (mxa > 0.0 && mxa < 1e300 && emn > 0u && emn < 0x7ffu) {
+                int ea;
                 (void)frexp(mxa, &ea);
-                (void)frexp(mna, &eb);
-                ex -= min(max((ea - eb) / 2 - 1, 0), 7);
+                const int eb = (int)emn - 1022;                  // frexp's convention: value = f 2^e, f in [0.5, 1)
+                if (eb <= ea) ex -= min(max((ea - eb) / 2 - 1, 0), 7);
             }
         }
         ex = min(max(ex - 1, -60), 60);
