@@ -130,7 +130,8 @@ int pcl_host_free(pcl_ctx *ctx, void *ptr);
 /* ------------------------------------------------------------------ batch
  * A batch = U sentence-level HMMs (AcousticModel.embedded, AcousticModel.py:957-1014), utterance u
  * having N[u] states and T[u] frames starting at row frame_begin[u] of the uploaded frame matrix
- * (frame_begin may be NULL when emissions are supplied with pcl_batch_set_emissions). */
+ * (frame_begin may be NULL when emissions are supplied with pcl_batch_set_emissions).  At most 65535 utterances, 2^31 - 1 rows
+ * (sum N) and frames (sum T) per batch: PCL_ERR_INVALID beyond that -- a corpus goes through in several batches. */
 int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, const int64_t *frame_begin,
                      pcl_batch **out);
 int pcl_batch_destroy(pcl_batch *b);

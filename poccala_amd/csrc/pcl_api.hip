@@ -546,6 +546,8 @@ int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, co
     if (!ctx || !out) return PCL_ERR_INVALID;
     *out = nullptr;
     if (U <= 0 || !N || !T) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: bad arguments (U=%d)", U);
+    // several kernels index the utterance with the grid's second dimension (HIP: at most 65535): say so here instead of failing a launch later
+    if (U > 65535) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_batch_create: %d utterances in one batch, at most 65535 (split the batch)", U);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pcl_batch_reap(ctx, false);                              // destroyed batches the GPU has finished with: their blocks first
     pcl_batch *b = new pcl_batch();

@@ -839,3 +839,27 @@ def test_exchange_world_4_and_8_equals_single_rank(world, payload):
             assert np.array_equal(g['split'][k], ranks[0]['split'][k]) and np.array_equal(g['split_pipe'][k], g['split'][k]), (r, k)
     lp = np.concatenate([g['lp'] for g in ranks])
     np.testing.assert_allclose(lp, single['lp'], rtol=1e-10 if payload == 'f64' else 1e-5)
+
+
+def test_batch_limits_are_said_at_create(eng):
+    """65536 utterances in one batch: several kernels index the utterance with the grid's second dimension; the library says so when the batch
+    is made (rounds 1-5a: a failed launch inside the first forward-backward)."""
+    from poccala_amd import PoccalaHipError
+    mean, var, w, trans, frames, lens, begin, labels = problem(5)
+    eng.load_model(mean, var, w)
+    eng.load_frames(frames)
+    eng.load_units(np.stack(trans))
+    U = 65536
+    with pytest.raises(PoccalaHipError, match='65535'):
+        eng.batch(np.full(U, 5, dtype=np.int32), np.full(U, 2, dtype=np.int32), np.zeros(U, dtype=np.int64))
+    with pytest.raises(PoccalaHipError, match='65535'):
+        eng.label_batch(np.zeros((U, 1), dtype=np.int32), np.full(U, 2, dtype=np.int32), np.zeros(U, dtype=np.int64))
+    # ... and the largest one that is allowed runs (one-unit sentence HMMs of two frames)
+    U = 65535
+    b = eng.label_batch(np.zeros((U, 1), dtype=np.int32), np.full(U, 2, dtype=np.int32), np.zeros(U, dtype=np.int64))
+    b.score()
+    b.forward_backward()
+    b.viterbi()
+    lp = b.get('logp')
+    assert lp.shape == (U,) and np.all(lp == lp[0]) and np.isfinite(lp[0])
+    b.close()
