@@ -54,12 +54,15 @@ def draw_hmm(rng):
 
 def draw(seed):
     rng = np.random.default_rng(seed)
-    U = int(rng.integers(1, 13))
+    long_ = seed >= 5000                             # seeds from 5000: a few long utterances (the scaled route's exponents, the hand-over to the log kernels)
+    U = int(rng.integers(1, 13)) if not long_ else int(rng.integers(1, 4))
     hmms, Bs = [], []
     for _ in range(U):
         a, pi, kind = draw_hmm(rng)
         n = a.shape[0]
         T = int(rng.integers(1, 151)) if rng.random() < 0.9 else int(rng.integers(1, 5))
+        if long_:
+            T = int(rng.integers(800, 5000))
         spread = float(rng.choice([1.0, 4.0, 40.0, 900.0]))
         b = float(rng.choice([0.0, -85.0, -3000.0])) + spread * rng.standard_normal((n, T))
         if rng.random() < 0.4:
@@ -107,7 +110,7 @@ def run_case(eng, seed):
         ctx = (seed, u, kind, int(N[u]), int(T[u]))
         # sums of up to 150 emissions of this size in float64 on both sides, in different orders
         big = float(np.abs(B[np.isfinite(B)]).max()) * T[u] if np.isfinite(B).any() else 1.0
-        at = max(1e-9, 64 * 2.2e-16 * big)
+        at = max(1e-9, 32 * 2.2e-16 * big * np.sqrt(T[u]))     # (the log-domain oracle rounds once per frame at the size of ln alpha ~ |b| T)
         if bw['n_pass'] > 16:                        # PCL_MAX_PASS (include/poccala_hip.h): the reference has no cap, and at its threshold (0.64 nats
             assert int(out['npass'][u]) == 16, ctx   # of gain from re-estimating pi alone) never gets near it; a caller's tiny threshold can
             continue
@@ -139,7 +142,7 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize('seed', list(range(30)))
+@pytest.mark.parametrize('seed', list(range(30)) + [5000, 5001, 5002])
 def test_random_hmms_against_the_oracle(eng, seed):
     run_case(eng, seed)
 
