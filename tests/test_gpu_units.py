@@ -863,3 +863,47 @@ def test_batch_limits_are_said_at_create(eng):
     lp = b.get('logp')
     assert lp.shape == (U,) and np.all(lp == lp[0]) and np.isfinite(lp[0])
     b.close()
+
+
+@pytest.mark.parametrize('payload', ['f64', 'f32'])
+def test_exchange_with_ranks_that_hold_no_utterance(payload):
+    """Two utterances on a world of four: ranks 2 and 3 have nothing to score (a corpus shard smaller than the node).  They zero their
+    statistics and take part in the exchange; every rank ends with the model a single rank re-estimates from the two utterances."""
+    from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+    from poccala_amd.distributed import shard_range
+    units, U, world = 3, 2, 4
+    mean, var, w, trans = synth.make_model(units, 5, 13, seed=431)
+    frames, lens, begin = synth.make_frames(U, 50, 13, seed=432, ragged=True)
+    labels = synth.make_labels(U, 3, units, seed=433)
+    pay = PCL_F32 if payload == 'f32' else PCL_F64
+
+    def body_for(n):
+        def body(rank, gather):
+            eng = Engine(0)
+            try:
+                if gather is not None:
+                    eng.comm_init_host(rank, n, gather)
+                eng.load_model(mean, var, w)
+                eng.load_units(np.stack(trans))
+                lo, hi = shard_range(U, rank, n)
+                eng.stats_zero()
+                if hi > lo:
+                    f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
+                    eng.load_frames(frames[f0:f1])
+                    b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi] - f0)
+                    b.score(PCL_F64); b.forward_backward(); b.accumulate(PCL_F64); b.accumulate_hmm()
+                    b.close()
+                eng.em_exchange(1e-3, pay, True)
+                return eng.model_download() + (eng.units_download(),), (lo, hi)
+            finally:
+                eng.close()
+        return body
+    single = _run_ranks(1, body_for(1))[0][0]
+    ranks = _run_ranks(world, body_for(world))
+    assert sorted(hi - lo for _, (lo, hi) in ranks) == [0, 0, 1, 1]
+    tol = dict(rtol=1e-12, atol=1e-12) if payload == 'f64' else dict(rtol=1e-5, atol=1e-6)
+    for r, (model, _) in enumerate(ranks):
+        for got, want, nm in zip(model, single, ('mean', 'var', 'weight', 'transitions')):
+            np.testing.assert_allclose(got, want, err_msg='%s on rank %d' % (nm, r), **tol)
+        for got, first in zip(model, ranks[0][0]):
+            assert np.array_equal(got, first), 'rank %d holds another model than rank 0' % r
