@@ -1,17 +1,12 @@
 #!/bin/bash
-# round 4 soak: randomised parity of the new forward-backward, more seeds of the suite's fuzz tests, decoder fuzz, streamed decode + EM loop
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/soak; mkdir -p $O
-step() {
-    local secs=$1 log=$2; shift 2
-    timeout -k 10 $secs "$@" > $log 2>&1
-    local rc=$?
-    echo "rc=$rc $log"; tail -3 $log
-    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step hung or was killed: stopping"; exit 1; fi
-    return 0
-}
-step 500 $O/fb_fuzz.log python tools/fb_linear_fuzz.py 0 150
-step 500 $O/parity_soak.log python tools/parity_soak.py 100 40
-step 500 $O/decode_fuzz.log python tools/decode_fuzz.py
-step 500 $O/soak_stream.log python tools/soak_stream_em.py
-step 700 $O/split_fuzz.log python tools/split_fuzz.py 100 60
+# round 5: the randomised harnesses at length (one call, ~18 min): E-step against the oracle, HMMs against the oracle, the token passing against its
+# restatement, a sweep against its unhurried twin.  Each under its own timeout; joined with && so that nothing runs after a failure or a kill.
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+S=${SOAK_SEED:-300}       # (E-step fuzz: seeds below 1000 are the small draws, from 1000 the big ones; HMM fuzz: from 5000 the long utterances)
+timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py 700 $S > gpurun_out/soak_estep.txt 2>&1; echo "estep rc=$? $(tail -1 gpurun_out/soak_estep.txt)"
+timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 60 $((S + 1200)) > gpurun_out/soak_estep_big.txt 2>&1; echo "estep big rc=$? $(tail -1 gpurun_out/soak_estep_big.txt)"
+timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 500 $S > gpurun_out/soak_hmm.txt 2>&1; echo "hmm rc=$? $(tail -1 gpurun_out/soak_hmm.txt)"
+timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 40 $((S + 5100)) > gpurun_out/soak_hmm_long.txt 2>&1; echo "hmm long rc=$? $(tail -1 gpurun_out/soak_hmm_long.txt)"
+timeout -k 10 200 python3 tools/decode_fuzz.py 150 $S > gpurun_out/soak_decode.txt 2>&1; echo "decode rc=$? $(tail -1 gpurun_out/soak_decode.txt)"
+timeout -k 10 420 python3 tools/sweep_fuzz.py 70 60 $S > gpurun_out/soak_sweep.txt 2>&1; echo "sweep rc=$? $(tail -1 gpurun_out/soak_sweep.txt)"
+grep -h "FAILED\|differs\|mismatch" gpurun_out/soak_*.txt | grep -v " 0 mismatch" | head -20
