@@ -79,6 +79,8 @@ def draw(seed):
         rows = rng.integers(0, frames.shape[0], size=k)
         cols = rng.integers(0, D, size=k)
         frames[rows, cols] = np.abs(frames[rows, cols]) * rng.choice([30.0, 300.0, 3000.0], size=k).astype(np.float32)   # (positive: the reference takes ln(o + 100))
+    if rng.random() < 0.3:                        # float64 features with more bits than an f32 holds (the reference's MFCCs are float64): the float64
+        frames = frames.astype(np.float64) * (1.0 + 1e-9 * rng.standard_normal(frames.shape))      # mode reads them as they are, the default mode rounds them
     return dict(units=units, M=M, D=D, mean=mean, var=var, w=w, trans=trans, U=U, L=L, labels=labels, lens=lens, begin=begin,
                 frames=frames, kind=str(kind), fkind=str(fkind), fix_pi=bool(rng.random() < 0.3), c_cov=float(rng.choice([1e-3, 1e-6])))
 
