@@ -121,6 +121,12 @@ def run_case(eng, seed, prec):
     b.accumulate(P)
     b.accumulate_hmm()
     Bd, logp, npass, lgam, path, point = (b.get(k) for k in ('B', 'logp', 'npass', 'lgamma', 'path', 'point'))
+    # the aligned frames regrouped per unit and GMM state (AcousticModel.py:758-764, 629-644, 937-955: next row f2) against the oracle's per-frame form
+    row_units = [np.concatenate([[lab[0]], np.repeat(lab, E), [lab[-1]]]).astype(np.int32) for lab in labels]
+    fu, fk = b.regroup(row_units, E)
+    for u in range(len(labels)):
+        unit_seq = row_units[u][path[u]]
+        assert np.array_equal(fu[u], unit_seq) and np.array_equal(fk[u], po.regroup_frame_states(unit_seq, E)), (seed, u)
     st = eng.stats_download()
     ks, ga = eng.hmm_acc_download()
     model = {u: dict(trans=trans[u], gmms=[(mean[u * E + k], var[u * E + k], w[u * E + k]) for k in range(E)]) for u in range(units)}
