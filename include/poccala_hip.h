@@ -71,7 +71,7 @@ typedef enum {
     PCL_GET_B = 0,       /* emission matrices, ragged, (N_u,T_u) row-major f64  == LHMM.B_p / embedded() B   */
     PCL_GET_ALPHA = 1,   /* forward  matrices of the final pass, same layout    == LHMM.__result_f           */
     PCL_GET_BETA = 2,    /* backward matrices of the final pass                 == LHMM.__result_b           */
-    PCL_GET_LGAMMA = 3,  /* ln gamma_t(i) = alpha+beta - LSE_i(alpha+beta), (N_u,T_u)  (LHMM.py:486-500)      */
+    PCL_GET_LGAMMA = 3,  /* ln gamma_t(i) = alpha+beta - LSE_i(alpha+beta), (N_u,T_u)  (LHMM.py:486-500); ln 0 for a one-frame utterance (the reference raises on it) */
     PCL_GET_KSAI = 4,    /* un-normalised ln xi, ragged dense (N_u,N_u) f64     == LHMM.__ksai (quirk Q5)    */
     PCL_GET_GAMMA = 5,   /* un-normalised ln gamma, ragged (N_u,) f64           == LHMM.__gamma              */
     PCL_GET_PI = 6,      /* pi after the final pass, ragged (N_u,) f64, LINEAR  == LHMM.pi                   */

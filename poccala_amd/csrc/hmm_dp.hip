@@ -946,6 +946,14 @@ int pcl_launch_ksai_gather(pcl_ctx *ctx, pcl_batch *b, double *dst) {
     return PCL_OK;
 }
 
+namespace {
+__global__ void one_frame_kernel(const UttDesc *__restrict__ utts, double *__restrict__ lgam) {
+    const UttDesc d = utts[blockIdx.x];
+    if (d.T != 1) return;
+    for (int i = threadIdx.x; i < d.N; i += blockDim.x) lgam[d.b_off + i] = -INFINITY;
+}
+}  // namespace
+
 int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshold) {
     const int NP = (b->Nmax + 63) / 64 * 64;
     if (NP > 64 * MAXW) PCL_FAIL(ctx, PCL_ERR_INVALID, "HMM with %d states exceeds the %d-state limit", b->Nmax, 64 * MAXW);
@@ -995,6 +1003,10 @@ int pcl_launch_forward_backward(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double t
         hipLaunchKernelGGL(hmm_fb_kernel<0>, dim3(b->U), dim3(NP), shm, ctx->stream, b->d_utt, b->Bt, b->row_ptr, b->col_idx,
                            b->csr_val, b->col_ptr, b->row_idx, b->csc_val, b->logpi, b->alpha, b->beta, b->lgam, b->xi_m,
                            b->xi_s, b->ksai, b->gamma_out, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, (const int *)nullptr);
+    // A one-frame utterance: LHMM.baulm_welch raises on it (the sum over t < T - 1 of LHMM.py:424-445 is empty: ValueError, golden G15), so
+    // under the reference's workers it adds nothing to any accumulator.  Here: ln P(O), alpha and beta are what one frame gives, the
+    // posteriors are ln 0 -- the accumulate passes (GMM statistics and per-unit transitions) then skip the utterance as a whole.
+    if (b->has_one_frame) hipLaunchKernelGGL(one_frame_kernel, dim3(b->U), dim3(64), 0, ctx->stream, b->d_utt, b->lgam);
     pcl_timer_end(ctx, "fb");
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;

@@ -583,6 +583,7 @@ int pcl_batch_create(pcl_ctx *ctx, int U, const int32_t *N, const int32_t *T, co
         to += T[u];
         b->Nmax = std::max(b->Nmax, (int)N[u]);
         b->Tmax = std::max(b->Tmax, (int)T[u]);
+        if (T[u] == 1) b->has_one_frame = true;
     }
     b->sumNT = bo;
     b->sumNN = mo;

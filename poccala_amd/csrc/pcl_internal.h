@@ -203,6 +203,7 @@ struct pcl_ctx {
 struct pcl_batch {
     pcl_ctx *ctx = nullptr;
     int U = 0, Nmax = 0, Tmax = 0;
+    bool has_one_frame = false;   // an utterance of ONE frame: the reference's Baum-Welch raises on it (golden G15) and it adds nothing to any accumulator
     long long sumNT = 0, sumN = 0, sumT = 0, sumNN = 0;
     long long max_frame_end = 0;   // max over utterances of frame_begin + T: re-validated against the CURRENT frame matrix
     int model_J = 0;               // J of the model the state lists were built for

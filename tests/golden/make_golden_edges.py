@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Golden G15: what the REFERENCE does on the inputs where the library documents a deviation -- a one-frame
+utterance, a two-frame utterance, an utterance too short for its label -- by running its own worker sequence
+(cal_observation_pro -> embedded -> LHMM(probmat).baulm_welch -> update_acc), recorded as data: arrays with their NaNs, or the
+exception's type name when the reference raises.  Runs in the build container only (imports /root/reference through
+make_golden.import_reference); nothing of the reference's source text is stored.
+
+    python tests/golden/make_golden_edges.py      # rewrites tests/golden/G15_edges.npz"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import RecLog, diag_cov, import_reference, rand_gmm  # noqa: E402
+
+S = 5
+
+
+def main():
+    warnings.simplefilter('ignore')
+    scratch, util, LHMM, Clustering, AcousticModel = import_reference()
+    GMM = Clustering.GMM
+    am = AcousticModel(RecLog(), 'XIF_tone', processes=1, console=False, state_num=5)
+    out = {}
+    cases = [('t1_l1', ['b'], 1), ('t2_l1', ['b'], 2), ('t3_l1', ['b'], 3), ('t1_l2', ['b', 'a1'], 1), ('t2_l4', ['b', 'a1', 'b', 'ing2'], 2)]
+    for ci, (tag, label, t) in enumerate(cases):
+        rng = np.random.default_rng(1500 + ci)
+        m, d = 3, 5
+        x = rng.standard_normal((t, d))
+        out[tag + '_x'] = x
+        out[tag + '_label'] = np.array(label)
+        unit_params, hmm_list = {}, []
+        for u in label:
+            if u not in unit_params:
+                unit_params[u] = [rand_gmm(np.random.default_rng(7000 + 10 * ci + len(unit_params) * 3 + k), m, d) for k in range(S - 2)]
+            params = unit_params[u]
+            trans = np.zeros((S, S))
+            trans[0][1] = 1.
+            for j in range(1, S - 1):
+                trans[j][j] = 0.5
+                trans[j][j + 1] = 0.5
+            gmms = [GMM(RecLog(), dimension=d, mix_level=m, alpha=w.copy(), mean=mean.copy(), covariance=diag_cov(var), gmm_id=k)
+                    for k, (mean, var, w) in enumerate(params)]
+            prof = [AcousticModel.VirtualState(1.)] + gmms + [AcousticModel.VirtualState(0.)]
+            h = LHMM({i: u for i in range(S)}, S, RecLog(), transmat=trans.copy(), profunc=prof, fix_code=0)
+            h.cal_observation_pro([x], [t])
+            h.clear_data()
+            hmm_list.append(h)
+        names = sorted(unit_params)
+        out[tag + '_unit_names'] = np.array(names)
+        for ui, u in enumerate(names):
+            for k, (mean, var, w) in enumerate(unit_params[u]):
+                out['%s_mean_%d_%d' % (tag, ui, k)] = mean
+                out['%s_var_%d_%d' % (tag, ui, k)] = var
+                out['%s_w_%d_%d' % (tag, ui, k)] = w
+        states, A, B, pi = am.embedded(list(label), hmm_list, 0, 15)
+        out[tag + '_emb_A'], out[tag + '_emb_B'], out[tag + '_emb_pi'] = A.copy(), B.copy(), pi.copy()
+        elog = RecLog()
+        raised = ''
+        try:
+            with np.errstate(all='ignore'):
+                embed = LHMM(states, S, elog, transmat=A, probmat=[B], pi=pi, hmm_list=hmm_list, fix_code=0)
+                embed.add_data([x])
+                embed.add_T([t])
+                embed.baulm_welch(show_q=False)
+        except Exception as ex:             # noqa: BLE001 -- the fixture records WHAT the reference does, whatever it is
+            raised = type(ex).__name__
+        out[tag + '_raised'] = np.array(raised)
+        qs = [float(msg.split(':')[1]) for (c, msg) in elog.msgs if msg.startswith('HMM 当前似然度')]
+        out[tag + '_q_trace'] = np.array(qs)
+        if not raised:
+            out[tag + '_pi'] = embed.pi.copy()
+            out[tag + '_ksai'] = embed._LHMM__ksai.copy()
+            out[tag + '_gamma'] = embed._LHMM__gamma.copy()
+            out[tag + '_logp'] = np.float64(util.log_sum_exp(embed._LHMM__result_f[0][:, -1]))
+        for pos, h in enumerate(hmm_list):              # whatever update_acc left (the initial ln 0 when it never ran)
+            out['%s_ksai_acc_%d' % (tag, pos)] = np.array(h.ksai_acc, dtype=np.float64)
+            out['%s_gamma_acc_%d' % (tag, pos)] = np.array(h.gamma_acc, dtype=np.float64)
+            for k in range(S - 2):
+                g = h.profunction[1 + k]
+                out['%s_acc_%d_%d' % (tag, pos, k)] = np.array(g.acc, dtype=np.float64)
+                out['%s_alpha_acc_%d_%d' % (tag, pos, k)] = np.float64(g.alpha_acc)
+                out['%s_mean_acc_%d_%d' % (tag, pos, k)] = np.array(g.mean_acc, dtype=np.float64)
+                out['%s_cov_acc_%d_%d' % (tag, pos, k)] = np.array(g._GMM__covariance_acc, dtype=np.float64)
+        print(tag, 'T', t, 'label', label, 'raised', repr(raised), 'q', qs, 'ksai_acc[0] nan?', bool(np.isnan(out[tag + '_ksai_acc_0']).any()),
+              'finite?', bool(np.isfinite(out[tag + '_ksai_acc_0']).any()), 'acc[0][0]', out[tag + '_acc_0_0'])
+    np.savez_compressed(os.path.join(HERE, 'G15_edges.npz'), **out)
+
+
+if __name__ == '__main__':
+    main()

@@ -907,3 +907,54 @@ def test_exchange_with_ranks_that_hold_no_utterance(payload):
             np.testing.assert_allclose(got, want, err_msg='%s on rank %d' % (nm, r), **tol)
         for got, first in zip(model, ranks[0][0]):
             assert np.array_equal(got, first), 'rank %d holds another model than rank 0' % r
+
+
+@pytest.mark.parametrize('tag', ['t1_l1', 't2_l1', 't3_l1', 't1_l2', 't2_l4'])
+def test_very_short_utterances_as_the_reference_has_them(eng, golden, tag):
+    """Golden G15 (the reference's own worker sequence on utterances of one, two and three frames, and on a label of four units over two
+    frames): with one frame LHMM.baulm_welch raises and every accumulator keeps its ln 0 -- the library adds nothing for that utterance;
+    with two or three frames the reference's accumulators through the C-ABI at 1e-9."""
+    from poccala_amd import PCL_F64
+    g = golden('G15_edges')
+    names = [str(u) for u in g[tag + '_unit_names']]
+    label = [names.index(str(u)) for u in g[tag + '_label']]
+    x = g[tag + '_x']
+    flat = np.zeros((S, S))
+    flat[0][1] = 1.
+    for j in range(1, S - 1):
+        flat[j][j] = flat[j][j + 1] = 0.5
+    mean = np.stack([g['%s_mean_%d_%d' % (tag, ui, k)] for ui in range(len(names)) for k in range(E)])
+    var = np.stack([g['%s_var_%d_%d' % (tag, ui, k)] for ui in range(len(names)) for k in range(E)])
+    w = np.stack([g['%s_w_%d_%d' % (tag, ui, k)] for ui in range(len(names)) for k in range(E)])
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack([flat] * len(names)))
+    eng.load_frames(x)
+    eng.stats_zero()
+    b = eng.label_batch([np.array(label)], np.array([x.shape[0]], dtype=np.int32), np.zeros(1, dtype=np.int64))
+    b.score(PCL_F64)
+    b.forward_backward()
+    b.accumulate(PCL_F64)
+    b.accumulate_hmm()
+    st = eng.stats_download()
+    ks, ga = eng.hmm_acc_download()
+    if x.shape[0] == 1:
+        assert str(g[tag + '_raised']) == 'ValueError'
+        assert not st['acc'].any() and not st['alpha_acc'].any() and not st['mean_acc'].any() and not st['cov_acc'].any()
+        assert np.isneginf(ks).all() and np.isneginf(ga).all() and np.isneginf(b.get('lgamma')[0]).all()
+        b.close()
+        return
+    np.testing.assert_allclose(b.get('logp')[0], float(g[tag + '_logp']), rtol=1e-10)
+    assert int(b.get('npass')[0]) == len(g[tag + '_q_trace'])
+    rk, rg = np.full((len(names), E, S), -np.inf), np.full((len(names), E), -np.inf)
+    ref = dict(acc=np.zeros_like(st['acc']), alpha_acc=np.zeros_like(st['alpha_acc']), mean_acc=np.zeros_like(st['mean_acc']), cov_acc=np.zeros_like(st['cov_acc']))
+    for pos, unit in enumerate(label):
+        rk[unit] = np.logaddexp(rk[unit], g['%s_ksai_acc_%d' % (tag, pos)])
+        rg[unit] = np.logaddexp(rg[unit], g['%s_gamma_acc_%d' % (tag, pos)])
+        for k in range(E):
+            for nm in ref:
+                ref[nm][unit * E + k] += np.exp(g['%s_%s_%d_%d' % (tag, nm, pos, k)])
+    fin_close(ks, rk, rtol=1e-9)
+    fin_close(ga, rg, rtol=1e-9)
+    for nm in ref:
+        np.testing.assert_allclose(st[nm], ref[nm], rtol=1e-9, atol=1e-13 * np.abs(ref[nm]).max(), err_msg=nm)
+    b.close()

@@ -234,3 +234,72 @@ def test_g11_multi_utterance_lhmm(golden, tag):
     ref = g['ksai_acc_' + tag]
     close(ua.ksai_acc[np.isfinite(ref)], ref[np.isfinite(ref)])
     close(ua.gamma_acc, g['gamma_acc_' + tag])
+
+
+# ------------------------------------------------------------------ G15: the edges (one / two / three frames, an utterance shorter than its label)
+EDGE_TAGS = ['t1_l1', 't2_l1', 't3_l1', 't1_l2', 't2_l4']
+
+
+def load_edge(g, tag):
+    names = [str(u) for u in g[tag + '_unit_names']]
+    label = [str(u) for u in g[tag + '_label']]
+    flat = np.zeros((S, S))
+    flat[0][1] = 1.
+    for j in range(1, S - 1):
+        flat[j][j] = flat[j][j + 1] = 0.5
+    model = {u: dict(trans=flat, gmms=[(g['%s_mean_%d_%d' % (tag, ui, k)], g['%s_var_%d_%d' % (tag, ui, k)], g['%s_w_%d_%d' % (tag, ui, k)])
+                                       for k in range(S - 2)]) for ui, u in enumerate(names)}
+    return label, model
+
+
+@pytest.mark.parametrize('tag', EDGE_TAGS)
+def test_g15_edges(golden, tag):
+    """What the reference does on very short utterances (tests/golden/make_golden_edges.py ran its worker sequence): with ONE frame
+    LHMM.baulm_welch raises ValueError (the sum over t < T - 1 is empty) and every accumulator keeps its ln 0 -- the restatement's
+    vectorised empty sums come out NaN there, which the GPU tests read as 'undefined in the reference'; with two or three frames, also
+    for a label far longer than the utterance, the reference runs and the restatement reproduces it."""
+    g = golden('G15_edges')
+    label, model = load_edge(g, tag)
+    x = g[tag + '_x']
+    raised = str(g[tag + '_raised'])
+    states, a, b, pi = po.score_label(x, label, model)
+    close(a, g[tag + '_emb_A'])
+    fin = np.isfinite(g[tag + '_emb_B'])
+    assert np.array_equal(np.isfinite(b), fin)
+    close(b[fin], g[tag + '_emb_B'][fin])
+    if x.shape[0] == 1:
+        assert raised == 'ValueError'
+        for pos in range(len(label)):
+            assert np.isneginf(g['%s_ksai_acc_%d' % (tag, pos)]).all() and np.isneginf(g['%s_gamma_acc_%d' % (tag, pos)]).all()
+            for k in range(S - 2):
+                assert np.isneginf(g['%s_acc_%d_%d' % (tag, pos, k)]).all() and np.isneginf(g['%s_alpha_acc_%d_%d' % (tag, pos, k)])
+        with np.errstate(all='ignore'):
+            bw = po.baum_welch(a, pi, [b])
+        assert np.isnan(bw['ksai']).all()
+        return
+    assert raised == ''
+    with np.errstate(all='ignore'):
+        bw, accs, _ = po.estep_utterance(x, label, model)
+    assert bw['n_pass'] == len(g[tag + '_q_trace'])
+    np.testing.assert_allclose(bw['q_trace'][1:], g[tag + '_q_trace'][1:], atol=2e-6)
+    close(bw['logp'][0], g[tag + '_logp'])
+    close(bw['pi'], g[tag + '_pi'], atol=1e-300)
+    for name, got in ((tag + '_ksai', bw['ksai']), (tag + '_gamma', bw['gamma'])):
+        ref = g[name]
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and np.array_equal(np.isnan(got), np.isnan(ref)), name
+        f = np.isfinite(ref)
+        close(got[f], ref[f])
+    for pos in range(len(label)):
+        ua = accs[pos]
+        for name, got in (('%s_ksai_acc_%d' % (tag, pos), ua.ksai_acc), ('%s_gamma_acc_%d' % (tag, pos), ua.gamma_acc)):
+            ref = g[name]
+            assert np.array_equal(np.isneginf(got), np.isneginf(ref)), name
+            f = np.isfinite(ref)
+            close(got[f], ref[f])
+        for k in range(S - 2):
+            for nm in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+                ref = g['%s_%s_%d_%d' % (tag, nm, pos, k)]
+                got = np.asarray(ua.gmm[k][nm])
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (nm, pos, k)
+                f = np.isfinite(ref)
+                close(got[f], ref[f], rtol=1e-9)
