@@ -87,6 +87,31 @@ def main():
                 out['%s_cov_acc_%d_%d' % (tag, pos, k)] = np.array(g._GMM__covariance_acc, dtype=np.float64)
         print(tag, 'T', t, 'label', label, 'raised', repr(raised), 'q', qs, 'ksai_acc[0] nan?', bool(np.isnan(out[tag + '_ksai_acc_0']).any()),
               'finite?', bool(np.isfinite(out[tag + '_ksai_acc_0']).any()), 'acc[0][0]', out[tag + '_acc_0_0'])
+    # ---- a frame far from the state's centre whose best mixture sits in the third 32-mixture tile, 89.2 / 90 / 91 nats above the first tile, a
+    #      runner-up 1 / 2 / 3 nats below it in the second: the case on which the matrix-pipe log-sum-exp of rounds 1-5 lost the runner-up
+    #      (DESIGN 4.10).  GMM.point of the reference itself on it (tests/test_gpu_parity.py:far_frame_problem is the same construction).
+    for gi, (gap, runner_up) in enumerate([(89.2, 1.0), (90.0, 2.0), (91.0, 3.0), (130.0, 1.0)]):
+        rng = np.random.default_rng(1600 + gi)
+        M, D, T, R = 96, 39, 6, 30.0
+        e = np.zeros(D)
+        e[0] = 1.0
+        C, p_best = 3.2, 3.0
+        p = np.full(M, p_best - (gap + 40.0) / R)
+        p[:32] = p_best - gap / R - rng.uniform(0, 0.3, 32) / R
+        p[40] = p_best - runner_up / R
+        p[77] = p_best
+        u = rng.standard_normal((M, D))
+        u[:, 0] = 0.0
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        mean = p[:, None] * e[None, :] + np.sqrt(C * C - p * p)[:, None] * u
+        var = np.ones((M, D))
+        w = np.full(M, 1.0 / M)
+        x = (R * e[None, :] + 0.003 * rng.standard_normal((T, D))).astype(np.float32).astype(np.float64)
+        gmm = GMM(RecLog(), dimension=D, mix_level=M, alpha=w.copy(), mean=mean.copy(), covariance=diag_cov(var))
+        val = np.array([gmm.point(x[t].copy(), log=True) for t in range(T)])
+        out['far%d_mean' % gi], out['far%d_var' % gi], out['far%d_w' % gi], out['far%d_x' % gi], out['far%d_point' % gi] = mean, var, w, x, val
+        out['far%d_gap' % gi] = np.array([gap, runner_up])
+        print('far frame', gap, runner_up, 'ln b', val[:3])
     np.savez_compressed(os.path.join(HERE, 'G15_edges.npz'), **out)
 
 

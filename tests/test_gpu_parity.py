@@ -1066,6 +1066,15 @@ def test_score_best_mixture_far_above_the_first_tile(eng_variant, gap, runner_up
     assert_f32_class(got, ref, f32_evaluation_bound(mean, var, w, x), what='best mixture %g nats above the first tile:' % gap)
 
 
+@pytest.mark.parametrize('gi', range(4))
+def test_score_far_frame_against_the_reference_itself(eng_variant, golden, gi):
+    """The same construction held to GMM.point of the REFERENCE (golden G15, tests/golden/make_golden_edges.py), not to the oracle."""
+    g = golden('G15_edges')
+    mean, var, w, x = g['far%d_mean' % gi][None], g['far%d_var' % gi][None], g['far%d_w' % gi][None], g['far%d_x' % gi].astype(np.float32)
+    got, _ = score_all_states(eng_variant, mean, var, w, x)
+    assert_f32_class(got, g['far%d_point' % gi][None], f32_evaluation_bound(mean, var, w, x), what='far frame (reference), gap %g:' % g['far%d_gap' % gi][0])
+
+
 def test_score_variants_wide_dynamic_range(eng_variant):
     """Variances from 1e-3 (the reference's floor) to 1e3 inside one state, a common offset, per-dimension scales six
     decades apart: the power-of-two feature scaling of the f16 kernel and the centring of all of them."""

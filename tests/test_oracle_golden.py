@@ -303,3 +303,12 @@ def test_g15_edges(golden, tag):
                 assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (nm, pos, k)
                 f = np.isfinite(ref)
                 close(got[f], ref[f], rtol=1e-9)
+
+
+@pytest.mark.parametrize('gi', range(4))
+def test_g15_far_frame_gmm_point(golden, gi):
+    """GMM.point of the reference on a frame 30 sigma from the state's centre whose best mixture is ~90 nats above the first 32 (the case
+    the matrix-pipe log-sum-exp of rounds 1-5 got wrong): the restatement reproduces the reference."""
+    g = golden('G15_edges')
+    got = po.gmm_point(g['far%d_x' % gi], g['far%d_mean' % gi], g['far%d_var' % gi], g['far%d_w' % gi])
+    close(got, g['far%d_point' % gi], rtol=1e-12)
