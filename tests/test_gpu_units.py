@@ -958,3 +958,60 @@ def test_very_short_utterances_as_the_reference_has_them(eng, golden, tag):
     for nm in ref:
         np.testing.assert_allclose(st[nm], ref[nm], rtol=1e-9, atol=1e-13 * np.abs(ref[nm]).max(), err_msg=nm)
     b.close()
+
+
+@pytest.mark.parametrize('kind', ['tight', 'wide', 'skewed'])
+def test_ill_conditioned_models_against_the_reference_itself(eng, golden, kind):
+    """Golden G16: the reference's own accumulators and re-estimated model on mixtures at the 1e-6 variance floor / variances over four
+    decades in one state / weights down to 1e-12, through the C-ABI in the float64 mode (the default mode is held to the oracle on such
+    draws by tests/test_gpu_fuzz_estep.py, and the oracle to this fixture by tests/test_oracle_golden.py)."""
+    from poccala_amd import PCL_F64
+    g = golden('G16_kinds')
+    names = [str(u) for u in g[kind + '_unit_names']]
+    label = [names.index(str(u)) for u in g[kind + '_label']]
+    x = g[kind + '_x']
+    flat = np.zeros((S, S))
+    flat[0][1] = 1.
+    for j in range(1, S - 1):
+        flat[j][j] = flat[j][j + 1] = 0.5
+    mean = np.stack([g['%s_mean_%d_%d' % (kind, ui, k)] for ui in range(len(names)) for k in range(E)])
+    var = np.stack([g['%s_var_%d_%d' % (kind, ui, k)] for ui in range(len(names)) for k in range(E)])
+    w = np.stack([g['%s_w_%d_%d' % (kind, ui, k)] for ui in range(len(names)) for k in range(E)])
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack([flat] * len(names)))
+    eng.load_frames(x)
+    eng.stats_zero()
+    b = eng.label_batch([np.array(label)], np.array([x.shape[0]], dtype=np.int32), np.zeros(1, dtype=np.int64))
+    b.score(PCL_F64)
+    fin = np.isfinite(g[kind + '_emb_B'])
+    Bd = b.get('B')[0]
+    assert np.array_equal(np.isfinite(Bd), fin)
+    np.testing.assert_allclose(Bd[fin], g[kind + '_emb_B'][fin], rtol=1e-11, atol=1e-10)
+    b.forward_backward()
+    b.accumulate(PCL_F64)
+    b.accumulate_hmm()
+    np.testing.assert_allclose(b.get('logp')[0], float(g[kind + '_logp']), rtol=1e-11)
+    assert int(b.get('npass')[0]) == len(g[kind + '_q_trace'])
+    st = eng.stats_download()
+    ks, ga = eng.hmm_acc_download()
+    for pos, unit in enumerate(label):                       # (two different units: a position is a unit)
+        fin_close(ks[unit], g['%s_ksai_acc_%d' % (kind, pos)], rtol=1e-9)
+        fin_close(ga[unit], g['%s_gamma_acc_%d' % (kind, pos)], rtol=1e-9)
+        for k in range(E):
+            j = unit * E + k
+            with np.errstate(all='ignore'):
+                for nm in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+                    ref = np.exp(g['%s_%s_%d_%d' % (kind, nm, pos, k)])
+                    np.testing.assert_allclose(st[nm][j], ref, rtol=1e-8, atol=1e-12 * max(float(np.max(ref)), 1e-300), err_msg='%s state %d' % (nm, j))
+    eng.em_exchange(1e-6)
+    nm_, nv_, nw_ = eng.model_download()
+    for pos, unit in enumerate(label):
+        for k in range(E):
+            j = unit * E + k
+            rw, rm, rv = g['%s_new_w_%d_%d' % (kind, pos, k)], g['%s_new_mean_%d_%d' % (kind, pos, k)], g['%s_new_var_%d_%d' % (kind, pos, k)]
+            seen = st['acc'][j] > 0.0                        # (a mixture with occupancy 0: the reference's 0 / 0; the library keeps its parameters)
+            ok = seen & np.isfinite(rm).all(axis=1)
+            np.testing.assert_allclose(nw_[j][ok], rw[ok], rtol=1e-8, atol=1e-300)
+            np.testing.assert_allclose(nm_[j][ok], rm[ok], rtol=1e-6, atol=1e-8)
+            np.testing.assert_allclose(nv_[j][ok], rv[ok], rtol=1e-7, atol=1e-12)
+    b.close()

@@ -312,3 +312,43 @@ def test_g15_far_frame_gmm_point(golden, gi):
     g = golden('G15_edges')
     got = po.gmm_point(g['far%d_x' % gi], g['far%d_mean' % gi], g['far%d_var' % gi], g['far%d_w' % gi])
     close(got, g['far%d_point' % gi], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ G16: the ill-conditioned model kinds the randomised GPU tests draw
+@pytest.mark.parametrize('kind', ['tight', 'wide', 'skewed'])
+def test_g16_ill_conditioned_kinds(golden, kind):
+    """The reference's own E-step and M-step on mixtures at the 1e-6 variance floor, variances over four decades inside a state, weights
+    down to 1e-12 (tests/golden/make_golden_kinds.py): the restatement reproduces every accumulator and the re-estimated model, so a GPU
+    result 'held to the oracle' on such a draw (tests/test_gpu_fuzz_estep.py) is held to the reference."""
+    g = golden('G16_kinds')
+    label, model = load_edge(g, kind)
+    x = g[kind + '_x']
+    with np.errstate(all='ignore'):
+        bw, accs, (_, a, b, pi) = po.estep_utterance(x, label, model)
+    fin = np.isfinite(g[kind + '_emb_B'])
+    assert np.array_equal(np.isfinite(b), fin)
+    close(b[fin], g[kind + '_emb_B'][fin], rtol=1e-10)
+    assert bw['n_pass'] == len(g[kind + '_q_trace'])
+    close(bw['logp'][0], g[kind + '_logp'])
+    for pos in range(len(label)):
+        ua = accs[pos]
+        for name, got in (('%s_ksai_acc_%d' % (kind, pos), ua.ksai_acc), ('%s_gamma_acc_%d' % (kind, pos), ua.gamma_acc)):
+            ref = g[name]
+            assert np.array_equal(np.isneginf(got), np.isneginf(ref)), name
+            f = np.isfinite(ref)
+            close(got[f], ref[f])
+        for k in range(S - 2):
+            for nm in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+                ref = g['%s_%s_%d_%d' % (kind, nm, pos, k)]
+                got = np.asarray(ua.gmm[k][nm])
+                assert np.array_equal(np.isneginf(got), np.isneginf(ref)), (nm, pos, k)
+                f = np.isfinite(ref)
+                close(got[f], ref[f], rtol=1e-9, atol=1e-9)
+            with np.errstate(all='ignore'):
+                w, mean, var = po.gmm_update_param(ua.gmm[k], c_covariance=1e-6)
+            rw, rm, rv = g['%s_new_w_%d_%d' % (kind, pos, k)], g['%s_new_mean_%d_%d' % (kind, pos, k)], g['%s_new_var_%d_%d' % (kind, pos, k)]
+            ok = np.isfinite(rm).all(axis=1) & np.isfinite(mean).all(axis=1)
+            assert np.array_equal(np.isfinite(rm).all(axis=1), np.isfinite(mean).all(axis=1))
+            close(w, rw, rtol=1e-9, atol=1e-300)
+            close(mean[ok], rm[ok], rtol=1e-6, atol=1e-8)
+            close(var[ok], rv[ok], rtol=1e-7, atol=1e-12)
