@@ -21,8 +21,10 @@ from oracle import poccala_oracle as po  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def draw_hmm(rng):
+def draw_hmm(rng, many_states=False):
     n = int(rng.choice([3, 4, 5, 8, 14, 33, 62, 64, 65, 100, 150])) if rng.random() < 0.7 else int(rng.integers(3, 151))
+    if many_states:                                  # up to the 1024-state limit: four and more wavefronts per HMM, the log-domain kernels beyond 256 states
+        n = int(rng.choice([192, 193, 255, 256, 257, 320, 511, 512, 700, 1024]))
     kind = rng.choice(['ergodic', 'banded', 'left-right', 'sparse'])
     a = np.zeros((n, n))
     if kind == 'ergodic':
@@ -54,15 +56,18 @@ def draw_hmm(rng):
 
 def draw(seed):
     rng = np.random.default_rng(seed)
-    long_ = seed >= 5000                             # seeds from 5000: a few long utterances (the scaled route's exponents, the hand-over to the log kernels)
-    U = int(rng.integers(1, 13)) if not long_ else int(rng.integers(1, 4))
+    long_ = 5000 <= seed < 9000                      # seeds from 5000: a few long utterances (the scaled route's exponents, the hand-over to the log kernels)
+    many = seed >= 9000                              # seeds from 9000: HMMs of 192 .. 1024 states
+    U = int(rng.integers(1, 13)) if not (long_ or many) else int(rng.integers(1, 4))
     hmms, Bs = [], []
     for _ in range(U):
-        a, pi, kind = draw_hmm(rng)
+        a, pi, kind = draw_hmm(rng, many)
         n = a.shape[0]
         T = int(rng.integers(1, 151)) if rng.random() < 0.9 else int(rng.integers(1, 5))
         if long_:
             T = int(rng.integers(800, 5000))
+        if many:
+            T = int(rng.integers(1, 120))
         spread = float(rng.choice([1.0, 4.0, 40.0, 900.0]))
         b = float(rng.choice([0.0, -85.0, -3000.0])) + spread * rng.standard_normal((n, T))
         if rng.random() < 0.4:
@@ -145,7 +150,7 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize('seed', list(range(30)) + [5000, 5001, 5002])
+@pytest.mark.parametrize('seed', list(range(30)) + [5000, 5001, 5002, 9001, 9002])
 def test_random_hmms_against_the_oracle(eng, seed):
     run_case(eng, seed)
 
