@@ -697,6 +697,13 @@ __global__ void hmm_viterbi_kernel(const UttDesc *__restrict__ utts, const doubl
             int e = 0x7fffffff;
             for (int k = 0; k < (int)(blockDim.x >> 6); ++k) e = min(e, red.ibuf[0][k]);
             if (e == 0x7fffffff) e = end_state_back ? max(N - 4, 0) : 0;
+            // fewer than four states with end_state_back: the reference's len(p_list) - 4 + (first argmax of p_list[-4:]) is a NEGATIVE index
+            // there, which NumPy wraps (LHMM.py:587-588) -- only `point` sees it, the backtrack starts from the stale index either way
+            if (end_state_back && N < 4) {
+                int r = N - 4 + e;
+                if (r < 0) r += N;
+                e = max(r, 0);
+            }
             s_end = e;
         }
         __syncthreads();

@@ -79,7 +79,7 @@ def draw(seed):
             b[:, int(rng.integers(0, T))] = -np.inf  # a frame nobody can emit: P(O) = 0
         hmms.append((a, pi, kind))
         Bs.append(b)
-    return dict(hmms=hmms, Bs=Bs, fix_pi=bool(rng.random() < 0.4), threshold=float(rng.choice([0.64, 0.64, 0.05, 1e9])))
+    return dict(hmms=hmms, Bs=Bs, fix_pi=bool(rng.random() < 0.4), threshold=float(rng.choice([0.64, 0.64, 0.05, 1e9])), end_state_back=bool(rng.random() < 0.3))
 
 
 def same(tag, what, got, want, rtol, atol):
@@ -102,7 +102,7 @@ def run_case(eng, seed):
         b.set_transitions([np.log(h[0]) for h in c['hmms']], [np.log(h[1]) for h in c['hmms']])
     b.set_emissions(c['Bs'])
     b.forward_backward(fix_pi=c['fix_pi'], threshold=c['threshold'])
-    b.viterbi()
+    b.viterbi(end_state_back=c['end_state_back'])
     out = {k: b.get(k) for k in ('alpha', 'beta', 'lgamma', 'ksai', 'gamma', 'pi', 'logp', 'npass', 'qtrace', 'path', 'point')}
     b.close()
     tag = 'hmm fuzz'
@@ -111,7 +111,7 @@ def run_case(eng, seed):
         B = c['Bs'][u]
         with np.errstate(all='ignore'):
             bw = po.baum_welch(a, pi, [B], fix_code=1 if c['fix_pi'] else 0, threshold=c['threshold'])
-            rp, rpath = po.viterbi(a, pi, B)
+            rp, rpath = po.viterbi(a, pi, B, end_state_back=c['end_state_back'])
         ctx = (seed, u, kind, int(N[u]), int(T[u]))
         # sums of up to 150 emissions of this size in float64 on both sides, in different orders
         big = float(np.abs(B[np.isfinite(B)]).max()) * T[u] if np.isfinite(B).any() else 1.0
