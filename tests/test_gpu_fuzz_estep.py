@@ -82,7 +82,8 @@ def draw(seed):
     if rng.random() < 0.3:                        # float64 features with more bits than an f32 holds (the reference's MFCCs are float64): the float64
         frames = frames.astype(np.float64) * (1.0 + 1e-9 * rng.standard_normal(frames.shape))      # mode reads them as they are, the default mode rounds them
     return dict(units=units, M=M, D=D, mean=mean, var=var, w=w, trans=trans, U=U, L=L, labels=labels, lens=lens, begin=begin,
-                frames=frames, kind=str(kind), fkind=str(fkind), fix_pi=bool(rng.random() < 0.3), c_cov=float(rng.choice([1e-3, 1e-6])))
+                frames=frames, kind=str(kind), fkind=str(fkind), fix_pi=bool(rng.random() < 0.3), c_cov=float(rng.choice([1e-3, 1e-6])),
+                end_state_back=bool(rng.random() < 0.5))      # (LHMM.viterbi's option, LHMM.py:586-599, quirk Q9)
 
 
 def lnb_bound(model, lab, x):
@@ -117,7 +118,7 @@ def run_case(eng, seed, prec):
     b = eng.label_batch(labels, lens, begin)
     b.score(P)
     b.forward_backward(fix_pi=c['fix_pi'])
-    b.viterbi()
+    b.viterbi(end_state_back=c['end_state_back'])
     b.accumulate(P)
     b.accumulate_hmm()
     Bd, logp, npass, lgam, path, point = (b.get(k) for k in ('B', 'logp', 'npass', 'lgamma', 'path', 'point'))
@@ -150,7 +151,7 @@ def run_case(eng, seed, prec):
         # ---- the DP on the device's emissions
         with np.errstate(all='ignore'):
             bw = po.baum_welch(a, pi, [Bd[u]], fix_code=fix_code)
-        rp, rpath = po.viterbi(a, pi, Bd[u])
+        rp, rpath = po.viterbi(a, pi, Bd[u], end_state_back=c['end_state_back'])
         assert np.array_equal(path[u].astype(np.float64), rpath) and rp == point[u], (seed, u)
         if not np.isfinite(bw['logp'][0]):           # an utterance too short for its label: P(O) = 0.  The reference goes on with NaNs; the library adds nothing
             assert np.isneginf(logp[u]), (seed, u, logp[u])
