@@ -1015,3 +1015,72 @@ def test_ill_conditioned_models_against_the_reference_itself(eng, golden, kind):
             np.testing.assert_allclose(nm_[j][ok], rm[ok], rtol=1e-6, atol=1e-8)
             np.testing.assert_allclose(nv_[j][ok], rv[ok], rtol=1e-7, atol=1e-12)
     b.close()
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_exchange_random_worlds(seed):
+    """Random world sizes (2 .. 8, threads on one device over the host transport), state counts that no world divides, mixtures, feature
+    dimensions, utterance counts (fewer utterances than ranks included), payloads: after the exchange every rank holds the model a single
+    rank re-estimates from all utterances (float64 payload 1e-12, f32 payload 1e-5), every rank the SAME bits, and the pipelined
+    accumulate + exchange equals the plain one bit for bit."""
+    from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+    from poccala_amd.distributed import shard_range
+    rng = np.random.default_rng(7100 + seed)
+    world = int(rng.choice([2, 3, 5, 6, 8]))
+    units = int(rng.integers(2, 8))
+    M = int(rng.choice([1, 3, 8, 33]))
+    D = int(rng.choice([13, 26, 39]))
+    U = int(rng.integers(1, 3 * world))
+    mean, var, w, _ = synth.make_model(units, M, D, seed=7200 + seed)
+    trans = [synth.random_left_right_transmat(rng) for _ in range(units)]
+    frames, lens, begin = synth.make_frames(U, 40, D, seed=7300 + seed, ragged=True)
+    labels = synth.make_labels(U, int(rng.integers(1, 4)), units, seed=7400 + seed)
+    pay = PCL_F32 if rng.random() < 0.5 else PCL_F64
+    c_cov = float(rng.choice([1e-3, 1e-6]))
+    n_chunks = int(rng.integers(1, 6))
+
+    def body_for(n):
+        def body(rank, gather):
+            eng = Engine(0)
+            try:
+                if gather is not None:
+                    eng.comm_init_host(rank, n, gather)
+                res = {}
+                for mode in ('plain', 'pipe'):
+                    eng.load_model(mean, var, w)
+                    eng.load_units(np.stack(trans))
+                    eng.stats_zero()
+                    lo, hi = shard_range(U, rank, n)
+                    b = None
+                    if hi > lo:
+                        f0, f1 = int(begin[lo]), int(begin[hi - 1] + lens[hi - 1])
+                        eng.load_frames(frames[f0:f1])
+                        b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi] - f0)
+                        b.score(PCL_F64); b.forward_backward(); b.accumulate_hmm()
+                    # (the pipelined form is a batch's call: a job in which some rank holds no utterance uses the plain exchange on every rank --
+                    #  all ranks must run the same sequence of collectives)
+                    if mode == 'plain' or U < n:
+                        if b is not None:
+                            b.accumulate(PCL_F64)
+                        eng.em_exchange(c_cov, pay, True)
+                    else:
+                        b.accumulate_exchange(PCL_F64, c_cov, pay, True, n_chunks=n_chunks)
+                    res[mode] = eng.model_download() + (eng.units_download(),)
+                    if b is not None:
+                        b.close()
+                return res
+            finally:
+                eng.close()
+        return body
+    single = _run_ranks(1, body_for(1))[0]
+    ranks = _run_ranks(world, body_for(world))
+    tol = dict(rtol=1e-12, atol=1e-12) if pay == PCL_F64 else dict(rtol=1e-5, atol=1e-6)
+    ctx = 'seed %d world %d units %d M %d D %d U %d payload %s' % (seed, world, units, M, D, U, 'f64' if pay == PCL_F64 else 'f32')
+    for r, g in enumerate(ranks):
+        for got, want, nm in zip(g['plain'], single['plain'], ('mean', 'var', 'weight', 'transitions')):
+            np.testing.assert_allclose(got, want, err_msg='%s: %s on rank %d' % (ctx, nm, r), **tol)
+        for got, first in zip(g['plain'], ranks[0]['plain']):
+            assert np.array_equal(got, first), '%s: rank %d holds another model than rank 0' % (ctx, r)
+        if True:
+            for got, plain in zip(g['pipe'], g['plain']):
+                assert np.array_equal(got, plain), '%s: pipelined differs from plain on rank %d' % (ctx, r)
