@@ -355,6 +355,10 @@ int pcl_em_exchange(pcl_ctx *ctx, double c_covariance, int payload, int update_t
  * reduce-scatter leaves early, M-steps / all-gathers / derive run at the end; PCL_PIPE_MODE=0: the whole chain per chunk (on one
  * rank: M-step + derive of finished chunks beside the rest of the pass).  Synchronous at return. */
 int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covariance, int payload, int update_transitions, int n_chunks);
+/* The same exchange for a rank that has NO batch for this last pass (fewer batches on this rank than on the others: every rank must run
+ * the same sequence of collectives): the rank's statistics -- zero, or whatever its earlier batches accumulated -- go through the
+ * n_chunks chunk exchanges of pcl_batch_accumulate_exchange without an accumulate pass in front.  Same arguments, same result. */
+int pcl_accumulate_exchange_idle(pcl_ctx *ctx, double c_covariance, int payload, int update_transitions, int n_chunks);
 /* Of the last pcl_batch_accumulate_exchange: its number of chunks and how many of them left for the exchange WHILE the accumulate pass was
  * still running (0: the pass released none -- states out of ascending order or on the direct-form kernel -- and the call was the plain
  * accumulate + exchange).  NULLs are skipped. */

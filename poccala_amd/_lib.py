@@ -75,6 +75,7 @@ PROTOTYPES = {
     'pcl_em_exchange': (_i, [_vp, _d, _i, _i]),
     'pcl_pipe_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     'pcl_batch_accumulate_exchange': (_i, [_vp, _i, _d, _i, _i, _i]),
+    'pcl_accumulate_exchange_idle': (_i, [_vp, _d, _i, _i, _i]),
     'pcl_comm_unique_id': (_i, [_vp]),
     'pcl_comm_init': (_i, [_vp, _i, _i, _vp]),
     'pcl_stats_allreduce': (_i, [_vp]),

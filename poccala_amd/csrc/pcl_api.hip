@@ -1380,6 +1380,21 @@ int pcl_batch_accumulate_exchange(pcl_batch *b, int precision, double c_covarian
     return PCL_OK;
 }
 
+int pcl_accumulate_exchange_idle(pcl_ctx *ctx, double c_covariance, int payload, int update_transitions, int n_chunks) {
+    if (!ctx) return PCL_ERR_INVALID;
+    if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_accumulate_exchange_idle: no model uploaded");
+    HIPCHK(ctx, pcl_stats_join(ctx));
+    if (payload != PCL_F64 && payload != PCL_F32) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_accumulate_exchange_idle: payload %d", payload);
+    if (n_chunks < 1) PCL_FAIL(ctx, PCL_ERR_INVALID, "pcl_accumulate_exchange_idle: n_chunks %d", n_chunks);
+    if (ctx->transport == 0 && ctx->nranks != 1) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_accumulate_exchange_idle: pcl_comm_init was not called");
+    if (update_transitions && !ctx->hmm_ksai) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_accumulate_exchange_idle: update_transitions without pcl_units_upload");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TRY(pcl_pipe_begin(ctx, c_covariance, payload, n_chunks));
+    TRY(pcl_pipe_finish(ctx, update_transitions));               // every chunk, in order: the collectives the other ranks' passes release
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
 int pcl_mstep(pcl_ctx *ctx, double c_covariance) {
     if (!ctx) return PCL_ERR_INVALID;
     if (!ctx->stats) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_mstep: no model uploaded");

@@ -391,6 +391,12 @@ class Engine(object):
         on one rank.  NOT the default: with it the re-estimated model depends on the world size."""
         return PCL_F32 if self.comm_info()['nranks'] > 1 else PCL_F64
 
+    def accumulate_exchange_idle(self, c_covariance=1e-3, payload=PCL_F64, update_transitions=False, n_chunks=8):
+        """Batch.accumulate_exchange for a rank that has no batch for this last pass (the others do): the same chunk exchanges, in the
+        same order, on whatever this rank's statistics hold."""
+        self._check(self._lib.pcl_accumulate_exchange_idle(self._ctx, float(c_covariance), int(payload), 1 if update_transitions else 0, int(n_chunks)))
+        self._model_key = None
+
     def em_exchange(self, c_covariance=1e-3, payload=PCL_F64, update_transitions=False):
         """reduce-scatter of the statistics by state range -> M-step on the owned states -> all-gather of the model
         (+ merge of the per-unit HMM accumulators, + the transition update on request).  One rank: the M-step.

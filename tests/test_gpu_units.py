@@ -1057,14 +1057,15 @@ def test_exchange_random_worlds(seed):
                         eng.load_frames(frames[f0:f1])
                         b = eng.label_batch(labels[lo:hi], lens[lo:hi], begin[lo:hi] - f0)
                         b.score(PCL_F64); b.forward_backward(); b.accumulate_hmm()
-                    # (the pipelined form is a batch's call: a job in which some rank holds no utterance uses the plain exchange on every rank --
-                    #  all ranks must run the same sequence of collectives)
-                    if mode == 'plain' or U < n:
+                    # (all ranks must run the same sequence of collectives: a rank without a batch takes the idle form of the pipelined call)
+                    if mode == 'plain':
                         if b is not None:
                             b.accumulate(PCL_F64)
                         eng.em_exchange(c_cov, pay, True)
-                    else:
+                    elif b is not None:
                         b.accumulate_exchange(PCL_F64, c_cov, pay, True, n_chunks=n_chunks)
+                    else:
+                        eng.accumulate_exchange_idle(c_cov, pay, True, n_chunks=n_chunks)
                     res[mode] = eng.model_download() + (eng.units_download(),)
                     if b is not None:
                         b.close()
