@@ -3,7 +3,7 @@
 # restatement, a sweep against its unhurried twin.  Each under its own timeout; joined with && so that nothing runs after a failure or a kill.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 S=${SOAK_SEED:-300}       # (E-step fuzz: seeds below 1000 are the small draws, from 1000 the big ones; HMM fuzz: from 5000 the long utterances)
-timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py 700 $S > gpurun_out/soak_estep.txt 2>&1; echo "estep rc=$? $(tail -1 gpurun_out/soak_estep.txt)"
+timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py $((S < 300 ? 1000 - S : 700 > 1000 - S ? 1000 - S : 700)) $S > gpurun_out/soak_estep.txt 2>&1; echo "estep rc=$? $(tail -1 gpurun_out/soak_estep.txt)"
 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 60 $((S + 1200)) > gpurun_out/soak_estep_big.txt 2>&1; echo "estep big rc=$? $(tail -1 gpurun_out/soak_estep_big.txt)"
 timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 500 $S > gpurun_out/soak_hmm.txt 2>&1; echo "hmm rc=$? $(tail -1 gpurun_out/soak_hmm.txt)"
 timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 40 $((S + 5100)) > gpurun_out/soak_hmm_long.txt 2>&1; echo "hmm long rc=$? $(tail -1 gpurun_out/soak_hmm_long.txt)"
