@@ -33,6 +33,8 @@ def draw(seed):
     E = S - 2
     M = int(rng.choice([1, 2, 3, 5, 8, 17, 31, 32, 33, 64, 65, 100, 130]))
     D = int(rng.choice([13, 26, 39, 47, 48, 64]))
+    if 3000 <= seed < 5000 and rng.random() < 0.5:
+        D = int(rng.choice([5, 8, 14, 20, 27, 33, 40, 45, 55]))     # dimensions the library pads to the next matrix-pipe size
     big = 1000 <= seed < 3000                     # seeds 1000 .. 2999: few units, many utterances -> a state's frame list spans several 256-frame scoring
     if big:                                       # tiles and 32-frame accumulate tiles; up to 13 mixture tiles per state
         units = int(rng.integers(2, 4))
