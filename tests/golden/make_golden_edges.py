@@ -112,6 +112,19 @@ def main():
         out['far%d_mean' % gi], out['far%d_var' % gi], out['far%d_w' % gi], out['far%d_x' % gi], out['far%d_point' % gi] = mean, var, w, x, val
         out['far%d_gap' % gi] = np.array([gap, runner_up])
         print('far frame', gap, runner_up, 'ln b', val[:3])
+    # ---- LHMM.viterbi with end_state_back on HMMs of fewer than four states: len(p_list) - 4 + argmax(p_list[-4:]) is a negative index there,
+    #      which NumPy wraps (LHMM.py:587-588); N = 2, 3 and, for comparison, 4 and 6
+    for n in (2, 3, 4, 6):
+        rng = np.random.default_rng(1800 + n)
+        t = 9
+        A = rng.dirichlet(np.ones(n), size=n)
+        pi = rng.dirichlet(np.ones(n))
+        prob = rng.standard_normal((n, t)) * 3 - 5
+        states = {i: 's%d' % i for i in range(n)}
+        point, path = LHMM.viterbi(RecLog(), states, A, prob, pi, end_state_back=True)
+        out['esb%d_A' % n], out['esb%d_pi' % n], out['esb%d_prob' % n] = A, pi, prob
+        out['esb%d_point' % n], out['esb%d_path' % n] = np.float64(point), np.array(path, dtype=np.float64)
+        print('end_state_back N', n, 'point', point, 'path', path)
     np.savez_compressed(os.path.join(HERE, 'G15_edges.npz'), **out)
 
 

@@ -242,3 +242,20 @@ def test_left_to_right_hmms_of_any_size_match_the_oracle(eng, fix_pi, wide):
             hold(tag, 'ln xi (sum over t)', lin['ksai'][u][fk], bw['ksai'][fk], 1e-10, 1e-9)
             hold(tag, 'ln gamma (sum over t)', lin['gamma'][u], bw['gamma'], 1e-10, 1e-9)
         np.testing.assert_allclose(lin['pi'][u], bw['pi'], rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 6])
+def test_viterbi_end_state_back_on_small_hmms_as_the_reference_has_it(eng, golden, n):
+    """Golden G15: LHMM.viterbi(end_state_back=True) of the reference itself on 2, 3, 4 and 6 states (a negative index wrapped by NumPy when
+    there are fewer than four, LHMM.py:587-588): score and path through the C-ABI, bit for bit."""
+    g = golden('G15_edges')
+    A, pi, prob = g['esb%d_A' % n], g['esb%d_pi' % n], g['esb%d_prob' % n]
+    eng.load_frames(np.zeros((prob.shape[1], max(eng.D, 1)), dtype=np.float32))
+    b = eng.batch([n], [prob.shape[1]], [0])
+    with np.errstate(divide='ignore'):
+        b.set_transitions([np.log(A)], [np.log(pi)])
+    b.set_emissions([prob])
+    b.viterbi(end_state_back=True)
+    assert b.get('point')[0] == float(g['esb%d_point' % n])
+    assert np.array_equal(b.get('path')[0].astype(np.float64), g['esb%d_path' % n])
+    b.close()

@@ -352,3 +352,13 @@ def test_g16_ill_conditioned_kinds(golden, kind):
             close(w, rw, rtol=1e-9, atol=1e-300)
             close(mean[ok], rm[ok], rtol=1e-6, atol=1e-8)
             close(var[ok], rv[ok], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 6])
+def test_g15_end_state_back_on_small_hmms(golden, n):
+    """LHMM.viterbi(end_state_back=True) of the reference on 2, 3, 4 and 6 states: with fewer than four, len(p_list) - 4 + argmax(p_list[-4:])
+    is a negative index that NumPy wraps (LHMM.py:587-588); the restatement reproduces score and path."""
+    g = golden('G15_edges')
+    point, path = po.viterbi(g['esb%d_A' % n], g['esb%d_pi' % n], g['esb%d_prob' % n], end_state_back=True)
+    assert point == float(g['esb%d_point' % n])
+    assert np.array_equal(path, g['esb%d_path' % n])
