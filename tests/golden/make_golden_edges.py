@@ -125,6 +125,42 @@ def main():
         out['esb%d_A' % n], out['esb%d_pi' % n], out['esb%d_prob' % n] = A, pi, prob
         out['esb%d_point' % n], out['esb%d_path' % n] = np.float64(point), np.array(path, dtype=np.float64)
         print('end_state_back N', n, 'point', point, 'path', path)
+    # ---- GMM.update_param after an E-step in which one mixture has weight 0 (ln 0 = -inf everywhere: its accumulators stay ln 0): what the
+    #      reference's M-step makes of 0 / 0 (Clustering.py:682-693)
+    rng = np.random.default_rng(1900)
+    m, d, t = 4, 5, 12
+    mean = rng.standard_normal((m, d))
+    var = rng.uniform(0.5, 2.0, (m, d))
+    w = rng.dirichlet(np.ones(m))
+    w[2] = 0.0
+    w /= w.sum()
+    x = rng.standard_normal((t, d))
+    lval = np.log(rng.dirichlet(np.ones(t)) * 3.0)                # ln gamma_t(j) of some state
+    gmm = GMM(RecLog(), dimension=d, mix_level=m, alpha=w.copy(), mean=mean.copy(), covariance=diag_cov(var))
+    with np.errstate(all='ignore'):
+        bval = np.array([gmm.point(x[i].copy(), log=True, record=True) for i in range(t)])
+        gmm.add_data(x) if hasattr(gmm, 'add_data') else None
+        try:
+            gmm.update_acc(lval, bval, x)
+            raised = ''
+        except Exception as ex:             # noqa: BLE001
+            raised = type(ex).__name__
+        out['zero_raised_acc'] = np.array(raised)
+        out['zero_acc'] = np.array(gmm.acc, dtype=np.float64)
+        out['zero_alpha_acc'] = np.float64(gmm.alpha_acc)
+        out['zero_mean_acc'] = np.array(gmm.mean_acc, dtype=np.float64)
+        out['zero_cov_acc'] = np.array(gmm._GMM__covariance_acc, dtype=np.float64)
+        try:
+            gmm.update_param(c_covariance=1e-3)
+            raised = ''
+        except Exception as ex:             # noqa: BLE001
+            raised = type(ex).__name__
+    out['zero_raised_mstep'] = np.array(raised)
+    out['zero_mean'], out['zero_var'], out['zero_w'], out['zero_x'], out['zero_lval'], out['zero_bval'] = mean, var, w, x, lval, bval
+    out['zero_new_w'] = np.array(gmm.alpha, dtype=np.float64)
+    out['zero_new_mean'] = np.array(gmm.mean, dtype=np.float64)
+    out['zero_new_var'] = np.array([np.diagonal(c) for c in gmm.covariance], dtype=np.float64)
+    print('zero-weight mixture: update_acc raised', repr(str(out['zero_raised_acc'])), 'update_param raised', repr(raised), 'acc', out['zero_acc'], 'new w', out['zero_new_w'], 'new mean[2]', out['zero_new_mean'][2], 'new var[2]', out['zero_new_var'][2])
     np.savez_compressed(os.path.join(HERE, 'G15_edges.npz'), **out)
 
 

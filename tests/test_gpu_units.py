@@ -1085,3 +1085,36 @@ def test_exchange_random_worlds(seed):
         if True:
             for got, plain in zip(g['pipe'], g['plain']):
                 assert np.array_equal(got, plain), '%s: pipelined differs from plain on rank %d' % (ctx, r)
+
+
+def test_zero_occupancy_mixture_as_the_reference_has_it(eng, golden):
+    """Golden G15: the reference's GMM.update_acc + update_param on a state one of whose mixtures has weight 0.  Through the C-ABI: the same
+    accumulators, the same re-estimated parameters for the mixtures that were responsible for something; for the one that was not, the reference's
+    0 / 0 is NaN mean and variance (the fixture holds them), the library's is weight 0 with mean and variance kept."""
+    from poccala_amd import PCL_F64
+    g = golden('G15_edges')
+    mean, var, w, x = g['zero_mean'][None], g['zero_var'][None], g['zero_w'][None], g['zero_x']
+    t = x.shape[0]
+    eng.load_model(mean, var, w)
+    eng.load_frames(x)
+    b = eng.batch([3], [t], [0])
+    b.set_states([np.array([-1, 0, -2], dtype=np.int32)])
+    ninf = np.full(t, -np.inf)
+    b.set_emissions([np.stack([np.zeros(t), g['zero_bval'], ninf])])
+    b.set_posteriors([np.stack([ninf, g['zero_lval'], ninf])])
+    eng.stats_zero()
+    b.accumulate(PCL_F64)
+    st = eng.stats_download()
+    with np.errstate(all='ignore'):
+        np.testing.assert_allclose(st['acc'][0], np.exp(g['zero_acc']), rtol=1e-9)
+        np.testing.assert_allclose(st['mean_acc'][0], np.exp(g['zero_mean_acc']), rtol=1e-9)
+        np.testing.assert_allclose(st['cov_acc'][0], np.exp(g['zero_cov_acc']), rtol=1e-9, atol=1e-300)
+    assert st['acc'][0][2] == 0.0
+    eng.mstep(1e-3)
+    nm, nv, nw = eng.model_download()
+    ok = ~np.isnan(g['zero_new_mean']).any(axis=1)
+    np.testing.assert_allclose(nw[0], g['zero_new_w'], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(nm[0][ok], g['zero_new_mean'][ok], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(nv[0][ok], g['zero_new_var'][ok], rtol=1e-8)
+    assert nw[0][2] == 0.0 and np.array_equal(nm[0][2], mean[0][2]) and np.array_equal(nv[0][2], var[0][2])
+    b.close()

@@ -362,3 +362,26 @@ def test_g15_end_state_back_on_small_hmms(golden, n):
     point, path = po.viterbi(g['esb%d_A' % n], g['esb%d_pi' % n], g['esb%d_prob' % n], end_state_back=True)
     assert point == float(g['esb%d_point' % n])
     assert np.array_equal(path, g['esb%d_path' % n])
+
+
+def test_g15_zero_occupancy_mixture(golden):
+    """A mixture of weight 0 collects nothing (its accumulators stay ln 0) and GMM.update_param of the reference makes 0 / 0 of it: weight 0,
+    mean and variance NaN (Clustering.py:682-693).  The restatement reproduces both; the library keeps the mixture's mean and variance
+    (tests/test_gpu_units.py::test_zero_occupancy_mixture_as_the_reference_has_it)."""
+    g = golden('G15_edges')
+    assert str(g['zero_raised_acc']) == '' and str(g['zero_raised_mstep']) == ''
+    acc = dict(acc=np.full(4, -np.inf), alpha_acc=-np.inf, mean_acc=np.full((4, 5), -np.inf), cov_acc=np.full((4, 5), -np.inf))
+    with np.errstate(all='ignore'):
+        po.gmm_update_acc(acc, g['zero_lval'], g['zero_bval'], g['zero_x'], g['zero_mean'], g['zero_var'], g['zero_w'])
+        w, mean, var = po.gmm_update_param(acc, c_covariance=1e-3)
+    for nm, ref in (('acc', g['zero_acc']), ('mean_acc', g['zero_mean_acc']), ('cov_acc', g['zero_cov_acc'])):
+        got = np.asarray(acc[nm])
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref)), nm
+        f = np.isfinite(ref)
+        close(got[f], ref[f], rtol=1e-10)
+    assert np.isneginf(g['zero_acc'][2]) and g['zero_new_w'][2] == 0.0 and np.isnan(g['zero_new_mean'][2]).all() and np.isnan(g['zero_new_var'][2]).all()
+    assert np.array_equal(np.isnan(mean), np.isnan(g['zero_new_mean'])) and np.array_equal(np.isnan(var), np.isnan(g['zero_new_var']))
+    ok = ~np.isnan(g['zero_new_mean']).any(axis=1)
+    close(w, g['zero_new_w'], rtol=1e-10, atol=1e-300)
+    close(mean[ok], g['zero_new_mean'][ok], rtol=1e-8, atol=1e-9)
+    close(var[ok], g['zero_new_var'][ok], rtol=1e-9)
