@@ -25,7 +25,8 @@ def main():
     GMM = Clustering.GMM
     am = AcousticModel(RecLog(), 'XIF_tone', processes=1, console=False, state_num=5)
     out = {}
-    cases = [('t1_l1', ['b'], 1), ('t2_l1', ['b'], 2), ('t3_l1', ['b'], 3), ('t1_l2', ['b', 'a1'], 1), ('t2_l4', ['b', 'a1', 'b', 'ing2'], 2)]
+    cases = [('t1_l1', ['b'], 1), ('t2_l1', ['b'], 2), ('t3_l1', ['b'], 3), ('t1_l2', ['b', 'a1'], 1), ('t2_l4', ['b', 'a1', 'b', 'ing2'], 2),
+             ('p0', ['b', 'a1'], 12)]        # p0: a frame no state can emit (its column of B set to ln 0): P(O) = 0
     for ci, (tag, label, t) in enumerate(cases):
         rng = np.random.default_rng(1500 + ci)
         m, d = 3, 5
@@ -57,6 +58,8 @@ def main():
                 out['%s_var_%d_%d' % (tag, ui, k)] = var
                 out['%s_w_%d_%d' % (tag, ui, k)] = w
         states, A, B, pi = am.embedded(list(label), hmm_list, 0, 15)
+        if tag == 'p0':
+            B[1:-1, 5] = -np.inf
         out[tag + '_emb_A'], out[tag + '_emb_B'], out[tag + '_emb_pi'] = A.copy(), B.copy(), pi.copy()
         elog = RecLog()
         raised = ''

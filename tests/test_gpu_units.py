@@ -1118,3 +1118,38 @@ def test_zero_occupancy_mixture_as_the_reference_has_it(eng, golden):
     np.testing.assert_allclose(nv[0][ok], g['zero_new_var'][ok], rtol=1e-8)
     assert nw[0][2] == 0.0 and np.array_equal(nm[0][2], mean[0][2]) and np.array_equal(nv[0][2], var[0][2])
     b.close()
+
+
+def test_impossible_utterance_as_the_reference_has_it(eng, golden):
+    """Golden G15 'p0': a frame no state can emit.  The reference does not raise: it leaves the per-unit accumulators at ln 0 and turns the GMM
+    accumulators of the label's states into NaN (the fixture holds them).  The library: ln P(O) = -inf and nothing added to either."""
+    from poccala_amd import PCL_F64
+    g = golden('G15_edges')
+    tag = 'p0'
+    names = [str(u) for u in g[tag + '_unit_names']]
+    label = [names.index(str(u)) for u in g[tag + '_label']]
+    x = g[tag + '_x']
+    flat = np.zeros((S, S))
+    flat[0][1] = 1.
+    for j in range(1, S - 1):
+        flat[j][j] = flat[j][j + 1] = 0.5
+    mean = np.stack([g['%s_mean_%d_%d' % (tag, ui, k)] for ui in range(len(names)) for k in range(E)])
+    var = np.stack([g['%s_var_%d_%d' % (tag, ui, k)] for ui in range(len(names)) for k in range(E)])
+    w = np.stack([g['%s_w_%d_%d' % (tag, ui, k)] for ui in range(len(names)) for k in range(E)])
+    assert np.isnan(g[tag + '_acc_0_0']).all() and np.isneginf(g[tag + '_ksai_acc_0']).all()      # what the reference left
+    eng.load_model(mean, var, w)
+    eng.load_units(np.stack([flat] * len(names)))
+    eng.load_frames(x)
+    eng.stats_zero()
+    b = eng.label_batch([np.array(label)], np.array([x.shape[0]], dtype=np.int32), np.zeros(1, dtype=np.int64))
+    b.score(PCL_F64)
+    b.set_emissions([g[tag + '_emb_B']])
+    b.forward_backward()
+    b.accumulate(PCL_F64)
+    b.accumulate_hmm()
+    assert np.isneginf(b.get('logp')[0]) and int(b.get('npass')[0]) == 1
+    st = eng.stats_download()
+    ks, ga = eng.hmm_acc_download()
+    assert not st['acc'].any() and not st['alpha_acc'].any() and not st['mean_acc'].any() and not st['cov_acc'].any()
+    assert np.isfinite(st['acc']).all() and np.isneginf(ks).all() and np.isneginf(ga).all()
+    b.close()

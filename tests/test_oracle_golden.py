@@ -385,3 +385,29 @@ def test_g15_zero_occupancy_mixture(golden):
     close(w, g['zero_new_w'], rtol=1e-10, atol=1e-300)
     close(mean[ok], g['zero_new_mean'][ok], rtol=1e-8, atol=1e-9)
     close(var[ok], g['zero_new_var'][ok], rtol=1e-9)
+
+
+def test_g15_impossible_utterance(golden):
+    """A frame no state can emit (P(O) = 0): the reference does not raise -- it leaves the HMM accumulators at ln 0 and turns the GMM
+    accumulators of every state of the label into NaN (inf - inf in the posteriors).  The restatement has the same patterns; the library
+    adds nothing to either (tests/test_gpu_units.py::test_impossible_utterance_as_the_reference_has_it)."""
+    g = golden('G15_edges')
+    tag = 'p0'
+    label, model = load_edge(g, tag)
+    assert str(g[tag + '_raised']) == '' and len(g[tag + '_q_trace']) == 1
+    x = g[tag + '_x']
+    with np.errstate(all='ignore'):
+        _, a, b, pi = po.score_label(x, label, model)
+        b = g[tag + '_emb_B']                                  # (the fixture's emissions: one column set to ln 0)
+        bw = po.baum_welch(a, pi, [b])
+        accs = [po.UnitAcc(S, model[u]['gmms']) for u in label]
+        po.update_acc(bw, [b], [x], accs, [model[u]['gmms'] for u in label], s=S)
+    assert bw['n_pass'] == 1 and np.isneginf(bw['logp'][0])
+    for pos in range(len(label)):
+        for name, got in (('%s_ksai_acc_%d' % (tag, pos), accs[pos].ksai_acc), ('%s_gamma_acc_%d' % (tag, pos), accs[pos].gamma_acc)):
+            ref = g[name]
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isneginf(got), np.isneginf(ref)), name
+        for k in range(S - 2):
+            for nm in ('acc', 'mean_acc', 'cov_acc'):
+                ref = g['%s_%s_%d_%d' % (tag, nm, pos, k)]
+                assert np.isnan(ref).all() and np.isnan(np.asarray(accs[pos].gmm[k][nm])).all(), (nm, pos, k)
