@@ -36,6 +36,11 @@ def draw(seed):
     if 3000 <= seed < 5000 and rng.random() < 0.5:
         D = int(rng.choice([5, 8, 14, 20, 27, 33, 40, 45, 55]))     # dimensions the library pads to the next matrix-pipe size
     big = 1000 <= seed < 3000                     # seeds 1000 .. 2999: few units, many utterances -> a state's frame list spans several 256-frame scoring
+    huge = 6000 <= seed < 7000                    # seeds 6000 .. 6999: the BASELINE mixture counts (64 and 128 mixture tiles per state), few short utterances
+    if huge:
+        units = 2
+        M = int(rng.choice([1024, 2048, 4096]))
+        D = int(rng.choice([13, 39]))
     if big:                                       # tiles and 32-frame accumulate tiles; up to 13 mixture tiles per state
         units = int(rng.integers(2, 4))
         M = int(rng.choice([65, 130, 257, 385]))
@@ -65,8 +70,10 @@ def draw(seed):
             trans.append(a)
     U = int(rng.integers(1, 10)) if not big else int(rng.integers(30, 70))
     L = int(rng.integers(1, 5)) if not big else int(rng.integers(1, 4))
+    if huge:
+        U, L = int(rng.integers(1, 4)), int(rng.integers(1, 3))
     labels = [rng.integers(0, units, size=L) for _ in range(U)]
-    lens = rng.integers(1 if rng.random() < 0.2 else 3 * L, 50, size=U).astype(np.int32)
+    lens = rng.integers(1 if rng.random() < 0.2 else 3 * L, 50 if not huge else 24, size=U).astype(np.int32)
     begin = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
     fkind = rng.choice(['noise', 'model', 'outliers'])
     frames = rng.standard_normal((int(lens.sum()), D)).astype(np.float32)
@@ -101,7 +108,7 @@ def run_case(eng, seed, prec):
       forward-backward device  vs  oracle ON THE DEVICE'S EMISSIONS        1e-9 in both modes (all DP state is float64): ln P(O), pass count,
                                                                            ln gamma_t(j), the per-unit ksai_acc / gamma_acc
       Viterbi          device  vs  oracle on the device's emissions        bit for bit
-      GMM statistics   device  vs  oracle's update_acc fed the device's ln gamma and ln b   float64 1e-9, default 1e-4 (+ the cov_acc term) + twice what
+      GMM statistics   device  vs  oracle's update_acc fed the device's ln gamma and ln b   float64 1e-9, default 1e-4 (+ the cov_acc term) + four times what
                                                                            the draw's emissions lost against float64
       both M-steps     device  vs  oracle's update_param ON THE DEVICE'S STATISTICS         1e-9
     and in float64 mode the chain is also held end to end (ln P(O) against the oracle on its own emissions)."""
@@ -193,7 +200,8 @@ def run_case(eng, seed, prec):
     # default mode: the north star's 1e-4, widened by what THIS draw's emissions lost against float64 (1.5e-5 nats at the BASELINE configs;
     # up to 2e-4 for states whose mixtures' variances span three decades, 1e-2 for variances at the 1e-6 floor under |x| ~ 1 -- in any f32
     # evaluation: the posteriors gamma_t(j,m) = w_m N_m / b_j inherit it)
-    srt = F32_RTOL + 2.0 * e_max if f32 else 10 * rt
+    srt = F32_RTOL + 4.0 * e_max if f32 else 10 * rt     # (a posterior = exp(ln w N_m - ln b): both terms carry the frame's evaluation error, and a single
+                                                         #  mixture's can be twice what their weighted mean ln b shows)
     c['statistics rtol'] = srt
     for key in (refs if srt < 1e-2 else ()):         # (frames thousands of sigma out: |ln b| ~ 1e7, an f32 evaluation is off by nats, the posteriors are not comparable)
         scale = float(np.abs(refs[key]).max())
@@ -201,7 +209,7 @@ def run_case(eng, seed, prec):
         if key == 'cov_acc' and f32:
             at = cov_acc_atol(refs['acc'], mean, var, at)
         # (recorded apart: the parity report shows which bound a figure was held to)
-        scfg = cfg if not f32 else cfg + (' (emissions as at the BASELINE configs: statistics at 1e-4 .. 1.5e-4)' if srt <= 1.5e-4 else ' (ill-conditioned draws: statistics at 1e-4 + 2 x the emission loss)')
+        scfg = cfg if not f32 else cfg + (' (emissions as at the BASELINE configs: statistics at 1e-4 .. 1.5e-4)' if srt <= 1.5e-4 else ' (ill-conditioned draws: statistics at 1e-4 + 4 x the emission loss)')
         hold(scfg, key, st[key], refs[key], srt, at)
     # both M-steps on the device's own statistics (Clustering.py:682-693, LHMM.py:519-520)
     eng.em_exchange(c['c_cov'], update_transitions=True)
@@ -239,7 +247,7 @@ def eng():
 # the first 24 draws, and the draws that found something (28: the flushed rescale of the matrix-pipe log-sum-exp; 39 / 52 / 66 / 110 / 119 / 159:
 # states with variances over three decades -> the f16 feature scale centred; 10 / 82: a cov_acc share a hair below zero; 36 / 266: one-frame
 # utterances; 41 / 50 / 291: frames thousands of sigma out)
-SEEDS = list(range(24)) + [28, 36, 39, 41, 50, 52, 66, 82, 110, 119, 159, 266, 291] + list(range(1000, 1004)) + list(range(3000, 3008))
+SEEDS = list(range(24)) + [28, 36, 39, 41, 50, 52, 66, 82, 110, 119, 159, 266, 291] + list(range(1000, 1004)) + list(range(3000, 3008)) + [6000, 6002, 6080]
 
 
 @pytest.mark.parametrize('seed', SEEDS)
