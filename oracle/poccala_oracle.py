@@ -8,7 +8,11 @@ and bench.py's cpu_baseline leg may import it; the product package
 
 Pinning: every function below is checked in tests/test_oracle_golden.py against
 golden vectors produced by running the reference itself in the build container
-(tests/golden/make_golden.py, groups G1..G9), rtol <= 1e-10.  `token_viterbi_step`
+(tests/golden/make_golden.py, groups G1..G9; make_golden_multi.py / _regroup.py G11, G12), rtol <= 1e-10; round 5 added
+the reference's own runs on what the randomised GPU tests draw: G16 (make_golden_kinds.py: mixtures at the 1e-6
+variance floor, variances over four decades in a state, weights down to 1e-12, E-step and M-step) and G15
+(make_golden_edges.py: utterances of one to three frames, P(O) = 0, a zero-occupancy mixture, Viterbi with
+end_state_back on 2-6 states, GMM.point on a frame 30 sigma from the state's centre).  `token_viterbi_step`
 (A16) is pinned through golden G14 (tests/golden/make_golden_decoder.py runs the
 reference's Decoder.Token.viterbi with a stand-in for the one module it cannot
 import; tests/test_decoder_golden.py + test_decoder_oracle.py).
