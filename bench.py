@@ -239,6 +239,7 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
                          'of scoring (scaled to all of them) + one faithful forward/backward lattice of %d frames per core, frames/s = cores / slowest '
                          'core\'s seconds per frame' % (len(labels[0]) * 3 // max(1, len(labels[0]) * 3 // CPU_FAITHFUL_ROWS), nrows, nfr))
     return dict(value=max(vec_value, gemm_value), unit='frames/s', cores=n_utt, kind='port', ipc_excluded=True, value_leg=lead,
+                sample_short='%d utterances, one per core, timed inside forked workers (frames / slowest worker): %d frames each (%s leg = value; vectorised leg %d frames); %d label states x %d mixtures + 3-pass forward-backward' % (n_utt, gemm[0][1] if lead == 'gemm' else nfr, lead, nfr, nrows, cfg['M']),
                 sample=common + '; value = the strongest of the CPU legs: ' + legs[lead],
                 vectorised_value=vec_value, vectorised_sample=legs['vectorised'],
                 gemm_value=gemm_value, gemm_sample=legs['gemm'],
@@ -247,6 +248,145 @@ def cpu_baseline(cfg, mean, var, w, trans, frames, lens, begin, labels):
                               gemm_max=max(t for t, _ in gemm), gemm_mean=float(np.mean([t for t, _ in gemm])),
                               faithful_s_per_frame_max=float(max(per_frame)), faithful_s_per_frame_mean=float(np.mean(per_frame))),
                 leg_wall_s=t_leg)
+
+
+# ------------------------------------------------------------------------------------------------
+# The line the driver reads.  Round 5's record had grown to 22.8 KB and the driver could not parse it (BENCH_r05.parsed == null):
+# the LAST stdout line is now a compact record of numbers (target <= 4 KB, never >= 8000 characters -- the driver's stdout tail),
+# strict JSON (no NaN / Infinity); the full record with its prose goes to bench_full.json next to this file and under gpurun_out/.
+# ------------------------------------------------------------------------------------------------
+COMPACT_TARGET_CHARS = 4096
+COMPACT_MAX_CHARS = 7900
+FULL_RECORD_NAME = 'bench_full.json'
+
+
+def _finite(o, sig=7):
+    """the same object with floats rounded to `sig` significant digits, non-finite floats and NumPy scalars mapped to JSON types"""
+    import math
+    if isinstance(o, dict):
+        return {str(k): _finite(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v, sig) for v in o]
+    if isinstance(o, (bool, np.bool_)):
+        return bool(o)
+    if isinstance(o, (int, np.integer)):
+        return int(o)
+    if isinstance(o, (float, np.floating)):
+        f = float(o)
+        if not math.isfinite(f):
+            return None
+        return float('%.*g' % (sig, f)) if sig else f
+    return o
+
+
+def _pick(d, *path):
+    for k in path:
+        if not isinstance(d, dict):
+            return None
+        d = d.get(k)
+    return d
+
+
+def compact_record(full):
+    """The driver's line from the full record: the contract's keys, `config`, `roofline` and `cpu_baseline` as numbers and short
+    names -- no prose.  Pure (tests/test_bench_schema.py builds it from committed full records)."""
+    cfg, rf, cpu, ex = full.get('config') or {}, full.get('roofline') or {}, full.get('cpu_baseline'), full.get('extra') or {}
+    workload = str(cfg.get('workload', ''))
+    out = {k: full.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                     'vs_baseline', 'dtype', 'data')}
+    out['config'] = {'workload': workload if len(workload) <= 330 else workload[:327] + '...'}
+    for k in ('utterances_total', 'frames_per_step_total', 'resident_batches', 'transport', 'rccl_nranks', 'device', 'cus'):
+        out['config'][k] = cfg.get(k)
+    r = {k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac')}
+    den = str(rf.get('frac_denominator') or '')
+    r['frac_denominator'] = den.split(':')[0][:96] if den else None
+    for k in ('frac_of_f16_dense_peak', 'frac_executed', 'traffic', 'traffic_over_algorithmic', 'kernel', 'kernel_avg_ms', 'launches',
+              'flop_per_launch', 'hbm_algorithmic_bytes_per_launch', 'fb_kernel_avg_ms', 'fb_kernel_alone_ms'):
+        r[k] = rf.get(k)
+    r['kernel_code_sha16'] = _pick(rf, 'traffic_raw', 'kernel_code_sha16')
+    r['traffic_file'] = _pick(rf, 'traffic_raw', 'file')
+    for k in ('sustained_value', 'fresh_batches_value', 'pcie_inclusive_value', 'strict_f32_value', 'strict_f32_frac',
+              'value_em2_model', 'value_em3_model', 'off_pipe_mixture_share_em2', 'off_pipe_mixture_share_em3'):
+        r[k] = rf.get(k)
+    r['estep_ms'] = ex.get('estep_ms')
+    per = _pick(ex, 'exchange', 'per_rank') or []              # N > 1: what the statistics exchange cost (max over ranks)
+    for k in ('exchange_ms', 'reduce_scatter_ms', 'mstep_owned_ms', 'all_gather_ms'):
+        r[k] = max([p_.get(k) or 0.0 for p_ in per]) if per else None
+    r['exchange_payload'] = _pick(ex, 'exchange', 'payload')
+    r['estep_pipelined_ms'] = _pick(ex, 'estep_pipelined', 'estep_ms')
+    r['accumulate_ms'] = ex.get('accumulate_ms')
+    r['estep_frac_executed'] = _pick(full, 'roofline_estep', 'frac_executed')
+    r['c4_ms_per_iteration'] = _pick(ex, 'configs', 'C4', 'ms_per_iteration')
+    r['c4_fresh_ms_per_iteration'] = _pick(ex, 'configs', 'C4', 'fresh_batches', 'ms_per_iteration')
+    em = _pick(ex, 'configs', 'C4', 'em_iterations') or []
+    r['c4_em_iteration_ms'] = [e.get('ms') for e in em] or None
+    r['c4_em_off_pipe_share'] = [e.get('mixtures_off_the_matrix_pipe') for e in em] or None
+    r['c2_frames_per_s'] = _pick(ex, 'configs', 'C2', 'value')
+    r['c3_frames_per_s'] = _pick(ex, 'configs', 'C3', 'value')
+    r['c5_frames_per_s'] = _pick(ex, 'configs', 'C5', 'value')
+    r['c5_shard_frames_per_s'] = _pick(ex, 'configs', 'C5shard', 'value')
+    r['c5_decode_kernel_ms'] = _pick(ex, 'configs', 'C5shard', 'decode_kernel_ms')
+    out['roofline'] = r
+    if cpu:
+        c = {k: cpu.get(k) for k in ('value', 'unit', 'cores', 'kind', 'value_leg')}
+        c['sample'] = cpu.get('sample_short') or str(cpu.get('sample', ''))[:200]
+        for k in ('gemm_value', 'vectorised_value', 'faithful_value'):
+            c[k] = cpu.get(k)
+        c['wall_s'] = sum((cpu.get('leg_wall_s') or {}).values()) or None
+        out['cpu_baseline'] = c
+        out['gpu_over_cpu'] = (full['value'] / cpu['value']) if cpu.get('value') and full.get('value') else None
+    else:
+        out['cpu_baseline'] = None
+    err = ex.get('error') if isinstance(ex, dict) else None
+    if err:
+        out['extra_error'] = str(err)[:200]
+    out['full_record'] = full.get('full_record')
+    out['final'] = bool(full.get('final', True))
+    return _finite(out)
+
+
+def compact_line(full):
+    """compact_record as ONE strict-JSON line that fits the driver's stdout tail: optional keys are dropped (last first) rather than
+    the line lost, should it ever outgrow the limit."""
+    rec = compact_record(full)
+    line = json.dumps(rec, allow_nan=False, separators=(', ', ': '))
+    optional = ['estep_pipelined_ms', 'mstep_owned_ms', 'c5_decode_kernel_ms', 'c5_shard_frames_per_s', 'c3_frames_per_s', 'c2_frames_per_s', 'c4_em_off_pipe_share', 'c4_em_iteration_ms',
+                'c4_fresh_ms_per_iteration', 'estep_frac_executed', 'accumulate_ms', 'fb_kernel_alone_ms', 'fb_kernel_avg_ms',
+                'hbm_algorithmic_bytes_per_launch', 'flop_per_launch', 'launches', 'traffic_file', 'frac_denominator']
+    while len(line) > COMPACT_TARGET_CHARS and optional:
+        rec['roofline'].pop(optional.pop(0), None)
+        line = json.dumps(rec, allow_nan=False, separators=(', ', ': '))
+    if len(line) >= COMPACT_MAX_CHARS:                     # cannot happen with the key set above; never lose the contract's keys to it
+        rec['config']['workload'] = rec['config']['workload'][:120]
+        rec.pop('extra_error', None)
+        line = json.dumps(rec, allow_nan=False, separators=(', ', ': '))
+    assert len(line) < COMPACT_MAX_CHARS and '\n' not in line, len(line)
+    return line
+
+
+def write_full_record(full):
+    """the whole record (prose, side measurements) as strict JSON: bench_full.json beside bench.py and under gpurun_out/ (merged back
+    from a GPU box).  Returns the path written first, or None -- a read-only tree must not cost the line."""
+    text = json.dumps(_finite(full, sig=0), allow_nan=False, indent=1)
+    first = None
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, FULL_RECORD_NAME), 'w') as f:
+                f.write(text)
+            first = first or os.path.join(os.path.basename(d) if d != ROOT else '', FULL_RECORD_NAME).lstrip('/')
+        except OSError:
+            pass
+    return first
+
+
+def emit(full, final):
+    """rank 0: write the full record, print the compact line (and flush): called once as soon as the headline, the roofline and the CPU
+    leg are final, and again at the end with what the untimed extras added -- a late failure leaves the early line as the last one."""
+    full = dict(full, final=final)
+    full['full_record'] = write_full_record(full)
+    print(compact_line(full))
+    sys.stdout.flush()
 
 
 # per scoring kernel: name, the peak its arithmetic is priced against, and what that peak means
@@ -833,35 +973,8 @@ def main():
     # beside the headline, from the same resident batches (outside the timed region): the same loop held for >= 10 s, and the
     # end-to-end pipeline of SURVEY 8(d) with every step's frames and results crossing PCIe
     sustained = pcie = fresh = None
-    if args.sustain > 0 and not align and P == PCL_F32:
-        t_mark2 = time.perf_counter()
-        try:
-            ns, tot, blocks, clocks = sustained_loop(eng, batches, P, args.sustain)
-            tot = ctl.allreduce_max(tot)
-            sustained = dict(value=frames_per_rank * world * ns / tot, seconds=tot, steps=ns,
-                             ms_per_100_steps=dict(min=min(blocks) * 1e3, median=float(np.median(blocks)) * 1e3, max=max(blocks) * 1e3),
-                             shader_mhz=dict(min=min(clocks), median=float(np.median(clocks)), max=max(clocks), probes=len(clocks)) if clocks else None,
-                             clock_source='on-device probe beside the scoring kernel: s_memtime (shader cycles) / s_memrealtime (100 MHz) over 2 ms, once per '
-                                          '100 steps; the PMC figure (GRBM_GUI_ACTIVE per kernel) is in profiles/; rocm-smi sclk is the requested level, not this')
-        except Exception as e:                 # noqa: never the headline's problem
-            sustained = dict(error=repr(e))
-        tl['sustained_loop_s'] = time.perf_counter() - t_mark2
-        t_mark2 = time.perf_counter()
-        try:
-            fresh = fresh_batch_loop(eng, P, cfg, lens_all, begin_all, max(4 * args.steps, 80), rank=rank, resident=batches)
-            fresh['value'] = fresh['value'] * world        # (whole job: every rank sweeps its own shard; rank 0's clock)
-        except Exception as e:                 # noqa: never the headline's problem
-            fresh = dict(error=repr(e))
-        tl['fresh_batch_loop_s'] = time.perf_counter() - t_mark2
-        t_mark2 = time.perf_counter()
-        if world == 1 and not reduced and nb >= 2:
-            try:
-                pcie = pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, max(args.steps, 20))
-            except Exception as e:             # noqa
-                pcie = dict(error=repr(e))
-        tl['pcie_inclusive_loop_s'] = time.perf_counter() - t_mark2
-
-    def make_line(extra):
+    loops = {}                                 # sustained / fresh / pcie as they complete (make_full reads them)
+    def make_full(extra):
         out = {
             'metric': 'frames/sec GMM-score+Viterbi forced alignment, 39-d MFCC, 2048-mix' if align else 'frames/sec GMM-score+fwd-bwd, 39-d MFCC, 2048-mix',
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -886,12 +999,16 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        sustained, fresh, pcie = loops.get('sustained'), loops.get('fresh'), loops.get('pcie')
         rf = out['roofline'] = dict(roofline)      # the loop-level figures the driver's record should keep (it keeps this object whole)
         rf['sustained_value'] = sustained.get('value') if sustained else None
         rf['fresh_batches_value'] = fresh.get('value') if fresh else None
         rf['pcie_inclusive_value'] = pcie.get('value') if pcie else None
         sf_ = (extra or {}).get('strict_f32') or {}
         rf['strict_f32_value'], rf['strict_f32_frac'] = sf_.get('value'), sf_.get('frac')
+        em_ = (extra or {}).get('em_shaped_models') or {}      # the headline loop on the models EM leaves (VERDICT r5 next #2b)
+        for key in ('value_em2_model', 'value_em3_model', 'off_pipe_mixture_share_em2', 'off_pipe_mixture_share_em3'):
+            rf[key] = em_.get(key)
         if sustained:
             out['value_sustained'] = sustained.get('value')
             out['sustained'] = sustained
@@ -913,21 +1030,52 @@ def main():
             out['gpu_over_cpu'] = {'vs_cpu_baseline_value': value / cpu['value'], 'vs_blas_gemm_formulation': value / cpu['gemm_value'],
                                    'vs_reference_arithmetic_vectorised': value / cpu['vectorised_value'], 'vs_reference_as_written': value / cpu['faithful_value'],
                                    'note': 'a GPU / CPU ratio says nothing about kernel quality (the roofline fractions do); north_star asks >= 200 against the reference CPU path'}
-        return json.dumps(out)
+        return out
 
-    # The timed number is final here.  What follows (the E-step with its exchange, side measurements) is outside the timed region and
-    # must not be able to take the line with it: an exception is reported inside `extra`, and if the extras or the shutdown do not come
-    # back within --extra-timeout seconds (a collective that never completes on some node), rank 0 prints the line without them.
+    # The headline, its roofline and the CPU leg are final: the line goes out NOW (rank 0), before anything else can hang, fail or
+    # outgrow a reader; it is printed again at the end with what the untimed measurements added (the driver reads the last line).
+    if rank == 0:
+        emit(make_full(None), final=False)
+    # What follows (the held loops, the E-step with its exchange, side measurements) is outside the timed region and must not be able
+    # to take the line with it: an exception is reported inside `extra`, and if it does not come back within --extra-timeout seconds
+    # (a collective that never completes on some node), rank 0 prints the line with what it has and the job exits non-zero.
     printed = threading.Event()
 
     def give_up():
         if rank == 0 and not printed.is_set():
-            print(make_line(dict(error='extras did not finish within %d s' % args.extra_timeout)))
-            sys.stdout.flush()
+            emit(make_full(dict(error='extras did not finish within %d s' % args.extra_timeout)), final=False)
         os._exit(3)                            # the line is out, but the job did NOT complete: launchers must see a failure
     dog = threading.Timer(args.extra_timeout, give_up)
     dog.daemon = True
     dog.start()
+    if args.sustain > 0 and not align and P == PCL_F32:
+        t_mark2 = time.perf_counter()
+        try:
+            ns, tot, blocks, clocks = sustained_loop(eng, batches, P, args.sustain)
+            tot = ctl.allreduce_max(tot)
+            loops['sustained'] = sustained = dict(value=frames_per_rank * world * ns / tot, seconds=tot, steps=ns,
+                             ms_per_100_steps=dict(min=min(blocks) * 1e3, median=float(np.median(blocks)) * 1e3, max=max(blocks) * 1e3),
+                             shader_mhz=dict(min=min(clocks), median=float(np.median(clocks)), max=max(clocks), probes=len(clocks)) if clocks else None,
+                             clock_source='on-device probe beside the scoring kernel: s_memtime (shader cycles) / s_memrealtime (100 MHz) over 2 ms, once per '
+                                          '100 steps; the PMC figure (GRBM_GUI_ACTIVE per kernel) is in profiles/; rocm-smi sclk is the requested level, not this')
+        except Exception as e:                 # noqa: never the headline's problem
+            loops['sustained'] = sustained = dict(error=repr(e))
+        tl['sustained_loop_s'] = time.perf_counter() - t_mark2
+        t_mark2 = time.perf_counter()
+        try:
+            loops['fresh'] = fresh = fresh_batch_loop(eng, P, cfg, lens_all, begin_all, max(4 * args.steps, 80), rank=rank, resident=batches)
+            fresh['value'] = fresh['value'] * world        # (whole job: every rank sweeps its own shard; rank 0's clock)
+        except Exception as e:                 # noqa: never the headline's problem
+            loops['fresh'] = fresh = dict(error=repr(e))
+        tl['fresh_batch_loop_s'] = time.perf_counter() - t_mark2
+        t_mark2 = time.perf_counter()
+        if world == 1 and not reduced and nb >= 2:
+            try:
+                loops['pcie'] = pcie = pcie_inclusive_loop(eng, P, cfg, frames, labels_all, lens_all, max(args.steps, 20))
+            except Exception as e:             # noqa
+                loops['pcie'] = pcie = dict(error=repr(e))
+        tl['pcie_inclusive_loop_s'] = time.perf_counter() - t_mark2
+
     extra = None
     comm_error = None
     if world > 1 or os.environ.get('POCCALA_FORCE_DIST'):          # FORCE_DIST: exercise RCCL at world 1
@@ -954,8 +1102,7 @@ def main():
             traceback.print_exc()
             extra = dict(error='%s: %s' % (type(e).__name__, e))
     if rank == 0:
-        print(make_line(extra))
-        sys.stdout.flush()
+        emit(make_full(extra), final=True)
         printed.set()
     barrier()
     for bt in batches:
@@ -1143,6 +1290,7 @@ def extras(args, eng, ctl, batches, labels, frames, frames_per_rank, total_frame
                                           'underflow compaction; aligned speech is peaked: extra.estep_peaked'))
     if ctl.world == 1 and P == PCL_F32 and not (args.utts or args.mix or args.units):
         more['frames'] = frames
+        more['batches'] = batches
         extra.update(side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs, more))
         more['tl']['total_before_line_s'] = time.perf_counter() - T_PROCESS_START
         extra['timeline_s'] = more['tl']
@@ -1163,19 +1311,10 @@ def smi_sample():
         return None
 
 
-def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs, more):
-    """What the judge asked to see beside the headline (VERDICT r1 next #6), all outside the timed region, N = 1 only:
-    strict-f32 scoring on the f32-input MFMA, the E-step on peaked (model-sampled) features, clock / power while scoring."""
+def clock_power_and_flip_rate(eng, cfg, labels, out, mark):
+    """--extra 2: clock / power while the scoring kernel runs back to back, and the forced-alignment flip rate of f32-class against float64 scoring."""
     import threading
-    from poccala_amd import Engine, PCL_F32, synth
-    out = {}
-    tl = more['tl']
-    t_sec = [time.perf_counter()]
-
-    def mark(name):
-        now = time.perf_counter()
-        tl[name] = now - t_sec[0]
-        t_sec[0] = now
+    from poccala_amd import PCL_F32, PCL_F64
     # ---- clock and power while the scoring kernel runs back to back for ~2 s (the 'power limited' claim)
     samples, stop = [], threading.Event()
 
@@ -1209,7 +1348,6 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
     b0.close()
     mark('clock_power_s')
     # ---- forced alignment, f32-class scoring against float64 scoring on the device (near-ties may flip), 64 utterances
-    from poccala_amd import PCL_F64
     nu = min(64, cfg['U'])
     ba = eng.label_batch(labels[:nu], np.full(nu, cfg['T'], dtype=np.int32), np.arange(nu, dtype=np.int64) * cfg['T'])
     ba.score(PCL_F32); ba.viterbi()
@@ -1230,6 +1368,25 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
                                       what='Viterbi paths under the default f32-class scoring against the same kernel chain under float64 scoring '
                                            '(PCL_F64, direct form): the float64 scoring removes every flip at score_f64_ms / score_f32_ms the cost')
     mark('alignment_flip_rate_s')
+
+
+def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_rank, pairs, more):
+    """What the judge asked to see beside the headline (VERDICT r1 next #6), all outside the timed region, N = 1 only:
+    strict-f32 scoring on the f32-input MFMA, the E-step on peaked (model-sampled) features, clock / power while scoring."""
+    import threading
+    from poccala_amd import Engine, PCL_F32, synth
+    out = {}
+    tl = more['tl']
+    t_sec = [time.perf_counter()]
+
+    def mark(name):
+        now = time.perf_counter()
+        tl[name] = now - t_sec[0]
+        t_sec[0] = now
+    level = int(args.extra)                    # 1 (default): what the driver's line carries; 2: every side measurement of rounds 2-5
+    if level >= 2:
+        clock_power_and_flip_rate(eng, cfg, labels, out, mark)
+    from poccala_amd import PCL_F64
     # ---- strict f32: v_mfma_f32_32x32x2_f32 (bit for bit an f32 FMA chain) through the SAME timed loop as the headline: a
     #      fresh engine with PCL_SCORE_VARIANT=3, the same resident batches, the same warm-up and step counts
     t_mark = time.perf_counter()
@@ -1256,69 +1413,100 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
     e3.close()
     frames0, lens0, begin0 = synth.make_frames(cfg['U'], cfg['T'], cfg['D'], seed=0)
     mark('strict_f32_loop_s')
-    # ---- the E-step on peaked posteriors: features sampled from the model along each utterance's label (aligned speech)
-    fr = synth.make_peaked_frames(labels, cfg['T'], mean, var, seed=5)
-    ep = Engine(eng.device)
-    ep.enable_timing(True)
-    ep.load_model(mean, var, w)
-    ep.load_units(np.stack(trans))
-    ep.load_frames(fr)
-    bp = ep.label_batch(labels, lens0, begin0)
-    for rep in range(3):
-        if rep == 1:
-            ep.kernel_time('accumulate')
-        ep.stats_zero(); ep.sync()
-        t1 = time.perf_counter()
-        bp.score(PCL_F32); bp.forward_backward(); bp.accumulate(PCL_F32); bp.accumulate_hmm(); ep.sync()
-        dt = time.perf_counter() - t1
-    acc_p = ep.kernel_time('accumulate')[0] / 2
-    lg = bp.get('lgamma')
-    surv = float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lg[::16]]))
-    out['estep_peaked'] = dict(estep_local_ms=dt * 1e3, accumulate_ms=acc_p, frames_per_s=frames_per_rank / dt, surviving_pair_fraction=surv,
-                               what='same shard, features sampled from the model along each label (one Gaussian of the state the frame is aligned to): '
-                                    'the posteriors of aligned speech; score + forward-backward + accumulate + per-unit merge, no exchange')
-    bp.close()
-    ep.close()
-    mark('estep_peaked_s')
-    # ---- the accumulate pass in its approximate mode (pcl_accumulate_prune) on the bench's own flat posteriors: a fresh context
-    #      with the ORIGINAL model (the main one has been through an M-step by now), pairs with gamma_t(j) < 2^-40 left out
-    ef = Engine(eng.device)
-    ef.enable_timing(True)
-    ef.load_model(mean, var, w)
-    ef.load_units(np.stack(trans))
-    ef.load_frames(frames0)
-    bf = ef.label_batch(labels, lens0, begin0)
-    bf.score(PCL_F32); bf.forward_backward(fix_pi=False)
-    ms_acc, st_acc = {}, {}
-    for name, thr in (('exact', -1e300), ('pruned', -40.0)):
-        ef.accumulate_prune(thr)
-        ef.stats_zero(); bf.accumulate(PCL_F32); ef.sync(); ef.kernel_time('accumulate')
-        ef.stats_zero(); bf.accumulate(PCL_F32)
-        ms_acc[name] = ef.kernel_time('accumulate')[0]
-        st_acc[name] = ef.stats_download(moments=False)
-    lg0 = bf.get('lgamma')
-    seen = st_acc['exact']['alpha_acc'] > 0
-    out['accumulate_pruned'] = dict(
-        log2_threshold=-40, accumulate_ms=ms_acc['pruned'], accumulate_exact_ms=ms_acc['exact'],
-        surviving_pair_fraction=float(np.mean([np.mean(l[1:-1] >= -40 * np.log(2)) for l in lg0[::16]])),
-        surviving_pair_fraction_exact=float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lg0[::16]])),
-        max_rel_dev_alpha_acc=float(np.max(np.abs(st_acc['pruned']['alpha_acc'][seen] - st_acc['exact']['alpha_acc'][seen]) / st_acc['exact']['alpha_acc'][seen])),
-        max_dev_acc_rel_to_state_occupancy=float(np.max(np.abs(st_acc['pruned']['acc'][seen] - st_acc['exact']['acc'][seen]) / st_acc['exact']['alpha_acc'][seen][:, None])),
-        what='OFF by default.  The default pass leaves out only (frame, state) pairs whose every term is exactly 0 in f32 (gamma_t(j) < 2^-150); '
-             'here pairs below 2^-40 (1e-12 of a frame) are left out too -- the deviations are measured against the exact pass of the same batch '
-             '(state occupancies are float64 sums; the mixture sums also carry the f32 regrouping noise of different tiles)')
-    del lg0, st_acc
-    bf.close()
-    ef.close()
-    mark('accumulate_pruned_s')
-    out['zero_change_route'] = zero_change_route()
-    mark('zero_change_route_s')
-    out['configs'] = other_configs(args, eng.device)
+    if level >= 2:
+        # ---- the E-step on peaked posteriors: features sampled from the model along each utterance's label (aligned speech)
+        fr = synth.make_peaked_frames(labels, cfg['T'], mean, var, seed=5)
+        ep = Engine(eng.device)
+        ep.enable_timing(True)
+        ep.load_model(mean, var, w)
+        ep.load_units(np.stack(trans))
+        ep.load_frames(fr)
+        bp = ep.label_batch(labels, lens0, begin0)
+        for rep in range(3):
+            if rep == 1:
+                ep.kernel_time('accumulate')
+            ep.stats_zero(); ep.sync()
+            t1 = time.perf_counter()
+            bp.score(PCL_F32); bp.forward_backward(); bp.accumulate(PCL_F32); bp.accumulate_hmm(); ep.sync()
+            dt = time.perf_counter() - t1
+        acc_p = ep.kernel_time('accumulate')[0] / 2
+        lg = bp.get('lgamma')
+        surv = float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lg[::16]]))
+        out['estep_peaked'] = dict(estep_local_ms=dt * 1e3, accumulate_ms=acc_p, frames_per_s=frames_per_rank / dt, surviving_pair_fraction=surv,
+                                   what='same shard, features sampled from the model along each label (one Gaussian of the state the frame is aligned to): '
+                                        'the posteriors of aligned speech; score + forward-backward + accumulate + per-unit merge, no exchange')
+        bp.close()
+        ep.close()
+        mark('estep_peaked_s')
+        # ---- the accumulate pass in its approximate mode (pcl_accumulate_prune) on the bench's own flat posteriors: a fresh context
+        #      with the ORIGINAL model (the main one has been through an M-step by now), pairs with gamma_t(j) < 2^-40 left out
+        ef = Engine(eng.device)
+        ef.enable_timing(True)
+        ef.load_model(mean, var, w)
+        ef.load_units(np.stack(trans))
+        ef.load_frames(frames0)
+        bf = ef.label_batch(labels, lens0, begin0)
+        bf.score(PCL_F32); bf.forward_backward(fix_pi=False)
+        ms_acc, st_acc = {}, {}
+        for name, thr in (('exact', -1e300), ('pruned', -40.0)):
+            ef.accumulate_prune(thr)
+            ef.stats_zero(); bf.accumulate(PCL_F32); ef.sync(); ef.kernel_time('accumulate')
+            ef.stats_zero(); bf.accumulate(PCL_F32)
+            ms_acc[name] = ef.kernel_time('accumulate')[0]
+            st_acc[name] = ef.stats_download(moments=False)
+        lg0 = bf.get('lgamma')
+        seen = st_acc['exact']['alpha_acc'] > 0
+        out['accumulate_pruned'] = dict(
+            log2_threshold=-40, accumulate_ms=ms_acc['pruned'], accumulate_exact_ms=ms_acc['exact'],
+            surviving_pair_fraction=float(np.mean([np.mean(l[1:-1] >= -40 * np.log(2)) for l in lg0[::16]])),
+            surviving_pair_fraction_exact=float(np.mean([np.mean(l[1:-1] >= -150 * np.log(2)) for l in lg0[::16]])),
+            max_rel_dev_alpha_acc=float(np.max(np.abs(st_acc['pruned']['alpha_acc'][seen] - st_acc['exact']['alpha_acc'][seen]) / st_acc['exact']['alpha_acc'][seen])),
+            max_dev_acc_rel_to_state_occupancy=float(np.max(np.abs(st_acc['pruned']['acc'][seen] - st_acc['exact']['acc'][seen]) / st_acc['exact']['alpha_acc'][seen][:, None])),
+            what='OFF by default.  The default pass leaves out only (frame, state) pairs whose every term is exactly 0 in f32 (gamma_t(j) < 2^-150); '
+                 'here pairs below 2^-40 (1e-12 of a frame) are left out too -- the deviations are measured against the exact pass of the same batch '
+                 '(state occupancies are float64 sums; the mixture sums also carry the f32 regrouping noise of different tiles)')
+        del lg0, st_acc
+        bf.close()
+        ef.close()
+        mark('accumulate_pruned_s')
+        out['zero_change_route'] = zero_change_route()
+        mark('zero_change_route_s')
+    models = {}
+    out['configs'] = other_configs(args, eng.device, models)
     mark('other_configs_s')
+    # ---- the headline's timed loop on the models EM leaves (VERDICT r5 next #2b): config 4's corpus through two M-steps at the
+    #      reference's variance floor (above), the model BEFORE iteration 2 / 3 loaded into the main engine, the same resident batches
+    try:
+        em = out['em_shaped_models'] = dict(
+            what='the headline loop (score + forward-backward, same resident batches, steps and warm-up) on the model config 4\'s EM leaves '
+                 'before its iteration 2 (split states: some mixtures per state off the matrix pipe) and before its iteration 3 (variance '
+                 'floor %g: most mixtures collapsed onto single frames); off_pipe_mixture_share = mixtures the direct-form kernels evaluate' % C4_BENCH_FLOOR)
+        for it in sorted(models):
+            m_, v_, w_, tr_ = models.pop(it)
+            eng.load_model(m_, v_, w_)
+            eng.load_units(tr_)
+            del m_, v_, w_
+            for bt in more['batches']:
+                bt.refresh_transitions()
+            n_off, off_limit = eng.model_split_info()
+            el, sc_ms, sc_n, fb_ms, fb_n = timed_steps(eng, more['batches'], PCL_F32, False, max(args.warmup, 1), args.steps, lambda: None)
+            names = ('score', 'score_subset', 'score_direct')
+            em['value_em%d_model' % it] = frames_per_rank * args.steps / el
+            em['ms_per_step_em%d_model' % it] = el / args.steps * 1e3
+            em['off_pipe_mixture_share_em%d' % it] = float(n_off.sum()) / float(len(n_off) * cfg['M'])
+            em['states_off_pipe_whole_em%d' % it] = int((n_off > off_limit).sum()) if off_limit > 0 else None
+            em['score_kernel_ms_em%d' % it] = sc_ms / max(sc_n, 1)
+    except Exception as e:                     # noqa: never the headline's problem
+        out['em_shaped_models'] = dict(out.get('em_shaped_models') or {}, error=repr(e))
+    models.clear()
+    mark('em_shaped_models_s')
     return out
 
 
-def other_configs(args, device):
+C4_BENCH_FLOOR = 1e-6     # the variance floor the reference's driver passes (init.py:30 -> Controller.py:151 -> Clustering.py:682-693)
+
+
+def other_configs(args, device, models=None):
     """One-line summaries of the other BASELINE configurations on this GPU (they are parity-test cases, not bench lines; the
     driver's record should still carry what they run at): C2 (score + forward-backward), C3 (score + Viterbi forced alignment)
     through the headline's timed loop, and the C5 shard (all-state scoring + token-passing decode).  Fresh engines, models of
@@ -1388,7 +1576,8 @@ def other_configs(args, device):
     try:
         run_c5_full(e, tree, args.max_tokens, n_chunks=3)                       # warm: batches per chunk shape, staging buffers, clocks
         out['C5'] = run_c5_full(e, tree, args.max_tokens)
-        out['C5_ragged'] = run_c5_full(e, tree, args.max_tokens, ragged=True)
+        if int(args.extra) >= 2:
+            out['C5_ragged'] = run_c5_full(e, tree, args.max_tokens, ragged=True)
     except Exception as ex:                    # noqa: never the headline's problem
         out['C5'] = dict(error=repr(ex))
     e.close()
@@ -1397,7 +1586,7 @@ def other_configs(args, device):
         from poccala_amd import PCL_F64
         e = Engine(device)
         e.enable_timing(True)
-        out['C4'] = run_c4_full(e, _Solo(), PCL_F32, PCL_F64, iters=1, warm=1)
+        out['C4'] = run_c4_full(e, _Solo(), PCL_F32, PCL_F64, iters=1, warm=1, c_cov=C4_BENCH_FLOOR, em_iters=3, keep_models=models)
         e.close()
     except Exception as ex:                    # noqa
         out['C4'] = dict(error=repr(ex))
@@ -1431,7 +1620,7 @@ def c4_corpus_batch(k, c=None):
     return frames, lens, labels
 
 
-def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, em_iters=0, cfg=None, n_batches=None):
+def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, em_iters=0, cfg=None, n_batches=None, keep_models=None):
     """Config 4 whole: ALL 8192 utterances through one EM iteration -- per batch of 1024: score -> forward-backward -> GMM
     statistics + per-unit transition accumulators, the 8 batches into ONE statistics block -> the exchange (reduce-scatter ->
     GMM.update_param on the owned states -> all-gather; one rank: the M-step) -> transition M-step -> the batches take the new
@@ -1648,6 +1837,8 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
             t_it = ctl.allreduce_max(time.perf_counter() - t1)
             kt_it = {k: eng.kernel_time(k)[0] for k in names}
             m_, v_, w_ = eng.model_download()
+            if keep_models is not None and world == 1 and it + 1 < em_iters:      # the model iteration it+2 runs on, for the caller (bench: the headline loop on it)
+                keep_models[it + 2] = (m_, v_, w_, eng.units_download())
             em_table.append(dict(iteration=it + 1, ms=t_it * 1e3, frames_per_s=nfr_all / t_it,
                                  mixtures_off_the_matrix_pipe=float(n_off.sum()) / float(len(n_off) * c['M']),
                                  states_off_the_matrix_pipe=int((n_off > off_limit).sum()) if off_limit > 0 else None,

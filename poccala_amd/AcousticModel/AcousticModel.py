@@ -403,7 +403,9 @@ class AcousticModel(DataInitialization):
             lp_all, n_utt, n_fr = [], 0, 0
             # one E-step per (fix_code, init): fix_code decides what is accumulated, init whether the unit logs start afresh
             # (init_unit(new_log=init), AcousticModel.py:897) -- every queued call keeps its own flag
-            for fix_code, init in sorted({(q[3], q[2]) for q in queued['train']}):
+            # groups in the order their first call was queued (the reference applies `init` per call, in call order: a first call with
+            # init=True must restart the unit logs BEFORE the later init=False calls write to them -- ADVICE r5: sorted() ran False first)
+            for fix_code, init in dict.fromkeys((q[3], q[2]) for q in queued['train']):
                 part = [q for q in queued['train'] if q[3] == fix_code and q[2] == init]
                 labels, datas = [q[0] for q in part], [q[1] for q in part]
                 units = self._worker_units(sorted({u for lab in labels for u in lab}), init)

@@ -96,6 +96,18 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 _lib = None
 
 
+HW_QUEUES = None      # set by load(): {'value': GPU_MAX_HW_QUEUES as this process has it, 'effective': False if HIP was already loaded}
+
+
+def _hip_runtime_loaded():
+    """True when libamdhip64 is already mapped into this process (its environment knobs were read then)."""
+    try:
+        with open('/proc/self/maps') as f:
+            return any('libamdhip64' in line for line in f)
+    except OSError:
+        return False
+
+
 def load():
     """dlopen the library and bind every prototype.  Raises if it is not built."""
     global _lib
@@ -109,7 +121,16 @@ def load():
     # that waits for an event (the download of step k waits for its forward-backward) holds up whatever sits behind it in that
     # queue (the scoring kernel of step k + 1).  Read when the HIP runtime starts: set before the library (and with it
     # libamdhip64) is loaded, unless the caller has chosen a value.
+    global HW_QUEUES
+    hip_was_loaded = _hip_runtime_loaded()
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    HW_QUEUES = dict(value=os.environ['GPU_MAX_HW_QUEUES'], effective=not hip_was_loaded)
+    if hip_was_loaded and int(HW_QUEUES['value'] or 0) >= 8:
+        # (the variable is read when the HIP runtime starts: a process that imported another HIP user first -- torch -- may run the
+        #  five streams of a context on four hardware queues; same results, the step-to-step overlap of bench.py suffers)
+        import warnings
+        warnings.warn('poccala_amd: libamdhip64 was loaded before this library; GPU_MAX_HW_QUEUES=%s may not be in effect '
+                      '(export it before the process starts)' % HW_QUEUES['value'], RuntimeWarning, stacklevel=2)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is not exported

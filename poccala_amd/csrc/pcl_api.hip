@@ -262,12 +262,16 @@ static void release_frames32(pcl_ctx *ctx) {
 int pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return PCL_OK;
     hipSetDevice(ctx->device);
+    // Drain first, release second: every stream of the context (twice -- a stream drained early may have been handed work by an event
+    // of one drained later only in the sense that its wait completes; nothing new is queued, so the second round returns at once and
+    // is there for the reader), THEN the communicator (collectives and the pipelined exchange run on these streams and stream_comm;
+    // rounds 1-5 destroyed it first), the buried batches, events, memory, streams.
+    for (int round = 0; round < 2; ++round) {
+        hipStream_t all[] = {ctx->stream, ctx->stream_dp, ctx->stream_aux, ctx->stream_d2h, ctx->stream_desc, ctx->stream_comm};
+        for (hipStream_t s : all)
+            if (s) hipStreamSynchronize(s);
+    }
     pcl_comm_destroy(ctx);
-    hipStreamSynchronize(ctx->stream);
-    hipStreamSynchronize(ctx->stream_dp);
-    hipStreamSynchronize(ctx->stream_aux);
-    if (ctx->stream_d2h) hipStreamSynchronize(ctx->stream_d2h);
-    if (ctx->stream_desc) hipStreamSynchronize(ctx->stream_desc);     // a descriptor copy still reading desc_pin
     pcl_batch_reap(ctx, true);
     if (ctx->ev_zero) hipEventDestroy(ctx->ev_zero);
     if (ctx->ev_zero_src) hipEventDestroy(ctx->ev_zero_src);
@@ -535,9 +539,18 @@ int pcl_host_alloc(pcl_ctx *ctx, size_t bytes, void **out) {
     return PCL_OK;
 }
 
+// hipHostFree does not wait for copies that still read or write the block: a result set queued by pcl_batch_fetch_async on stream_d2h
+// (or a chunk staged by pcl_frames_stage) and never waited for would be DMA into unmapped host memory -- a GPU-side fault at the next
+// teardown (round 5 saw one at a fixture's engine.close(), which freed its page-locked result buffers before pcl_destroy drained the
+// streams).  Freeing page-locked memory is rare (engine close, a staging buffer outgrown): drain every stream of the context first.
 int pcl_host_free(pcl_ctx *ctx, void *ptr) {
     if (!ctx) return PCL_ERR_INVALID;
-    if (ptr) HIPCHK(ctx, hipHostFree(ptr));
+    if (!ptr) return PCL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t all[] = {ctx->stream_d2h, ctx->stream_aux, ctx->stream_dp, ctx->stream, ctx->stream_desc, ctx->stream_comm};
+    for (hipStream_t s : all)
+        if (s) HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipHostFree(ptr));
     return PCL_OK;
 }
 
@@ -1065,7 +1078,8 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
     if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_forward_backward: no transitions set");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_forward_backward: no emissions (score or set_emissions first)");  // LHMM.py:69
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (b->fetch_pending) {                                  // the copies of the previous results read lgam / ksai: main stream first (stream_dp follows it below)
+    const bool after_fetch = b->fetch_pending;
+    if (b->fetch_pending) {                                  // the copies of the previous results read lgam / ksai: main stream first (stream_dp waits for them below)
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_fetch, 0));
         b->fetch_pending = false;
     }
@@ -1084,7 +1098,7 @@ int pcl_batch_forward_backward(pcl_batch *b, int fix_pi, double threshold) {
         // stream_dp waits for everything queued on the main stream so far (the scoring of this batch), runs the
         // recursion, and leaves an event for whoever touches the batch next
         if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
-        HIPCHK(ctx, pcl_dp_follows_main(b));
+        HIPCHK(ctx, pcl_dp_follows_main(b, after_fetch));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream_dp;                      // the launcher and its timer use ctx->stream
         const int rc = pcl_launch_forward_backward(ctx, b, fix_pi ? 1 : 0, threshold);
@@ -1108,6 +1122,7 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
     if (!b->have_trans) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no transitions set");
     if (!b->have_B) PCL_FAIL(ctx, PCL_ERR_STATE, "pcl_batch_viterbi: no emissions (score or set_emissions first)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool after_fetch = b->fetch_pending;
     if (b->fetch_pending) {                                  // result copies still reading this batch's path / point buffers
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b->ev_fetch, 0));
         b->fetch_pending = false;
@@ -1122,7 +1137,7 @@ int pcl_batch_viterbi(pcl_batch *b, int end_state_back) {
         // the NEXT batch's scoring; in order with a forward-backward of the same batch already queued there (round 4: on the main
         // stream the 0.35 ms recursion sat between two scoring kernels -- config 3's step is score + Viterbi)
         if (!b->ev_dp) HIPCHK(ctx, hipEventCreateWithFlags(&b->ev_dp, hipEventDisableTiming));
-        HIPCHK(ctx, pcl_dp_follows_main(b));
+        HIPCHK(ctx, pcl_dp_follows_main(b, after_fetch));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream_dp;                      // the launcher and its timer use ctx->stream
         const int rc = pcl_launch_viterbi(ctx, b, end_state_back ? 1 : 0);

@@ -440,11 +440,19 @@ static inline bool pcl_fewer_markers() {
     static const bool on = !(getenv("PCL_FEWER_MARKERS") && atoi(getenv("PCL_FEWER_MARKERS")) == 0);
     return on;
 }
-// stream_dp behind this batch's main-stream work
-static inline hipError_t pcl_dp_follows_main(pcl_batch *b) {
+// stream_dp behind this batch's main-stream work.  `after_fetch`: result copies of an earlier recursion (pcl_batch_fetch_async) were
+// still pending when the caller was entered -- the caller put the MAIN stream behind them, but under the shortcut below stream_dp does
+// not follow the main stream's head, so it waits for the copies itself (score -> FB -> fetch_async -> FB again would
+// otherwise overwrite lgam / ksai / logp / path under the D2H copies).  The shortcut is good for ONE recursion per scoring: whatever
+// the main stream queues on this batch afterwards (the accumulate pass reads lgam) has to be ahead of the next recursion, so the flag
+// is consumed here and the next caller records a fresh event on the main stream.
+static inline hipError_t pcl_dp_follows_main(pcl_batch *b, bool after_fetch = false) {
     pcl_ctx *ctx = b->ctx;
     hipError_t e;
-    if (pcl_fewer_markers() && b->mark_is_score && b->ev_mark) return hipStreamWaitEvent(ctx->stream_dp, b->ev_mark, 0);
+    if (after_fetch && b->ev_fetch && (e = hipStreamWaitEvent(ctx->stream_dp, b->ev_fetch, 0)) != hipSuccess) return e;
+    const bool shortcut = pcl_fewer_markers() && b->mark_is_score && b->ev_mark;
+    b->mark_is_score = false;
+    if (shortcut) return hipStreamWaitEvent(ctx->stream_dp, b->ev_mark, 0);
     if (!b->ev_main && (e = hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming)) != hipSuccess) return e;
     if ((e = hipEventRecord(b->ev_main, ctx->stream)) != hipSuccess) return e;
     return hipStreamWaitEvent(ctx->stream_dp, b->ev_main, 0);

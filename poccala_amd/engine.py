@@ -45,6 +45,7 @@ class Engine(object):
         self._batches = weakref.WeakSet()   # live batches: destroyed before the context (a sweep makes millions: dead ones leave by themselves)
         self._pinned = []    # page-locked host allocations (pinned_empty)
         self._pinned_sizes, self._pinned_named = {}, {}
+        self._slot_busy = {}   # result slot -> weakref of the batch with un-waited copies into it
         self._staged = None
 
     # ------------------------------------------------------------------ plumbing
@@ -58,6 +59,7 @@ class Engine(object):
                 b.close()
             self._batches = weakref.WeakSet()
             self._stream_pool, self._stream_pinned = {}, [None]
+            self._lib.pcl_sync(self._ctx)             # result copies into the page-locked buffers freed below may still be in flight
             for p in self._pinned:
                 self._lib.pcl_host_free(self._ctx, p)
             self._pinned, self._pinned_sizes, self._pinned_named = [], {}, {}
@@ -198,17 +200,30 @@ class Engine(object):
 
     def _pinned_views(self, name, shapes):
         """Arrays of the given (shape, dtype) list over ONE grow-only page-locked buffer per name (kept with the engine, reused by
-        every caller of that name; grown by doubling, the old buffer freed)."""
+        every caller of that name; grown by doubling).  A block that was outgrown is RETIRED, not freed: views handed out earlier
+        may still be alive (a dict from an earlier result_buffers() call passes fetch_async's size checks), and an asynchronous
+        DMA into freed page-locked memory corrupts the host.  Retired blocks go with the engine; doubling bounds
+        them by the size of the live block."""
         need = [int(np.prod(sh)) * np.dtype(dt).itemsize for sh, dt in shapes]
         off = np.concatenate([[0], np.cumsum([(n + 63) // 64 * 64 for n in need])])
         total = int(off[-1]) or 64
         cur = self._pinned_named.get(name)
         if cur is None or cur.nbytes < total:
-            if cur is not None:
-                self.pinned_free(cur)
             cur = self.pinned_empty((max(total, 2 * (cur.nbytes if cur is not None else 0)),), np.uint8)
-            self._pinned_named[name] = cur
+            self._pinned_named[name] = cur               # (the outgrown block stays in self._pinned until close())
         return [cur[int(off[k]):int(off[k]) + need[k]].view(dt).reshape(sh) for k, (sh, dt) in enumerate(shapes)]
+
+    def _slots_of(self, arrays):
+        """result slots whose LIVE block holds any of the arrays"""
+        out = set()
+        for a in arrays:
+            addr = a.__array_interface__['data'][0]
+            for name, blk in self._pinned_named.items():
+                if name.startswith('fetch_results_'):
+                    lo = blk.__array_interface__['data'][0]
+                    if lo <= addr < lo + blk.nbytes:
+                        out.add(int(name[len('fetch_results_'):]))
+        return out
 
     def batch(self, N, T, frame_begin=None):
         return Batch(self, N, T, frame_begin)
@@ -441,6 +456,7 @@ class Batch(object):
             engine._check(self._lib.pcl_batch_create(engine._ctx, self.U, ptr(self.N), ptr(self.T), ptr(fb),
                                                      C.byref(self._b)))
         engine._batches.add(self)
+        self._fetch_slots = set()                     # engine result slots with un-waited copies of this batch (fetch_async)
         n64, t64 = self.N.astype(np.int64), self.T.astype(np.int64)
         self._nt_off = np.concatenate([[0], np.cumsum(n64 * t64)])
         self._nn_off = np.concatenate([[0], np.cumsum(n64 * n64)])
@@ -452,6 +468,9 @@ class Batch(object):
     def close(self):
         if getattr(self, '_b', None):
             if getattr(self.eng, '_ctx', None):       # the context frees its batches when it closes
+                if getattr(self, '_fetch_slots', None):       # copies into an engine slot nobody waited for: the slot's next user must not race them
+                    self._lib.pcl_batch_fetch_wait(self._b)
+                    self._fetch_slots.clear()
                 self._lib.pcl_batch_destroy(self._b)
             self._b = None
 
@@ -580,7 +599,13 @@ class Batch(object):
     def result_buffers(self, want=('logp', 'lgamma', 'ksai_nz', 'path', 'point'), slot=0):
         """Page-locked destination arrays for fetch_async.  They belong to the ENGINE, one grow-only set per `slot` (a pipeline that
         keeps k result sets in flight uses slots 0 .. k-1): calling this once per batch of a stream re-uses the slot's memory
-        instead of page-locking ~150 MB per call until the engine closes."""
+        instead of page-locking ~150 MB per call until the engine closes.  ALIASING: every batch that asks for the same slot gets
+        views of the SAME memory -- two batches with results in flight at once need two slots.  Asking for a slot while another
+        live batch still has un-waited copies into it raises instead of handing out memory a DMA is writing."""
+        busy = self.eng._slot_busy.get(slot)
+        other = busy() if busy is not None else None
+        if other is not None and other is not self and getattr(other, '_b', None) and other._fetch_slots:
+            raise RuntimeError('result_buffers: slot %d still receives the results of another batch (fetch_wait() it first, or use another slot)' % slot)
         shapes = self._result_shapes()
         names = [k for k in ('logp', 'lgamma', 'ksai_nz', 'path', 'point') if k in want]
         views = self.eng._pinned_views('fetch_results_%d' % slot, [((shapes[k][0],), shapes[k][1]) for k in names])
@@ -601,9 +626,13 @@ class Batch(object):
                                  % (k, np.dtype(dt).name, n, getattr(a, 'dtype', type(a)), getattr(a, 'shape', '')))
         g = lambda k: ptr(bufs[k]) if k in bufs else None
         self._check(self._lib.pcl_batch_fetch_async(self._b, g('logp'), g('lgamma'), g('ksai_nz'), g('path'), g('point')))
+        for slot in self.eng._slots_of(bufs.values()):          # (engine-owned destinations: the slot is busy until fetch_wait)
+            self.eng._slot_busy[slot] = weakref.ref(self)
+            self._fetch_slots.add(slot)
 
     def fetch_wait(self):
         self._check(self._lib.pcl_batch_fetch_wait(self._b))
+        self._fetch_slots.clear()
 
     def lgamma_views(self, flat):
         """fetch_async's time-major ln gamma_t(j) as the reference's (N, T) matrices (transposed views, no copy)."""

@@ -18,7 +18,33 @@ def _label_job(args):
     lg = l - po.lse(l, axis=0)[None, :]
     if want_bw == 'xi':                            # + the un-normalised ln xi (N,N) and ln gamma (N,) of the final pass (quirk Q5)
         return bref, float(bw['logp'][0]), lg, a, pi, bw['ksai'], bw['gamma']
+    if want_bw == 'xi+bound':                      # ... + the analytical f32 input-rounding bound of every emitting row (models EM has sharpened)
+        rows = [model[u]['gmms'][k] for u in lab for k in range(len(model[u]['gmms']))]
+        return bref, float(bw['logp'][0]), lg, a, pi, bw['ksai'], bw['gamma'], f32_evaluation_bound_rows(rows, x)
     return bref, float(bw['logp'][0]), lg, a, pi
+
+
+def f32_evaluation_bound_rows(gmms, x, t_chunk=20):
+    """tests/test_gpu_parity.py:f32_evaluation_bound for a list of (mean, var, w) states, in frame chunks (bounds the (T,M,D)
+    temporaries at M = 2048): what an f32 evaluation of the Gaussian exponent may lose per (state, frame) -- parameters and frames
+    are f32 roundings, every standardised residual carries up to 2^-23 (|x_d| + |mu_d|) / sigma_d, weighted with the mixture
+    posteriors.  Returns (len(gmms), T)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.zeros((len(gmms), x.shape[0]))
+    for j, (mean, var, w) in enumerate(gmms):
+        sig = np.sqrt(var)
+        with np.errstate(divide='ignore'):
+            lw = np.log(w)
+        for s in range(0, x.shape[0], t_chunk):
+            xs = x[s:s + t_chunk]
+            z = (xs[:, None, :] - mean[None]) / sig[None]
+            comp = lw[None] - 0.5 * (z ** 2).sum(-1) - 0.5 * var.sum(-1)[None]       # (the log-sum-exp weights: quirk Q1's constant, -1/2 sum var, per mixture)
+            comp -= comp.max(1, keepdims=True)
+            post = np.exp(comp)
+            post /= post.sum(1, keepdims=True)
+            per = 2.0 ** -23 * (((np.abs(xs)[:, None, :] + np.abs(mean)[None]) / sig[None]) * np.abs(z)).sum(-1)
+            out[j, s:s + t_chunk] = (post * per).sum(1)
+    return out
 
 
 def _rows_job(args):

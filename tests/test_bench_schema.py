@@ -120,3 +120,91 @@ def test_newest_committed_bench_line_has_the_contract_schema():
         # the line's traffic figure comes from the summary committed beside it, taken from the kernel the line ran
         summ = open(os.path.join(ROOT, 'profiles', 'r%02d_bench_summary.txt' % rnd)).read()
         assert r['traffic_raw']['kernel_code_sha16'] in summ
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the line the driver reads is a COMPACT record (BENCH_r05.parsed was null: the 22.8-KB line outgrew the reader)
+# ------------------------------------------------------------------------------------------------
+COMPACT_TOP = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+               'config', 'roofline', 'cpu_baseline', 'gpu_over_cpu', 'full_record', 'final'}
+COMPACT_ROOFLINE = {'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_denominator', 'frac_of_f16_dense_peak', 'frac_executed', 'traffic',
+                    'traffic_over_algorithmic', 'kernel', 'kernel_avg_ms', 'kernel_code_sha16', 'sustained_value', 'fresh_batches_value',
+                    'pcie_inclusive_value', 'strict_f32_value', 'strict_f32_frac', 'estep_ms', 'c4_ms_per_iteration', 'c5_frames_per_s',
+                    'value_em2_model', 'value_em3_model', 'off_pipe_mixture_share_em2', 'off_pipe_mixture_share_em3'}
+COMPACT_CPU = {'value', 'unit', 'cores', 'kind', 'sample', 'value_leg', 'gemm_value', 'vectorised_value', 'faithful_value'}
+
+
+def _strict_loads(text):
+    def no_constants(name):
+        raise AssertionError('non-strict JSON constant %s in the line' % name)
+    return json.loads(text, parse_constant=no_constants)
+
+
+def _no_prose(o, limit, path=''):
+    """every string of the compact record is a name, not a paragraph"""
+    if isinstance(o, dict):
+        for k, v in o.items():
+            _no_prose(v, limit, path + '/' + k)
+    elif isinstance(o, list):
+        for v in o:
+            _no_prose(v, limit, path)
+    elif isinstance(o, str):
+        assert len(o) <= limit, (path, len(o))
+
+
+def test_compact_line_from_the_round5_record_fits_the_driver_and_keeps_the_contract():
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_line.json')))        # the record the driver could NOT parse
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert len(line) <= bench.COMPACT_TARGET_CHARS < bench.COMPACT_MAX_CHARS < 8000 and '\n' not in line
+    d = _strict_loads(line)
+    assert COMPACT_TOP <= set(d) and COMPACT_ROOFLINE <= set(d['roofline']) and COMPACT_CPU <= set(d['cpu_baseline'])
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    _no_prose(d, 340)
+    # the numbers are the full record's (7 significant digits)
+    assert d['value'] == pytest.approx(full['value'], rel=1e-6) and d['ms_per_step'] == pytest.approx(full['ms_per_step'], rel=1e-6)
+    r, rf = d['roofline'], full['roofline']
+    for k in ('achieved', 'peak', 'frac', 'traffic', 'kernel_avg_ms', 'sustained_value', 'strict_f32_value'):
+        assert r[k] == pytest.approx(rf[k], rel=1e-6), k
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-5)
+    assert r['kernel_code_sha16'] == rf['traffic_raw']['kernel_code_sha16'] and r['kernel'] == rf['kernel']
+    assert r['estep_ms'] == pytest.approx(full['extra']['estep_ms'], rel=1e-6)
+    assert r['c4_ms_per_iteration'] == pytest.approx(full['extra']['configs']['C4']['ms_per_iteration'], rel=1e-6)
+    assert r['c5_frames_per_s'] == pytest.approx(full['extra']['configs']['C5']['value'], rel=1e-6)
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == full['cpu_baseline']['cores'] and c['value'] == pytest.approx(max(c['gemm_value'], c['vectorised_value']))
+    assert d['gpu_over_cpu'] == pytest.approx(full['value'] / full['cpu_baseline']['value'], rel=1e-5)
+    assert d['value'] == pytest.approx(d['config']['frames_per_step_total'] / (d['ms_per_step'] * 1e-3), rel=1e-5)
+
+
+def test_compact_line_is_strict_json_whatever_the_extras_left_behind():
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_line.json')))
+    full['roofline']['sustained_value'] = float('nan')             # a side measurement that divided by zero
+    full['roofline']['traffic'] = float('inf')
+    full['extra']['estep_ms'] = np.float32(48.5)                   # NumPy scalars straight from a kernel timer
+    full['extra']['configs']['C4']['em_iterations'] = [dict(ms=np.float64(360.0), mixtures_off_the_matrix_pipe=0.0),
+                                                        dict(ms=float('nan'), mixtures_off_the_matrix_pipe=np.float64(0.028))]
+    full['extra']['error'] = 'RuntimeError: ' + 'x' * 5000          # an exception message of any length
+    full['config']['workload'] = 'w' * 4000
+    d = _strict_loads(bench.compact_line(full))
+    assert d['roofline']['sustained_value'] is None and d['roofline']['traffic'] is None and d['roofline']['estep_ms'] == 48.5
+    assert d['roofline']['c4_em_iteration_ms'] == [360.0, None] and len(d['extra_error']) <= 200 and len(d['config']['workload']) <= 330
+    # an early line (no extras yet, no CPU leg on ranks > 0) is just as valid
+    early = {k: v for k, v in full.items() if k not in ('extra', 'roofline_estep', 'cpu_baseline')}
+    e = _strict_loads(bench.compact_line(dict(early, final=False)))
+    assert e['final'] is False and e['cpu_baseline'] is None and e['roofline']['estep_ms'] is None and e['value'] == pytest.approx(full['value'], rel=1e-6)
+
+
+def test_full_record_goes_to_a_file_not_to_stdout(tmp_path, monkeypatch, capsys):
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_line.json')))
+    full['roofline']['sustained_value'] = float('nan')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    bench.emit(full, final=True)
+    out = capsys.readouterr().out
+    assert out.count('\n') == 1 and len(out) < 8000                    # ONE line, and it is the compact one
+    d = _strict_loads(out)
+    assert d['final'] is True and d['full_record'] == bench.FULL_RECORD_NAME
+    for where in (tmp_path / bench.FULL_RECORD_NAME, tmp_path / 'gpurun_out' / bench.FULL_RECORD_NAME):
+        whole = _strict_loads(where.read_text())
+        assert whole['extra']['configs']['C4']['ms_per_iteration'] == full['extra']['configs']['C4']['ms_per_iteration']
+        assert whole['roofline']['sustained_value'] is None and whole['roofline']['note'] == full['roofline']['note']

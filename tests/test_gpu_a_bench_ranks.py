@@ -52,6 +52,21 @@ def _free_port():
     return p
 
 
+def _full_record():
+    """the whole record rank 0 wrote beside bench.py (the stdout line is the compact one since round 6)"""
+    return json.load(open(os.path.join(ROOT, 'bench_full.json')))
+
+
+def _final_line(out):
+    """bench.py prints the compact line as soon as the headline is final (final: false) and again at the end (final: true): the
+    driver reads the LAST one.  Every line must fit the driver's stdout tail."""
+    lines = _json_lines(out)
+    assert 1 <= len(lines) <= 2 and lines[-1]['final'] is True and all(len(json.dumps(l)) < 8000 for l in lines), out[-3000:]
+    if len(lines) == 2:
+        assert lines[0]['final'] is False and lines[0]['value'] == lines[1]['value'] and lines[0]['ms_per_step'] == lines[1]['ms_per_step']
+    return lines[-1]
+
+
 def _check_line(d, n):
     assert d['metric'].startswith('frames/sec GMM-score+fwd-bwd')
     assert d['n_gpus'] == n and d['scaling'] == 'weak' and d['unit'] == 'frames/s'
@@ -60,25 +75,29 @@ def _check_line(d, n):
     # value = the frames ALL ranks processed / the slowest rank's time for exactly `steps` steps
     total = d['config']['frames_per_step_total']
     assert total == n * 32 * 300
-    assert d['value'] == pytest.approx(total * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps']), rel=1e-9)
-    ex = d['extra']
+    assert d['value'] == pytest.approx(total * d['steps'] / (d['ms_per_step'] * 1e-3 * d['steps']), rel=1e-5)
+    assert 'extra_error' not in d, d.get('extra_error')
+    r = d['roofline']
+    assert r['kernel_avg_ms'] > 0 and d['cpu_baseline'] is None      # (the CPU leg runs at N = 1 only)
+    assert r['estep_ms'] > 0 and r['exchange_ms'] >= 0 and r['reduce_scatter_ms'] >= 0 and r['all_gather_ms'] >= 0 and r['exchange_payload'] == 'f32'
+    full = _full_record()
+    assert full['value'] == pytest.approx(d['value'], rel=1e-6) and full['final'] is True
+    ex = full['extra']
     assert 'error' not in ex, ex.get('error')
     per = ex['exchange']['per_rank']
-    assert sorted(r['rank'] for r in per) == list(range(n))
-    for r in per:
-        assert r['estep_ms'] > 0 and r['exchange_ms'] >= 0 and r['reduce_scatter_ms'] >= 0 and r['all_gather_ms'] >= 0
+    assert sorted(r_['rank'] for r_ in per) == list(range(n))
+    for r_ in per:
+        assert r_['estep_ms'] > 0 and r_['exchange_ms'] >= 0 and r_['reduce_scatter_ms'] >= 0 and r_['all_gather_ms'] >= 0
+    assert r['exchange_ms'] == pytest.approx(max(r_['exchange_ms'] for r_ in per), rel=1e-6)
     assert ex['exchange']['payload'] == 'f32' and ex['exchange']['wire']['world'] == n
     assert ex['estep_pipelined'].get('error') is None and len(ex['estep_pipelined']['per_rank']) == n
-    assert d['roofline']['kernel_avg_ms'] > 0 and d['cpu_baseline'] is None      # (the CPU leg runs at N = 1 only)
 
 
 def test_bench_self_spawned_two_ranks():
     """`python bench.py --gpus 2` with no launcher variables: bench.py spawns its rank processes (before anything touches HIP)."""
     rc, out, err, dt = _run([sys.executable, 'bench.py', '--gpus', '2'] + SMALL, _env(), 600)
     assert rc == 0, err[-2000:]
-    lines = _json_lines(out)
-    assert len(lines) == 1, out
-    _check_line(lines[0], 2)
+    _check_line(_final_line(out), 2)
 
 
 def test_bench_under_the_drivers_launcher_four_ranks():
@@ -89,9 +108,7 @@ def test_bench_under_the_drivers_launcher_four_ranks():
            '--master-port', str(_free_port()), 'bench.py', '--gpus', '4'] + SMALL
     rc, out, err, dt = _run(cmd, _env(), 900)
     assert rc == 0, err[-2000:]
-    lines = _json_lines(out)
-    assert len(lines) == 1, out
-    _check_line(lines[0], 4)
+    _check_line(_final_line(out), 4)
 
 
 def test_a_dying_rank_fails_the_job():
@@ -102,7 +119,7 @@ def test_a_dying_rank_fails_the_job():
     assert dt < 240, dt
     # (rank 0 may still print its line -- the timed number was final before the death -- but then only with the failure inside `extra`)
     lines = _json_lines(out)
-    assert len(lines) <= 1 and all('error' in l.get('extra', {}) for l in lines)
+    assert len(lines) <= 2 and all('extra_error' in l for l in lines if l['final'])
 
 
 def test_the_watchdog_fires_when_the_communicator_never_comes_up():
@@ -111,10 +128,10 @@ def test_the_watchdog_fires_when_the_communicator_never_comes_up():
     rc, out, err, dt = _run([sys.executable, 'bench.py', '--gpus', '2', '--extra-timeout', '20'] + SMALL, _env(POCCALA_TEST_HANG_COMM='1'), 600)
     assert rc == 3, (rc, err[-2000:])
     lines = _json_lines(out)
-    assert len(lines) == 1
-    d = lines[0]
-    assert d['n_gpus'] == 2 and d['value'] > 0
-    assert 'did not finish' in d['extra']['error']
+    assert len(lines) == 2 and not lines[0]['final'] and not lines[1]['final']        # the early line, and the watchdog's
+    d = lines[-1]
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['value'] == lines[0]['value']
+    assert 'did not finish' in d['extra_error']
 
 
 def test_bench_config4_strong_scaling_line_two_ranks():

@@ -1,0 +1,147 @@
+"""Deep parity at full C4-shard size on the models EM leaves (VERDICT r5 next #2a).
+
+Every full-size oracle comparison of rounds 1-5 ran on the synthetic flat-start model (every mixture on the matrix pipe).  One and
+two M-steps at the reference's variance floor (c_covariance = 1e-6: init.py:30 -> Controller.py:151 -> Clustering.py:682-693) on the
+shard's own statistics give the two models the later EM iterations actually run on:
+
+  stage 2 (before iteration 2): every state has a few mixtures whose own conditioning is beyond the centred f32-class expansion --
+          SPLIT states: matrix-pipe kernels + the subset launch of the direct-form kernel + the float64 log-add merge, at J = 3000,
+          M = 2048, 1024 utterances (tile lists, d_bad_idx, grid limits at their real sizes);
+  stage 3 (before iteration 3): most mixtures have collapsed onto single frames (variances at the floor) -- the direct-form kernels
+          with partial-distance elimination evaluate most or all of every state.
+
+Held against the oracle run on the DOWNLOADED model, exactly as test_c4_shard_deep_parity does on the initial one: emissions of
+every label state, ln P(O), gamma_t(j), xi / P(O), gamma / P(O) of ~10 utterances (random ones + owners of last tiles), the GMM
+statistics (acc, alpha_acc, mean_acc, cov_acc per mixture) of a handful of states chosen to cover split and whole-off-pipe states.
+(The per-unit HMM accumulators are float64 functions of xi / gamma and of the transitions alone: test_c4_shard_deep_parity holds them
+at full size.)"""
+import numpy as np
+import pytest
+
+from _parity import cov_acc_atol, hold, note
+from oracle import poccala_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+S = 5
+F32_RTOL = 1e-4
+F32_LOGLIK_ATOL = 5e-5
+C_COV = 1e-6
+
+
+def _last_tile_utterances(labels, n_units, how_many):
+    last = {}
+    for u, lab in enumerate(labels):
+        for unit in lab:
+            last[int(unit)] = u
+    units = sorted(last, key=lambda k: last[k])[:how_many // 2] + sorted(last, key=lambda k: -last[k])[:how_many - how_many // 2]
+    return sorted({last[k] for k in units})
+
+
+def _estep(eng, b, P):
+    b.score(P)
+    b.forward_backward(fix_pi=False)
+    eng.stats_zero()
+    b.accumulate(P)
+    b.accumulate_hmm()
+
+
+def _check_stage(eng, b, stage, frames, lens, begin, labels, c):
+    from poccala_amd import PCL_F32
+    from _oracle_pool import label_jobs, state_statistics
+    mean, var, w = eng.model_download()
+    trans = eng.units_download()
+    n_off, limit = eng.model_split_info()
+    J, M = mean.shape[0], mean.shape[1]
+    share = float(n_off.sum()) / (J * M)
+    split = int(((n_off > 0) & (n_off <= limit)).sum()) if limit > 0 else 0
+    whole = int((n_off > limit).sum()) if limit > 0 else int((n_off > 0).sum())
+    tag = 'C4shard EM-shaped model, stage %d' % stage
+    note(tag, 'mixtures off the matrix pipe', share)
+    note(tag, 'split states / whole states off the pipe / limit', [split, whole, int(limit)])
+    note(tag, 'variances at the floor', float(np.mean(var <= C_COV * 1.0000001)))
+    print('%s: %.1f %% of the mixtures off the pipe, %d split states, %d whole states off (limit %d)' % (tag, 100 * share, split, whole, limit))
+    if stage == 2:
+        assert 0.005 < share < 0.35 and split >= 1000, (share, split, whole)          # the split-state regime, on most states
+    else:
+        assert share >= 0.5, share                                                 # most of the model is the direct-form kernels' by now
+    _estep(eng, b, PCL_F32)
+    B, lp, lg, ks, ga = b.get('B'), b.get('logp'), b.get('lgamma'), b.get('ksai'), b.get('gamma')
+    st = eng.stats_download()
+    pick = sorted(set(np.random.default_rng(700 + stage).choice(c['U'], 6, replace=False).tolist()) | set(_last_tile_utterances(labels, c['units'], 4)))
+    jobs = []
+    for u in pick:
+        model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)]) for unit in set(labels[u])}
+        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, 'xi+bound'))
+    for u, (bref, lpref, lgref, _, _, ksref, garef, bound) in zip(pick, label_jobs(jobs)):
+        fin = np.isfinite(bref[1:-1])
+        assert np.array_equal(np.isfinite(B[u][1:-1]), fin) and np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1]))
+        hold(tag, 'ln b_j(o_t)', B[u][1:-1][fin], bref[1:-1][fin], 5e-6, (F32_LOGLIK_ATOL + bound)[fin])
+        hold(tag, 'ln P(O)', lp[u], lpref, F32_RTOL)
+        hold(tag, 'gamma_t(j) normalised', np.exp(lg[u]), np.exp(lgref), F32_RTOL, 1e-6)
+        fk = np.isfinite(ksref)
+        assert np.array_equal(np.isfinite(ks[u]), fk)
+        hold(tag, 'xi_ij / P(O) (sum over t)', np.exp(ks[u][fk] - lp[u]), np.exp(ksref[fk] - lpref), F32_RTOL, 1e-6)
+        hold(tag, 'gamma_i / P(O) (sum over t)', np.exp(ga[u][1:-1] - lp[u]), np.exp(garef[1:-1] - lpref), F32_RTOL, 1e-6)
+    # ---- GMM statistics per mixture: the device's own ln gamma and ln b into the oracle's update_acc, for states of every kind
+    seen = np.flatnonzero(st['alpha_acc'] > 0)
+    kinds = {'most occupied': int(seen[np.argmax(st['alpha_acc'][seen])]), 'last state seen': int(seen[-1])}
+    sp = seen[(n_off[seen] > 0) & (n_off[seen] <= limit)] if limit > 0 else seen[:0]
+    wh = seen[n_off[seen] > limit] if limit > 0 else seen[n_off[seen] > 0]
+    if len(sp):
+        kinds['split state with the most off-pipe mixtures'] = int(sp[np.argmax(n_off[sp])])
+    if len(wh):
+        kinds['whole state off the pipe'] = int(wh[np.argmax(st['alpha_acc'][wh])])
+    e = S - 2
+    jobs, owner = [], []
+    for j in sorted(set(kinds.values())):
+        unit, k = divmod(j, e)
+        for u, lab in enumerate(labels):
+            for pos in np.flatnonzero(np.asarray(lab) == unit):
+                row = 1 + int(pos) * e + k
+                jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), lg[u][row].copy(), B[u][row].copy(), mean[j], var[j], w[j]))
+                owner.append(j)
+    res = state_statistics(jobs)
+    for j in sorted(set(kinds.values())):
+        ref = dict(acc=0.0, alpha_acc=0.0, mean_acc=0.0, cov_acc=0.0)
+        for o, r in zip(owner, res):
+            if o == j:
+                for key in ref:
+                    ref[key] = ref[key] + r[key]
+        for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+            got, want = np.asarray(st[key][j]), np.asarray(ref[key])
+            bound = 1e-6 * float(np.abs(want).max())
+            if key == 'cov_acc':
+                bound = cov_acc_atol(np.asarray(ref['acc']), mean[j], var[j], bound)
+            hold(tag + ' accumulate', key, got, want, F32_RTOL, bound)
+    print('%s: statistics of states %s (%d occurrences)' % (tag, kinds, len(jobs)))
+    return mean, var, w
+
+
+def test_c4_shard_deep_parity_on_the_models_em_leaves():
+    from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+    c = synth.CONFIGS['C4shard']
+    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
+    labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
+    eng = Engine(0)
+    try:
+        eng.load_model(mean, var, w)
+        eng.load_frames(frames)
+        eng.load_units(np.stack(trans))
+        del mean, var, w
+        b = eng.label_batch(labels, lens, begin)
+        lp_mean = []
+        for stage in (2, 3):
+            _estep(eng, b, PCL_F32)                                   # iteration stage-1 on the whole shard ...
+            lp_mean.append(float(b.get('logp').mean()))
+            eng.em_exchange(C_COV, PCL_F64, True)                     # ... its M-step (GMM + transitions; one rank: no wire), layouts re-derived
+            b.refresh_transitions()
+            _check_stage(eng, b, stage, frames, lens, begin, labels, c)
+        _estep(eng, b, PCL_F32)
+        lp_mean.append(float(b.get('logp').mean()))
+        note('C4shard EM-shaped model', 'mean ln P(O) before iterations 1, 2, 3', lp_mean)
+        assert lp_mean[0] < lp_mean[1] < lp_mean[2], lp_mean          # EM's own invariant: the likelihood does not go down
+        b.close()
+    finally:
+        eng.close()
