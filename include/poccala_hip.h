@@ -87,6 +87,12 @@ typedef enum {
 
 /* ---------------------------------------------------------------- context */
 int pcl_init(int device, pcl_ctx **out);
+/* pcl_destroy may be called with work in flight: it drains every stream of the context first (so asynchronous result copies have
+ * landed when it returns), then releases the communicator, the batches already handed to pcl_batch_destroy, the model and the
+ * streams.  Batches the caller never destroyed are NOT walked: their device blocks stay in the process-wide pool's books (a
+ * leak, not a fault) -- destroy batches first.  Page-locked host memory from pcl_host_alloc belongs to the caller: free it
+ * with pcl_host_free BEFORE pcl_destroy (pcl_host_free itself waits for every stream of the context, because hipHostFree does
+ * not wait for copies still using the block).  tools/lifecycle_stress.py exercises all of this. */
 int pcl_destroy(pcl_ctx *ctx);
 const char *pcl_last_error(pcl_ctx *ctx); /* ctx may be NULL: error of a failed pcl_init */
 int pcl_sync(pcl_ctx *ctx);

@@ -273,8 +273,13 @@ int pcl_destroy(pcl_ctx *ctx) {
     }
     pcl_comm_destroy(ctx);
     pcl_batch_reap(ctx, true);
+    // (round 6, tools/lifecycle_stress.py: a context destroyed with an asynchronous pcl_stats_zero still un-joined -- zero_pending --
+    //  had ev_zero destroyed HERE and then synchronised on by free_model below: a use of a dead event, SIGSEGV inside the runtime.
+    //  The streams are drained: nothing is pending any more, and the handles are cleared as they go.)
+    ctx->zero_pending = false;
     if (ctx->ev_zero) hipEventDestroy(ctx->ev_zero);
     if (ctx->ev_zero_src) hipEventDestroy(ctx->ev_zero_src);
+    ctx->ev_zero = ctx->ev_zero_src = nullptr;
     if (ctx->desc_pin) hipHostFree(ctx->desc_pin);
     ctx->desc_pin = nullptr;
     drop_timers(ctx);

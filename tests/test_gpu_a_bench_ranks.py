@@ -103,7 +103,9 @@ def test_bench_self_spawned_two_ranks():
 def test_bench_under_the_drivers_launcher_four_ranks():
     """The driver's form, word for word: python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1
     --master-port P bench.py --gpus 4 --steps K --warmup W (the launcher imports torch; the ranks never do)."""
-    pytest.importorskip('torch')
+    import importlib.util
+    if importlib.util.find_spec('torch') is None:      # (found, NOT imported: torch's wheel bundles a second HIP runtime, and two of them in
+        pytest.skip('torch is not installed')          #  this process end in a double free at interpreter exit -- the launcher runs in a child)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), 'bench.py', '--gpus', '4'] + SMALL
     rc, out, err, dt = _run(cmd, _env(), 900)
