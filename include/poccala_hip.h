@@ -309,6 +309,10 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
  * more than *limit of its mixtures are out (env PCL_SPLIT_MAX = share of M, default 0.5 (the measured break-even of the two routes: pipe 16 + subset 139 f against direct form 92 ms per batch at the bench shape); 0 = whole states, as before).
  * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
 int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
+/* Diagnostics of the coarse pass over the off-pipe mixtures (csrc/gmm_score_coarse.hip; counted only under env PCL_COARSE_STATS=1):
+ * *pairs = (frame, mixture) pairs evaluated exactly since the last reset -- the pairs the bound on the matrix pipe could not rule
+ * out; every other pair of an off-pipe mixture was proven to lie 2^-36 below its frame's likelihood.  reset != 0 clears the count. */
+int pcl_coarse_counter(pcl_ctx *ctx, unsigned long long *pairs, int reset);
 
 /* How much of a CU the matrix-core scoring kernel takes.  0 (default): three workgroups per CU, the fastest for the kernel alone.
  * 2: two -- a third of the registers stays free for kernels of OTHER streams, which is what lets the token passing of chunk k-1

@@ -732,12 +732,12 @@ int pcl_launch_accumulate(pcl_ctx *ctx, pcl_batch *b, int precision) {
     b->acc_split.clear();
     for (int pass = 0; pass < 2; ++pass)
         for (size_t k = 0; k < ns; ++k) {
-            const bool bad = mfma && pcl_state_uses_valu(ctx, b->work_states[k]);
+            const bool bad = mfma && pcl_state_acc_uses_valu(ctx, b->work_states[k]);
             if (bad != (pass == 1)) continue;
             b->acc_ws.push_back(b->work_states[k]);
             b->acc_lo.push_back(b->state_seg_lo[k]);
             b->acc_hi.push_back(b->state_seg_hi[k]);
-            const int sp = (mfma && pass == 0 && pcl_state_is_split(ctx, b->work_states[k])) ? 1 : 0;
+            const int sp = (mfma && pass == 0 && pcl_state_acc_is_split(ctx, b->work_states[k])) ? 1 : 0;
             b->acc_split.push_back(sp);
             n_split += sp;
             n_good += pass == 0;

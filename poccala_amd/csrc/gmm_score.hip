@@ -443,6 +443,26 @@ int pcl_launch_score_subset(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, 
     return PCL_OK;
 }
 
+// ... the same for the tiles the coarse pass flagged (gmm_score_coarse.hip: a scaled feature out of the f16 range): a fixed grid scans the flags,
+// one frame per lane so that a workgroup covers a matrix-pipe tile
+int pcl_launch_score_subset_flagged(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags) {
+    if (n_tiles == 0) return PCL_OK;
+    if (pcl_coarse_tile_frames() != WG) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: coarse tile size mismatch");
+    pcl_timer_begin(ctx, "score_subset_fixup");
+    const MasterModel mm{ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Dhost, ctx->model_flags, ctx->d_bad, ctx->d_bad_idx, ctx->d_nbad};
+    const int fix_grid = std::min(n_tiles, 1024);
+    switch (ctx->D) {
+#define CASESF(DD) case DD: hipLaunchKernelGGL((gmm_score_kernel<DD, 1, PCL_CH32, float, true, true>), dim3(fix_grid), dim3(WG), 0, ctx->stream, ctx->frames32, \
+                                                (const float *)nullptr, ctx->Mpad, tiles, b->d_segs, b->Bt, flags, n_tiles, mm); break;
+        CASESF(13) CASESF(26) CASESF(39) CASESF(47)
+#undef CASESF
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no subset scoring kernel for D=%d", ctx->D);
+    }
+    pcl_timer_end(ctx, "score_subset_fixup");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
 int pcl_launch_score(pcl_ctx *ctx, pcl_batch *b, int precision, const ScoreTile *tiles, int n_tiles) {
     if (n_tiles == 0) return PCL_OK;
     const int D = ctx->D;

@@ -1,0 +1,560 @@
+// gmm_score_coarse.hip -- the off-pipe ("tight") mixtures of split states: a COARSE pass on the f16 matrix pipe that proves almost
+// every (frame, mixture) pair negligible, and an exact float64 evaluation of the few pairs it cannot (round 6).
+//
+// Reference rows: as gmm_score.hip (A1/A4/A6: util.gaussian_function util.py:20-31, Clustering.GMM.point Clustering.py:740-767); the
+// models in question are the ones Clustering.GMM.update_param (Clustering.py:682-693, variance floor init.py:30 -> Controller.py:151)
+// leaves after one or two M-steps: mixtures much tighter than their state's spread.
+//
+// Why.  A mixture whose cancelling term cond_m = log2e sum_d (mu_md - c_jd)^2 / (2 var_md) is beyond cond_max cannot be evaluated by the
+// centred f32-class expansion of gmm_score_split.hip to 5e-5 nats (error ~ 5e-7 cond_m), so it is left out of the matrix-pipe layouts
+// and evaluated in direct form, 78 FMAs per (frame, mixture) pair on the VALU (gmm_score.hip, SUBSET): at config 4's third EM iteration
+// 57 % of the mixtures are such, and the direct-form launch is 52 ms per 1024-utterance batch beside the pipe's 15 (whole states in
+// direct form, the round 4-5 route: 66 ms).  But 99.9 % of those pairs contribute nothing: a tight mixture is hundreds of nats below
+// the frame's likelihood for every frame that is not within a few of ITS sigmas.  Proving that needs no precision, only a BOUND:
+//
+//   v_up[f,m] = k2_m - log2e sum_d (x_fd - mu_md)^2 / (2 var'_md),   var' = max(var, vfloor_m)  >=  the mixture's true log2 value
+//
+// (a larger variance can only raise the exponent; the constant k2_m is the TRUE one -- quirk Q1's constant has no determinant).  v_up is
+// the same contraction over [x'^2, x', 1] as the main kernel's, with coefficients that fit the f16 pieces because of the floor:
+// vfloor_m = max(2^-10, log2e/2 sum_d (mu_md - c_jd)^2 / 2.5e4) bounds a' = log2e / (2 var') by 739 and the cancelling term by 2.5e4.
+// The pipe computes it with an absolute error below E_m = 2^-20 (|k''_m - K0| + 8 kq'_m + 2 |k2_m|) + 0.25 (a few times the nominal
+// 2^-22 of the two-piece products; kq' = the cancelling term under var'), which is ADDED to the mixture's folded constant.  With the
+// spare-slot reference set to  t_f = log2e ln b1_f - 36 - K0  (ln b1 = what the pipe wrote for the state's on-pipe mixtures; 36: a
+// term 2^-36 below the total changes ln b by 1e-11 even if all 2048 were dropped at the threshold), the accumulator of a pair is
+//   acc >= 0   <=>   the pair MAY reach 2^-36 of the frame's likelihood,
+// one v_max tree + one ballot per 32 x 32 tile instead of the log-sum-exp.  Pairs that pass are evaluated EXACTLY by their lane
+// (float64, master copy: k2 - log2e sum (x - mu)^2 / (2 var)) into a per-lane online log-sum-exp, the threshold is raised when an
+// exact value lifts the frame's maximum (states without on-pipe mixtures start at -inf and settle after their first tile), and the
+// result is log-added to the pipe's in float64: ln b = ln(e^pipe + e^tight), the reference's sum over all mixtures -- deterministic
+// (a lane owns its frame; no atomics).  Frames whose scaled features leave the f16 range raise the tile's flag and the direct-form
+// subset kernel rescoring flagged tiles follows in the same call, as for the main kernel.
+//
+// Layout of the tight mixtures: [J][Mpad32/32 tiles][2 pieces][KS8][64 lanes][8 f16], the state's bad_idx list in order, 32 per tile,
+// nct[j] tiles used; own power-of-two feature scales fscale_c and K0 (kzero_c); exact constants k2c[j][idx] (float64).  Derived on
+// first use after a model change (pcl_ensure_coarse), one workgroup per state.
+#include <stdlib.h>
+
+#include "pcl_internal.h"
+
+namespace {
+
+constexpr int WG = 256;
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
+constexpr float COARSE_MARGIN = 36.f;         // log2 units below the frame's likelihood: nothing (see above)
+constexpr double VMIN_C = 0.0009765625;       // 2^-10: the variance floor of the bound
+constexpr double KQ_MAX = 2.5e4;              // the cancelling term the folded constant may carry (f16 pieces reach 6e4)
+constexpr double EPS_C = 9.5367431640625e-07; // 2^-20
+
+struct CoarseExact {
+    const double *mean64, *var64, *k2c;
+    const int *bad_idx, *nbad;
+    int Mpad, Dhost;
+};
+
+#ifndef PCL_COARSE_NT
+#define PCL_COARSE_NT 2
+#endif
+
+template <int D, int NT>
+__global__ __launch_bounds__(WG, 2) void gmm_score_coarse_kernel(
+    const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
+    int nmt_max, const int *__restrict__ nct, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
+    int *__restrict__ flags, const double *__restrict__ kzero, CoarseExact ex, unsigned long long *__restrict__ counters) {
+    static_assert(D % 8 != 0, "the folded constants need a spare slot");
+    constexpr int KS8 = (D + 7) / 8;
+    constexpr int CH = 2 * KS8;
+    constexpr int SC = D / 8, JC = D % 8;
+    constexpr float FMAXH = 6.0e4f, TMAX = 5.0e4f;
+    const ScoreTile tile = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int n_mtiles = (tile.seg_lo >= tile.seg_hi) ? 0 : nct[tile.state];
+    if (n_mtiles == 0) {                      // padding tile of the XCD-aware order, or a state without tight mixtures
+        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+        return;
+    }
+    __shared__ int s_ovf;
+    if (threadIdx.x == 0) s_ovf = 0;
+    __syncthreads();
+    const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
+    const bool wave_active = tile.vstart + wave * NT * 32 < vend;
+
+    // ---- B operand: as gmm_score_split16_kernel, with the coarse layout's scales
+    h8v xb[NT][2][KS8];
+    long long oidx[NT], frow[NT];
+    bool valid[NT];
+    const float *cen = centers + (size_t)tile.state * D;
+    const float *fs = fscale + ((size_t)tile.state * 2 + half) * (KS8 * 8);
+    bool ovf = false;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        int v = tile.vstart + (wave * NT + c) * 32 + col;
+        valid[c] = v < vend;
+        if (!valid[c]) v = tile.vstart;
+        int lo = tile.seg0, hi = tile.seg_hi - 1;
+        if (lo < hi && segs[lo + 1].vstart <= v) {
+            ++lo;
+            if (lo < hi && segs[lo + 1].vstart <= v) {
+                ++lo;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (segs[mid].vstart <= v) lo = mid; else hi = mid - 1;
+                }
+            }
+        }
+        const ScoreSeg sg = segs[lo];
+        const long long t = v - sg.vstart;
+        frow[c] = sg.frame0 + t;
+        const float *fp = frames + frow[c] * D;
+#pragma unroll
+        for (int s = 0; s < KS8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * s + j;
+                float val = 0.f;
+                if (d < D) {
+                    const float xc = fp[d] - cen[d];
+                    val = (half ? xc : xc * xc) * fs[d];
+                    ovf |= valid[c] && __builtin_fabsf(val) > FMAXH;
+                    val = __builtin_fminf(__builtin_fmaxf(val, -FMAXH), FMAXH);
+                }
+                if (d == D) val = half ? 0.f : 1.f;              // x1: [1 | -t (set below)]
+                const _Float16 h1 = (_Float16)val;
+                xb[c][0][s][j] = h1;
+                xb[c][1][s][j] = (_Float16)(val - (float)h1);
+            }
+        oidx[c] = sg.out0 + t * (long long)sg.out_stride;
+    }
+    if (__any(ovf) && lane == 0) s_ovf = 1;
+    __syncthreads();
+    if (s_ovf) {                              // a frame out of the f16 range: the direct-form subset kernel rescoring flagged tiles does this one
+        if (threadIdx.x == 0) flags[blockIdx.x] = 1;
+        return;
+    }
+    if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+
+    // ---- per frame: what the pipe wrote (ln b of the on-pipe mixtures) and the threshold t = log2e ln b1 - margin - K0 its spare slot carries
+    const float k0f = (float)kzero[tile.state];
+    double pipe_ln[NT];
+    float tcur[NT];                           // (f16-exact)
+    auto set_threshold = [&](int c, float t) {
+        // rounded so that the f16 value is not ABOVE what was asked for (a higher threshold could miss a pair): less 2^-10 |t|
+        t = t - __builtin_fabsf(t) * 0.0009765625f;
+        t = __builtin_fminf(__builtin_fmaxf(t, -TMAX), TMAX);
+        const _Float16 r1 = (_Float16)(-t);
+        tcur[c] = -(float)r1;
+        if (half) xb[c][0][SC][JC] = r1;
+    };
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        pipe_ln[c] = valid[c] ? out[oidx[c]] : 0.0;
+        const double t2 = pipe_ln[c] * LOG2E - (double)COARSE_MARGIN - (double)k0f;
+        set_threshold(c, valid[c] ? (t2 > -1.0e30 ? (float)t2 : -TMAX) : TMAX);
+    }
+
+    __shared__ __attribute__((aligned(16))) uint4 abuf[2][CH * 64];
+    const uint4 *pstate = pm + (size_t)tile.state * nmt_max * (CH * 64);
+    auto dma = [&](int buf, int stage) {
+        const uint4 *src = pstate + (size_t)stage * (CH * 64);
+        for (int p = wave; p < CH; p += WG / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&abuf[buf][p * 64], 16, 0, 0);
+    };
+    const int n_tight = ex.nbad[tile.state];
+    const size_t srow = (size_t)tile.state * ex.Mpad;
+    unsigned long long n_cand = 0;
+
+    // ---- the pairs that pass wait in a queue of their wave and are evaluated 64 at a time, a lane per PAIR (one lane at a time beside
+    //      63 idle ones, with its 117 dependent loads, made the exact part ten times the matrix pipe's: 43 ms per batch at 73 % off-pipe
+    //      mixtures).  Queue order = (m-tile, frame slot c, accumulator row, lane): fixed, so the sums are too.  Lane L owns frame slot
+    //      L = c * 32 + col: the online log-sum-exp (log2 domain, float64) of the slot's exact values.
+    constexpr int QCAP = 64, SLOTS = NT * 32;
+    static_assert(SLOTS <= 64, "a lane per frame slot");
+    __shared__ int q_idx[WG / 64][QCAP], q_slot[WG / 64][QCAP];
+    __shared__ double q_val[WG / 64][QCAP];
+    __shared__ long long frow_tab[WG / 64][SLOTS];
+    if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) frow_tab[wave][c * 32 + col] = frow[c];
+    }
+    int qn = 0;                               // wave-uniform
+    double tmaxL = -INFINITY, tsumL = 0.0;
+    auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < qn) {
+            const int idx = q_idx[wave][lane];
+            double v = -INFINITY;
+            if (idx < n_tight) {
+                const double k2 = ex.k2c[srow + idx];
+                if (k2 > -1.0e300) {                             // (not a zero weight)
+                    const size_t jm = (srow + ex.bad_idx[srow + idx]) * D;
+                    const float *fp = frames + frow_tab[wave][q_slot[wave][lane]] * D;
+                    double q = 0.0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d)
+                        if (d < ex.Dhost) {
+                            const double dx = (double)fp[d] - ex.mean64[jm + d];
+                            q += dx * dx * (0.5 / ex.var64[jm + d]);
+                        }
+                    v = k2 - LOG2E * q;
+                    ++n_cand;
+                }
+            }
+            q_val[wave][lane] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int i = 0; i < qn; ++i) {
+            if (q_slot[wave][i] != lane) continue;
+            const double v = q_val[wave][i];
+            if (!(v > -1.0e300)) continue;
+            if (tsumL == 0.0) {
+                tmaxL = v;
+                tsumL = 1.0;
+            } else if (v > tmaxL) {
+                tsumL = tsumL * ::exp2(tmaxL - v) + 1.0;
+                tmaxL = v;
+            } else {
+                tsumL += ::exp2(v - tmaxL);
+            }
+        }
+        qn = 0;
+        // an exact value that lifts a frame's maximum raises its threshold
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const double tm = __shfl(tmaxL, c * 32 + col, 64);
+            const float want = (float)(tm - (double)COARSE_MARGIN - (double)k0f);
+            if (valid[c] && tm > -1.0e300 && want > tcur[c] + 4.f) set_threshold(c, want);
+        }
+    };
+
+    auto process = [&](int mt) {
+        const uint4 *ab = &abuf[mt & 1][0];
+        f16v acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        auto pass = [&](int pa, int pb) {
+#pragma unroll
+            for (int s = 0; s < KS8; ++s) {
+                const h8v a = *reinterpret_cast<const h8v *>(&ab[(pa * KS8 + s) * 64 + lane]);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[c][pb][s], acc[c], 0, 0, 0);
+            }
+        };
+        pass(1, 0);
+        pass(0, 1);
+        pass(0, 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            float gm = acc[c][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
+            if (!__any(gm >= 0.f)) continue;                     // the common case: nobody of this tile can reach any of the 32 frames
+            unsigned int mask = 0u;                              // (the rows that passed, as bits: no dynamic index into the accumulator registers)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mask |= (acc[c][r] >= 0.f ? 1u : 0u) << r;
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const bool hit = (mask >> r) & 1u;
+                const unsigned long long bal = __ballot(hit);
+                if (!bal) continue;
+                const int cnt = __popcll(bal);
+                if (qn + cnt > QCAP) flush();
+                if (hit) {
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    q_idx[wave][pos] = mt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    q_slot[wave][pos] = c * 32 + col;
+                }
+                qn += cnt;
+            }
+        }
+    };
+
+    dma(0, 0);
+    for (int st = 0; st < n_mtiles; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < n_mtiles) dma((st + 1) & 1, st + 1);
+        if (wave_active) process(st);
+    }
+    if (qn) flush();
+    constexpr double LN2 = 0.693147180559945309417232121458;
+    if (lane < SLOTS && tsumL > 0.0) {
+        // lane L = c * 32 + col finishes frame slot L: its own col, the c-th of its frames
+        bool ok = false;
+        long long oi = 0;
+        double old = 0.0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            if ((lane >> 5) == c) {
+                ok = valid[c];
+                oi = oidx[c];
+                old = pipe_ln[c];
+            }
+        if (ok) {
+            const double res = LN2 * (tmaxL + ::log2(tsumL));
+            const double hi = ::fmax(old, res), lo = ::fmin(old, res);
+            out[oi] = (hi > -INFINITY) ? hi + ::log1p(::exp(lo - hi)) : -INFINITY;
+        }
+    }
+    if (counters) {                           // diagnostics (PCL_COARSE_STATS=1): pairs evaluated exactly
+        for (int o = 32; o >= 1; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
+        if (lane == 0 && n_cand) atomicAdd(counters, n_cand);
+    }
+}
+
+// ---------------------------------------------------------------- the coarse layout of one state's tight mixtures
+// One workgroup per state.  Pass A: per-feature maxima of the coefficients under the floored variances and the largest k''; pass B:
+// the tiles.  8 lanes per mixture, 32 mixtures per step, derive_kernel's arrangement (model_derive.hip).
+template <int DMAX>
+__global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
+                                                            const double *__restrict__ w64, const float *__restrict__ centers, int M, int Mpad,
+                                                            int Mpad32, int D, int Dhost, int flags, const int *__restrict__ bad_idx,
+                                                            const int *__restrict__ nbad, uint4 *__restrict__ pmc, float *__restrict__ fscale_c,
+                                                            double *__restrict__ kzero_c, double *__restrict__ k2c, int *__restrict__ nct) {
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int nb = nbad[j], ntl = (nb + 31) / 32, nmt = Mpad32 / 32, KS8 = (D + 7) / 8;
+    if (tid == 0) nct[j] = ntl;
+    if (nb == 0) return;
+    __shared__ float fa[32 * DMAX], fb[32 * DMAX], cen[DMAX], isc[2 * 64];
+    __shared__ float kc[32];
+    __shared__ unsigned int mxa[64], mxb[64];
+    __shared__ int kbits;
+    for (int d = tid; d < D; d += 256) cen[d] = centers[(size_t)j * D + d];
+    if (tid < 64) mxa[tid] = mxb[tid] = 0u;
+    if (tid == 0) kbits = (int)0x80808080;
+    __syncthreads();
+    const int ml = tid >> 3, sub = tid & 7;
+    const size_t srow = (size_t)j * Mpad;
+    constexpr int PER = (DMAX + 7) / 8;
+    // one tile's rows: coefficients under the floored variance into fa / fb (pass B) or the maxima (pass A); returns k'' (lane sub == 0)
+    auto rows = [&](int t, bool write, double &k2_out, double &kq_out, bool &real_out) {
+        const int idx = t * 32 + ml;
+        const bool real_m = idx < nb;
+        const size_t jm = (srow + (real_m ? bad_idx[srow + idx] : 0)) * D;
+        double v[PER], dm[PER];
+        double s2 = 0.0, sumvar = 0.0, sumlog = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int dd = sub + 8 * k;
+            v[k] = 1.0;
+            dm[k] = 0.0;
+            if (dd < D && dd < Dhost && real_m) {
+                v[k] = var64[jm + dd];
+                dm[k] = mean64[jm + dd] - (double)cen[dd];
+                s2 += dm[k] * dm[k];
+                sumvar += v[k];
+                if (flags & PCL_MODEL_LOGDET) sumlog += log(v[k]);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s2 += __shfl_xor(s2, o, 64);
+            sumvar += __shfl_xor(sumvar, o, 64);
+            sumlog += __shfl_xor(sumlog, o, 64);
+        }
+        const double vfloor = fmax(VMIN_C, 0.5 * LOG2E * s2 / KQ_MAX);
+        double kq = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int dd = sub + 8 * k;
+            if (dd < D) {
+                float a = 0.f, b = 0.f;
+                if (dd < Dhost && real_m) {
+                    const double ap = LOG2E * 0.5 / fmax(v[k], vfloor);
+                    kq += ap * dm[k] * dm[k];
+                    a = (float)(-ap);
+                    b = (float)(2.0 * ap * dm[k]);
+                    if (!write) {
+                        atomicMax(&mxa[dd], __float_as_uint(-a));
+                        atomicMax(&mxb[dd], __float_as_uint(fabsf(b)));
+                    }
+                }
+                if (write) {
+                    fa[ml * D + dd] = a;
+                    fb[ml * D + dd] = b;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) kq += __shfl_xor(kq, o, 64);
+        double k2 = -INFINITY;
+        if (real_m) {
+            const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;      // util.py:29 (quirk Q1)
+            k2 = LOG2E * (log(w64[srow + bad_idx[srow + idx]]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
+        }
+        k2_out = k2;
+        kq_out = kq;
+        real_out = real_m;
+    };
+    // ---- pass A
+    float kmax = -INFINITY;
+    bool any = false;
+    for (int t = 0; t < ntl; ++t) {
+        double k2, kq;
+        bool real_m;
+        rows(t, false, k2, kq, real_m);
+        if (sub == 0 && real_m) {
+            k2c[srow + t * 32 + ml] = k2;
+            if (k2 > -INFINITY) {
+                const float kp = (float)(k2 - kq);
+                kmax = any ? fmaxf(kmax, kp) : kp;
+                any = true;
+            }
+        }
+    }
+    if (any) {
+        const int i = __float_as_int(kmax);
+        atomicMax(&kbits, i >= 0 ? i : i ^ 0x7fffffff);
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * KS8 * 8; t += 256) {
+        const int h = t / (KS8 * 8), dd = t % (KS8 * 8);
+        const float mx = (dd < Dhost && dd < 64) ? __uint_as_float(h ? mxb[dd] : mxa[dd]) : 0.f;
+        int e = 1;
+        if (mx > 0.f && mx < 1e30f) (void)frexpf(mx, &e);             // mx = f 2^e, f in [0.5, 1): the largest coefficient lands in [1, 2)
+        e = min(max(e - 1, -60), 60);
+        const float sc = ldexpf(1.0f, e);
+        fscale_c[((size_t)j * 2 + h) * (KS8 * 8) + dd] = sc;
+        isc[h * 64 + dd] = 1.0f / sc;
+    }
+    double k0 = 0.0;
+    {
+        const int i = kbits;
+        const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
+        if (i != (int)0x80808080 && f > -3.0e38f) k0 = (double)f;
+    }
+    if (tid == 0) kzero_c[j] = k0;
+    __syncthreads();
+    // ---- pass B
+    for (int t = 0; t < ntl; ++t) {
+        double k2, kq;
+        bool real_m;
+        rows(t, true, k2, kq, real_m);
+        if (sub == 0) {
+            float c = -6.0e4f;                                    // log zero: padding rows, zero weights
+            if (real_m && k2 > -INFINITY) {
+                const double kpp = k2 - kq - k0;
+                const double em = EPS_C * (fabs(kpp) + 8.0 * kq + 2.0 * fabs(k2)) + 0.25;
+                const double kk = kpp + em;
+                c = (kk > -5.0e4) ? (float)kk : -6.0e4f;          // (cannot be: kq <= KQ_MAX)
+            }
+            kc[ml] = c;
+        }
+        __syncthreads();
+        uint4 *pf = pmc + ((size_t)j * nmt + t) * (2 * KS8 * 64);
+        for (int e = tid; e < 2 * KS8 * 64; e += 256) {
+            const int p = (e >> 6) / KS8, s = (e >> 6) % KS8, ln = e & 63, half = ln >> 5, cl = ln & 31;
+            unsigned short h[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int dd = 8 * s + x;
+                float val = 0.f;
+                bool is_const = false;
+                if (dd < D) {
+                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) * isc[half * 64 + dd];
+                    if (kc[cl] <= -6.0e4f) val = 0.f;
+                } else if (dd == D) {
+                    is_const = true;
+                    val = half ? 1.f : kc[cl];
+                }
+                const _Float16 h1 = (_Float16)val;
+                _Float16 hp;
+                if (!is_const) hp = p ? (_Float16)(val - (float)h1) : h1;
+                else if (half == 0) hp = p ? ((val <= -6.0e4f) ? (_Float16)0.f : (_Float16)(val - (float)h1)) : h1;    // k1 | k2
+                else hp = p ? (_Float16)1.f : (_Float16)0.f;                                                       // a1: 0, a2: 1
+                h[x] = __builtin_bit_cast(unsigned short, hp);
+            }
+            pf[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+        }
+        __syncthreads();
+    }
+}
+
+template <int D>
+void launch_coarse_t(pcl_ctx *ctx, pcl_batch *b, const CoarseExact &ex, unsigned long long *counters) {
+    hipLaunchKernelGGL((gmm_score_coarse_kernel<D, PCL_COARSE_NT>), dim3(b->n_tiles_c), dim3(WG), 0, ctx->stream, ctx->frames32,
+                       reinterpret_cast<const uint4 *>(ctx->pmc), ctx->fscale_c, ctx->centers32, ctx->Mpad32 / 32, ctx->d_nct, b->d_tiles_c, b->d_segs,
+                       b->Bt, b->d_tile_flags_c, ctx->kzero_c, ex, counters);
+}
+
+}  // namespace
+
+bool pcl_coarse_enabled_for(const pcl_ctx *ctx, int D) {
+    return ctx->coarse_on && ctx->score_variant == 7 && (D == 13 || D == 26 || D == 39 || D == 47);
+}
+bool pcl_coarse_enabled(const pcl_ctx *ctx) { return pcl_coarse_enabled_for(ctx, ctx->D); }
+
+int pcl_coarse_tile_frames() { return WG / 64 * PCL_COARSE_NT * 32; }
+
+void pcl_coarse_release(pcl_ctx *ctx) {
+    dev_free(ctx->pmc);
+    dev_free(ctx->fscale_c);
+    dev_free(ctx->kzero_c);
+    dev_free(ctx->k2c);
+    dev_free(ctx->d_nct);
+    dev_free(ctx->d_coarse_counter);
+    ctx->coarse_gen = -1;
+}
+
+// the coarse layout of the current model (derived on first use after the model changed)
+int pcl_ensure_coarse(pcl_ctx *ctx) {
+    if (ctx->coarse_gen == ctx->model_gen && ctx->pmc) return PCL_OK;
+    const int KS8 = (ctx->D + 7) / 8, nmt = ctx->Mpad32 / 32;
+    if (!ctx->pmc) {
+        TRY(dev_alloc(ctx, &ctx->pmc, (size_t)ctx->J * nmt * (2 * KS8 * 64) * 8));      // unsigned short elements: 8 per uint4
+        TRY(dev_alloc(ctx, &ctx->fscale_c, (size_t)ctx->J * 2 * KS8 * 8));
+        TRY(dev_alloc(ctx, &ctx->kzero_c, (size_t)ctx->J));
+        TRY(dev_alloc(ctx, &ctx->k2c, (size_t)ctx->J * ctx->Mpad));
+        TRY(dev_alloc(ctx, &ctx->d_nct, (size_t)ctx->J));
+        TRY(dev_alloc(ctx, &ctx->d_coarse_counter, (size_t)1));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_coarse_counter, 0, sizeof(unsigned long long), ctx->stream));
+    }
+    pcl_timer_begin(ctx, "derive_coarse");
+    if (ctx->D > 48) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: coarse layout for D=%d", ctx->D);
+    hipLaunchKernelGGL((coarse_derive_kernel<48>), dim3(ctx->J), dim3(256), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->centers32, ctx->M,
+                       ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->model_flags, ctx->d_bad_idx, ctx->d_nbad, reinterpret_cast<uint4 *>(ctx->pmc),
+                       ctx->fscale_c, ctx->kzero_c, ctx->k2c, ctx->d_nct);
+    pcl_timer_end(ctx, "derive_coarse");
+    HIPCHK(ctx, hipGetLastError());
+    ctx->coarse_gen = ctx->model_gen;
+    return PCL_OK;
+}
+
+// the tight mixtures of the split states: coarse pass + exact evaluation of what it cannot rule out, log-added to the pipe's result
+int pcl_launch_score_coarse(pcl_ctx *ctx, pcl_batch *b) {
+    if (b->n_tiles_c == 0) return PCL_OK;
+    TRY(pcl_ensure_coarse(ctx));
+    static const bool stats = getenv("PCL_COARSE_STATS") && atoi(getenv("PCL_COARSE_STATS")) != 0;
+    const CoarseExact ex{ctx->mean64, ctx->var64, ctx->k2c, ctx->d_bad_idx, ctx->d_nbad, ctx->Mpad, ctx->Dhost};
+    unsigned long long *counters = stats ? ctx->d_coarse_counter : nullptr;
+    pcl_timer_begin(ctx, "score_coarse");
+    switch (ctx->D) {
+        case 47: launch_coarse_t<47>(ctx, b, ex, counters); break;
+        case 39: launch_coarse_t<39>(ctx, b, ex, counters); break;
+        case 26: launch_coarse_t<26>(ctx, b, ex, counters); break;
+        case 13: launch_coarse_t<13>(ctx, b, ex, counters); break;
+        default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no coarse scoring kernel for D=%d", ctx->D);
+    }
+    pcl_timer_end(ctx, "score_coarse");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_coarse_counter(pcl_ctx *ctx, unsigned long long *pairs, int reset) {
+    if (!ctx || !pairs) return PCL_ERR_INVALID;
+    *pairs = 0;
+    if (!ctx->d_coarse_counter) return PCL_OK;
+    HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_coarse_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d_coarse_counter, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}

@@ -217,8 +217,12 @@ int pcl_init(int device, pcl_ctx **out) {
         return PCL_ERR_INVALID;
     }
     if (const char *cm = getenv("PCL_MFMA_COND_MAX")) ctx->cond_max = (float)atof(cm);
-    if (const char *sm = getenv("PCL_SPLIT_MAX")) ctx->split_frac = std::min(1.0f, std::max(0.0f, (float)atof(sm)));
+    if (const char *sm = getenv("PCL_SPLIT_MAX")) {
+        ctx->split_frac = std::min(1.0f, std::max(0.0f, (float)atof(sm)));
+        ctx->split_frac_set = true;
+    }
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
+    if (const char *co = getenv("PCL_COARSE")) ctx->coarse_on = atoi(co) != 0;
     if (const char *tm = getenv("PCL_TIMERS")) ctx->timing = atoi(tm) != 0;
     *out = ctx;
     return PCL_OK;
@@ -226,6 +230,7 @@ int pcl_init(int device, pcl_ctx **out) {
 
 static void free_model(pcl_ctx *ctx) {
     pcl_accumulate_release(ctx);                                 // (sized for the model's states and mixtures)
+    pcl_coarse_release(ctx);
     dev_free(ctx->params32);
     dev_free(ctx->params64);
     dev_free(ctx->mean32);
@@ -424,7 +429,14 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->d_bad, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_bad_idx, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_nbad, (size_t)J));
-    ctx->split_max = (int)(ctx->split_frac * (float)M);
+    // with the coarse pass (gmm_score_coarse.hip) a state's off-pipe mixtures cost the scoring about what they would cost on the pipe, so
+    // states stay split for scoring up to PCL_COARSE_SPLIT_FRAC of their mixtures (beyond it the pipe pass over the few that are left
+    // is mostly log-zero tiles, and the whole-state direct form with its partial-distance test is the cheaper route: measured
+    // 33 ms per batch against 12 + 54 at 98 %); PCL_SPLIT_MAX overrides both limits; the accumulate pass keeps the round 4-5 half
+    ctx->acc_split_max = (int)((ctx->split_frac_set ? ctx->split_frac : 0.5f) * (float)M);
+    float coarse_frac = PCL_COARSE_SPLIT_FRAC;
+    if (const char *cs = getenv("PCL_COARSE_SPLIT_MAX")) coarse_frac = std::min(1.0f, std::max(0.0f, (float)atof(cs)));      // (scoring only: A/B)
+    ctx->split_max = (int)(((ctx->split_frac_set || !pcl_coarse_enabled_for(ctx, Dd)) ? ctx->split_frac : coarse_frac) * (float)M);
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->var64, v64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->w64, w64.data(), nw * sizeof(double), hipMemcpyHostToDevice));
@@ -643,7 +655,7 @@ static void batch_free_now(pcl_batch *b) {
     dev_free(b->xi_m); dev_free(b->xi_s); dev_free(b->bp); dev_free(b->d_row_state);
     dev_free(b->Bp); dev_free(b->alpha_e); dev_free(b->beta_e); dev_free(b->fb_kmax); dev_free(b->fb_dump); dev_free(b->fb_part_m); dev_free(b->fb_part_e);
     dev_free(b->d_dups);
-    dev_free(b->d_segs); dev_free(b->d_seg_of_row); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tiles_s); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
+    dev_free(b->d_segs); dev_free(b->d_seg_of_row); dev_free(b->d_tiles); dev_free(b->d_tiles_v); dev_free(b->d_tiles_s); dev_free(b->d_tiles_c); dev_free(b->d_tile_flags_c); dev_free(b->d_tile_flags); dev_free(b->tmp); dev_free(b->nz_tmp);
     delete b;
 }
 
@@ -886,7 +898,9 @@ int pcl_batch_set_states_impl(pcl_batch *b, const int32_t *row_state) {
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
     dev_free(b->d_tiles_s);
-    b->n_tiles_s = 0;
+    dev_free(b->d_tiles_c);
+    dev_free(b->d_tile_flags_c);
+    b->n_tiles_s = b->n_tiles_c = 0;
     b->tile_frames = 0;
     TRY(dev_alloc(ctx, &b->d_segs, (size_t)b->n_segs));
     if (b->n_segs) HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_segs, b->segs.data(), (size_t)b->n_segs * sizeof(ScoreSeg)));
@@ -1009,15 +1023,26 @@ static int build_tiles(pcl_batch *b, int precision) {
     if (mfma)
         for (size_t k : good)
             if (pcl_state_is_split(ctx, b->work_states[k])) split.push_back(k);
-    const std::vector<ScoreTile> tiles_s = split.empty() ? std::vector<ScoreTile>() : make_tiles(b, split, pcl_score_subset_tile_frames(ctx->D));
+    // ... at the direct-form tile size (the subset launch, rounds 4-5) or, with the coarse pass, at the matrix pipe's
+    const bool coarse = mfma && ctx->score_variant == 7 && pcl_coarse_enabled(ctx);
+    const std::vector<ScoreTile> tiles_s = (split.empty() || coarse) ? std::vector<ScoreTile>() : make_tiles(b, split, pcl_score_subset_tile_frames(ctx->D));
+    const std::vector<ScoreTile> tiles_c = (split.empty() || !coarse) ? std::vector<ScoreTile>() : make_tiles(b, split, pcl_coarse_tile_frames());
     dev_free(b->d_tiles);
     dev_free(b->d_tiles_v);
     dev_free(b->d_tiles_s);
+    dev_free(b->d_tiles_c);
+    dev_free(b->d_tile_flags_c);
     pcl_desc_group uploads(ctx);                                   // the tile lists: staged, one wait at the end
     b->n_tiles_s = (int)tiles_s.size();
     if (!tiles_s.empty()) {
         TRY(dev_alloc(ctx, &b->d_tiles_s, tiles_s.size()));
         HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_tiles_s, tiles_s.data(), tiles_s.size() * sizeof(ScoreTile)));
+    }
+    b->n_tiles_c = (int)tiles_c.size();
+    if (!tiles_c.empty()) {
+        TRY(dev_alloc(ctx, &b->d_tiles_c, tiles_c.size()));
+        TRY(dev_alloc(ctx, &b->d_tile_flags_c, tiles_c.size()));
+        HIPCHK(ctx, pcl_h2d_fresh(ctx, b->d_tiles_c, tiles_c.data(), tiles_c.size() * sizeof(ScoreTile)));
     }
     dev_free(b->d_tile_flags);
     TRY(dev_alloc(ctx, &b->d_tile_flags, tiles.size()));
@@ -1064,7 +1089,11 @@ int pcl_batch_score(pcl_batch *b, int precision) {
             TRY(pcl_launch_score_fixup(ctx, b, b->d_tiles, b->n_tiles, b->d_tile_flags));   // tiles with out-of-range features
 #endif
         } else TRY(pcl_launch_score_mfma(ctx, b, b->d_tiles, b->n_tiles));
-        TRY(pcl_launch_score_subset(ctx, b, b->d_tiles_s, b->n_tiles_s));         // split states: their off-pipe mixtures, log-added
+        if (b->n_tiles_c) {                                                       // split states: their off-pipe mixtures, log-added --
+            TRY(pcl_launch_score_coarse(ctx, b));                                 // proven negligible by a bound on the matrix pipe, or evaluated exactly
+            TRY(pcl_launch_score_subset_flagged(ctx, b, b->d_tiles_c, b->n_tiles_c, b->d_tile_flags_c));   // (tiles with features out of the f16 range)
+        }
+        TRY(pcl_launch_score_subset(ctx, b, b->d_tiles_s, b->n_tiles_s));         // ... or all of them in direct form (PCL_COARSE=0)
         TRY(pcl_launch_score(ctx, b, PCL_F32, b->d_tiles_v, b->n_tiles_v));      // ill-conditioned states, direct form
     } else {
         TRY(pcl_launch_score(ctx, b, precision, b->d_tiles, b->n_tiles));

@@ -124,8 +124,22 @@ struct pcl_ctx {
     int *d_nbad = nullptr;             // [J]
     std::vector<int> nbad;
     float split_frac = 0.5f;           // env PCL_SPLIT_MAX: the share of a state's mixtures that may be off the pipe (0 = no splitting)
+    bool split_frac_set = false;       // PCL_SPLIT_MAX was given (otherwise: 1.0 for scoring when the coarse pass is available, 0.5 for the accumulate pass)
     int split_max = 0;                 // = split_frac * M: mixtures per state that may be off the pipe (0: no splitting -- whole states, as before round 4)
     int model_gen = 0;           // bumped whenever the layouts (and cond) are re-derived
+    // Coarse layout of the off-pipe mixtures (gmm_score_coarse.hip): their bound v_up on the matrix pipe, exact evaluation of what it
+    // cannot rule out.  Derived on first use after the model changed (coarse_gen != model_gen).
+    unsigned short *pmc = nullptr;     // [J][Mpad32/32][2][KS8f][64 lanes][8]: the state's bad_idx list, 32 per tile
+    float *fscale_c = nullptr;         // [J][2][KS8f*8]
+    double *kzero_c = nullptr;         // [J]
+    double *k2c = nullptr;             // [J][Mpad] exact log2-domain constant of the idx-th off-pipe mixture
+    int *d_nct = nullptr;              // [J] coarse tiles in use
+    unsigned long long *d_coarse_counter = nullptr;   // PCL_COARSE_STATS=1: pairs evaluated exactly
+    int coarse_gen = -1;
+    bool coarse_on = true;             // env PCL_COARSE=0 (read when the context is made): the direct-form subset launch of rounds 4-5 instead (A/B)
+    // the accumulate pass keeps the round 4-5 rule (whole states in direct form above acc_split_max off-pipe mixtures): its subset launch has
+    // no coarse pass, and at a high share of off-pipe mixtures the whole-state kernel is the cheaper of its two routes
+    int acc_split_max = 0;
     float *mean32 = nullptr;     // J * Mpad * D raw means (accumulate kernel)
     double *mean64 = nullptr;    // float64 master copy of the model: mean, var (J*Mpad*D), weight (J*Mpad)
     double *var64 = nullptr, *w64 = nullptr;
@@ -256,6 +270,9 @@ struct pcl_batch {
     int *d_tile_flags = nullptr;             // split-f16 scoring: per tile, 1 = a scaled feature left the f16 range (rescored)
     ScoreTile *d_tiles_v = nullptr;          // MFMA mode only: tiles of ill-conditioned states for the VALU kernel
     ScoreTile *d_tiles_s = nullptr;          // MFMA mode only: tiles of the split states for the subset launch (their off-pipe mixtures)
+    ScoreTile *d_tiles_c = nullptr;          // ... and for the coarse pass (gmm_score_coarse.hip): the same states at the matrix-pipe tile size
+    int *d_tile_flags_c = nullptr;           // coarse pass: per tile, 1 = a scaled feature left the f16 range (the direct-form subset kernel rescored it)
+    int n_tiles_c = 0;
     int n_segs = 0, n_tiles = 0, n_tiles_v = 0, n_tiles_s = 0, tile_frames = 0, tile_gen = -1;
     double *tmp = nullptr;                   // sumNT staging buffer for layout conversion
     double *nz_tmp = nullptr;                // nnz staging buffer for the sparse xi download
@@ -512,6 +529,21 @@ inline bool pcl_state_uses_valu(const pcl_ctx *ctx, int j) {
     return ctx->cond[j] > ctx->cond_max;
 }
 inline bool pcl_state_is_split(const pcl_ctx *ctx, int j) { return !ctx->nbad.empty() && ctx->nbad[j] > 0 && !pcl_state_uses_valu(ctx, j); }
+// ... and for the accumulate pass (its own limit: see acc_split_max)
+inline bool pcl_state_acc_uses_valu(const pcl_ctx *ctx, int j) {
+    if (ctx->cond.empty()) return false;
+    if (ctx->split_max > 0 && !ctx->nbad.empty()) return ctx->nbad[j] > ctx->acc_split_max || ctx->cond[j] >= 1.0e30f;
+    return ctx->cond[j] > ctx->cond_max;
+}
+inline bool pcl_state_acc_is_split(const pcl_ctx *ctx, int j) { return !ctx->nbad.empty() && ctx->nbad[j] > 0 && !pcl_state_acc_uses_valu(ctx, j); }
+constexpr float PCL_COARSE_SPLIT_FRAC = 0.85f;
+bool pcl_coarse_enabled(const pcl_ctx *ctx);
+bool pcl_coarse_enabled_for(const pcl_ctx *ctx, int D);   // ... for a model of (padded) dimension D about to be uploaded
+int pcl_coarse_tile_frames();
+void pcl_coarse_release(pcl_ctx *ctx);
+int pcl_ensure_coarse(pcl_ctx *ctx);
+int pcl_launch_score_coarse(pcl_ctx *ctx, pcl_batch *b);
+int pcl_launch_score_subset_flagged(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
 inline float pcl_split_threshold(const pcl_ctx *ctx) { return ctx->split_max > 0 ? ctx->cond_max : 3.0e38f; }   // cond_m above this: off the pipe
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);
 int pcl_launch_mstep(pcl_ctx *ctx, double floor_var);

@@ -343,6 +343,12 @@ class Engine(object):
         self._check(self._lib.pcl_model_split_info(self._ctx, ptr(n_off), ptr(lim)))
         return n_off, int(lim[0])
 
+    def coarse_pairs(self, reset=True):
+        """(frame, mixture) pairs of off-pipe mixtures evaluated exactly since the last reset (counted under PCL_COARSE_STATS=1)."""
+        n = np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.pcl_coarse_counter(self._ctx, ptr(n), 1 if reset else 0))
+        return int(n[0])
+
     # ------------------------------------------------------------------ RCCL
     def comm_unique_id(self):
         buf = np.zeros(128, dtype=np.uint8)

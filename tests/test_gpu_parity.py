@@ -725,7 +725,7 @@ def test_ill_conditioned_states_use_direct_form(eng):
 # ------------------------------------------------------------------ split states: single tight mixtures leave the matrix-core path
 def split_model(seed, units=4, M=64, D=39):
     """The bench model with a few mixtures per state collapsed to a variance of 1e-3 .. 1e-2 (what an M-step leaves when a mixture
-    owns one or two frames): state j gets j % 4 * 3 of them -- none for every fourth state -- and the last state 40 of 64, more than
+    owns one or two frames): state j gets j % 4 * 3 of them -- none for every fourth state -- and the last state 58 of 64, more than
     the share a split state may have (it goes to the direct-form kernels as a whole)."""
     from poccala_amd import synth
     rng = np.random.default_rng(seed)
@@ -733,7 +733,7 @@ def split_model(seed, units=4, M=64, D=39):
     J = mean.shape[0]
     tight = []
     for j in range(J):
-        n = (j % 4) * 3 if j < J - 1 else 40
+        n = (j % 4) * 3 if j < J - 1 else (58 * M) // 64
         idx = np.sort(rng.choice(M, n, replace=False))
         var[j, idx] = rng.uniform(1e-3, 1e-2, (n, D))
         tight.append(idx)
@@ -759,7 +759,7 @@ def test_split_states_merge_both_kernels(eng):
     cond, cmax = eng.model_conditioning()
     n_off, limit = eng.model_split_info()
     cm = mixture_conditioning(mean, var)
-    assert limit == int(np.float32(0.5) * np.float32(M))
+    assert limit == int(np.float32(0.85) * np.float32(M))            # (scoring, with the coarse pass; the accumulate pass keeps 0.5)
     assert np.array_equal(n_off, [len(t) for t in tight]) and np.array_equal(n_off, (cm > cmax).sum(1))
     assert ((cond > cmax) == (n_off > 0)).all()                      # cond stays the state's worst mixture
     split = (n_off > 0) & (n_off <= limit)
@@ -777,9 +777,9 @@ def test_split_states_merge_both_kernels(eng):
     rows = np.concatenate([[-1], np.arange(J), [-2]]).astype(np.int32)
     b.set_states([rows])
     eng.enable_timing(True)
-    eng.kernel_time('score_subset')
+    eng.kernel_time('score_coarse'); eng.kernel_time('score_subset')
     b.score(PCL_F32)
-    assert eng.kernel_time('score_subset')[1] == 1                   # the subset launch ran
+    assert eng.kernel_time('score_coarse')[1] == 1 and eng.kernel_time('score_subset')[1] == 0      # the coarse pass ran, the direct-form subset launch did not
     eng.enable_timing(False)
     got = b.get('B')[0][1:-1]
     ref = np.stack([po.gmm_point(x.astype(np.float64), mean[j], var[j], w[j]) for j in range(J)])
@@ -813,6 +813,32 @@ def test_split_states_merge_both_kernels(eng):
         b2.close()
     finally:
         e2.close()
+
+    # ... and from a context with the round 4-5 route (PCL_COARSE=0: every off-pipe mixture in direct form, limit 0.5): within the bound of
+    # the oracle, the same bits where no mixture is off the pipe, and the two routes within 1e-9 of each other (both sum exact terms)
+    os.environ['PCL_COARSE'] = '0'
+    try:
+        e3 = Engine(0)
+    finally:
+        del os.environ['PCL_COARSE']
+    try:
+        e3.load_model(mean, var, w)
+        n3_, lim3 = e3.model_split_info()
+        assert lim3 == M // 2 and np.array_equal(n3_, n_off)
+        e3.load_frames(x)
+        b3 = e3.batch([J + 2], [T], [0])
+        b3.set_states([rows])
+        e3.enable_timing(True)
+        b3.score(PCL_F32)
+        assert e3.kernel_time('score_subset')[1] == 1 and e3.kernel_time('score_coarse')[1] == 0
+        got3 = b3.get('B')[0][1:-1]
+        assert_f32_class(got3, ref, bound, what='direct-form subset route:')
+        assert np.array_equal(got3[n_off == 0], got[n_off == 0])
+        both = split & (n_off <= lim3)
+        hold('split states f32', 'ln b, coarse route against direct-form route', got[both], got3[both], 0.0, 2 * F32_LOGLIK_ATOL)
+        b3.close()
+    finally:
+        e3.close()
 
     # E-step statistics: matrix-core pass + masked fix-up + subset pass into one statistics block
     U, L, PER = 6, 3, 6
@@ -962,6 +988,7 @@ def eng_variant(request):
             del os.environ['PCL_SCORE_VARIANT']
         else:
             os.environ['PCL_SCORE_VARIANT'] = old
+    e.score_variant = request.param
     yield e
     e.close()
 
@@ -1123,7 +1150,9 @@ def test_estep_variants_split_states(eng_variant):
     J, M, D = mean.shape
     eng.load_model(mean, var, w)
     n_off, limit = eng.model_split_info()
-    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == int(np.float32(0.5) * np.float32(M))
+    # (variant 7 keeps states split for SCORING up to 0.85 of their mixtures -- the coarse pass, gmm_score_coarse.hip --; the others, and every
+    #  variant's accumulate pass, up to half)
+    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == int(np.float32(0.85 if eng.score_variant == 7 else 0.5) * np.float32(M))
     U, L, PER = 5, 3, 5
     labels = [list(rng.integers(0, len(trans), L)) for _ in range(U)]
     TU = L * (S - 2) * PER

@@ -14,7 +14,7 @@ labels = synth.make_labels(U, c['L'], c['units'], seed=2000)
 eng = Engine(0); eng.enable_timing(True)
 eng.load_model(mean, var, w); eng.load_units(np.stack(trans)); eng.load_frames(frames)
 b = eng.label_batch(labels, lens, begin)
-names = ('score', 'score_subset', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'acc_consume', 'acc_subset', 'mstep', 'derive')
+names = ('score', 'score_coarse', 'score_subset_fixup', 'derive_coarse', 'score_subset', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'acc_consume', 'acc_subset', 'mstep', 'derive')
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     cond, cmax = eng.model_conditioning()
     n_off, lim = eng.model_split_info()
@@ -28,6 +28,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     t1 = time.perf_counter()
     kt = {k: round(eng.kernel_time(k)[0], 3) for k in names}
     lp = b.get('logp'); st = eng.stats_download(moments=False)
+    if os.environ.get('PCL_COARSE_STATS'):
+        kt['exact_pairs_per_pass'] = eng.coarse_pairs() // 2      # (two E-steps since the last reset)
     import xxhash
     hb = xxhash.xxh3_64(np.ascontiguousarray(np.concatenate([x.ravel() for x in b.get('B')[::32]])).tobytes()).hexdigest()
     hs = xxhash.xxh3_64(np.ascontiguousarray(st['acc']).tobytes()).hexdigest()
