@@ -533,9 +533,8 @@ int pcl_ensure_coarse(pcl_ctx *ctx) {
 int pcl_launch_score_coarse(pcl_ctx *ctx, pcl_batch *b) {
     if (b->n_tiles_c == 0) return PCL_OK;
     TRY(pcl_ensure_coarse(ctx));
-    static const bool stats = getenv("PCL_COARSE_STATS") && atoi(getenv("PCL_COARSE_STATS")) != 0;
     const CoarseExact ex{ctx->mean64, ctx->var64, ctx->k2c, ctx->d_bad_idx, ctx->d_nbad, ctx->Mpad, ctx->Dhost};
-    unsigned long long *counters = stats ? ctx->d_coarse_counter : nullptr;
+    unsigned long long *counters = ctx->coarse_stats ? ctx->d_coarse_counter : nullptr;
     pcl_timer_begin(ctx, "score_coarse");
     switch (ctx->D) {
         case 47: launch_coarse_t<47>(ctx, b, ex, counters); break;

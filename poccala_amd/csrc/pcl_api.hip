@@ -223,6 +223,8 @@ int pcl_init(int device, pcl_ctx **out) {
     }
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
     if (const char *co = getenv("PCL_COARSE")) ctx->coarse_on = atoi(co) != 0;
+    if (const char *cs = getenv("PCL_COARSE_STATS")) ctx->coarse_stats = atoi(cs) != 0;
+    if (const char *cm_ = getenv("PCL_COARSE_SPLIT_MAX")) ctx->coarse_split_frac = std::min(1.0f, std::max(0.0f, (float)atof(cm_)));   // (scoring only: A/B, tests)
     if (const char *tm = getenv("PCL_TIMERS")) ctx->timing = atoi(tm) != 0;
     *out = ctx;
     return PCL_OK;
@@ -430,13 +432,11 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->d_bad_idx, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_nbad, (size_t)J));
     // with the coarse pass (gmm_score_coarse.hip) a state's off-pipe mixtures cost the scoring about what they would cost on the pipe, so
-    // states stay split for scoring up to PCL_COARSE_SPLIT_FRAC of their mixtures (beyond it the pipe pass over the few that are left
+    // states stay split for scoring up to coarse_split_frac (0.85) of their mixtures (beyond it the pipe pass over the few that are left
     // is mostly log-zero tiles, and the whole-state direct form with its partial-distance test is the cheaper route: measured
     // 33 ms per batch against 12 + 54 at 98 %); PCL_SPLIT_MAX overrides both limits; the accumulate pass keeps the round 4-5 half
     ctx->acc_split_max = (int)((ctx->split_frac_set ? ctx->split_frac : 0.5f) * (float)M);
-    float coarse_frac = PCL_COARSE_SPLIT_FRAC;
-    if (const char *cs = getenv("PCL_COARSE_SPLIT_MAX")) coarse_frac = std::min(1.0f, std::max(0.0f, (float)atof(cs)));      // (scoring only: A/B)
-    ctx->split_max = (int)(((ctx->split_frac_set || !pcl_coarse_enabled_for(ctx, Dd)) ? ctx->split_frac : coarse_frac) * (float)M);
+    ctx->split_max = (int)(((ctx->split_frac_set || !pcl_coarse_enabled_for(ctx, Dd)) ? ctx->split_frac : ctx->coarse_split_frac) * (float)M);
     HIPCHK(ctx, hipMemcpy(ctx->mean64, m64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->var64, v64.data(), nm * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->w64, w64.data(), nw * sizeof(double), hipMemcpyHostToDevice));

@@ -136,6 +136,8 @@ struct pcl_ctx {
     int *d_nct = nullptr;              // [J] coarse tiles in use
     unsigned long long *d_coarse_counter = nullptr;   // PCL_COARSE_STATS=1: pairs evaluated exactly
     int coarse_gen = -1;
+    float coarse_split_frac = 0.85f;   // env PCL_COARSE_SPLIT_MAX: the share of a state's mixtures that may be off the pipe with the coarse pass (see pcl_model_upload)
+    bool coarse_stats = false;         // env PCL_COARSE_STATS=1 (read when the context is made): count the pairs evaluated exactly (pcl_coarse_counter)
     bool coarse_on = true;             // env PCL_COARSE=0 (read when the context is made): the direct-form subset launch of rounds 4-5 instead (A/B)
     // the accumulate pass keeps the round 4-5 rule (whole states in direct form above acc_split_max off-pipe mixtures): its subset launch has
     // no coarse pass, and at a high share of off-pipe mixtures the whole-state kernel is the cheaper of its two routes
@@ -536,7 +538,6 @@ inline bool pcl_state_acc_uses_valu(const pcl_ctx *ctx, int j) {
     return ctx->cond[j] > ctx->cond_max;
 }
 inline bool pcl_state_acc_is_split(const pcl_ctx *ctx, int j) { return !ctx->nbad.empty() && ctx->nbad[j] > 0 && !pcl_state_acc_uses_valu(ctx, j); }
-constexpr float PCL_COARSE_SPLIT_FRAC = 0.85f;
 bool pcl_coarse_enabled(const pcl_ctx *ctx);
 bool pcl_coarse_enabled_for(const pcl_ctx *ctx, int D);   // ... for a model of (padded) dimension D about to be uploaded
 int pcl_coarse_tile_frames();
