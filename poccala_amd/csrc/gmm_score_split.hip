@@ -62,7 +62,7 @@ template <int D, int NT>
 __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_MINW * 256 / WG : 1) void gmm_score_split16_kernel(
     const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
     int n_mtiles, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
-    int *__restrict__ flags, const double *__restrict__ kzero) {
+    int *__restrict__ flags, const double *__restrict__ kzero, const int *__restrict__ n_on_pipe) {
     static_assert(D % 8 != 0, "the folded constants need a spare slot");
     constexpr int KS8 = (D + 7) / 8;       // K-steps of 16 over the 2D features (8 per half-wave)
     constexpr int CH = 2 * KS8;            // 1-KiB chunks per m-tile: two f16 pieces
@@ -133,10 +133,12 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
     if (__any(ovf) && lane == 0) s_ovf = 1;
 
     float sm[NT], ref[NT];
+    bool inited[NT];                          // the lane's frame has a log-sum-exp reference (a real value was seen)
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         sm[c] = 0.f;
         ref[c] = 0.f;
+        inited[c] = false;
     }
     bool ref_ovf = false;
 
@@ -202,14 +204,17 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
 #pragma unroll
                 for (int r = 0; r < w; ++r) es[r] += es[r + w];
             const float snew = sm[c] + es[0];
-            if (mt == 0 || __any(!(snew < 3.0e38f))) {
+            // (round 6: the reference is taken at the first tile that HAS a real value, not at tile 0 -- with most of a state's mixtures off
+            //  the pipe its first 32 are often all log zero, which used to flag every tile of the state for the direct-form fix-up: 34 ms
+            //  per EM iteration at 91 % off-pipe mixtures; a frame that never sees a value above the f16 constants' reach is flagged at the end)
+            if (__any(!inited[c]) || __any(!(snew < 3.0e38f))) {
                 float gm = acc[c][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) gm = __builtin_fmaxf(gm, acc[c][r]);
                 const float gp = __builtin_fmaxf(gm, __shfl_xor(gm, 32, 64));
                 float s = sm[c];
-                if (mt == 0 && !(gp > -5.0e4f)) ref_ovf = true;      // log zero everywhere, or out of the f16 constants' reach
-                if ((mt == 0 || gp > 0.f) && gp > -5.0e4f) {
+                const bool first = !inited[c];
+                if ((first || gp > 0.f) && gp > -5.0e4f) {
                     // the reference the pipe subtracts is the f16-rounded one: shift by what it actually moves
                     const _Float16 r1 = (_Float16)__builtin_fminf(__builtin_fmaxf(-(ref[c] + gp), -FMAXH), FMAXH);
                     const float nref = -(float)r1, dl = nref - ref[c];
@@ -217,11 +222,12 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
                     // (in two half-steps: this path is entered when a sum overflows, i.e. with dl ~ 128, and exp2(-128) is a denormal that
                     //  v_exp_f32 flushes to 0 -- which dropped everything summed so far, up to a third of the frame's mass, rounds 1-5)
 #ifdef PCL_LSE_FLUSH_REPRO                                    // mutation build (tests are expected to FAIL on it): rounds 1-5
-                    s = (mt == 0) ? 0.f : s * __builtin_amdgcn_exp2f(-dl);
+                    s = first ? 0.f : s * __builtin_amdgcn_exp2f(-dl);
 #else
                     const float hs = __builtin_amdgcn_exp2f(-0.5f * dl);
-                    s = (mt == 0) ? 0.f : (s * hs) * hs;
+                    s = first ? 0.f : (s * hs) * hs;
 #endif
+                    inited[c] = true;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[c][r] -= dl;
                     ref[c] = nref;
@@ -260,6 +266,12 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
 #endif
     constexpr double LN2 = 0.693147180559945309417232121458;
     const double k0 = kzero[tile.state];
+    // a frame no tile gave a reference: every on-pipe mixture log zero for it -- right (-inf) when the state HAS no on-pipe mixture, otherwise
+    // out of the f16 constants' reach: the direct-form fix-up rescored the tile
+    if (wave_active && n_on_pipe[tile.state] > 0) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ref_ovf |= !inited[c];
+    }
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         const double S = (double)sm[c] + (double)__shfl_xor(sm[c], 32, 64);
@@ -279,7 +291,7 @@ void launch16_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles)
     const size_t pad = (ctx->score_wgs_per_cu == 2 && static_lds < (56u << 10)) ? (56u << 10) - static_lds : 0;
     hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), pad, ctx->stream, ctx->frames32,
                        reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs,
-                       b->Bt, b->d_tile_flags, ctx->kzero);
+                       b->Bt, b->d_tile_flags, ctx->kzero, ctx->d_non);
 }
 
 }  // namespace

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(PRE_T, 4) void state_prepass_kernel(const double *_
                                                              const double *__restrict__ w64, int M, int Mpad, int D, int Dhost, int KS8,
                                                              int flags, float *__restrict__ centers, float *__restrict__ fscale,
                                                              double *__restrict__ kzero, int j0, float cond_split,
-                                                             unsigned char *__restrict__ bad, int *__restrict__ bad_idx, int *__restrict__ nbad) {
+                                                             unsigned char *__restrict__ bad, int *__restrict__ bad_idx, int *__restrict__ nbad,
+                                                             int *__restrict__ n_on_pipe) {
     __shared__ double part[64 * 40];
     __shared__ float cen[64];
     __shared__ unsigned long long fbits[2][64];
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(PRE_T, 4) void state_prepass_kernel(const double *_
         __syncthreads();
         int before = 0;
         for (int wv = 0; wv < (tid >> 6); ++wv) before += cnt[wv];
-        if (tid == PRE_T - 1) nbad[j] = before + inc;
+        if (tid == PRE_T - 1) {
+            nbad[j] = before + inc;
+            n_on_pipe[j] = M - (before + inc);                   // (gmm_score_split.hip: a state without on-pipe mixtures writes -inf and raises no flag)
+        }
         int pos = before + inc - c;
         for (int m = lo; m < hi; ++m)
             if (bad[(size_t)j * Mpad + m]) bad_idx[(size_t)j * Mpad + pos++] = m;
@@ -461,7 +465,7 @@ int pcl_launch_derive_range(pcl_ctx *ctx, int j_lo, int j_hi) {
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(j_hi - j_lo), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
                        ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, j_lo, pcl_split_threshold(ctx), ctx->d_bad,
-                       ctx->d_bad_idx, ctx->d_nbad);
+                       ctx->d_bad_idx, ctx->d_nbad, ctx->d_non);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond + j_lo, 0, (size_t)(j_hi - j_lo) * sizeof(float), ctx->stream));
     return launch_derive_kernel(ctx, eager_layouts(ctx), j_lo, j_hi);
 }
@@ -481,7 +485,7 @@ int pcl_launch_derive(pcl_ctx *ctx) {
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(ctx->J), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
                        ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, 0, pcl_split_threshold(ctx), ctx->d_bad,
-                       ctx->d_bad_idx, ctx->d_nbad);
+                       ctx->d_bad_idx, ctx->d_nbad, ctx->d_non);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     const int what = eager_layouts(ctx);
     const int rc = launch_derive_kernel(ctx, what, 0, ctx->J);

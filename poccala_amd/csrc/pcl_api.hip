@@ -248,6 +248,7 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->d_bad);
     dev_free(ctx->d_bad_idx);
     dev_free(ctx->d_nbad);
+    dev_free(ctx->d_non);
     ctx->nbad.clear();
     if (ctx->zero_pending && ctx->ev_zero) (void)hipEventSynchronize(ctx->ev_zero);
     ctx->zero_pending = false;
@@ -431,6 +432,7 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->d_bad, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_bad_idx, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_nbad, (size_t)J));
+    TRY(dev_alloc(ctx, &ctx->d_non, (size_t)J));
     // with the coarse pass (gmm_score_coarse.hip) a state's off-pipe mixtures cost the scoring about what they would cost on the pipe, so
     // states stay split for scoring up to coarse_split_frac (0.85) of their mixtures (beyond it the pipe pass over the few that are left
     // is mostly log-zero tiles, and the whole-state direct form with its partial-distance test is the cheaper route: measured

@@ -122,6 +122,7 @@ struct pcl_ctx {
     unsigned char *d_bad = nullptr;    // [J][Mpad] 1 = the mixture is off the matrix pipe
     int *d_bad_idx = nullptr;          // [J][Mpad] the state's off-pipe mixtures in ascending order (first nbad[j] entries)
     int *d_nbad = nullptr;             // [J]
+    int *d_non = nullptr;              // [J] mixtures on the pipe (M - nbad)
     std::vector<int> nbad;
     float split_frac = 0.5f;           // env PCL_SPLIT_MAX: the share of a state's mixtures that may be off the pipe (0 = no splitting)
     bool split_frac_set = false;       // PCL_SPLIT_MAX was given (otherwise: 1.0 for scoring when the coarse pass is available, 0.5 for the accumulate pass)
@@ -136,7 +137,7 @@ struct pcl_ctx {
     int *d_nct = nullptr;              // [J] coarse tiles in use
     unsigned long long *d_coarse_counter = nullptr;   // PCL_COARSE_STATS=1: pairs evaluated exactly
     int coarse_gen = -1;
-    float coarse_split_frac = 0.85f;   // env PCL_COARSE_SPLIT_MAX: the share of a state's mixtures that may be off the pipe with the coarse pass (see pcl_model_upload)
+    float coarse_split_frac = 0.95f;   // env PCL_COARSE_SPLIT_MAX: the share of a state's mixtures that may be off the pipe with the coarse pass (see pcl_model_upload)
     bool coarse_stats = false;         // env PCL_COARSE_STATS=1 (read when the context is made): count the pairs evaluated exactly (pcl_coarse_counter)
     bool coarse_on = true;             // env PCL_COARSE=0 (read when the context is made): the direct-form subset launch of rounds 4-5 instead (A/B)
     // the accumulate pass keeps the round 4-5 rule (whole states in direct form above acc_split_max off-pipe mixtures): its subset launch has

@@ -109,7 +109,7 @@ def test_coarse_pass_against_the_oracle_over_six_decades_of_variance(seed, D):
         eng.enable_timing(True)
         got = score_all(eng, mean, var, w, x)
         n_off, limit = eng.model_split_info()
-        assert limit == int(np.float32(0.85) * np.float32(M)) and (n_off <= limit).all() and n_off[0] == 0 and (n_off[1:] > 0).all()
+        assert limit == int(np.float32(0.95) * np.float32(M)) and (n_off <= limit).all() and n_off[0] == 0 and (n_off[1:] > 0).all()
         assert eng.kernel_time('score_coarse')[1] == 1 and eng.kernel_time('score_subset')[1] == 0 and eng.kernel_time('score_direct')[1] == 0
         exact = eng.coarse_pairs()
         all_pairs = int(n_off.sum()) * len(x)
