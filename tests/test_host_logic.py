@@ -209,3 +209,46 @@ def test_worker_shim_copies_what_it_queues_and_warns_when_dropped(tmp_path):
         del am
         gc.collect()
     assert any('never flushed' in str(x.message) for x in w)
+
+
+def test_the_builds_classes_read_their_own_tree_as_the_reference_did(golden, tmp_path):
+    """G17's inputs through the BUILD's host classes alone (no GPU): AcousticModel.init_unit / save_parameter / save_batch_acc write the
+    tree, fresh LHMM + GMM objects read it back (init_parameter, init_acc: the merge of the two accumulator files) and re-estimate
+    (update_param) -- and arrive at what the REFERENCE arrived at from the same tree (fixture G17)."""
+    from poccala_amd.AcousticModel.AcousticModel import AcousticModel
+    g = golden('G17_tree')
+    units = [str(u) for u in g['units']]
+    S, e = 5, 3
+    M, D = g['mean_0_0'].shape
+    am = AcousticModel(None, 'XIF_tone', parameters_path=str(tmp_path), state_num=S, mix_level=M, dct_num=D, delta_1=False, delta_2=False)
+    hmms = {}
+    for ui, u in enumerate(units):
+        h = am.init_unit(u)
+        h.transmat[:] = g['trans_%d' % ui]
+        for k in range(e):
+            gm = h.profunction[1 + k]
+            gm.alpha, gm.mean = g['w_%d_%d' % (ui, k)].copy(), g['mean_%d_%d' % (ui, k)].copy()
+            gm.covariance = np.array([np.diag(v) for v in g['var_%d_%d' % (ui, k)]])
+        am.save_parameter(u, h)
+        hmms[u] = h
+    for bi in range(2):
+        stats = {key: g['batch%d_%s' % (bi, key)] for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc')}
+        hacc = {u: (g['batch%d_ksai_%d' % (bi, ui)], g['batch%d_gamma_%d' % (bi, ui)]) for ui, u in enumerate(units)}
+        am.save_batch_acc(stats, hacc, hmms)
+    for ui, u in enumerate(units):
+        h = am.init_unit(u)
+        am.init_parameter(u, h)
+        np.testing.assert_array_equal(h.transmat, g['trans_%d' % ui])
+        h.init_acc(am.unit_path(u))
+        for k in range(e):
+            h.profunction[1 + k].init_acc(am.unit_path(u))
+        np.testing.assert_allclose(h.ksai_acc, g['ref_ksai_acc_%d' % ui], rtol=1e-12)
+        np.testing.assert_allclose(h.gamma_acc, g['ref_gamma_acc_%d' % ui], rtol=1e-12)
+        h.update_param(c_covariance=float(g['c_covariance']))
+        np.testing.assert_allclose(h.transmat, g['new_trans_%d' % ui], rtol=1e-12, atol=1e-300)
+        for k in range(e):
+            gm = h.profunction[1 + k]
+            np.testing.assert_allclose(gm.acc, g['ref_acc_%d_%d' % (ui, k)], rtol=1e-12)
+            np.testing.assert_allclose(gm.alpha, g['new_w_%d_%d' % (ui, k)], rtol=1e-10)
+            np.testing.assert_allclose(gm.mean, g['new_mean_%d_%d' % (ui, k)], rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(gm.diag_variance(), g['new_var_%d_%d' % (ui, k)], rtol=1e-9)

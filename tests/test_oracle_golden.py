@@ -411,3 +411,31 @@ def test_g15_impossible_utterance(golden):
             for nm in ('acc', 'mean_acc', 'cov_acc'):
                 ref = g['%s_%s_%d_%d' % (tag, nm, pos, k)]
                 assert np.isnan(ref).all() and np.isnan(np.asarray(accs[pos].gmm[k][nm])).all(), (nm, pos, k)
+
+
+def test_g17_the_reference_read_the_builds_tree_and_the_oracle_agrees_with_what_it_made_of_it(golden):
+    """G17 (tests/golden/check_tree_with_reference.py): the build's host classes wrote a parameter tree and two batches' accumulator
+    files, the REFERENCE read them (init_parameter / init_acc / update_param, LHMM.py:243-290,509-524, Clustering.py:297-367,682-693).
+    The accumulators it merged are the log of the summed batch statistics, and the oracle's M-step on those sums gives the
+    reference's new A, w, mu, sigma^2."""
+    g = golden('G17_tree')
+    units = [str(u) for u in g['units']]
+    e = 3
+    for ui, _ in enumerate(units):
+        with np.errstate(divide='ignore'):
+            ks = po.logaddexp_q4(g['batch0_ksai_%d' % ui], g['batch1_ksai_%d' % ui])
+            ga = po.logaddexp_q4(g['batch0_gamma_%d' % ui], g['batch1_gamma_%d' % ui])
+        np.testing.assert_allclose(g['ref_ksai_acc_%d' % ui], ks, rtol=1e-12)
+        np.testing.assert_allclose(g['ref_gamma_acc_%d' % ui], ga, rtol=1e-12)
+        np.testing.assert_allclose(g['new_trans_%d' % ui], po.hmm_update_param(g['trans_%d' % ui], ks, ga), rtol=1e-12, atol=1e-300)
+        for k in range(e):
+            j = ui * e + k
+            with np.errstate(divide='ignore'):
+                acc = {key: np.log(g['batch0_' + key][j] + g['batch1_' + key][j]) for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc')}
+            np.testing.assert_allclose(g['ref_acc_%d_%d' % (ui, k)], acc['acc'], rtol=1e-12)
+            np.testing.assert_allclose(g['ref_alpha_acc_%d_%d' % (ui, k)], acc['alpha_acc'], rtol=1e-12)
+            w, mean, var = po.gmm_update_param(acc, c_covariance=float(g['c_covariance']))
+            np.testing.assert_allclose(g['new_w_%d_%d' % (ui, k)], w, rtol=1e-10)
+            np.testing.assert_allclose(g['new_mean_%d_%d' % (ui, k)], mean, rtol=1e-9, atol=1e-10)      # (exp(ln sum) - 100: the bias costs digits, Clustering.py:686)
+            np.testing.assert_allclose(g['new_var_%d_%d' % (ui, k)], var, rtol=1e-9)
+            assert (g['new_var_%d_%d' % (ui, k)] >= float(g['c_covariance'])).all()
