@@ -904,7 +904,7 @@ int pcl_launch_fb_linear(pcl_ctx *ctx, pcl_batch *b, int fix_pi, double threshol
     }
     hipLaunchKernelGGL(hmm_fbl_kernel, dim3(b->U), dim3(128), 0, ctx->stream, b->d_utt, b->Bp, b->fb_kmax, b->row_ptr, b->col_idx, b->csr_val,
                        b->logpi, b->alpha, b->alpha_e, b->beta, b->beta_e, b->pi_out, b->logp, b->qtrace, b->npass, fix_pi, threshold, b->Bt, b->col_ptr,
-                       b->row_idx, b->csc_val, reinterpret_cast<const double2 *>(ctx->d_softplus));
+                       b->row_idx, b->csc_val, reinterpret_cast<const double2 *>(ctx->d_softplus), b->fb_dump);
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

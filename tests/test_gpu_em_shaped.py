@@ -11,7 +11,7 @@ shard's own statistics give the two models the later EM iterations actually run 
           with partial-distance elimination evaluate most or all of every state.
 
 Held against the oracle run on the DOWNLOADED model, exactly as test_c4_shard_deep_parity does on the initial one: emissions of
-every label state, ln P(O), gamma_t(j), xi / P(O), gamma / P(O) of ~10 utterances (random ones + owners of last tiles), the GMM
+every label state, ln P(O), gamma_t(j), xi / P(O), gamma / P(O) of ~6 utterances per stage (random ones + owners of last tiles; the soak runs more), the GMM
 statistics (acc, alpha_acc, mean_acc, cov_acc per mixture) of a handful of states chosen to cover split and whole-off-pipe states.
 (The per-unit HMM accumulators are float64 functions of xi / gamma and of the transitions alone: test_c4_shard_deep_parity holds them
 at full size.)"""
@@ -68,7 +68,7 @@ def _check_stage(eng, b, stage, frames, lens, begin, labels, c):
     _estep(eng, b, PCL_F32)
     B, lp, lg, ks, ga = b.get('B'), b.get('logp'), b.get('lgamma'), b.get('ksai'), b.get('gamma')
     st = eng.stats_download()
-    pick = sorted(set(np.random.default_rng(700 + stage).choice(c['U'], 6, replace=False).tolist()) | set(_last_tile_utterances(labels, c['units'], 4)))
+    pick = sorted(set(np.random.default_rng(700 + stage).choice(c['U'], 4, replace=False).tolist()) | set(_last_tile_utterances(labels, c['units'], 2)))
     jobs = []
     for u in pick:
         model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)]) for unit in set(labels[u])}

@@ -4,6 +4,8 @@ Tolerances (BASELINE.json north_star): log-likelihoods and gamma/xi occupancies 
 for the float32 scoring path, Viterbi state sequences bit-exact.  The float64 path (PCL_F64) is held
 to 1e-9.  All DP state is float64 in both modes.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,7 @@ from oracle import poccala_oracle as po
 pytestmark = pytest.mark.gpu
 
 S = 5
+SOAK = bool(os.environ.get('POCCALA_SOAK'))      # tools/gpu_soak.sh: the full-size tests at their round-5 depth (the suite keeps the driver's 900 s in sight)
 F32_RTOL = 1e-4      # the north-star bound
 F32_LOGLIK_ATOL = 5e-5   # absolute bound on ln b_j(o_t): 3x the measured worst case (1.5e-5 at |ln b| ~ 85, ~2e-7 relative)
 
@@ -1430,8 +1433,8 @@ def test_c4_shard_deep_parity(eng):
     B, lp, lg, ks, ga, npass = b.get('B'), b.get('logp'), b.get('lgamma'), b.get('ksai'), b.get('gamma'), b.get('npass')
     hk, hg = eng.hmm_acc_download()
     b.close()
-    tail_utts, _ = _last_tile_utterances(labels, c['units'], 8)
-    pick = sorted(set(np.random.default_rng(77).choice(c['U'], 16, replace=False).tolist()) | set(tail_utts))
+    tail_utts, _ = _last_tile_utterances(labels, c['units'], 4 if not SOAK else 8)
+    pick = sorted(set(np.random.default_rng(77).choice(c['U'], 8 if not SOAK else 16, replace=False).tolist()) | set(tail_utts))
     jobs = []
     for u in pick:
         model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)])
@@ -1483,8 +1486,8 @@ def test_c3_deep_parity_and_flip_rate(eng):
     b.viterbi()
     B, paths, pts = b.get('B'), b.get('path'), b.get('point')
     b.close()
-    tail_utts, _ = _last_tile_utterances(labels, c['units'], 8)
-    pick = sorted(set(np.random.default_rng(78).choice(c['U'], 16, replace=False).tolist()) | set(tail_utts))
+    tail_utts, _ = _last_tile_utterances(labels, c['units'], 4 if not SOAK else 8)
+    pick = sorted(set(np.random.default_rng(78).choice(c['U'], 8 if not SOAK else 16, replace=False).tolist()) | set(tail_utts))
     jobs = []
     for u in pick:
         model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)])
@@ -1525,7 +1528,7 @@ def test_c5_shard_full_size(eng):
         assert B[u].shape == (J + 2, c['T']) and np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1])) and np.isfinite(B[u][1:-1]).all()
     assert np.array_equal(B[3], B[9])                                # same frames, same tile positions or not: same bits
     gm = [(mean[j], var[j], w[j]) for j in range(J)]
-    for u in (0, c['U'] - 1):
+    for u in ((0, c['U'] - 1) if SOAK else (c['U'] - 1,)):      # (the suite: the last utterance -- its tiles end the lists; the soak: both ends)
         ref = state_rows(frames[begin[u]:begin[u] + lens[u]].astype(np.float64), gm)
         np.testing.assert_allclose(B[u][1:-1], ref, rtol=0, atol=F32_LOGLIK_ATOL)
 
