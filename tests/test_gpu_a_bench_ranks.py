@@ -127,7 +127,7 @@ def test_a_dying_rank_fails_the_job():
 def test_the_watchdog_fires_when_the_communicator_never_comes_up():
     """POCCALA_TEST_HANG_COMM: every rank sleeps where pcl_comm_init would be.  The timed number is final by then: rank 0 prints the
     line WITHOUT the extras after --extra-timeout seconds and the job exits non-zero (3)."""
-    rc, out, err, dt = _run([sys.executable, 'bench.py', '--gpus', '2', '--extra-timeout', '8'] + SMALL, _env(POCCALA_TEST_HANG_COMM='1'), 600)
+    rc, out, err, dt = _run([sys.executable, 'bench.py', '--gpus', '2', '--extra-timeout', '4'] + SMALL, _env(POCCALA_TEST_HANG_COMM='1'), 600)
     assert rc == 3, (rc, err[-2000:])
     lines = _json_lines(out)
     assert len(lines) == 2 and not lines[0]['final'] and not lines[1]['final']        # the early line, and the watchdog's

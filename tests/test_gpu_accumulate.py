@@ -116,7 +116,7 @@ def test_statistics_per_mixture_c2(prec, image_mb, peaked):
     run_case('C2', prec, image_mb, peaked, n_extra=2, min_groups=3 if image_mb else 1)
 
 
-@pytest.mark.parametrize('prec,peaked', [('f32', False), ('f32', True)] + ([('f64', False)] if os.environ.get('POCCALA_SOAK') else []))      # (f64 at M = 2048: the soak; the suite holds f64 at C2)
+@pytest.mark.parametrize('prec,peaked', [('f32', False)] + ([('f32', True), ('f64', False)] if os.environ.get('POCCALA_SOAK') else []))      # (peaked posteriors and f64 at M = 2048: the soak; the suite holds both at C2)
 def test_statistics_per_mixture_c4_shard(prec, peaked):
     """M = 2048, J = 3000: the bench workload (8 slice workgroups per state, 7 state groups at the default 2 GB image budget)."""
     run_case('C4shard', prec, None, peaked, n_extra=1, min_groups=0 if peaked else 3)

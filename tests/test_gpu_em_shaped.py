@@ -15,6 +15,8 @@ every label state, ln P(O), gamma_t(j), xi / P(O), gamma / P(O) of ~6 utterances
 statistics (acc, alpha_acc, mean_acc, cov_acc per mixture) of a handful of states chosen to cover split and whole-off-pipe states.
 (The per-unit HMM accumulators are float64 functions of xi / gamma and of the transitions alone: test_c4_shard_deep_parity holds them
 at full size.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,6 +26,7 @@ from oracle import poccala_oracle as po
 pytestmark = pytest.mark.gpu
 
 S = 5
+SOAK = bool(os.environ.get('POCCALA_SOAK'))
 F32_RTOL = 1e-4
 F32_LOGLIK_ATOL = 5e-5
 C_COV = 1e-6
@@ -72,11 +75,15 @@ def _check_stage(eng, b, stage, frames, lens, begin, labels, c):
     jobs = []
     for u in pick:
         model = {int(unit): dict(trans=trans[unit], gmms=[(mean[unit * 3 + k], var[unit * 3 + k], w[unit * 3 + k]) for k in range(3)]) for unit in set(labels[u])}
-        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, 'xi+bound'))
-    for u, (bref, lpref, lgref, _, _, ksref, garef, bound) in zip(pick, label_jobs(jobs)):
+        jobs.append((frames[begin[u]:begin[u] + lens[u]].astype(np.float64), [int(x) for x in labels[u]], model, 0, 'xi+bound' if SOAK else 'xi'))
+    for u, res in zip(pick, label_jobs(jobs)):
+        # (the analytical f32 input-rounding bound of every row costs as much as the oracle itself: the soak computes and allows it, the
+        #  suite holds ln b to 5e-5 + 5e-6 |ln b| alone -- measured use of THAT allowance: 0.52 at stage 2, 0.8 at stage 3)
+        bref, lpref, lgref, _, _, ksref, garef = res[:7]
+        bound = res[7] if SOAK else 0.0
         fin = np.isfinite(bref[1:-1])
         assert np.array_equal(np.isfinite(B[u][1:-1]), fin) and np.all(B[u][0] == 0) and np.all(np.isneginf(B[u][-1]))
-        hold(tag, 'ln b_j(o_t)', B[u][1:-1][fin], bref[1:-1][fin], 5e-6, (F32_LOGLIK_ATOL + bound)[fin])
+        hold(tag, 'ln b_j(o_t)', B[u][1:-1][fin], bref[1:-1][fin], 5e-6, (F32_LOGLIK_ATOL + bound + np.zeros_like(bref[1:-1]))[fin])
         hold(tag, 'ln P(O)', lp[u], lpref, F32_RTOL)
         hold(tag, 'gamma_t(j) normalised', np.exp(lg[u]), np.exp(lgref), F32_RTOL, 1e-6)
         fk = np.isfinite(ksref)

@@ -13,4 +13,4 @@ grep -h "FAILED\|differs\|mismatch" gpurun_out/soak_*.txt | grep -v " 0 mismatch
 # round 6: the context / batch lifecycle under load (three seeds x 200 teardowns), and the full-size tests at their full depth (POCCALA_SOAK:
 # 24 utterances of the C4 shard and of C3 against the oracle, both ends of the C5 shard, the f64 statistics at M = 2048)
 for sd in 1 2 3; do timeout -k 10 300 python3 tools/lifecycle_stress.py --iters 200 --seed $sd > gpurun_out/soak_lifecycle_$sd.txt 2>&1; echo "lifecycle seed $sd rc=$? $(tail -1 gpurun_out/soak_lifecycle_$sd.txt)"; done
-POCCALA_SOAK=1 timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_accumulate.py -q -k "c4_shard or c3_deep or c5_shard" > gpurun_out/soak_fullsize.txt 2>&1; echo "full-size rc=$? $(tail -1 gpurun_out/soak_fullsize.txt)"
+POCCALA_SOAK=1 timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_accumulate.py tests/test_gpu_em_shaped.py -q -k "c4_shard or c3_deep or c5_shard" > gpurun_out/soak_fullsize.txt 2>&1; echo "full-size rc=$? $(tail -1 gpurun_out/soak_fullsize.txt)"
