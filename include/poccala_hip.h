@@ -306,7 +306,11 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
  * state's list of such mixtures and the two parts are merged -- ln(e^a + e^b) of the two partial log-sum-exps in scoring,
  * += into the same statistics in the accumulate pass -- so the result is the reference's sum over all mixtures
  * (Clustering.py:740-767, :653-680) whichever kernel evaluated a term.  A state leaves the matrix cores as a whole only when
- * more than *limit of its mixtures are out (env PCL_SPLIT_MAX = share of M, default 0.5 (the measured break-even of the two routes: pipe 16 + subset 139 f against direct form 92 ms per batch at the bench shape); 0 = whole states, as before).
+ * more than *limit of its mixtures are out.  Round 6: in SCORING the list is no longer evaluated in direct form but by the coarse pass
+ * (csrc/gmm_score_coarse.hip: a bound of each off-pipe mixture computed on the matrix pipe rules out almost every (frame, mixture) pair,
+ * the pairs it cannot rule out are evaluated exactly in float64), and *limit is 0.95 M there (env PCL_COARSE_SPLIT_MAX; PCL_COARSE=0:
+ * direct form, limit 0.5 M).  The accumulate pass keeps direct form and 0.5 M.  env PCL_SPLIT_MAX = share of M sets both limits;
+ * 0 = whole states, as before round 4.  *limit reports the scoring limit.
  * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
 int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
 /* Diagnostics of the coarse pass over the off-pipe mixtures (csrc/gmm_score_coarse.hip; counted only under env PCL_COARSE_STATS=1):

@@ -56,9 +56,12 @@ struct CoarseExact {
 #ifndef PCL_COARSE_NT
 #define PCL_COARSE_NT 2
 #endif
+#ifndef PCL_COARSE_MINW
+#define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at (199 VGPRs: 2; 3 spills 28 registers -- A/B in profiles/r06_coarse_ab.txt)
+#endif
 
 template <int D, int NT>
-__global__ __launch_bounds__(WG, 2) void gmm_score_coarse_kernel(
+__global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
     const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
     int nmt_max, const int *__restrict__ nct, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
     int *__restrict__ flags, const double *__restrict__ kzero, CoarseExact ex, unsigned long long *__restrict__ counters) {
