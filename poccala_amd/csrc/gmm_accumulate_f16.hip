@@ -239,7 +239,7 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
     const uint4 *__restrict__ images, const uint4 *__restrict__ pm16f, const float *__restrict__ centers, const float *__restrict__ fscale,
     const double *__restrict__ means64, int M, int Mpad, int n_mtiles, int n_states, const int *__restrict__ work_states,
     const int *__restrict__ tile_off, int tile_base, double bias, double *__restrict__ st_acc, double *__restrict__ st_alpha,
-    double *__restrict__ st_mean, double *__restrict__ st_cov) {
+    double *__restrict__ st_mean, double *__restrict__ st_cov, const int *__restrict__ npt, const int *__restrict__ nbad, const int *__restrict__ good_idx) {
     using I = Img<D>;
     constexpr int KS = I::KS, NCT = I::NCT, NB = I::NB;
     constexpr int NSLOT = PCL_ACC16_NSLOT;                       // tile t in slot t % NSLOT: t .. t + 2 being read, the rest landing
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and the compiler must know: everything per-wave below
                                                                          // (DMA block loop, counted waits) is otherwise compiled as EXEC-masked vector control flow
     const int mt = slice * AW + wave;                            // this wave's m-tile
-    const bool live = mt < n_mtiles;                             // (a wave past the end only helps with the DMA)
+    const bool live = mt < npt[j];                               // (a wave past the tiles in use -- a split state's on-pipe mixtures sit at the front, round 6 -- only helps with the DMA)
 
     // parameters of this wave's m-tile: the scoring layout of variant 7 as it is (B operand of product (1))
     h8v pf[2][KS];
@@ -466,7 +466,10 @@ __global__ __launch_bounds__(AW * 64, AW == 8 ? 1 : 2) void acc16_consumer_kerne
     //      feature d in register r (r & 4 == 0) and S1 of the same d in register r + 4.  S0 is row (s = KS - 1, i = D & 7) of the last
     //      tile.  cov = S2 - 2 dl S1 + dl^2 S0, mean = S1 + (c + bias) S0, all times 2^E / the feature's power-of-two scale.
     if (!live) return;
-    const int m = mt * 32 + col;
+    // the mixture this lane's layout row stands for: the row itself, or -- a split state, whose on-pipe mixtures are compacted to the front of
+    // its tiles -- the row-th entry of the state's on-pipe list; rows beyond the list are padding
+    const int row_ = mt * 32 + col, nb_ = nbad[j];
+    const int m = good_idx ? ((row_ < M - nb_) ? (nb_ ? good_idx[(size_t)j * Mpad + row_] : row_) : M) : row_;      // (good_idx == nullptr: PCL_COMPACT_MAIN=0)
     constexpr int C0 = ((KS - 1) & 1) * 16 + (D & 7), CT0 = (KS - 1) >> 1;          // where S0 lives: row C0 of tile CT0
     constexpr int R0 = (C0 & 3) + 4 * (C0 >> 3), H0 = (C0 >> 2) & 1;
     float s0f = ST[CT0][R0];
@@ -563,7 +566,7 @@ int pcl_launch_acc16_consume(pcl_ctx *ctx, pcl_batch *b, int first, int ns, int 
     hipLaunchKernelGGL((acc16_consumer_kernel<DD, FR>), dim3(nblocks), dim3(AW * 64), 0, stream,                              \
                        reinterpret_cast<const uint4 *>(b->ctx->acc.acc16_images[buf]), reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->centers32, ctx->fscale, \
                        ctx->mean64, ctx->M, ctx->Mpad, nmt, ns, ws, b->ctx->acc.acc16_tile_off[buf], 0, 100.0, ctx->st_acc, ctx->st_alpha,      \
-                       ctx->st_mean, ctx->st_cov)
+                       ctx->st_mean, ctx->st_cov, ctx->d_npt, ctx->d_nbad, (ctx->compact_main && ctx->D <= 48) ? ctx->d_good_idx : (const int *)nullptr)
 #define CONSUME16(DD)                     \
     do {                                  \
         if (fresh) CONSUME16F(DD, true);  \

@@ -22,8 +22,8 @@
 // spare-slot reference set to  t_f = log2e ln b1_f - 36 - K0  (ln b1 = what the pipe wrote for the state's on-pipe mixtures; 36: a
 // term 2^-36 below the total changes ln b by 1e-11 even if all 2048 were dropped at the threshold), the accumulator of a pair is
 //   acc >= 0   <=>   the pair MAY reach 2^-36 of the frame's likelihood,
-// one v_max tree + one ballot per 32 x 32 tile instead of the log-sum-exp.  Pairs that pass are evaluated EXACTLY by their lane
-// (float64, master copy: k2 - log2e sum (x - mu)^2 / (2 var)) into a per-lane online log-sum-exp, the threshold is raised when an
+// one v_max tree + one ballot per 32 x 32 tile instead of the log-sum-exp.  Pairs that pass are evaluated in DIRECT FORM, a lane per pair
+// (rows made from the master copy in the f32 arithmetic of the direct-form kernels, see `flush`), into a per-frame online log-sum-exp (float64), the threshold is raised when an
 // exact value lifts the frame's maximum (states without on-pipe mixtures start at -inf and settle after their first tile), and the
 // result is log-added to the pipe's in float64: ln b = ln(e^pipe + e^tight), the reference's sum over all mixtures -- deterministic
 // (a lane owns its frame; no atomics).  Frames whose scaled features leave the f16 range raise the tile's flag and the direct-form
@@ -33,6 +33,8 @@
 // nct[j] tiles used; own power-of-two feature scales fscale_c and K0 (kzero_c); exact constants k2c[j][idx] (float64).  Derived on
 // first use after a model change (pcl_ensure_coarse), one workgroup per state.
 #include <stdlib.h>
+
+#include <vector>
 
 #include "pcl_internal.h"
 
@@ -197,14 +199,23 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
                 if (k2 > -1.0e300) {                             // (not a zero weight)
                     const size_t jm = (srow + ex.bad_idx[srow + idx]) * D;
                     const float *fp = frames + frow_tab[wave][q_slot[wave][lane]] * D;
-                    double q = 0.0;
+                    // The direct form in the f32 arithmetic of the accumulate pass's subset kernel (gmm_accumulate.hip MASTER rows: s = sqrtf of the
+                    // f32 coefficient, c = (float)(-mu s), y = fma(x, s, c), q = fma(y, y, q) over d ascending, k2 as a float) -- on purpose.  A first
+                    // version evaluated these pairs in float64; the soak then failed 18 of 1520 random E-steps on `acc` by 1.2-3.9e-4: the posterior the
+                    // accumulate pass forms, exp2(v_m - ln b), is exp2 of the DIFFERENCE of its own f32 value of a tight mixture and the scoring's value,
+                    // and where one such mixture carries the frame the two must round alike to cancel (as they did in rounds 4-5, both direct form).
+                    float q = 0.f;
 #pragma unroll
                     for (int d = 0; d < D; ++d)
                         if (d < ex.Dhost) {
-                            const double dx = (double)fp[d] - ex.mean64[jm + d];
-                            q += dx * dx * (0.5 / ex.var64[jm + d]);
+                            const double vv = ex.var64[jm + d], mu = ex.mean64[jm + d];
+                            const float a = (float)(-LOG2E * (0.5 / vv));
+                            const float sf = sqrtf(-a);
+                            const float cv = (float)(-mu * (double)sf);
+                            const float y = __builtin_fmaf(fp[d], sf, cv);
+                            q = __builtin_fmaf(y, y, q);
                         }
-                    v = k2 - LOG2E * q;
+                    v = (double)((float)k2 - q);
                     ++n_cand;
                 }
             }
@@ -482,6 +493,96 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
     }
 }
 
+// ---------------------------------------------------------------- split states: the on-pipe mixtures compacted to the front of the main layout
+// derive_kernel (model_derive.hip) writes pm16f tile by tile in mixture order, an off-pipe mixture as a zero-weight row -- so the matrix-pipe
+// kernels walked all M / 32 tiles of a state even when most of its rows were such (13.5 ms per batch beside the coarse pass at 57 %
+// off-pipe mixtures).  For a state that HAS off-pipe mixtures this kernel rewrites the state's tiles from its on-pipe list (good_idx,
+// ascending): row r = mixture good_idx[r], ceil(on-pipe / 32) tiles in use (npt[j], written by the prepass), the rest untouched and
+// never read.  Same coefficients, scales, K0 and arithmetic as derive_kernel (one division per element, the per-mixture sums in its
+// order).  The scoring kernel reads npt[j]; the accumulate consumer maps a row back through good_idx at its flush.  One workgroup per state.
+template <int DMAX>
+__global__ __launch_bounds__(256) void compact_main_kernel(const double *__restrict__ mean64, const double *__restrict__ var64,
+                                                           const double *__restrict__ w64, const float *__restrict__ centers, int M, int Mpad,
+                                                           int Mpad32, int D, int Dhost, int flags, int j0, const int *__restrict__ good_idx,
+                                                           const int *__restrict__ nbad, const float *__restrict__ fscale,
+                                                           const double *__restrict__ kzero, uint4 *__restrict__ pm16f) {
+    const int j = j0 + blockIdx.x, tid = threadIdx.x;
+    const int nb = nbad[j];
+    if (nb == 0) return;                                         // not a split state: derive_kernel's tiles stand
+    const int non = M - nb, ntl = (non + 31) / 32, nmt = Mpad32 / 32, KS8 = (D + 7) / 8;
+    __shared__ float fa[32 * DMAX], fb[32 * DMAX], cen[DMAX], isc[2 * 64];
+    __shared__ float kc[32];
+    for (int d = tid; d < D; d += 256) cen[d] = centers[(size_t)j * D + d];
+    for (int t = tid; t < 2 * KS8 * 8; t += 256) isc[(t / (KS8 * 8)) * 64 + t % (KS8 * 8)] = 1.0f / fscale[(size_t)j * 2 * (KS8 * 8) + t];
+    __syncthreads();
+    const double k0 = kzero[j];
+    const int ml = tid >> 3, sub = tid & 7;
+    const size_t srow = (size_t)j * Mpad;
+    for (int t = 0; t < ntl; ++t) {
+        const int idx = t * 32 + ml;
+        const bool real_m = idx < non;
+        const int m = real_m ? good_idx[srow + idx] : 0;
+        const size_t jm = (srow + m) * D;
+        double sumvar = 0.0, sumlog = 0.0, kq = 0.0;
+        for (int dd = sub; dd < D; dd += 8) {
+            float a = 0.f, b = 0.f;
+            if (dd < Dhost && real_m) {
+                const double v = var64[jm + dd], dm = mean64[jm + dd] - (double)cen[dd];
+                const double hr = 0.5 / v;
+                sumvar += v;
+                if (flags & PCL_MODEL_LOGDET) sumlog += log(v);
+                kq += dm * dm * hr;
+                a = (float)(-LOG2E * hr);
+                b = (float)(2.0 * LOG2E * dm * hr);
+            }
+            fa[ml * D + dd] = a;
+            fb[ml * D + dd] = b;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            sumvar += __shfl_xor(sumvar, o, 64);
+            sumlog += __shfl_xor(sumlog, o, 64);
+            kq += __shfl_xor(kq, o, 64);
+        }
+        if (sub == 0) {
+            float c = -6.0e4f;
+            if (real_m) {
+                const double tail = (flags & PCL_MODEL_LOGDET) ? sumlog : sumvar;      // util.py:29 (quirk Q1)
+                const double k2 = LOG2E * (log(w64[srow + m]) - 0.5 * Dhost * LOG_2PI - 0.5 * tail);
+                const double kp = k2 - LOG2E * kq - k0;
+                if (kp > -5.0e4) c = (float)kp;
+            }
+            kc[ml] = c;
+        }
+        __syncthreads();
+        uint4 *pf = pm16f + ((size_t)j * nmt + t) * (2 * KS8 * 64);
+        for (int e = tid; e < 2 * KS8 * 64; e += 256) {
+            const int p = (e >> 6) / KS8, s = (e >> 6) % KS8, ln = e & 63, half = ln >> 5, cl = ln & 31;
+            unsigned short h[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int dd = 8 * s + x;
+                float val = 0.f;
+                bool is_const = false;
+                if (dd < D) {
+                    val = (half ? fb[cl * D + dd] : fa[cl * D + dd]) * isc[half * 64 + dd];
+                } else if (dd == D) {
+                    is_const = true;
+                    val = half ? 1.f : kc[cl];
+                }
+                const _Float16 h1 = (_Float16)val;
+                _Float16 hp;
+                if (!is_const) hp = p ? (_Float16)(val - (float)h1) : h1;
+                else if (half == 0) hp = p ? ((val <= -6.0e4f) ? (_Float16)0.f : (_Float16)(val - (float)h1)) : h1;    // k1 | k2
+                else hp = p ? (_Float16)1.f : (_Float16)0.f;                                                       // a1: 0, a2: 1
+                h[x] = __builtin_bit_cast(unsigned short, hp);
+            }
+            pf[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+        }
+        __syncthreads();
+    }
+}
+
 template <int D>
 void launch_coarse_t(pcl_ctx *ctx, pcl_batch *b, const CoarseExact &ex, unsigned long long *counters) {
     hipLaunchKernelGGL((gmm_score_coarse_kernel<D, PCL_COARSE_NT>), dim3(b->n_tiles_c), dim3(WG), 0, ctx->stream, ctx->frames32,
@@ -547,6 +648,21 @@ int pcl_launch_score_coarse(pcl_ctx *ctx, pcl_batch *b) {
         default: PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: no coarse scoring kernel for D=%d", ctx->D);
     }
     pcl_timer_end(ctx, "score_coarse");
+    HIPCHK(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+int pcl_launch_compact_main(pcl_ctx *ctx, int j_lo, int j_hi) {
+    if (j_hi <= j_lo) return PCL_OK;
+    if (!ctx->compact_main || ctx->D > 48) {                                                   // (the tile counts then cover the whole layout)
+        std::vector<int> full((size_t)(j_hi - j_lo), ctx->Mpad32 / 32);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_npt + j_lo, full.data(), full.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return PCL_OK;
+    }
+    hipLaunchKernelGGL((compact_main_kernel<48>), dim3(j_hi - j_lo), dim3(256), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->centers32, ctx->M,
+                       ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->model_flags, j_lo, ctx->d_good_idx, ctx->d_nbad, ctx->fscale, ctx->kzero,
+                       reinterpret_cast<uint4 *>(ctx->pm16f));
     HIPCHK(ctx, hipGetLastError());
     return PCL_OK;
 }

@@ -61,8 +61,8 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 template <int D, int NT>
 __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_MINW * 256 / WG : 1) void gmm_score_split16_kernel(
     const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
-    int n_mtiles, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
-    int *__restrict__ flags, const double *__restrict__ kzero, const int *__restrict__ n_on_pipe) {
+    int nmt_max, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
+    int *__restrict__ flags, const double *__restrict__ kzero, const int *__restrict__ n_on_pipe, const int *__restrict__ npt) {
     static_assert(D % 8 != 0, "the folded constants need a spare slot");
     constexpr int KS8 = (D + 7) / 8;       // K-steps of 16 over the 2D features (8 per half-wave)
     constexpr int CH = 2 * KS8;            // 1-KiB chunks per m-tile: two f16 pieces
@@ -77,11 +77,30 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
         if (threadIdx.x == 0) flags[blockIdx.x] = 0;
         return;
     }
+    // tiles of the state's layout in use: all of them, or -- a split state, whose on-pipe mixtures are compacted to the front (round 6) --
+    // ceil(on-pipe / 32)
+    const int n_mtiles = npt[tile.state];
     __shared__ int s_ovf;
     if (threadIdx.x == 0) s_ovf = 0;
     __syncthreads();
     const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
     const bool wave_active = tile.vstart + wave * NT * 32 < vend;
+    if (n_mtiles == 0) {                    // not one mixture of the state on the pipe: ln 0 for every frame (the coarse pass adds the rest), no flag
+        if (wave_active) {
+            for (int c = 0; c < NT; ++c) {
+                const int v = tile.vstart + (wave * NT + c) * 32 + col;
+                if (v < vend && half == 0) {
+                    int lo = tile.seg0;
+                    const int hi = tile.seg_hi - 1;
+                    while (lo < hi && segs[lo + 1].vstart <= v) ++lo;
+                    const ScoreSeg sg = segs[lo];
+                    out[sg.out0 + (long long)(v - sg.vstart) * sg.out_stride] = -INFINITY;
+                }
+            }
+        }
+        if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+        return;
+    }
 
     // ---- B operand: scaled features of this lane's frames in two f16 pieces (spare slot: x1 = [1 | -ref'])
     h8v xb[NT][2][KS8];
@@ -145,7 +164,7 @@ __global__ __launch_bounds__(WG, PCL_SPLIT16_MINW * 256 / WG > 0 ? PCL_SPLIT16_M
     // MTS m-tiles per LDS stage: one workgroup barrier per MTS x 32 mixtures
     constexpr int MTS = PCL_SPLIT16_MTS;
     __shared__ __attribute__((aligned(16))) uint4 abuf[2][MTS * CH * 64];
-    const uint4 *pstate = pm + (size_t)tile.state * n_mtiles * (CH * 64);
+    const uint4 *pstate = pm + (size_t)tile.state * nmt_max * (CH * 64);
     auto dma = [&](int buf, int stage) {
         const uint4 *src = pstate + (size_t)stage * (MTS * CH * 64);
         const int nch = min(MTS, n_mtiles - stage * MTS) * CH;
@@ -291,7 +310,7 @@ void launch16_t(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles)
     const size_t pad = (ctx->score_wgs_per_cu == 2 && static_lds < (56u << 10)) ? (56u << 10) - static_lds : 0;
     hipLaunchKernelGGL((gmm_score_split16_kernel<D, PCL_SPLIT16_NT>), dim3(n_tiles), dim3(WG), pad, ctx->stream, ctx->frames32,
                        reinterpret_cast<const uint4 *>(ctx->pm16f), ctx->fscale, ctx->centers32, ctx->Mpad32 / 32, tiles, b->d_segs,
-                       b->Bt, b->d_tile_flags, ctx->kzero, ctx->d_non);
+                       b->Bt, b->d_tile_flags, ctx->kzero, ctx->d_non, ctx->d_npt);
 }
 
 }  // namespace

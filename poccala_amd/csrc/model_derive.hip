@@ -39,7 +39,7 @@ __global__ __launch_bounds__(PRE_T, 4) void state_prepass_kernel(const double *_
                                                              int flags, float *__restrict__ centers, float *__restrict__ fscale,
                                                              double *__restrict__ kzero, int j0, float cond_split,
                                                              unsigned char *__restrict__ bad, int *__restrict__ bad_idx, int *__restrict__ nbad,
-                                                             int *__restrict__ n_on_pipe) {
+                                                             int *__restrict__ n_on_pipe, int *__restrict__ good_idx, int *__restrict__ npt) {
     __shared__ double part[64 * 40];
     __shared__ float cen[64];
     __shared__ unsigned long long fbits[2][64];
@@ -192,10 +192,13 @@ __global__ __launch_bounds__(PRE_T, 4) void state_prepass_kernel(const double *_
         if (tid == PRE_T - 1) {
             nbad[j] = before + inc;
             n_on_pipe[j] = M - (before + inc);                   // (gmm_score_split.hip: a state without on-pipe mixtures writes -inf and raises no flag)
+            npt[j] = (M - (before + inc) + 31) / 32;             // 32-mixture tiles of the matrix-pipe layout in use (round 6: a split state's on-pipe mixtures are compacted to the front)
         }
-        int pos = before + inc - c;
-        for (int m = lo; m < hi; ++m)
+        int pos = before + inc - c, gpos = lo - pos;             // (the complement list: on-pipe mixtures in ascending order)
+        for (int m = lo; m < hi; ++m) {
             if (bad[(size_t)j * Mpad + m]) bad_idx[(size_t)j * Mpad + pos++] = m;
+            else good_idx[(size_t)j * Mpad + gpos++] = m;
+        }
     }
 }
 
@@ -455,6 +458,9 @@ static int launch_derive_kernel(pcl_ctx *ctx, int what, int j_lo, int j_hi) {
                        ctx->params32, ctx->params64, ctx->mean32, ctx->pm32, reinterpret_cast<uint4 *>(ctx->pm16f),
                        ctx->kzero, ctx->fscale, ctx->d_cond, what, j_lo, ctx->d_bad);
     HIPCHK(ctx, hipGetLastError());
+    // split states: their on-pipe mixtures compacted to the front of the state's tiles (gmm_score_coarse.hip), so that the matrix-pipe
+    // kernels walk ceil(on-pipe / 32) tiles instead of all of them
+    if (what & PCL_LAYOUT_PM16F) TRY(pcl_launch_compact_main(ctx, j_lo, j_hi));
     return PCL_OK;
 }
 
@@ -465,7 +471,7 @@ int pcl_launch_derive_range(pcl_ctx *ctx, int j_lo, int j_hi) {
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(j_hi - j_lo), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
                        ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, j_lo, pcl_split_threshold(ctx), ctx->d_bad,
-                       ctx->d_bad_idx, ctx->d_nbad, ctx->d_non);
+                       ctx->d_bad_idx, ctx->d_nbad, ctx->d_non, ctx->d_good_idx, ctx->d_npt);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond + j_lo, 0, (size_t)(j_hi - j_lo) * sizeof(float), ctx->stream));
     return launch_derive_kernel(ctx, eager_layouts(ctx), j_lo, j_hi);
 }
@@ -485,7 +491,7 @@ int pcl_launch_derive(pcl_ctx *ctx) {
     const int KS8f = (ctx->D + 7) / 8;
     hipLaunchKernelGGL(state_prepass_kernel, dim3(ctx->J), dim3(PRE_T), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->M, ctx->Mpad,
                        ctx->D, ctx->Dhost, KS8f, ctx->model_flags, ctx->centers32, ctx->fscale, ctx->kzero, 0, pcl_split_threshold(ctx), ctx->d_bad,
-                       ctx->d_bad_idx, ctx->d_nbad, ctx->d_non);
+                       ctx->d_bad_idx, ctx->d_nbad, ctx->d_non, ctx->d_good_idx, ctx->d_npt);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_cond, 0, (size_t)ctx->J * sizeof(float), ctx->stream));
     const int what = eager_layouts(ctx);
     const int rc = launch_derive_kernel(ctx, what, 0, ctx->J);

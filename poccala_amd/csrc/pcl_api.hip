@@ -223,6 +223,7 @@ int pcl_init(int device, pcl_ctx **out) {
     }
     if (const char *ds = getenv("PCL_DP_STREAM")) ctx->dp_async = atoi(ds) != 0;
     if (const char *co = getenv("PCL_COARSE")) ctx->coarse_on = atoi(co) != 0;
+    if (const char *cm2 = getenv("PCL_COMPACT_MAIN")) ctx->compact_main = atoi(cm2) != 0;
     if (const char *cs = getenv("PCL_COARSE_STATS")) ctx->coarse_stats = atoi(cs) != 0;
     if (const char *cm_ = getenv("PCL_COARSE_SPLIT_MAX")) ctx->coarse_split_frac = std::min(1.0f, std::max(0.0f, (float)atof(cm_)));   // (scoring only: A/B, tests)
     if (const char *tm = getenv("PCL_TIMERS")) ctx->timing = atoi(tm) != 0;
@@ -249,6 +250,8 @@ static void free_model(pcl_ctx *ctx) {
     dev_free(ctx->d_bad_idx);
     dev_free(ctx->d_nbad);
     dev_free(ctx->d_non);
+    dev_free(ctx->d_good_idx);
+    dev_free(ctx->d_npt);
     ctx->nbad.clear();
     if (ctx->zero_pending && ctx->ev_zero) (void)hipEventSynchronize(ctx->ev_zero);
     ctx->zero_pending = false;
@@ -433,6 +436,8 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->d_bad_idx, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_nbad, (size_t)J));
     TRY(dev_alloc(ctx, &ctx->d_non, (size_t)J));
+    TRY(dev_alloc(ctx, &ctx->d_good_idx, (size_t)J * Mpad));
+    TRY(dev_alloc(ctx, &ctx->d_npt, (size_t)J));
     // with the coarse pass (gmm_score_coarse.hip) a state's off-pipe mixtures cost the scoring about what they would cost on the pipe, so
     // states stay split for scoring up to coarse_split_frac (0.85) of their mixtures (beyond it the pipe pass over the few that are left
     // is mostly log-zero tiles, and the whole-state direct form with its partial-distance test is the cheaper route: measured

@@ -123,6 +123,9 @@ struct pcl_ctx {
     int *d_bad_idx = nullptr;          // [J][Mpad] the state's off-pipe mixtures in ascending order (first nbad[j] entries)
     int *d_nbad = nullptr;             // [J]
     int *d_non = nullptr;              // [J] mixtures on the pipe (M - nbad)
+    int *d_good_idx = nullptr;         // [J][Mpad] the state's ON-pipe mixtures in ascending order (first M - nbad[j] entries): row r of a split state's matrix-pipe layout is mixture good_idx[r]
+    bool compact_main = true;          // env PCL_COMPACT_MAIN=0 (read when the context is made): every state keeps derive_kernel's tiles in mixture order, all of them walked (A/B)
+    int *d_npt = nullptr;              // [J] 32-mixture tiles of the matrix-pipe layout in use: ceil((M - nbad) / 32)
     std::vector<int> nbad;
     float split_frac = 0.5f;           // env PCL_SPLIT_MAX: the share of a state's mixtures that may be off the pipe (0 = no splitting)
     bool split_frac_set = false;       // PCL_SPLIT_MAX was given (otherwise: 1.0 for scoring when the coarse pass is available, 0.5 for the accumulate pass)
@@ -545,6 +548,7 @@ int pcl_coarse_tile_frames();
 void pcl_coarse_release(pcl_ctx *ctx);
 int pcl_ensure_coarse(pcl_ctx *ctx);
 int pcl_launch_score_coarse(pcl_ctx *ctx, pcl_batch *b);
+int pcl_launch_compact_main(pcl_ctx *ctx, int j_lo, int j_hi);
 int pcl_launch_score_subset_flagged(pcl_ctx *ctx, pcl_batch *b, const ScoreTile *tiles, int n_tiles, const int *flags);
 inline float pcl_split_threshold(const pcl_ctx *ctx) { return ctx->split_max > 0 ? ctx->cond_max : 3.0e38f; }   // cond_m above this: off the pipe
 int pcl_launch_cast(pcl_ctx *ctx, const double *src64, float *f32, double *dst64, size_t n);

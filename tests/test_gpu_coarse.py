@@ -69,7 +69,8 @@ def frames_for(rng, mean, var, tight, per_state):
             comp[: 2 * n // 3] = rng.choice(tight[j], 2 * n // 3)
         x = mean[j, comp] + np.sqrt(var[j, comp]) * rng.standard_normal((n, D))
         x[: n // 3] = mean[j, comp[: n // 3]]                        # exactly on the mean
-        x[-n // 6:] = rng.standard_normal((n // 6 if n // 6 else 1, D))[: len(x[-n // 6:])]
+        k = max(1, n // 6)
+        x[n - k:] = rng.standard_normal((k, D))
         xs.append(x)
         own += [j] * n
     return np.concatenate(xs).astype(np.float32), np.array(own)
