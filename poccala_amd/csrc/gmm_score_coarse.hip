@@ -59,7 +59,7 @@ struct CoarseExact {
 #define PCL_COARSE_NT 2
 #endif
 #ifndef PCL_COARSE_MINW
-#define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at (199 VGPRs: 2; 3 spills 28 registers -- A/B in profiles/r06_coarse_ab.txt)
+#define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at: 2 (199 VGPRs, nothing spilled).  3 (168 VGPRs, 28 spilled) measured 4 % faster on the shard probe and 8-10 % slower inside config 4's EM iterations (coarse 93 / 137 ms against 86 / 124): profiles/r06_coarse_ab.txt
 #endif
 
 template <int D, int NT>
@@ -275,13 +275,29 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
             unsigned int mask = 0u;                              // (the rows that passed, as bits: no dynamic index into the accumulator registers)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mask |= (acc[c][r] >= 0.f ? 1u : 0u) << r;
+            const float t_mfma = tcur[c];                        // the threshold these accumulators are relative to
 #pragma unroll 1
             for (int r = 0; r < 16; ++r) {
-                const bool hit = (mask >> r) & 1u;
-                const unsigned long long bal = __ballot(hit);
+                bool hit = (mask >> r) & 1u;
+                unsigned long long bal = __ballot(hit);
                 if (!bal) continue;
-                const int cnt = __popcll(bal);
-                if (qn + cnt > QCAP) flush();
+                int cnt = __popcll(bal);
+                if (qn + cnt > QCAP) {
+                    flush();
+                    // the flush may have raised this frame's threshold (a state whose on-pipe part says little: the first rows of its first tile
+                    // all pass): what is still waiting in `mask` is tested again before it is queued
+                    const float dlt = tcur[c] - t_mfma;
+                    if (__any(dlt > 0.f)) {
+                        unsigned int again = 0u;
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) again |= (acc[c][rr] >= dlt ? 1u : 0u) << rr;
+                        mask &= again;
+                        hit = (mask >> r) & 1u;
+                        bal = __ballot(hit);
+                        if (!bal) continue;
+                        cnt = __popcll(bal);
+                    }
+                }
                 if (hit) {
                     const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                     q_idx[wave][pos] = mt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);

@@ -52,7 +52,7 @@ run dec_write "WRITE_SIZE" $DEC
 run dec_clk "GRBM_GUI_ACTIVE" $DEC
 run dec_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $DEC
 fi
-RND=${RND:-r05}
+RND=${RND:-r06}
 python3 $R/tools/make_profile_summary.py $OUT $RND
 find $OUT -name "*.csv" -size +1M -delete
 cat $OUT/failures.log 2>/dev/null
