@@ -308,6 +308,8 @@ def compact_record(full):
     for k in ('sustained_value', 'fresh_batches_value', 'pcie_inclusive_value', 'strict_f32_value', 'strict_f32_frac',
               'value_em2_model', 'value_em3_model', 'off_pipe_mixture_share_em2', 'off_pipe_mixture_share_em3'):
         r[k] = rf.get(k)
+    for k in ('score_kernel_ms_em3', 'coarse_kernel_ms_em3'):
+        r[k] = _pick(ex, 'em_shaped_models', k)
     r['estep_ms'] = ex.get('estep_ms')
     per = _pick(ex, 'exchange', 'per_rank') or []              # N > 1: what the statistics exchange cost (max over ranks)
     for k in ('exchange_ms', 'reduce_scatter_ms', 'mstep_owned_ms', 'all_gather_ms'):
@@ -350,7 +352,7 @@ def compact_line(full):
     the line lost, should it ever outgrow the limit."""
     rec = compact_record(full)
     line = json.dumps(rec, allow_nan=False, separators=(', ', ': '))
-    optional = ['estep_pipelined_ms', 'mstep_owned_ms', 'c5_decode_kernel_ms', 'c5_shard_frames_per_s', 'c3_frames_per_s', 'c2_frames_per_s', 'c4_em_off_pipe_share', 'c4_em_iteration_ms',
+    optional = ['estep_pipelined_ms', 'mstep_owned_ms', 'coarse_kernel_ms_em3', 'score_kernel_ms_em3', 'c5_decode_kernel_ms', 'c5_shard_frames_per_s', 'c3_frames_per_s', 'c2_frames_per_s', 'c4_em_off_pipe_share', 'c4_em_iteration_ms',
                 'c4_fresh_ms_per_iteration', 'estep_frac_executed', 'accumulate_ms', 'fb_kernel_alone_ms', 'fb_kernel_avg_ms',
                 'hbm_algorithmic_bytes_per_launch', 'flop_per_launch', 'launches', 'traffic_file', 'frac_denominator']
     while len(line) > COMPACT_TARGET_CHARS and optional:
@@ -1489,13 +1491,17 @@ def side_measurements(args, eng, cfg, labels, mean, var, w, trans, frames_per_ra
             for bt in more['batches']:
                 bt.refresh_transitions()
             n_off, off_limit = eng.model_split_info()
+            eng.kernel_time('score_coarse'); eng.kernel_time('score_direct')
             el, sc_ms, sc_n, fb_ms, fb_n = timed_steps(eng, more['batches'], PCL_F32, False, max(args.warmup, 1), args.steps, lambda: None)
-            names = ('score', 'score_subset', 'score_direct')
+            co_ms, co_n = eng.kernel_time('score_coarse')
+            di_ms, di_n = eng.kernel_time('score_direct')
             em['value_em%d_model' % it] = frames_per_rank * args.steps / el
             em['ms_per_step_em%d_model' % it] = el / args.steps * 1e3
             em['off_pipe_mixture_share_em%d' % it] = float(n_off.sum()) / float(len(n_off) * cfg['M'])
             em['states_off_pipe_whole_em%d' % it] = int((n_off > off_limit).sum()) if off_limit > 0 else None
             em['score_kernel_ms_em%d' % it] = sc_ms / max(sc_n, 1)
+            em['coarse_kernel_ms_em%d' % it] = co_ms / max(co_n, 1) if co_n else 0.0      # (gmm_score_coarse_kernel: the off-pipe mixtures)
+            em['direct_kernel_ms_em%d' % it] = di_ms / max(di_n, 1) if di_n else 0.0      # (whole states in direct form: none below 95 % off-pipe mixtures)
     except Exception as e:                     # noqa: never the headline's problem
         out['em_shaped_models'] = dict(out.get('em_shaped_models') or {}, error=repr(e))
     models.clear()

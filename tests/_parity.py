@@ -1,7 +1,7 @@
 """Parity bookkeeping for the GPU tests: every comparison against the oracle that the north star bounds (1e-4 relative on
 log-likelihoods and gamma / xi occupancies in f32, and what follows from them: the E-step statistics and the re-estimated
 model) goes through `hold`, which ASSERTS the bound and RECORDS the measured worst case.  The session writes the records to
-gpurun_out/r05_parity_report.json (what travels back from the GPU box; copied to profiles/ on request, see `write`), so that the numbers the
+gpurun_out/r06_parity_report.json (what travels back from the GPU box; copied to profiles/ on request, see `write`), so that the numbers the
 asserts saw are on file, not only printed.
 
 A record: config / quantity -> {bound: {rtol, atol}, max_abs, max_rel (over entries with |want| > atol / rtol, i.e. where the
@@ -84,7 +84,7 @@ def note(config, key, value):
 
 
 SOFT = bool(os.environ.get('POCCALA_PARITY_SOFT'))
-REPORT_NAME = 'r05_parity_report.json'
+REPORT_NAME = 'r06_parity_report.json'
 
 
 def violations():
@@ -93,8 +93,8 @@ def violations():
 
 
 def write():
-    """gpurun_out/r05_parity_report.json <- the records of this session (gpurun_out/ is what travels back from the GPU box; it is
-    scratch).  The tracked copy profiles/r05_parity_report.json is written ONLY when POCCALA_PARITY_REPORT=1 asks for it (the full
+    """gpurun_out/r06_parity_report.json <- the records of this session (gpurun_out/ is what travels back from the GPU box; it is
+    scratch).  The tracked copy profiles/r06_parity_report.json is written ONLY when POCCALA_PARITY_REPORT=1 asks for it (the full
     suite on the GPU box at the end of a round), merged into what the file holds, so that ordinary test runs neither dirty the
     repository nor overwrite the committed evidence.  The body says which mode the session ran in: in soft mode
     (POCCALA_PARITY_SOFT, discovery runs) entries are recorded WITHOUT being asserted and the session fails at its end if any was

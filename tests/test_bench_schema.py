@@ -106,9 +106,30 @@ def test_newest_committed_bench_line_has_the_contract_schema():
     lines = [f for f in lines if 'f32mfma' not in f and 'valu' not in f]
     assert lines
     d = json.load(open(lines[-1]))
-    _validate_line(d)
     rnd = int(os.path.basename(lines[-1])[1:3])
-    if rnd >= 5:                                                     # round 5 on: the whole record is inside `roofline`
+    if rnd >= 6:                                                     # round 6 on: the committed line IS the driver's compact line
+        text = open(lines[-1]).read().strip()
+        assert len(text) < 8000 and '\n' not in text
+        d = _strict_loads(text)
+        assert COMPACT_TOP <= set(d) and COMPACT_ROOFLINE <= set(d['roofline']) and COMPACT_CPU <= set(d['cpu_baseline']) and d['final'] is True
+        assert d['metric'] == 'frames/sec GMM-score+fwd-bwd, 39-d MFCC, 2048-mix' and d['unit'] == 'frames/s' and d['vs_baseline'] is None
+        assert d['value'] == pytest.approx(d['config']['frames_per_step_total'] / (d['ms_per_step'] * 1e-3), rel=1e-5)
+        r = d['roofline']
+        assert r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-5) and r['frac_of_f16_dense_peak'] == pytest.approx(r['achieved'] / 2516.6, rel=1e-5)
+        assert r['kernel_avg_ms'] <= d['ms_per_step'] * 1.02
+        assert r['traffic'] is not None and r['kernel_code_sha16'], 'the line was printed without a PMC traffic figure'
+        summ = open(os.path.join(ROOT, 'profiles', 'r%02d_bench_summary.txt' % rnd)).read()
+        assert r['kernel_code_sha16'] in summ and r['traffic_file'] == 'profiles/r%02d_bench_summary.txt' % rnd
+        for k in ('value_em2_model', 'value_em3_model', 'estep_ms', 'c4_ms_per_iteration', 'c5_frames_per_s', 'sustained_value', 'strict_f32_value'):
+            assert r[k] is not None and r[k] > 0, k
+        assert len(r['c4_em_iteration_ms']) == 3 and max(r['c4_em_iteration_ms']) <= 1.3 * r['c4_em_iteration_ms'][0]      # VERDICT r5 next #3, in the record
+        c = d['cpu_baseline']
+        assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] == pytest.approx(max(c['gemm_value'], c['vectorised_value']))
+        full = json.load(open(os.path.join(ROOT, 'profiles', 'r%02d_bench_full.json' % rnd)))      # ... and the full record beside it is the same run
+        assert full['value'] == pytest.approx(d['value'], rel=1e-6) and full['roofline']['kernel_avg_ms'] == pytest.approx(r['kernel_avg_ms'], rel=1e-6)
+        return
+    _validate_line(d)
+    if rnd >= 5:                                                     # round 5: the whole record is inside `roofline`
         r = d['roofline']
         for k in ('frac_of_f16_dense_peak', 'frac_executed', 'frac_denominator', 'sustained_value', 'strict_f32_value', 'strict_f32_frac',
                   'pcie_inclusive_value', 'fresh_batches_value'):
