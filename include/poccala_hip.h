@@ -308,13 +308,13 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
  * (Clustering.py:740-767, :653-680) whichever kernel evaluated a term.  A state leaves the matrix cores as a whole only when
  * more than *limit of its mixtures are out.  Round 6: in SCORING the list is no longer evaluated in direct form but by the coarse pass
  * (csrc/gmm_score_coarse.hip: a bound of each off-pipe mixture computed on the matrix pipe rules out almost every (frame, mixture) pair,
- * the pairs it cannot rule out are evaluated exactly in float64), and *limit is 0.95 M there (env PCL_COARSE_SPLIT_MAX; PCL_COARSE=0:
+ * the pairs it cannot rule out are evaluated in direct form), and *limit is 0.95 M there (env PCL_COARSE_SPLIT_MAX; PCL_COARSE=0:
  * direct form, limit 0.5 M).  The accumulate pass keeps direct form and 0.5 M.  env PCL_SPLIT_MAX = share of M sets both limits;
  * 0 = whole states, as before round 4.  *limit reports the scoring limit.
  * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
 int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
 /* Diagnostics of the coarse pass over the off-pipe mixtures (csrc/gmm_score_coarse.hip; counted only under env PCL_COARSE_STATS=1):
- * *pairs = (frame, mixture) pairs evaluated exactly since the last reset -- the pairs the bound on the matrix pipe could not rule
+ * *pairs = (frame, mixture) pairs evaluated in direct form since the last reset -- the pairs the bound on the matrix pipe could not rule
  * out; every other pair of an off-pipe mixture was proven to lie 2^-36 below its frame's likelihood.  reset != 0 clears the count. */
 int pcl_coarse_counter(pcl_ctx *ctx, unsigned long long *pairs, int reset);
 

@@ -1,5 +1,5 @@
 // gmm_score_coarse.hip -- the off-pipe ("tight") mixtures of split states: a COARSE pass on the f16 matrix pipe that proves almost
-// every (frame, mixture) pair negligible, and an exact float64 evaluation of the few pairs it cannot (round 6).
+// every (frame, mixture) pair negligible, and a direct-form evaluation of the few pairs it cannot (round 6).
 //
 // Reference rows: as gmm_score.hip (A1/A4/A6: util.gaussian_function util.py:20-31, Clustering.GMM.point Clustering.py:740-767); the
 // models in question are the ones Clustering.GMM.update_param (Clustering.py:682-693, variance floor init.py:30 -> Controller.py:151)
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
             out[oi] = (hi > -INFINITY) ? hi + ::log1p(::exp(lo - hi)) : -INFINITY;
         }
     }
-    if (counters) {                           // diagnostics (PCL_COARSE_STATS=1): pairs evaluated exactly
+    if (counters) {                           // diagnostics (PCL_COARSE_STATS=1): pairs evaluated in direct form
         for (int o = 32; o >= 1; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
         if (lane == 0 && n_cand) atomicAdd(counters, n_cand);
     }
