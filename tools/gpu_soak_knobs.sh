@@ -8,4 +8,10 @@ PCL_FB_LINEAR=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 200 0 > gpu
 PCL_FB_LINEAR=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 100 0 > gpurun_out/knob_estep_log.txt 2>&1; echo "estep fb log-domain rc=$? $(tail -1 gpurun_out/knob_estep_log.txt)"
 PCL_DP_STREAM=0 PCL_FEWER_MARKERS=0 PCL_ZERO_ASYNC=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 100 0 > gpurun_out/knob_estep_1s.txt 2>&1; echo "one stream rc=$? $(tail -1 gpurun_out/knob_estep_1s.txt)"
 PCL_SPLIT_MAX=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_nosplit.txt 2>&1; echo "no split states rc=$? $(tail -1 gpurun_out/knob_estep_nosplit.txt)"
+# round 6: the round 4-5 routes beside the coarse pass / the compacted main layout, states without an on-pipe mixture through the coarse pass, and the
+# BASELINE mixture counts (seeds 6000..: 1024 / 2048 / 4096 mixtures per state) on the default route
+PCL_COARSE=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_nocoarse.txt 2>&1; echo "PCL_COARSE=0 rc=$? $(tail -1 gpurun_out/knob_estep_nocoarse.txt)"
+PCL_COMPACT_MAIN=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_nocompact.txt 2>&1; echo "PCL_COMPACT_MAIN=0 rc=$? $(tail -1 gpurun_out/knob_estep_nocompact.txt)"
+PCL_COARSE_SPLIT_MAX=1.0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_split1.txt 2>&1; echo "PCL_COARSE_SPLIT_MAX=1.0 rc=$? $(tail -1 gpurun_out/knob_estep_split1.txt)"
+timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py 100 6000 > gpurun_out/knob_estep_bigM.txt 2>&1; echo "seeds 6000.. rc=$? $(tail -1 gpurun_out/knob_estep_bigM.txt)"
 grep -h FAILED gpurun_out/knob_*.txt | head -20
