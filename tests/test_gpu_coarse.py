@@ -201,3 +201,55 @@ def test_coarse_pass_inside_the_e_step_matches_the_direct_form_route():
     for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
         a, d = res['coarse'][1][key], res['direct'][1][key]
         hold('coarse pass in the E-step', key + ' against the direct-form route', a, d, 1e-4 + 4.0 * e_max, 1e-6 * np.abs(d).max())
+
+
+def test_compacted_main_layout_agrees_with_the_layout_in_mixture_order():
+    """A split state's on-pipe mixtures are compacted to the front of its matrix-pipe tiles (compact_main_kernel): the scoring kernel walks
+    ceil(on-pipe / 32) tiles, the accumulate consumer maps a layout row back to its mixture at the flush.  Against PCL_COMPACT_MAIN=0 (every
+    state in mixture order, off-pipe mixtures as zero-weight rows, all tiles walked) on the same E-step: the same ln b up to the order of an
+    f32 sum, the same statistics per MIXTURE -- which is what a wrong row -> mixture map would break -- and the states without off-pipe
+    mixtures bit for bit."""
+    from poccala_amd import PCL_F32, synth
+    from poccala_amd.engine import make_sentence_batch
+    units, M, D, U, T, L = 4, 160, 39, 6, 60, 3
+    J = units * 3
+    shares = [0.0, 0.1, 0.45, 0.0, 0.3, 0.2, 0.45, 0.05, 0.0, 0.4, 0.25, 0.35]          # (<= 0.5: the accumulate pass keeps these states on the consumer)
+    mean, var, w, tight = tight_model(41, J, M, D, shares)
+    _, _, _, trans = synth.make_model(units, M, D, seed=41)
+    rng = np.random.default_rng(41)
+    labels = synth.make_labels(U, L, units, seed=42)
+    lens = np.full(U, T, dtype=np.int32)
+    begin = np.arange(U, dtype=np.int64) * T
+    st = np.concatenate([np.repeat([u * 3 + k for u in lab for k in range(3)], T // 9 + 1)[:T] for lab in labels])
+    comp = np.array([rng.choice(tight[j]) if (t % 3 == 0 and len(tight[j])) else rng.integers(0, M) for t, j in enumerate(st)])
+    x = (mean[st, comp] + np.sqrt(var[st, comp]) * rng.standard_normal((len(st), D))).astype(np.float32)
+    res = {}
+    for name, env in (('compact', {}), ('mixture order', dict(PCL_COMPACT_MAIN=0))):
+        e = _engine(**env)
+        try:
+            e.enable_timing(True)
+            e.load_model(mean, var, w)
+            e.load_units(np.stack(trans))
+            e.load_frames(x)
+            b, _ = make_sentence_batch(e, labels, lens, begin, trans)
+            b.score(PCL_F32); b.forward_backward(fix_pi=False)
+            e.stats_zero(); b.accumulate(PCL_F32)
+            assert e.kernel_time('acc_consume')[1] >= 1                       # the matrix-pipe consumer ran (these states are split, not whole)
+            res[name] = (b.get('B'), b.get('logp').copy(), e.stats_download())
+            b.close()
+        finally:
+            e.close()
+    Bc, Bm = res['compact'][0], res['mixture order'][0]
+    for u, lab in enumerate(labels):
+        for pos, unit in enumerate(lab):
+            for k in range(3):
+                j, row = unit * 3 + k, 1 + pos * 3 + k
+                if shares[j] == 0.0:
+                    assert np.array_equal(Bc[u][row], Bm[u][row])         # not a split state: nothing about it changed
+                else:
+                    hold('compacted main layout', 'ln b against the layout in mixture order', Bc[u][row], Bm[u][row], 0.0, F32_LOGLIK_ATOL)      # (each is within it of the oracle: another sum order, another f16-rounded reference)
+    hold('compacted main layout', 'ln P(O)', res['compact'][1], res['mixture order'][1], 1e-7)
+    for key in ('acc', 'alpha_acc', 'mean_acc', 'cov_acc'):
+        a, d = res['compact'][2][key], res['mixture order'][2][key]
+        assert np.array_equal(a == 0, d == 0), key                          # the same mixtures seen
+        hold('compacted main layout', key + ' per mixture', a, d, 1e-4, 1e-6 * np.abs(d).max())
