@@ -300,7 +300,11 @@ __global__ __launch_bounds__(WG, MINW) void gmm_accumulate_kernel(
             }
         }
     }
-    if (live) {
+    // (round 6) a mixture that received nothing from this batch -- every posterior exactly 0 in f32: S0 is a sum of non-negative terms --
+    // adds +0 to 2 D + 1 float64 sums: skipped, the same bits.  On the models EM leaves most mixtures own a handful of frames of the whole
+    // corpus and see none of them in most batches, and this flush (79 lane-strided float64 read-modify-writes per mixture, 7.7 GB per pass at
+    // C4) was most of the kernel: 14.1 ms per batch whatever the arithmetic did (profiles/r06_accumulate_direct.txt).
+    if (live && S0 != (real)0) {
         const size_t jm = (size_t)j * Mpad + m;
         const double a0 = (double)S0;
         st_acc[jm] += a0;                                                   // Clustering.py:665
