@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, the record: the bench line as the driver runs it, smoke, the whole GPU suite (parity report on request)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout -k 10 500 python3 bench.py --gpus 1 --steps 25 --warmup 5 > gpurun_out/r06_bench_stdout.txt 2> gpurun_out/r06_bench_stderr.txt; echo "bench rc=$?"
+timeout -k 10 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_bench_stdout.txt 2> gpurun_out/r06_bench_stderr.txt; echo "bench rc=$?"
 tail -1 gpurun_out/r06_bench_stdout.txt > gpurun_out/r06_bench_line.json; cp bench_full.json gpurun_out/r06_bench_full.json; wc -c gpurun_out/r06_bench_stdout.txt gpurun_out/r06_bench_line.json
 python3 - <<'PY'
 import json
