@@ -23,15 +23,19 @@
 // term 2^-36 below the total changes ln b by 1e-11 even if all 2048 were dropped at the threshold), the accumulator of a pair is
 //   acc >= 0   <=>   the pair MAY reach 2^-36 of the frame's likelihood,
 // one v_max tree + one ballot per 32 x 32 tile instead of the log-sum-exp.  Pairs that pass are evaluated in DIRECT FORM, a lane per pair
-// (rows made from the master copy in the f32 arithmetic of the direct-form kernels, see `flush`), into a per-frame online log-sum-exp (float64), the threshold is raised when an
-// exact value lifts the frame's maximum (states without on-pipe mixtures start at -inf and settle after their first tile), and the
-// result is log-added to the pipe's in float64: ln b = ln(e^pipe + e^tight), the reference's sum over all mixtures -- deterministic
-// (a lane owns its frame; no atomics).  Frames whose scaled features leave the f16 range raise the tile's flag and the direct-form
-// subset kernel rescoring flagged tiles follows in the same call, as for the main kernel.
+// (rows made from the master copy in the f32 arithmetic of the direct-form kernels, see `flush`), into a per-frame online log-sum-exp
+// (float64); the threshold is raised when such a value lifts the frame's maximum and what is still waiting is tested again (a state
+// whose on-pipe part says little settles after the first rows of its first tile); the result is log-added to the pipe's in float64:
+// ln b = ln(e^pipe + e^tight), the reference's sum over all mixtures -- deterministic (a lane owns its frame; no atomics).  Frames whose
+// scaled features leave the f16 range raise the tile's flag and the direct-form subset kernel rescoring flagged tiles follows in the
+// same call, as for the main kernel.  States stay on this route up to 95 % off-pipe mixtures (pcl_model_upload); beyond, the on-pipe
+// part is too thin a reference (with none at all and every mixture collapsed the bound under the floored variance sits far above the
+// true values and every pair passes) and whole states take the direct form with its partial-distance test.
 //
 // Layout of the tight mixtures: [J][Mpad32/32 tiles][2 pieces][KS8][64 lanes][8 f16], the state's bad_idx list in order, 32 per tile,
-// nct[j] tiles used; own power-of-two feature scales fscale_c and K0 (kzero_c); exact constants k2c[j][idx] (float64).  Derived on
-// first use after a model change (pcl_ensure_coarse), one workgroup per state.
+// nct[j] tiles used; own power-of-two feature scales fscale_c and K0 (kzero_c); constants k2c[j][idx] (float64).  Derived on first use
+// after a model change (pcl_ensure_coarse), one workgroup per state.  The same file holds compact_main_kernel: a split state's ON-pipe
+// mixtures compacted to the front of the main layout, so that the matrix-pipe kernels walk ceil(on-pipe / 32) tiles.
 #include <stdlib.h>
 
 #include <vector>
