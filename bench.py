@@ -1701,7 +1701,7 @@ def run_c4_full(eng, ctl, P, payload, iters=1, warm=1, model=None, c_cov=1e-3, e
     for _ in range(warm):
         estep()                                # (lazy buffers, clocks; no M-step: the model stays the initial one)
     eng.sync()
-    names = ('score', 'score_coarse', 'score_subset', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive', 'derive_coarse')
+    names = ('score', 'score_coarse', 'score_subset', 'score_subset_fixup', 'score_direct', 'score_fixup', 'fb', 'accumulate', 'hmm_acc', 'reduce_scatter', 'mstep_owned', 'all_gather', 'derive', 'derive_coarse')
     elapsed = 0.0
     for it in range(iters):
         if it:

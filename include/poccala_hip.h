@@ -308,7 +308,7 @@ int pcl_model_conditioning(pcl_ctx *ctx, float *cond, float *cond_max);
  * (Clustering.py:740-767, :653-680) whichever kernel evaluated a term.  A state leaves the matrix cores as a whole only when
  * more than *limit of its mixtures are out.  Round 6: in SCORING the list is no longer evaluated in direct form but by the coarse pass
  * (csrc/gmm_score_coarse.hip: a bound of each off-pipe mixture computed on the matrix pipe rules out almost every (frame, mixture) pair,
- * the pairs it cannot rule out are evaluated in direct form), and *limit is 0.95 M there (env PCL_COARSE_SPLIT_MAX; PCL_COARSE=0:
+ * the pairs it cannot rule out are evaluated in direct form), and *limit is 0.99 M there (env PCL_COARSE_SPLIT_MAX; PCL_COARSE=0:
  * direct form, limit 0.5 M).  The accumulate pass keeps direct form and 0.5 M.  env PCL_SPLIT_MAX = share of M sets both limits;
  * 0 = whole states, as before round 4.  *limit reports the scoring limit.
  * n_off: J ints, off-pipe mixtures per state (may be NULL); limit: 1 int (may be NULL). */
@@ -317,6 +317,10 @@ int pcl_model_split_info(pcl_ctx *ctx, int *n_off, int *limit);
  * *pairs = (frame, mixture) pairs evaluated in direct form since the last reset -- the pairs the bound on the matrix pipe could not rule
  * out; every other pair of an off-pipe mixture was proven to lie 2^-36 below its frame's likelihood.  reset != 0 clears the count. */
 int pcl_coarse_counter(pcl_ctx *ctx, unsigned long long *pairs, int reset);
+/* ... and *tiles_given_up (may be NULL) = tiles of 256 frames x one state on which the pass gave up -- a wave had evaluated more than
+ * max(4096, 2 x the state's off-pipe mixtures) pairs: the state's on-pipe part is no reference for those frames -- and which the direct-form
+ * subset kernel rescored in the same call (as it does tiles with a feature out of the f16 range).  Same results either way. */
+int pcl_coarse_counters(pcl_ctx *ctx, unsigned long long *pairs, unsigned long long *tiles_given_up, int reset);
 
 /* How much of a CU the matrix-core scoring kernel takes.  0 (default): three workgroups per CU, the fastest for the kernel alone.
  * 2: two -- a third of the registers stays free for kernels of OTHER streams, which is what lets the token passing of chunk k-1

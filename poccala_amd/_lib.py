@@ -55,6 +55,7 @@ PROTOTYPES = {
     'pcl_model_conditioning': (_i, [_vp, _vp, _vp]),
     'pcl_model_split_info': (_i, [_vp, _vp, _vp]),
     'pcl_coarse_counter': (_i, [_vp, _vp, _i]),
+    'pcl_coarse_counters': (_i, [_vp, _vp, _vp, _i]),
     'pcl_score_occupancy': (_i, [_vp, _i]),
     'pcl_batch_regroup': (_i, [_vp, _vp, _i, _vp, _vp]),
     'pcl_mfcc': (_i, [_vp, _i, _vp, _vp, _i, _d, _d, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_int64]),

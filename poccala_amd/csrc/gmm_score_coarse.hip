@@ -28,7 +28,7 @@
 // whose on-pipe part says little settles after the first rows of its first tile); the result is log-added to the pipe's in float64:
 // ln b = ln(e^pipe + e^tight), the reference's sum over all mixtures -- deterministic (a lane owns its frame; no atomics).  Frames whose
 // scaled features leave the f16 range raise the tile's flag and the direct-form subset kernel rescoring flagged tiles follows in the
-// same call, as for the main kernel.  States stay on this route up to 95 % off-pipe mixtures (pcl_model_upload); beyond, the on-pipe
+// same call, as for the main kernel.  States stay on this route up to 99 % off-pipe mixtures (pcl_model_upload); beyond, the on-pipe
 // part is too thin a reference (with none at all and every mixture collapsed the bound under the floored variance sits far above the
 // true values and every pair passes) and whole states take the direct form with its partial-distance test.
 //
@@ -52,10 +52,21 @@ constexpr float COARSE_MARGIN = 36.f;         // log2 units below the frame's li
 constexpr double VMIN_C = 0.0009765625;       // 2^-10: the variance floor of the bound
 constexpr double KQ_MAX = 2.5e4;              // the cancelling term the folded constant may carry (f16 pieces reach 6e4)
 constexpr double EPS_C = 9.5367431640625e-07; // 2^-20
+// The one-product pass (NP = 1).  Operands are single f16 values: a coefficient and a feature each carry a relative error 2^-11, a product
+// (1 + d1)(1 + d2) - 1 <= 2^-10 (1 + 2^-12); the matrix pipe's f32 sums add ~2^-20 of the terms.  QUADRATIC terms a x'^2 (a <= 0) need no
+// allowance: both factors are rounded toward zero, so the term can only come out too HIGH (the bound stays a bound).  LINEAR terms b x'
+// change sign: with u_d = sqrt(a'_d) x'_d, w_d = sqrt(a'_d) (mu_d - c_d) (kq' = sum w^2, q' = sum (u - w)^2 = the distance term of v_up),
+//   sum |b x'| = 2 sum |u w| <= sum u^2 / 2 + 2 kq' <= q' + 3 kq'          (u^2 <= 2 (u - w)^2 + 2 w^2)
+// and a pair that matters has q' <= k2_m - threshold <= G_f := k2max_j - threshold_f.  So the error is below EPS1 (G_f + 3 kq'_m): the
+// mixture's part goes into its folded constant (E_m += EPS1 3 kq'_m, and 2^-10 |constant| for the constant's own single piece), the
+// frame's part lowers the frame's threshold (set_threshold).  For a collapsed mixture (kq' = 2.5e4) that is ~75-125 log2 units on a
+// distance of tens of thousands; for a moderately tight one (kq' in the hundreds) about one.
+constexpr double EPS1 = 0.0009765625 * 1.02;  // 2^-10 (1 + 2^-12) + the f32 sums, rounded up
 
 struct CoarseExact {
-    const double *mean64, *var64, *k2c;
-    const int *bad_idx, *nbad;
+    const float2 *rows;          // [J][Mpad][D] (s_d, c_d) of the tight mixtures in bad_idx order: the direct form's f32 rows (coarse_derive_kernel)
+    const double *k2c;
+    const int *nbad;
     int Mpad, Dhost;
 };
 
@@ -66,11 +77,22 @@ struct CoarseExact {
 #define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at: 2 (199 VGPRs, nothing spilled).  3 (168 VGPRs, 28 spilled) measured 4 % faster on the shard probe and 8-10 % slower inside config 4's EM iterations (coarse 93 / 137 ms against 86 / 124): profiles/r06_coarse_ab.txt
 #endif
 
-template <int D, int NT>
+// f16 rounded TOWARD ZERO (the one-product pass: a quadratic term a x'^2, a <= 0, may only come out too high)
+__device__ __forceinline__ _Float16 f16_toward_zero(float val) {
+    _Float16 h = (_Float16)val;
+    if (__builtin_fabsf((float)h) > __builtin_fabsf(val)) h = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, h) - 1));
+    return h;
+}
+
+// NP = 3: the two-piece operands and their three products (round 6's first form, error 2^-20 of the terms); NP = 1: ONE product of the
+// leading pieces -- a third of the matrix-pipe work and half the layout traffic -- with what that costs in precision paid for in the
+// bound instead (see EPS1 above): the pairs that pass are evaluated in direct form either way.
+template <int D, int NT, int NP>
 __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
     const float *__restrict__ frames, const uint4 *__restrict__ pm, const float *__restrict__ fscale, const float *__restrict__ centers,
     int nmt_max, const int *__restrict__ nct, const ScoreTile *__restrict__ tiles, const ScoreSeg *__restrict__ segs, double *__restrict__ out,
-    int *__restrict__ flags, const double *__restrict__ kzero, CoarseExact ex, unsigned long long *__restrict__ counters) {
+    int *__restrict__ flags, const double *__restrict__ kzero, const float *__restrict__ kgap, CoarseExact ex,
+    unsigned long long *__restrict__ counters) {
     static_assert(D % 8 != 0, "the folded constants need a spare slot");
     constexpr int KS8 = (D + 7) / 8;
     constexpr int CH = 2 * KS8;
@@ -86,21 +108,28 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         if (threadIdx.x == 0) flags[blockIdx.x] = 0;
         return;
     }
-    __shared__ int s_ovf;
-    if (threadIdx.x == 0) s_ovf = 0;
+    __shared__ int s_ovf, s_bail[2];
+    if (threadIdx.x == 0) s_ovf = s_bail[0] = s_bail[1] = 0;
     __syncthreads();
     const int vend = segs[tile.seg_hi - 1].vstart + segs[tile.seg_hi - 1].len;
     const bool wave_active = tile.vstart + wave * NT * 32 < vend;
 
     // ---- B operand: as gmm_score_split16_kernel, with the coarse layout's scales
-    h8v xb[NT][2][KS8];
+    constexpr int NPB = NP == 1 ? 1 : 2;
+    constexpr int PCS = NP == 1 ? KS8 : CH, MT = NP == 1 ? 4 : 2;
+    constexpr int SLOTS = NT * 32;
+    static_assert(SLOTS <= 64, "a lane per frame slot");
+    __shared__ __attribute__((aligned(16))) uint4 abuf[2][MT * PCS * 64];   // the stages of the mixture tiles (below); first, the wave's frames
+    __shared__ long long frow_tab[WG / 64][SLOTS];
+    static_assert(sizeof(uint4) * 2 * MT * PCS * 64 >= sizeof(float) * (WG / 64) * SLOTS * D, "the frames of a workgroup fit the stage buffers");
+    h8v xb[NT][NPB][KS8];
     long long oidx[NT], frow[NT];
     bool valid[NT];
     const float *cen = centers + (size_t)tile.state * D;
     const float *fs = fscale + ((size_t)tile.state * 2 + half) * (KS8 * 8);
     bool ovf = false;
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
+    for (int c = 0; c < NT; ++c) {                               // which frame each column is (the tile's segments: ragged utterances)
         int v = tile.vstart + (wave * NT + c) * 32 + col;
         valid[c] = v < vend;
         if (!valid[c]) v = tile.vstart;
@@ -118,7 +147,32 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         const ScoreSeg sg = segs[lo];
         const long long t = v - sg.vstart;
         frow[c] = sg.frame0 + t;
-        const float *fp = frames + frow[c] * D;
+        oidx[c] = sg.out0 + t * (long long)sg.out_stride;
+        if (half == 0) frow_tab[wave][c * 32 + col] = frow[c];
+    }
+    // The wave's 64 frames come through LDS: element e = column * D + d of a 32-frame group is loaded by lane e % 64 -- consecutive lanes,
+    // consecutive addresses (frames of a segment are adjacent) -- straight into the stage buffer (which the mixture tiles need only after
+    // the barrier below), and a column reads its own row back.  A lane loading its own frame's 39 values one by one was 78 load
+    // instructions of 32 cache lines each per wave: 2.2 ms per batch of texture-unit time, more than the products of 40 mixture tiles.
+    float *stg = reinterpret_cast<float *>(&abuf[0][0]) + wave * (SLOTS * D);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int i = 0; i < (32 * D + 63) / 64; ++i) {
+            const int e = i * 64 + lane;
+            if (e < 32 * D) {
+                const int cx = e / D, d = e - cx * D;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(frames + frow_tab[wave][c * 32 + cx] * D + d),
+                                                 (__attribute__((address_space(3))) void *)(stg + c * 32 * D + i * 64), 4, 0, 0);
+            }
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const float *fp = stg + (c * 32 + col) * D;
 #pragma unroll
         for (int s = 0; s < KS8; ++s)
 #pragma unroll
@@ -132,11 +186,14 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
                     val = __builtin_fminf(__builtin_fmaxf(val, -FMAXH), FMAXH);
                 }
                 if (d == D) val = half ? 0.f : 1.f;              // x1: [1 | -t (set below)]
-                const _Float16 h1 = (_Float16)val;
-                xb[c][0][s][j] = h1;
-                xb[c][1][s][j] = (_Float16)(val - (float)h1);
+                if constexpr (NP == 1) {
+                    xb[c][0][s][j] = (half || d >= D) ? (_Float16)val : f16_toward_zero(val);
+                } else {
+                    const _Float16 h1 = (_Float16)val;
+                    xb[c][0][s][j] = h1;
+                    xb[c][NPB - 1][s][j] = (_Float16)(val - (float)h1);
+                }
             }
-        oidx[c] = sg.out0 + t * (long long)sg.out_stride;
     }
     if (__any(ovf) && lane == 0) s_ovf = 1;
     __syncthreads();
@@ -148,9 +205,12 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
 
     // ---- per frame: what the pipe wrote (ln b of the on-pipe mixtures) and the threshold t = log2e ln b1 - margin - K0 its spare slot carries
     const float k0f = (float)kzero[tile.state];
+    const float kg = (NP == 1) ? kgap[tile.state] : 0.f;      // >= (the state's largest k2) - K0
     double pipe_ln[NT];
     float tcur[NT];                           // (f16-exact)
     auto set_threshold = [&](int c, float t) {
+        // one product: the frame's share of the linear terms' rounding, EPS1 (k2max - threshold) (see coarse_derive_kernel)
+        if constexpr (NP == 1) t -= (float)EPS1 * __builtin_fmaxf(kg - t, 0.f);
         // rounded so that the f16 value is not ABOVE what was asked for (a higher threshold could miss a pair): less 2^-10 |t|
         t = t - __builtin_fabsf(t) * 0.0009765625f;
         t = __builtin_fminf(__builtin_fmaxf(t, -TMAX), TMAX);
@@ -165,13 +225,18 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         set_threshold(c, valid[c] ? (t2 > -1.0e30 ? (float)t2 : -TMAX) : TMAX);
     }
 
-    __shared__ __attribute__((aligned(16))) uint4 abuf[2][CH * 64];
+    // A stage = MT mixture tiles (one product: 4 tiles' leading pieces, 20 KB at D = 39; three: 2 tiles, both pieces): a tile of one
+    // product is ~400 cycles of work for a wave, a fraction of the latency of the loads that bring the next -- two tiles in flight
+    // left the kernel waiting on them (70 ms per batch where a third of the products should have given 30).
     const uint4 *pstate = pm + (size_t)tile.state * nmt_max * (CH * 64);
     auto dma = [&](int buf, int stage) {
-        const uint4 *src = pstate + (size_t)stage * (CH * 64);
-        for (int p = wave; p < CH; p += WG / 64)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64 + lane),
-                                             (__attribute__((address_space(3))) void *)&abuf[buf][p * 64], 16, 0, 0);
+        const int nt = min(MT, n_mtiles - stage * MT);
+        const uint4 *src = pstate + (size_t)stage * MT * (CH * 64);
+        for (int r = wave; r < nt * PCS; r += WG / 64) {
+            const int i = r / PCS, p = r - i * PCS;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)i * (CH * 64) + p * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)&abuf[buf][r * 64], 16, 0, 0);
+        }
     };
     const int n_tight = ex.nbad[tile.state];
     const size_t srow = (size_t)tile.state * ex.Mpad;
@@ -181,16 +246,17 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
     //      63 idle ones, with its 117 dependent loads, made the exact part ten times the matrix pipe's: 43 ms per batch at 73 % off-pipe
     //      mixtures).  Queue order = (m-tile, frame slot c, accumulator row, lane): fixed, so the sums are too.  Lane L owns frame slot
     //      L = c * 32 + col: the online log-sum-exp (log2 domain, float64) of the slot's exact values.
-    constexpr int QCAP = 64, SLOTS = NT * 32;
-    static_assert(SLOTS <= 64, "a lane per frame slot");
+    constexpr int QCAP = 64;
     __shared__ int q_idx[WG / 64][QCAP], q_slot[WG / 64][QCAP];
     __shared__ double q_val[WG / 64][QCAP];
-    __shared__ long long frow_tab[WG / 64][SLOTS];
-    if (half == 0) {
-#pragma unroll
-        for (int c = 0; c < NT; ++c) frow_tab[wave][c * 32 + col] = frow[c];
-    }
     int qn = 0;                               // wave-uniform
+    // The way out.  The bound is only as good as its reference: a state whose few on-pipe mixtures are themselves nearly collapsed gives
+    // frames far from all of them a likelihood so low that every tight mixture passes, and a lane per pair with gathered rows is several
+    // times the direct-form kernel's cost per pair (config 4's seventh EM iteration: 673 such states, 252 ms of coarse pass against the
+    // 45 ms their direct form takes).  A wave that has evaluated more than max(4096, 2 x tight mixtures) pairs -- 3 % of its 64 frames'
+    // -- gives up: the workgroup raises the tile's flag at the next stage boundary and the direct-form subset kernel rescoring flagged
+    // tiles does the tile (nothing has been written yet: results leave the kernel at its end).
+    int n_eval = 0;                           // wave-uniform
     double tmaxL = -INFINITY, tsumL = 0.0;
     auto flush = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -198,27 +264,42 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         if (lane < qn) {
             const int idx = q_idx[wave][lane];
             double v = -INFINITY;
+#ifdef PCL_COARSE_EXP
+            if (idx < n_tight && !(PCL_COARSE_EXP & 1)) {
+#else
             if (idx < n_tight) {
+#endif
                 const double k2 = ex.k2c[srow + idx];
                 if (k2 > -1.0e300) {                             // (not a zero weight)
-                    const size_t jm = (srow + ex.bad_idx[srow + idx]) * D;
+                    const float2 *rw = ex.rows + (srow + idx) * D;
                     const float *fp = frames + frow_tab[wave][q_slot[wave][lane]] * D;
                     // The direct form in the f32 arithmetic of the accumulate pass's subset kernel (gmm_accumulate.hip MASTER rows: s = sqrtf of the
                     // f32 coefficient, c = (float)(-mu s), y = fma(x, s, c), q = fma(y, y, q) over d ascending, k2 as a float) -- on purpose.  A first
                     // version evaluated these pairs in float64; the soak then failed 18 of 1520 random E-steps on `acc` by 1.2-3.9e-4: the posterior the
                     // accumulate pass forms, exp2(v_m - ln b), is exp2 of the DIFFERENCE of its own f32 value of a tight mixture and the scoring's value,
                     // and where one such mixture carries the frame the two must round alike to cancel (as they did in rounds 4-5, both direct form).
+                    // The rows (s, c) come ready from coarse_derive_kernel: made here from the float64 master copy (a division, a square root and
+                    // two 8-byte loads from random rows of two 1.9 GB arrays per term, one after the other) a flush took ~50 us and the evaluation
+                    // of 0.02 % of the pairs 36 % of the launch (profiles/r06_coarse_parts.txt).
+                    constexpr int CHK = 13;                      // (terms loaded together: 39 registers in flight, not 117)
                     float q = 0.f;
 #pragma unroll
-                    for (int d = 0; d < D; ++d)
-                        if (d < ex.Dhost) {
-                            const double vv = ex.var64[jm + d], mu = ex.mean64[jm + d];
-                            const float a = (float)(-LOG2E * (0.5 / vv));
-                            const float sf = sqrtf(-a);
-                            const float cv = (float)(-mu * (double)sf);
-                            const float y = __builtin_fmaf(fp[d], sf, cv);
-                            q = __builtin_fmaf(y, y, q);
-                        }
+                    for (int d0 = 0; d0 < D; d0 += CHK) {
+                        float2 r[CHK];
+                        float xv[CHK];
+#pragma unroll
+                        for (int i = 0; i < CHK; ++i)
+                            if (d0 + i < D) {
+                                r[i] = rw[d0 + i];
+                                xv[i] = fp[d0 + i];
+                            }
+#pragma unroll
+                        for (int i = 0; i < CHK; ++i)
+                            if (d0 + i < D && d0 + i < ex.Dhost) {
+                                const float y = __builtin_fmaf(xv[i], r[i].x, r[i].y);
+                                q = __builtin_fmaf(y, y, q);
+                            }
+                    }
                     v = (double)((float)k2 - q);
                     ++n_cand;
                 }
@@ -242,6 +323,7 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
                 tsumL += ::exp2(v - tmaxL);
             }
         }
+        n_eval += qn;
         qn = 0;
         // an exact value that lifts a frame's maximum raises its threshold
 #pragma unroll
@@ -252,13 +334,14 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         }
     };
 
-    auto process = [&](int mt) {
-        const uint4 *ab = &abuf[mt & 1][0];
+    auto process = [&](int mt, const uint4 *ab) {
         f16v acc[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        // (the compiler puts s_waitcnt vmcnt(0) before these reads -- LDS-DMA writes LDS -- so a tile's first read waits for the next stage's
+        //  loads; reading through inline asm instead, without that wait, measured no faster: 10.8 ms against 10.3, profiles/r06_coarse_parts.txt)
         auto pass = [&](int pa, int pb) {
 #pragma unroll
             for (int s = 0; s < KS8; ++s) {
@@ -267,9 +350,18 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
                 for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[c][pb][s], acc[c], 0, 0, 0);
             }
         };
-        pass(1, 0);
-        pass(0, 1);
+        if constexpr (NP != 1) {
+            pass(1, 0);
+            pass(0, NPB - 1);
+        }
+#ifdef PCL_COARSE_EXP
+        if (!(PCL_COARSE_EXP & 2))
+#endif
         pass(0, 0);
+#ifdef PCL_COARSE_EXP
+        if (PCL_COARSE_EXP & 2) for (int c = 0; c < NT; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = -1.f - (float)ab[lane].x * 1e-30f;
+        if (PCL_COARSE_EXP & 4) for (int c = 0; c < NT; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = -1.f - __builtin_fabsf(acc[c][r]) * 1e-30f;
+#endif
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             float gm = acc[c][0];
@@ -280,8 +372,13 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) mask |= (acc[c][r] >= 0.f ? 1u : 0u) << r;
             const float t_mfma = tcur[c];                        // the threshold these accumulators are relative to
-#pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
+            unsigned int rows_any = 0u;                          // (wave-uniform: the accumulator rows in which some lane passed -- one or two of the 16)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rows_any |= (__ballot(acc[c][r] >= 0.f) != 0ull ? 1u : 0u) << r;
+            rows_any = __builtin_amdgcn_readfirstlane(rows_any);
+            while (rows_any) {
+                const int r = __builtin_ctz(rows_any);
+                rows_any &= rows_any - 1u;
                 bool hit = (mask >> r) & 1u;
                 unsigned long long bal = __ballot(hit);
                 if (!bal) continue;
@@ -312,12 +409,26 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         }
     };
 
+    const int n_stages = (n_mtiles + MT - 1) / MT;
+    const int budget = max(4096, 2 * n_tight);
     dma(0, 0);
-    for (int st = 0; st < n_mtiles; ++st) {
+    for (int st = 0; st < n_stages; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (st + 1 < n_mtiles) dma((st + 1) & 1, st + 1);
-        if (wave_active) process(st);
+        // (slot st & 1 was written during stage st - 1 and is read by every wave after this barrier; what stage st raises goes to the other slot)
+        if (s_bail[st & 1]) {
+            if (threadIdx.x == 0) flags[blockIdx.x] = 1;
+            if (counters && lane == 0 && n_eval) atomicAdd(counters, (unsigned long long)n_eval);
+            if (counters && threadIdx.x == 0) atomicAdd(counters + 1, 1ull);
+            return;
+        }
+        if (st + 1 < n_stages) dma((st + 1) & 1, st + 1);
+        if (wave_active) {
+#pragma unroll 1
+            for (int i = 0; i < MT && n_eval <= budget; ++i)
+                if (st * MT + i < n_mtiles) process(st * MT + i, &abuf[st & 1][i * PCS * 64]);
+            if (n_eval > budget && lane == 0) s_bail[(st + 1) & 1] = 1;
+        }
     }
     if (qn) flush();
     constexpr double LN2 = 0.693147180559945309417232121458;
@@ -353,18 +464,22 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
                                                             const double *__restrict__ w64, const float *__restrict__ centers, int M, int Mpad,
                                                             int Mpad32, int D, int Dhost, int flags, const int *__restrict__ bad_idx,
                                                             const int *__restrict__ nbad, uint4 *__restrict__ pmc, float *__restrict__ fscale_c,
-                                                            double *__restrict__ kzero_c, double *__restrict__ k2c, int *__restrict__ nct) {
+                                                            double *__restrict__ kzero_c, double *__restrict__ k2c, int *__restrict__ nct,
+                                                            int np, float *__restrict__ kgap_c, float2 *__restrict__ rows_c) {
     const int j = blockIdx.x, tid = threadIdx.x;
     const int nb = nbad[j], ntl = (nb + 31) / 32, nmt = Mpad32 / 32, KS8 = (D + 7) / 8;
-    if (tid == 0) nct[j] = ntl;
+    if (tid == 0) {
+        nct[j] = ntl;
+        kgap_c[j] = 0.f;
+    }
     if (nb == 0) return;
     __shared__ float fa[32 * DMAX], fb[32 * DMAX], cen[DMAX], isc[2 * 64];
     __shared__ float kc[32];
     __shared__ unsigned int mxa[64], mxb[64];
-    __shared__ int kbits;
+    __shared__ int kbits, k2bits;
     for (int d = tid; d < D; d += 256) cen[d] = centers[(size_t)j * D + d];
     if (tid < 64) mxa[tid] = mxb[tid] = 0u;
-    if (tid == 0) kbits = (int)0x80808080;
+    if (tid == 0) kbits = k2bits = (int)0x80808080;
     __syncthreads();
     const int ml = tid >> 3, sub = tid & 7;
     const size_t srow = (size_t)j * Mpad;
@@ -415,6 +530,16 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
                 if (write) {
                     fa[ml * D + dd] = a;
                     fb[ml * D + dd] = b;
+                    if (real_m) {
+                        // the direct form's row of this mixture, in the arithmetic of the accumulate pass's MASTER rows (gmm_accumulate.hip) -- see `flush`
+                        float2 rc = make_float2(0.f, 0.f);
+                        if (dd < Dhost) {
+                            const float a32 = (float)(-LOG2E * (0.5 / v[k]));
+                            const float sf = sqrtf(-a32);
+                            rc = make_float2(sf, (float)(-mean64[jm + dd] * (double)sf));
+                        }
+                        rows_c[(srow + idx) * D + dd] = rc;
+                    }
                 }
             }
         }
@@ -430,7 +555,7 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
         real_out = real_m;
     };
     // ---- pass A
-    float kmax = -INFINITY;
+    float kmax = -INFINITY, k2max = -INFINITY;
     bool any = false;
     for (int t = 0; t < ntl; ++t) {
         double k2, kq;
@@ -439,15 +564,17 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
         if (sub == 0 && real_m) {
             k2c[srow + t * 32 + ml] = k2;
             if (k2 > -INFINITY) {
-                const float kp = (float)(k2 - kq);
+                const float kp = (float)(k2 - kq), k2f = (float)k2;
                 kmax = any ? fmaxf(kmax, kp) : kp;
+                k2max = any ? fmaxf(k2max, k2f) : k2f;
                 any = true;
             }
         }
     }
     if (any) {
-        const int i = __float_as_int(kmax);
+        const int i = __float_as_int(kmax), i2 = __float_as_int(k2max);
         atomicMax(&kbits, i >= 0 ? i : i ^ 0x7fffffff);
+        atomicMax(&k2bits, i2 >= 0 ? i2 : i2 ^ 0x7fffffff);
     }
     __syncthreads();
     for (int t = tid; t < 2 * KS8 * 8; t += 256) {
@@ -466,7 +593,13 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
         const float f = __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
         if (i != (int)0x80808080 && f > -3.0e38f) k0 = (double)f;
     }
-    if (tid == 0) kzero_c[j] = k0;
+    if (tid == 0) {
+        kzero_c[j] = k0;
+        const int i2 = k2bits;
+        const float f2 = __int_as_float(i2 >= 0 ? i2 : i2 ^ 0x7fffffff);
+        // (the state's largest k2) - K0, rounded up: what a frame's threshold is measured from in the one-product pass
+        kgap_c[j] = (i2 != (int)0x80808080 && f2 > -3.0e38f) ? (float)((double)f2 - k0) + 1.0f + 1.0e-6f * fabsf(f2) : 0.f;
+    }
     __syncthreads();
     // ---- pass B
     for (int t = 0; t < ntl; ++t) {
@@ -477,8 +610,10 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
             float c = -6.0e4f;                                    // log zero: padding rows, zero weights
             if (real_m && k2 > -INFINITY) {
                 const double kpp = k2 - kq - k0;
-                const double em = EPS_C * (fabs(kpp) + 8.0 * kq + 2.0 * fabs(k2)) + 0.25;
-                const double kk = kpp + em;
+                double em = EPS_C * (fabs(kpp) + 8.0 * kq + 2.0 * fabs(k2)) + 0.25;
+                if (np == 1) em += EPS1 * 3.0 * kq + 0.5;         // the mixture's share of the linear terms' rounding + what f16 subnormals lose
+                double kk = kpp + em;
+                if (np == 1) kk += 0.0009765625 * fabs(kk);       // its own single piece (2^-11 |kk| to nearest), and (float) below
                 c = (kk > -5.0e4) ? (float)kk : -6.0e4f;          // (cannot be: kq <= KQ_MAX)
             }
             kc[ml] = c;
@@ -500,11 +635,11 @@ __global__ __launch_bounds__(256) void coarse_derive_kernel(const double *__rest
                     is_const = true;
                     val = half ? 1.f : kc[cl];
                 }
-                const _Float16 h1 = (_Float16)val;
+                const _Float16 h1 = (np == 1 && !is_const && half == 0) ? f16_toward_zero(val) : (_Float16)val;
                 _Float16 hp;
                 if (!is_const) hp = p ? (_Float16)(val - (float)h1) : h1;
                 else if (half == 0) hp = p ? ((val <= -6.0e4f) ? (_Float16)0.f : (_Float16)(val - (float)h1)) : h1;    // k1 | k2
-                else hp = p ? (_Float16)1.f : (_Float16)0.f;                                                       // a1: 0, a2: 1
+                else hp = (p != 0) == (np != 1) ? (_Float16)1.f : (_Float16)0.f;       // the threshold's slot: a1: 0, a2: 1 (one product: a1: 1, a2: 0)
                 h[x] = __builtin_bit_cast(unsigned short, hp);
             }
             pf[e] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
@@ -603,11 +738,16 @@ __global__ __launch_bounds__(256) void compact_main_kernel(const double *__restr
     }
 }
 
+template <int D, int NP>
+void launch_coarse_p(pcl_ctx *ctx, pcl_batch *b, const CoarseExact &ex, unsigned long long *counters) {
+    hipLaunchKernelGGL((gmm_score_coarse_kernel<D, PCL_COARSE_NT, NP>), dim3(b->n_tiles_c), dim3(WG), 0, ctx->stream, ctx->frames32,
+                       reinterpret_cast<const uint4 *>(ctx->pmc), ctx->fscale_c, ctx->centers32, ctx->Mpad32 / 32, ctx->d_nct, b->d_tiles_c, b->d_segs,
+                       b->Bt, b->d_tile_flags_c, ctx->kzero_c, ctx->kgap_c, ex, counters);
+}
 template <int D>
 void launch_coarse_t(pcl_ctx *ctx, pcl_batch *b, const CoarseExact &ex, unsigned long long *counters) {
-    hipLaunchKernelGGL((gmm_score_coarse_kernel<D, PCL_COARSE_NT>), dim3(b->n_tiles_c), dim3(WG), 0, ctx->stream, ctx->frames32,
-                       reinterpret_cast<const uint4 *>(ctx->pmc), ctx->fscale_c, ctx->centers32, ctx->Mpad32 / 32, ctx->d_nct, b->d_tiles_c, b->d_segs,
-                       b->Bt, b->d_tile_flags_c, ctx->kzero_c, ex, counters);
+    if (ctx->coarse_np == 1) launch_coarse_p<D, 1>(ctx, b, ex, counters);
+    else launch_coarse_p<D, 3>(ctx, b, ex, counters);
 }
 
 }  // namespace
@@ -623,6 +763,8 @@ void pcl_coarse_release(pcl_ctx *ctx) {
     dev_free(ctx->pmc);
     dev_free(ctx->fscale_c);
     dev_free(ctx->kzero_c);
+    dev_free(ctx->kgap_c);
+    dev_free(ctx->rows_c);
     dev_free(ctx->k2c);
     dev_free(ctx->d_nct);
     dev_free(ctx->d_coarse_counter);
@@ -637,16 +779,18 @@ int pcl_ensure_coarse(pcl_ctx *ctx) {
         TRY(dev_alloc(ctx, &ctx->pmc, (size_t)ctx->J * nmt * (2 * KS8 * 64) * 8));      // unsigned short elements: 8 per uint4
         TRY(dev_alloc(ctx, &ctx->fscale_c, (size_t)ctx->J * 2 * KS8 * 8));
         TRY(dev_alloc(ctx, &ctx->kzero_c, (size_t)ctx->J));
+        TRY(dev_alloc(ctx, &ctx->kgap_c, (size_t)ctx->J));
+        TRY(dev_alloc(ctx, &ctx->rows_c, (size_t)ctx->J * ctx->Mpad * ctx->D * 2));
         TRY(dev_alloc(ctx, &ctx->k2c, (size_t)ctx->J * ctx->Mpad));
         TRY(dev_alloc(ctx, &ctx->d_nct, (size_t)ctx->J));
-        TRY(dev_alloc(ctx, &ctx->d_coarse_counter, (size_t)1));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_coarse_counter, 0, sizeof(unsigned long long), ctx->stream));
+        TRY(dev_alloc(ctx, &ctx->d_coarse_counter, (size_t)2));              // [pairs evaluated in direct form, tiles given up]
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_coarse_counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
     }
     pcl_timer_begin(ctx, "derive_coarse");
     if (ctx->D > 48) PCL_FAIL(ctx, PCL_ERR_INVALID, "internal: coarse layout for D=%d", ctx->D);
     hipLaunchKernelGGL((coarse_derive_kernel<48>), dim3(ctx->J), dim3(256), 0, ctx->stream, ctx->mean64, ctx->var64, ctx->w64, ctx->centers32, ctx->M,
                        ctx->Mpad, ctx->Mpad32, ctx->D, ctx->Dhost, ctx->model_flags, ctx->d_bad_idx, ctx->d_nbad, reinterpret_cast<uint4 *>(ctx->pmc),
-                       ctx->fscale_c, ctx->kzero_c, ctx->k2c, ctx->d_nct);
+                       ctx->fscale_c, ctx->kzero_c, ctx->k2c, ctx->d_nct, ctx->coarse_np, ctx->kgap_c, reinterpret_cast<float2 *>(ctx->rows_c));
     pcl_timer_end(ctx, "derive_coarse");
     HIPCHK(ctx, hipGetLastError());
     ctx->coarse_gen = ctx->model_gen;
@@ -657,7 +801,7 @@ int pcl_ensure_coarse(pcl_ctx *ctx) {
 int pcl_launch_score_coarse(pcl_ctx *ctx, pcl_batch *b) {
     if (b->n_tiles_c == 0) return PCL_OK;
     TRY(pcl_ensure_coarse(ctx));
-    const CoarseExact ex{ctx->mean64, ctx->var64, ctx->k2c, ctx->d_bad_idx, ctx->d_nbad, ctx->Mpad, ctx->Dhost};
+    const CoarseExact ex{reinterpret_cast<const float2 *>(ctx->rows_c), ctx->k2c, ctx->d_nbad, ctx->Mpad, ctx->Dhost};
     unsigned long long *counters = ctx->coarse_stats ? ctx->d_coarse_counter : nullptr;
     pcl_timer_begin(ctx, "score_coarse");
     switch (ctx->D) {
@@ -687,12 +831,18 @@ int pcl_launch_compact_main(pcl_ctx *ctx, int j_lo, int j_hi) {
     return PCL_OK;
 }
 
-int pcl_coarse_counter(pcl_ctx *ctx, unsigned long long *pairs, int reset) {
+int pcl_coarse_counters(pcl_ctx *ctx, unsigned long long *pairs, unsigned long long *tiles_given_up, int reset) {
     if (!ctx || !pairs) return PCL_ERR_INVALID;
+    unsigned long long both[2] = {0, 0};
     *pairs = 0;
+    if (tiles_given_up) *tiles_given_up = 0;
     if (!ctx->d_coarse_counter) return PCL_OK;
-    HIPCHK(ctx, hipMemcpyAsync(pairs, ctx->d_coarse_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d_coarse_counter, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(both, ctx->d_coarse_counter, sizeof(both), hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d_coarse_counter, 0, sizeof(both), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *pairs = both[0];
+    if (tiles_given_up) *tiles_given_up = both[1];
     return PCL_OK;
 }
+
+int pcl_coarse_counter(pcl_ctx *ctx, unsigned long long *pairs, int reset) { return pcl_coarse_counters(ctx, pairs, nullptr, reset); }

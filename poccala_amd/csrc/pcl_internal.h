@@ -136,11 +136,14 @@ struct pcl_ctx {
     unsigned short *pmc = nullptr;     // [J][Mpad32/32][2][KS8f][64 lanes][8]: the state's bad_idx list, 32 per tile
     float *fscale_c = nullptr;         // [J][2][KS8f*8]
     double *kzero_c = nullptr;         // [J]
+    float *rows_c = nullptr;           // [J][Mpad][D][2]: the tight mixtures' direct-form rows (s_d, c_d) in bad_idx order, for the pairs the coarse pass cannot rule out
+    float *kgap_c = nullptr;           // [J]: (the state's largest tight k2) - K0, rounded up (the one-product pass: see EPS1 in gmm_score_coarse.hip)
+    int coarse_np = 1;                 // env PCL_COARSE_PASSES (read when the context is made): 1 = one f16 product per term, 3 = the two-piece operands' three
     double *k2c = nullptr;             // [J][Mpad] exact log2-domain constant of the idx-th off-pipe mixture
     int *d_nct = nullptr;              // [J] coarse tiles in use
     unsigned long long *d_coarse_counter = nullptr;   // PCL_COARSE_STATS=1: pairs evaluated exactly
     int coarse_gen = -1;
-    float coarse_split_frac = 0.95f;   // env PCL_COARSE_SPLIT_MAX: the share of a state's mixtures that may be off the pipe with the coarse pass (see pcl_model_upload)
+    float coarse_split_frac = 0.99f;   // env PCL_COARSE_SPLIT_MAX: the share of a state's mixtures that may be off the pipe with the coarse pass (see pcl_model_upload)
     bool coarse_stats = false;         // env PCL_COARSE_STATS=1 (read when the context is made): count the pairs evaluated exactly (pcl_coarse_counter)
     bool coarse_on = true;             // env PCL_COARSE=0 (read when the context is made): the direct-form subset launch of rounds 4-5 instead (A/B)
     // the accumulate pass keeps the round 4-5 rule (whole states in direct form above acc_split_max off-pipe mixtures): its subset launch has

@@ -349,6 +349,13 @@ class Engine(object):
         self._check(self._lib.pcl_coarse_counter(self._ctx, ptr(n), 1 if reset else 0))
         return int(n[0])
 
+    def coarse_counters(self, reset=True):
+        """(pairs evaluated exactly, tiles the coarse pass gave up and the direct-form subset kernel rescored) since the last reset
+        (counted under PCL_COARSE_STATS=1)."""
+        n, g = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
+        self._check(self._lib.pcl_coarse_counters(self._ctx, ptr(n), ptr(g), 1 if reset else 0))
+        return int(n[0]), int(g[0])
+
     # ------------------------------------------------------------------ RCCL
     def comm_unique_id(self):
         buf = np.zeros(128, dtype=np.uint8)

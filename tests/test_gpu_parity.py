@@ -728,7 +728,7 @@ def test_ill_conditioned_states_use_direct_form(eng):
 # ------------------------------------------------------------------ split states: single tight mixtures leave the matrix-core path
 def split_model(seed, units=4, M=64, D=39):
     """The bench model with a few mixtures per state collapsed to a variance of 1e-3 .. 1e-2 (what an M-step leaves when a mixture
-    owns one or two frames): state j gets j % 4 * 3 of them -- none for every fourth state -- and the last state 62 of 64, more than
+    owns one or two frames): state j gets j % 4 * 3 of them -- none for every fourth state -- and the last state all of them, more than
     the share a split state may have (it goes to the direct-form kernels as a whole)."""
     from poccala_amd import synth
     rng = np.random.default_rng(seed)
@@ -736,7 +736,7 @@ def split_model(seed, units=4, M=64, D=39):
     J = mean.shape[0]
     tight = []
     for j in range(J):
-        n = (j % 4) * 3 if j < J - 1 else (62 * M) // 64
+        n = (j % 4) * 3 if j < J - 1 else M
         idx = np.sort(rng.choice(M, n, replace=False))
         var[j, idx] = rng.uniform(1e-3, 1e-2, (n, D))
         tight.append(idx)
@@ -762,7 +762,7 @@ def test_split_states_merge_both_kernels(eng):
     cond, cmax = eng.model_conditioning()
     n_off, limit = eng.model_split_info()
     cm = mixture_conditioning(mean, var)
-    assert limit == int(np.float32(0.95) * np.float32(M))            # (scoring, with the coarse pass; the accumulate pass keeps 0.5)
+    assert limit == int(np.float32(0.99) * np.float32(M))            # (scoring, with the coarse pass; the accumulate pass keeps 0.5)
     assert np.array_equal(n_off, [len(t) for t in tight]) and np.array_equal(n_off, (cm > cmax).sum(1))
     assert ((cond > cmax) == (n_off > 0)).all()                      # cond stays the state's worst mixture
     split = (n_off > 0) & (n_off <= limit)
@@ -1153,9 +1153,9 @@ def test_estep_variants_split_states(eng_variant):
     J, M, D = mean.shape
     eng.load_model(mean, var, w)
     n_off, limit = eng.model_split_info()
-    # (variant 7 keeps states split for SCORING up to 0.95 of their mixtures -- the coarse pass, gmm_score_coarse.hip --; the others, and every
+    # (variant 7 keeps states split for SCORING up to 0.99 of their mixtures -- the coarse pass, gmm_score_coarse.hip --; the others, and every
     #  variant's accumulate pass, up to half)
-    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == int(np.float32(0.95 if eng.score_variant == 7 else 0.5) * np.float32(M))
+    assert np.array_equal(n_off, [len(t) for t in tight]) and limit == int(np.float32(0.99 if eng.score_variant == 7 else 0.5) * np.float32(M))
     U, L, PER = 5, 3, 5
     labels = [list(rng.integers(0, len(trans), L)) for _ in range(U)]
     TU = L * (S - 2) * PER
