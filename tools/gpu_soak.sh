@@ -5,7 +5,8 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 S=${SOAK_SEED:-300}       # (E-step fuzz: seeds below 1000 are the small draws, from 1000 the big ones; HMM fuzz: from 5000 the long utterances)
 P=${SOAK_PART:-12}      # 1 = the randomised harnesses (~18 min), 2 = lifecycle + the full-size tests at full depth (~6 min); a gpurun call lasts at most 20 min: run the parts in two calls
 if [[ $P == *1* ]]; then
-timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py $((S < 300 ? 1000 - S : 700 > 1000 - S ? 1000 - S : 700)) $S > gpurun_out/soak_estep.txt 2>&1; echo "estep rc=$? $(tail -1 gpurun_out/soak_estep.txt)"
+ES=$((S % 300))            # (the small draws are the seeds below 1000: 700 of them from S mod 300 -- a seed of 20000 used to ask for a negative count and ran none)
+timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py 700 $ES > gpurun_out/soak_estep.txt 2>&1; echo "estep rc=$? $(tail -1 gpurun_out/soak_estep.txt)"
 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 60 $((S + 1200)) > gpurun_out/soak_estep_big.txt 2>&1; echo "estep big rc=$? $(tail -1 gpurun_out/soak_estep_big.txt)"
 timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 500 $S > gpurun_out/soak_hmm.txt 2>&1; echo "hmm rc=$? $(tail -1 gpurun_out/soak_hmm.txt)"
 timeout -k 10 200 python3 tests/test_gpu_fuzz_hmm.py 40 $((S + 5100)) > gpurun_out/soak_hmm_long.txt 2>&1; echo "hmm long rc=$? $(tail -1 gpurun_out/soak_hmm_long.txt)"
