@@ -308,21 +308,40 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        // The values into their frames' log-sum-exps, in queue order.  In three steps so that the float64 exp2 -- a hundred instructions --
+        // runs twice per flush for all lanes at once: (1) the owner lane of a frame slot takes the maximum of its running one and its new
+        // values; (2) every entry's lane forms exp2(value - its slot's maximum), every owner rescales its running sum; (3) the owner adds
+        // its entries' terms in queue order.  (An online update per entry ran the exp2 once per ENTRY with one lane active: with ~17
+        // entries a flush that was most of the time the direct-form evaluation took.)
+        double nm = tmaxL;
+        bool got = false;
 #pragma unroll 1
-        for (int i = 0; i < qn; ++i) {
-            if (q_slot[wave][i] != lane) continue;
-            const double v = q_val[wave][i];
-            if (!(v > -1.0e300)) continue;
-            if (tsumL == 0.0) {
-                tmaxL = v;
-                tsumL = 1.0;
-            } else if (v > tmaxL) {
-                tsumL = tsumL * ::exp2(tmaxL - v) + 1.0;
-                tmaxL = v;
-            } else {
-                tsumL += ::exp2(v - tmaxL);
+        for (int i = 0; i < qn; ++i)
+            if (q_slot[wave][i] == lane) {
+                const double vi = q_val[wave][i];
+                if (vi > -1.0e300) {
+                    nm = ::fmax(nm, vi);
+                    got = true;
+                }
             }
+        {
+            const int my_slot = lane < qn ? q_slot[wave][lane] : lane;
+            const double vmine = lane < qn ? q_val[wave][lane] : -INFINITY;
+            const double nm_slot = __shfl(nm, my_slot, 64);
+            const double e = (vmine > -1.0e300) ? ::exp2(vmine - nm_slot) : 0.0;
+            if (got) {                                       // (tsumL == 0 with tmaxL = -inf before the first value: 0 * exp2(-inf) = 0)
+                tsumL *= ::exp2(tmaxL - nm);
+                tmaxL = nm;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < qn) q_val[wave][lane] = e;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int i = 0; i < qn; ++i)
+            if (q_slot[wave][i] == lane) tsumL += q_val[wave][i];
         n_eval += qn;
         qn = 0;
         // an exact value that lifts a frame's maximum raises its threshold
