@@ -44,7 +44,10 @@
 
 namespace {
 
-constexpr int WG = 256;
+#ifndef PCL_COARSE_NT
+#define PCL_COARSE_NT 2
+#endif
+constexpr int WG = 8 * 32 / PCL_COARSE_NT * 64 / 32;      // a workgroup covers 256 frames: 4 waves of two 32-frame groups (or 8 of one)
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
@@ -70,9 +73,6 @@ struct CoarseExact {
     int Mpad, Dhost;
 };
 
-#ifndef PCL_COARSE_NT
-#define PCL_COARSE_NT 2
-#endif
 #ifndef PCL_COARSE_MINW
 #define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at: 2 (199 VGPRs, nothing spilled).  3 (168 VGPRs, 28 spilled) measured 4 % faster on the shard probe and 8-10 % slower inside config 4's EM iterations (coarse 93 / 137 ms against 86 / 124): profiles/r06_coarse_ab.txt
 #endif
@@ -225,9 +225,13 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         set_threshold(c, valid[c] ? (t2 > -1.0e30 ? (float)t2 : -TMAX) : TMAX);
     }
 
-    // A stage = MT mixture tiles (one product: 4 tiles' leading pieces, 20 KB at D = 39; three: 2 tiles, both pieces): a tile of one
-    // product is ~400 cycles of work for a wave, a fraction of the latency of the loads that bring the next -- two tiles in flight
-    // left the kernel waiting on them (70 ms per batch where a third of the products should have given 30).
+    // A stage = MT mixture tiles (one product: 4 tiles' leading pieces, 20 KB at D = 39; three: 2 tiles, both pieces), by LDS-DMA one
+    // stage ahead.  The kernel stays latency bound (matrix pipe 17 % busy at a clock the power cap does not reach, SQ_WAIT_ANY 61 % of the
+    // wave time: profiles/r06_coarse_summary.txt) and the obvious suspects were each measured and are NOT it (profiles/r06_coarse_rework.txt):
+    // the compiler's s_waitcnt vmcnt(0) before LDS reads that follow an LDS-DMA (reads through inline asm: 10.8 ms against 10.3), the
+    // stages themselves (global loads to registers + ds_write, the classic double buffer: 14.1; every wave reading its A operand from
+    // global memory with no stage and no barrier at all: 9.3), occupancy (one 32-frame group per wave, 8 waves per workgroup, at 2 / 3 / 4
+    // waves per SIMD: 17.6 / 15.3 / 12.5).  What is left is the serial shape of a wave's own work: products -> max tree -> branch.
     const uint4 *pstate = pm + (size_t)tile.state * nmt_max * (CH * 64);
     auto dma = [&](int buf, int stage) {
         const int nt = min(MT, n_mtiles - stage * MT);

@@ -98,14 +98,14 @@ def check(tag, got, mean, var, w, x):
     return hold(tag, 'ln b', got[fin], ref[fin], 5e-6, (F32_LOGLIK_ATOL + bound)[fin])
 
 
-@pytest.mark.parametrize('seed,D', [(11, 39), (12, 39), (13, 13), (14, 26)])
-def test_coarse_pass_against_the_oracle_over_six_decades_of_variance(seed, D):
+@pytest.mark.parametrize('seed,D,passes', [(11, 39, 1), (12, 39, 1), (13, 13, 1), (14, 26, 1), (11, 39, 3), (13, 13, 3)])
+def test_coarse_pass_against_the_oracle_over_six_decades_of_variance(seed, D, passes):
     rng = np.random.default_rng(seed)
     J, M = 8, 96
     shares = [0.0, 0.05, 0.3, 0.5, 0.7, 0.84, 0.3, 0.6]
     mean, var, w, tight = tight_model(seed, J, M, D, shares)
     x, own = frames_for(rng, mean, var, tight, 300)
-    eng = _engine(PCL_COARSE_STATS=1)
+    eng = _engine(PCL_COARSE_STATS=1, PCL_COARSE_PASSES=passes)     # (1: one f16 product per term, the default; 3: the two-piece operands' three)
     try:
         eng.enable_timing(True)
         got = score_all(eng, mean, var, w, x)
@@ -114,7 +114,7 @@ def test_coarse_pass_against_the_oracle_over_six_decades_of_variance(seed, D):
         assert eng.kernel_time('score_coarse')[1] == 1 and eng.kernel_time('score_subset')[1] == 0 and eng.kernel_time('score_direct')[1] == 0
         exact = eng.coarse_pairs()
         all_pairs = int(n_off.sum()) * len(x)
-        note('coarse pass, seed %d D=%d' % (seed, D), 'pairs evaluated exactly / pairs of off-pipe mixtures', [exact, all_pairs])
+        note('coarse pass, seed %d D=%d, %d product(s)' % (seed, D, passes), 'pairs evaluated exactly / pairs of off-pipe mixtures', [exact, all_pairs])
         # frames ON a collapsed mixture and within a few sigma of a tight one do pass -- that is a third of the frames times one mixture or so;
         # the rest of the pairs must have been ruled out by the bound
         assert 0 < exact < 0.05 * all_pairs, (exact, all_pairs)

@@ -52,8 +52,21 @@ run dec_write "WRITE_SIZE" $DEC
 run dec_clk "GRBM_GUI_ACTIVE" $DEC
 run dec_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $DEC
 fi
+if has coarse; then
+# the coarse pass on the C4 shard's model after two EM iterations (73 % off-pipe mixtures): the model is made once, outside the profiler, and left
+# under /tmp of this box; every pass loads it and scores the batch four times
+timeout 300 python3 $R/tools/coarse_time_probe.py make 2 > $OUT/coarse_make.log 2>&1 || echo "coarse model failed" >> $OUT/failures.log
+run coarse_trace "" $R/tools/coarse_time_probe.py time
+run coarse_fetch "FETCH_SIZE" $R/tools/coarse_time_probe.py time
+run coarse_write "WRITE_SIZE" $R/tools/coarse_time_probe.py time
+run coarse_clk "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" $R/tools/coarse_time_probe.py time
+run coarse_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" $R/tools/coarse_time_probe.py time
+run coarse_sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" $R/tools/coarse_time_probe.py time
+run coarse_lds "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" $R/tools/coarse_time_probe.py time
+rm -f /tmp/em_model_*.npy
+fi
 RND=${RND:-r06}
 python3 $R/tools/make_profile_summary.py $OUT $RND
 find $OUT -name "*.csv" -size +1M -delete
 cat $OUT/failures.log 2>/dev/null
-tail -22 $OUT/${RND}_bench_summary.txt; tail -22 $OUT/${RND}_accumulate_summary.txt; cat $OUT/${RND}_fb_summary.txt; tail -12 $OUT/${RND}_decode_summary.txt
+tail -22 $OUT/${RND}_bench_summary.txt; tail -22 $OUT/${RND}_accumulate_summary.txt; cat $OUT/${RND}_fb_summary.txt; tail -12 $OUT/${RND}_decode_summary.txt; has coarse && tail -30 $OUT/${RND}_coarse_summary.txt

@@ -13,5 +13,7 @@ PCL_SPLIT_MAX=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > g
 PCL_COARSE=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_nocoarse.txt 2>&1; echo "PCL_COARSE=0 rc=$? $(tail -1 gpurun_out/knob_estep_nocoarse.txt)"
 PCL_COMPACT_MAIN=0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_nocompact.txt 2>&1; echo "PCL_COMPACT_MAIN=0 rc=$? $(tail -1 gpurun_out/knob_estep_nocompact.txt)"
 PCL_COARSE_SPLIT_MAX=1.0 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_split1.txt 2>&1; echo "PCL_COARSE_SPLIT_MAX=1.0 rc=$? $(tail -1 gpurun_out/knob_estep_split1.txt)"
+PCL_COARSE_PASSES=3 timeout -k 10 200 python3 tests/test_gpu_fuzz_estep.py 150 0 > gpurun_out/knob_estep_np3.txt 2>&1; echo "PCL_COARSE_PASSES=3 rc=$? $(tail -1 gpurun_out/knob_estep_np3.txt)"
+PCL_COARSE_PASSES=3 timeout -k 10 200 python3 tools/coarse_fuzz.py 40 500 > gpurun_out/knob_coarse_np3.txt 2>&1; echo "PCL_COARSE_PASSES=3 coarse fuzz rc=$? $(tail -1 gpurun_out/knob_coarse_np3.txt)"
 timeout -k 10 300 python3 tests/test_gpu_fuzz_estep.py 100 6000 > gpurun_out/knob_estep_bigM.txt 2>&1; echo "seeds 6000.. rc=$? $(tail -1 gpurun_out/knob_estep_bigM.txt)"
 grep -h FAILED gpurun_out/knob_*.txt | head -20

@@ -159,3 +159,29 @@ try:
 except (KeyError, IndexError, ZeroDivisionError) as e:
     out.append('(derived block incomplete: %r)' % (e,))
 open(os.path.join(P, '%s_decode_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
+
+# ---------------------------------------------------------------- the coarse pass (tools/coarse_time_probe.py time: the C4 shard's model after two EM iterations)
+out = ['# rocprofv3 summaries, %s: python3 tools/coarse_time_probe.py time (one MI355X; C4 shard, the model two EM iterations at the variance floor 1e-6' % RND,
+       '# leave: 73 % of the mixtures off the matrix pipe; four scoring calls = main kernel over the on-pipe 27 % + the coarse pass over the rest)',
+       '', '## --kernel-trace --stats (%s_coarse_kernel_stats.csv)' % RND]
+kt, lines = kernel_stats('coarse_trace', '%s_coarse_kernel_stats.csv' % RND)
+out += lines + ['', '## --pmc passes (<= 4 counters per pass), per-dispatch averages']
+lines, val = counters(['coarse_fetch', 'coarse_write', 'coarse_clk', 'coarse_sq1', 'coarse_sq2', 'coarse_lds'], ['gmm_score_coarse_kernel', 'gmm_score_split16_kernel'])
+out += lines
+try:
+    for name in ('gmm_score_coarse_kernel', 'gmm_score_split16_kernel'):
+        v = val[name]
+        ms = pick(kt, name)
+        cyc = v['GRBM_GUI_ACTIVE'] / 8
+        wc = v['SQ_WAVE_CYCLES']
+        out += ['', '## derived, %s (%.2f ms per launch)' % (name, ms),
+                'FETCH_SIZE %.3f GB raw (x 2: the layouts are read with 16-byte lanes) + WRITE_SIZE %.3f GB per launch' % (v['FETCH_SIZE'] * 1024 / 1e9, v['WRITE_SIZE'] * 1024 / 1e9),
+                'clock held %.2f GHz; matrix pipe busy %.0f %% of the SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))'
+                % (cyc / ms / 1e6, 100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024)),
+                'wave time: SQ_WAIT_ANY %.0f %%, SQ_WAIT_INST_ANY %.0f %%, SQ_WAIT_INST_LDS %.0f %% of SQ_WAVE_CYCLES; LDS bank conflicts %.1f %% of SQ_LDS_IDX_ACTIVE'
+                % (100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, 100 * v.get('SQ_WAIT_INST_LDS', 0) / wc,
+                   100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, v.get('SQ_LDS_IDX_ACTIVE', 1.0)))]
+except (KeyError, IndexError, ZeroDivisionError) as e:
+    out.append('(derived block incomplete: %r)' % (e,))
+if kt:
+    open(os.path.join(P, '%s_coarse_summary.txt' % RND), 'w').write('\n'.join(out) + '\n')
