@@ -51,7 +51,11 @@ constexpr int WG = 8 * 32 / PCL_COARSE_NT * 64 / 32;      // a workgroup covers 
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
+#ifdef PCL_COARSE_MARGIN_REPRO                // mutation build (tools/gpu_mutation_check.sh: the tests are expected to FAIL on it): a pair as large as
+constexpr float COARSE_MARGIN = 0.f;          // everything the pipe summed is ruled out
+#else
 constexpr float COARSE_MARGIN = 36.f;         // log2 units below the frame's likelihood: nothing (see above)
+#endif
 constexpr double VMIN_C = 0.0009765625;       // 2^-10: the variance floor of the bound
 constexpr double KQ_MAX = 2.5e4;              // the cancelling term the folded constant may carry (f16 pieces reach 6e4)
 constexpr double EPS_C = 9.5367431640625e-07; // 2^-20

@@ -2,7 +2,8 @@
 # The mutation builds: the library with a known, fixed bug restored must FAIL the test that guards the fix.  Build them HERE first:
 #   tools/build_variant.sh lseflush "-DPCL_LSE_FLUSH_REPRO -fno-slp-vectorize" gmm_score_split.hip gmm_score_mfma.hip
 #   tools/build_variant.sh race "-DPCL_DESC_RACE_REPRO" pcl_api.hip hmm_units.hip
-# then:  gpurun -- 'bash tools/gpu_mutation_check.sh'.  Exit code 0 = both mutants were caught (and the shipped library passes the same tests).
+#   tools/build_variant.sh coarsemargin "-DPCL_COARSE_MARGIN_REPRO" gmm_score_coarse.hip      (round 6: the coarse pass rules out pairs that matter)
+# then:  gpurun -- 'bash tools/gpu_mutation_check.sh'.  Exit code 0 = every mutant was caught (and the shipped library passes the same tests).
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 rc=0
 check() { # name, library, expected ("fail" / "pass"), pytest args...
@@ -17,4 +18,6 @@ check shipped_lse $L pass tests/test_gpu_parity.py -k "far_above_the_first_tile"
 check mutant_lse $GRAFT_REPO_ROOT/build_ab/lib_lseflush.so fail tests/test_gpu_parity.py -k "far_above_the_first_tile"
 check shipped_race $L pass tests/test_gpu_sweep.py
 check mutant_race $GRAFT_REPO_ROOT/build_ab/lib_race.so fail tests/test_gpu_sweep.py
+check shipped_coarse $L pass tests/test_gpu_coarse.py -k "six_decades or e_step"
+check mutant_coarse $GRAFT_REPO_ROOT/build_ab/lib_coarsemargin.so fail tests/test_gpu_coarse.py -k "six_decades or e_step"
 exit $rc
