@@ -47,7 +47,8 @@ namespace {
 #ifndef PCL_COARSE_NT
 #define PCL_COARSE_NT 2
 #endif
-constexpr int WG = 8 * 32 / PCL_COARSE_NT * 64 / 32;      // a workgroup covers 256 frames: 4 waves of two 32-frame groups (or 8 of one)
+constexpr int WG = 64 * (256 / (32 * PCL_COARSE_NT));     // a workgroup covers 256 frames: 4 waves of two 32-frame groups (NT = 1: 8 waves of one -- measured slower)
+static_assert(PCL_COARSE_NT == 1 || PCL_COARSE_NT == 2, "32-frame groups per wave");
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 constexpr double LOG2E = 1.4426950408889634074, LOG_2PI = 1.8378770664093454836;
@@ -78,7 +79,7 @@ struct CoarseExact {
 };
 
 #ifndef PCL_COARSE_MINW
-#define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at: 2 (199 VGPRs, nothing spilled).  3 (168 VGPRs, 28 spilled) measured 4 % faster on the shard probe and 8-10 % slower inside config 4's EM iterations (coarse 93 / 137 ms against 86 / 124): profiles/r06_coarse_ab.txt
+#define PCL_COARSE_MINW 2    // waves per SIMD the register allocation aims at: 2 (212 VGPRs at D = 39 with one product, nothing spilled).  3 measured 4 % faster on the shard probe and 8-10 % slower inside config 4's EM iterations on the first form of the kernel (profiles/r06_coarse_ab.txt)
 #endif
 
 // f16 rounded TOWARD ZERO (the one-product pass: a quadratic term a x'^2, a <= 0, may only come out too high)
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(WG, PCL_COARSE_MINW) void gmm_score_coarse_kernel(
         if (lane < qn) {
             const int idx = q_idx[wave][lane];
             double v = -INFINITY;
-#ifdef PCL_COARSE_EXP
-            if (idx < n_tight && !(PCL_COARSE_EXP & 1)) {
+#ifdef PCL_COARSE_EXP                         // timing builds only (tools/coarse_time_probe.py): the launch WITHOUT a part, wrong results on purpose --
+            if (idx < n_tight && !(PCL_COARSE_EXP & 1)) {        // 1: the surviving pairs are not evaluated, 2: no products, 4: nothing passes
 #else
             if (idx < n_tight) {
 #endif
