@@ -440,10 +440,10 @@ int pcl_model_upload(pcl_ctx *ctx, int J, int M, int D, const double *mean, cons
     TRY(dev_alloc(ctx, &ctx->d_good_idx, (size_t)J * Mpad));
     TRY(dev_alloc(ctx, &ctx->d_npt, (size_t)J));
     // with the coarse pass (gmm_score_coarse.hip) a state's off-pipe mixtures cost the scoring about what they would cost on the pipe, so
-    // states stay split for scoring up to coarse_split_frac (0.99) of their mixtures.  Beyond it the route stops paying: by then a state's
-    // surviving broad mixtures have themselves crossed cond_max (variance 0.3-0.9, two or three sigma off the centre) -- off-pipe, yet real
-    // contributors to most frames, tens of candidates per frame for a pass that evaluates a pair per lane -- and the whole-state direct
-    // form with its partial-distance test is the cheaper route.  Config 4's EM iterations 5 / 6 / 7 (98.8 / 99.7 / 99.8 % off-pipe) at
+    // states stay split for scoring up to coarse_split_frac (0.99) of their mixtures.  Beyond it the route stops paying: tens of pairs per
+    // frame and state pass the bound (many of a state's broader mixtures have by then crossed cond_max themselves and sit, off-pipe,
+    // within reach of most frames) for a pass that evaluates a pair per lane, and the whole-state direct form with its
+    // partial-distance test is the cheaper route.  Config 4's EM iterations 5 / 6 / 7 (98.8 / 99.7 / 99.8 % off-pipe) at
     // the limits 0.95, 0.99, 0.998: 274 / 256 / 275, 206 / 260 / 306 and 160 / 276 / 362 ms (profiles/r06_coarse_rework.txt).  PCL_SPLIT_MAX overrides both limits; the accumulate pass keeps the round 4-5 half
     ctx->acc_split_max = (int)((ctx->split_frac_set ? ctx->split_frac : 0.5f) * (float)M);
     ctx->split_max = (int)(((ctx->split_frac_set || !pcl_coarse_enabled_for(ctx, Dd)) ? ctx->split_frac : ctx->coarse_split_frac) * (float)M);
