@@ -37,7 +37,8 @@ def run_case(cfg_name, prec, image_mb, peaked, n_extra=1, min_groups=0):
     from _parity import cov_acc_atol, hold
     P = PCL_F32 if prec == 'f32' else PCL_F64
     c = synth.CONFIGS[cfg_name]
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    from _models import full_size_model
+    mean, var, w, trans = full_size_model(c, 1) if cfg_name == 'C4shard' else synth.make_model(c['units'], c['M'], c['D'], seed=1)
     labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
     if peaked:
         frames = synth.make_peaked_frames(labels, c['T'], mean, var, seed=5)

@@ -369,7 +369,8 @@ def test_c5_decode_at_shard_shape(eng):
     cap = 8192
     tree, lx = synth.make_pronunciation_tree(20000, c['units'])
     assert len(tree['names']) > 80000
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=5)
+    from _models import full_size_model
+    mean, var, w, trans = full_size_model(c, 5)
     frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=6)
     eng.load_model(mean, var, w)
     eng.load_units(np.stack(trans))
@@ -436,7 +437,8 @@ def test_c5_full_corpus_streamed():
     c = synth.CONFIGS['C5shard']
     cap, per, n_chunks = 8192, 139, 24
     tree, lx = synth.make_pronunciation_tree(20000, c['units'])
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=5)
+    from _models import full_size_model
+    mean, var, w, trans = full_size_model(c, 5)
     eng = Engine(0)
     try:
         eng.load_model(mean, var, w)

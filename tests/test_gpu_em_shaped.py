@@ -127,8 +127,9 @@ def _check_stage(eng, b, stage, frames, lens, begin, labels, c):
 
 def test_c4_shard_deep_parity_on_the_models_em_leaves():
     from poccala_amd import Engine, PCL_F32, PCL_F64, synth
+    from _models import full_size_model
     c = synth.CONFIGS['C4shard']
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    mean, var, w, trans = full_size_model(c, 1)
     frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
     labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
     eng = Engine(0)

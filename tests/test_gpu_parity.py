@@ -1247,8 +1247,9 @@ def test_c4_shard_full_size_properties(eng):
     Gaussians and its Baum-Welch pass against the oracle."""
     from poccala_amd import PCL_F32, synth
     from poccala_amd.engine import make_sentence_batch
+    from _models import full_size_model
     c = synth.CONFIGS['C4shard']
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    mean, var, w, trans = full_size_model(c, 1)
     frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
     labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
     eng.load_model(mean, var, w)
@@ -1418,8 +1419,9 @@ def test_c4_shard_deep_parity(eng):
     from poccala_amd import PCL_F32, synth
     from poccala_amd.engine import embedded_structure
     from _oracle_pool import bw_unit_jobs, label_jobs
+    from _models import full_size_model
     c = synth.CONFIGS['C4shard']
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    mean, var, w, trans = full_size_model(c, 1)
     frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=0)
     labels = synth.make_labels(c['U'], c['L'], c['units'], seed=2)
     eng.load_model(mean, var, w)
@@ -1515,7 +1517,8 @@ def test_c5_shard_full_size(eng):
     from _oracle_pool import state_rows
     c = synth.CONFIGS['C5shard']
     J = c['units'] * 3
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=5)
+    from _models import full_size_model
+    mean, var, w, trans = full_size_model(c, 5)
     frames, lens, begin = synth.make_frames(c['U'], c['T'], c['D'], seed=6)
     frames[begin[9]:begin[9] + lens[9]] = frames[begin[3]:begin[3] + lens[3]]      # two utterances with identical frames
     eng.load_model(mean, var, w)
@@ -1545,7 +1548,8 @@ def test_c4_full_size_one_statistics_block():
     from poccala_amd import Engine, PCL_F32, synth
     c = synth.CONFIGS['C4shard']
     NB = 8
-    mean, var, w, trans = synth.make_model(c['units'], c['M'], c['D'], seed=1)
+    from _models import full_size_model
+    mean, var, w, trans = full_size_model(c, 1)
     eng = Engine(0)
     try:
         parts = []
